@@ -1,0 +1,284 @@
+/*
+ * nbnxm_hip.h — C ABI of the MI355X (gfx950) non-bonded FEP path.
+ *
+ * This is the drop-in boundary: every entry point replaces one function of the
+ * reference's Nbnxm GPU API (C++, namespace Nbnxm, CUDA backend).  The reference
+ * passes C++ objects (nbnxn_atomdata_t, interaction_const_t, NbnxnPairlistGpu,
+ * t_nblist, gmx_enerdata_t); across this ABI the same data travels as plain
+ * pointers + sizes, so that the mdrun side needs only a thin shim.
+ *
+ * Reference files are cited relative to /root/reference/src/gromacs/.
+ *
+ * Conventions kept from the reference (nbnxm/gpu_types_common.h):
+ *  - all device work is stream-ordered on the per-locality stream;
+ *  - outputs (f, fShift, energies, dV/dlambda, foreign terms) are ACCUMULATED by the
+ *    kernels into buffers cleared by nbnxm_gpu_clear_outputs();
+ *  - energies / dV/dl / fshift / foreign arrays are only downloaded for the Local locality;
+ *  - errors are fatal (message on stderr + abort()), as GMX_RELEASE_ASSERT / gmx_fatal are.
+ *
+ * Pair-list layout: the reference's CUDA layout, i.e. 8-atom clusters, 8 clusters per
+ * super-cluster, 4 j-clusters per packed group and c_nbnxnGpuClusterpairSplit = 2
+ * (two {imask, excl_ind} per group, exclusion words for 4+4 j-atoms).  One 64-lane
+ * wavefront covers the whole 8x(4+4) cluster pair: lanes 0-31 use imei[0], lanes 32-63 imei[1].
+ */
+#ifndef NBNXM_HIP_H
+#define NBNXM_HIP_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- constants (nbnxm/pairlistparams.h:58-98, nbnxm/pairlist.h:125,174-180) -------------- */
+#define NBNXM_GPU_CLUSTER_SIZE 8
+#define NBNXM_GPU_NUM_CLUSTER_PER_SUPERCLUSTER 8
+#define NBNXM_GPU_JGROUP_SIZE 4
+#define NBNXM_GPU_CLUSTERPAIR_SPLIT 2
+#define NBNXM_GPU_EXCL_SIZE 32 /* c_nbnxnGpuClusterSize^2 / split */
+#define NBNXM_CI_SHIFT_MASK 127
+#define NBNXM_NUM_SHIFT_VECTORS 45     /* gmx::c_numShiftVectors, pbcutil/ishift.h */
+#define NBNXM_CENTRAL_SHIFT_INDEX 22   /* gmx::c_centralShiftIndex */
+
+/* Nbnxm::ElecType / Nbnxm::VdwType, nbnxm/nbnxm.h:181-214 (same numeric values) */
+enum nbnxm_elec_type
+{
+    NBNXM_ELEC_CUT = 0,
+    NBNXM_ELEC_RF,
+    NBNXM_ELEC_EWALD_TAB,
+    NBNXM_ELEC_EWALD_TAB_TWIN,
+    NBNXM_ELEC_EWALD_ANA,
+    NBNXM_ELEC_EWALD_ANA_TWIN,
+    NBNXM_ELEC_COUNT
+};
+enum nbnxm_vdw_type
+{
+    NBNXM_VDW_CUT = 0,
+    NBNXM_VDW_CUT_COMB_GEOM,
+    NBNXM_VDW_CUT_COMB_LB,
+    NBNXM_VDW_FSWITCH,
+    NBNXM_VDW_PSWITCH,
+    NBNXM_VDW_EWALD_GEOM,
+    NBNXM_VDW_EWALD_LB,
+    NBNXM_VDW_COUNT
+};
+
+/* gmx::InteractionLocality / gmx::AtomLocality, mdtypes/locality.h */
+enum nbnxm_locality
+{
+    NBNXM_LOCAL = 0,
+    NBNXM_NONLOCAL = 1
+};
+
+/* ---- pair-list element types (nbnxm/pairlist.h:198-280) ----------------------------------- */
+typedef struct
+{
+    int sci;           /* i-super-cluster */
+    int shift;         /* shift vector index (low 7 bits) + flags */
+    int cjPackedBegin; /* first packed j-group */
+    int cjPackedEnd;   /* one past the last packed j-group */
+} nbnxn_sci_t;
+
+typedef struct
+{
+    unsigned int imask;    /* bit (jm*8 + i): j-cluster jm of the group interacts with i-cluster i */
+    int          excl_ind; /* index into the exclusion-mask array, 0 = shared "all interacting" */
+} nbnxn_im_ei_t;
+
+typedef struct
+{
+    int           cj[NBNXM_GPU_JGROUP_SIZE];
+    nbnxn_im_ei_t imei[NBNXM_GPU_CLUSTERPAIR_SPLIT];
+} nbnxn_cj_packed_t;
+
+typedef struct
+{
+    /* word ((j & 3)*8 + i) of half (j >> 2); bit (jm*8 + ci): atom pair interacts */
+    unsigned int pair[NBNXM_GPU_EXCL_SIZE];
+} nbnxn_excl_t;
+
+/* ---- parameters ---------------------------------------------------------------------------- */
+typedef struct { float c2, c3, cpot; } nbnxm_shift_consts_t;   /* mdtypes/interaction_const.h shift_consts_t */
+typedef struct { float c3, c4, c5; } nbnxm_switch_consts_t;    /* switch_consts_t */
+
+/* What gpu_init()/initNbparam()/set_cutoff_parameters() read from interaction_const_t and
+ * PairlistParams (nbnxm/nbnxm_gpu_data_mgmt.cpp:201-223,421-489). */
+typedef struct
+{
+    int   elecType; /* nbnxm_elec_type, already resolved as nbnxmGpuPickElectrostaticsKernelType does */
+    int   vdwType;  /* nbnxm_vdw_type,  as nbnxmGpuPickVdwKernelType does */
+    float epsfac;
+    float c_rf;          /* reactionFieldShift */
+    float k_rf;          /* reactionFieldCoefficient (two_k_rf = 2 k_rf is derived) */
+    float ewaldcoeff_q;  /* ewald_beta */
+    float sh_ewald;
+    float sh_lj_ewald;
+    float ewaldcoeff_lj;
+    float rcoulomb;
+    float rvdw;
+    float rvdw_switch;
+    float rlistOuter;
+    float rlistInner;
+    int   useDynamicPruning;
+    nbnxm_shift_consts_t  dispersion_shift;
+    nbnxm_shift_consts_t  repulsion_shift;
+    nbnxm_switch_consts_t vdw_switch;
+    /* Ewald force table (coulombEwaldTables->tableF); may be NULL/0 for non-tabulated types */
+    float        coulomb_tab_scale;
+    int          coulomb_tab_size;
+    const float* coulomb_tab;
+} nbnxm_interaction_params_t;
+
+/* gmx::StepWorkload subset the path reads (mdtypes/simulation_workload.h) */
+typedef struct
+{
+    int computeForces; /* always 1 in the reference's GPU path; kept for symmetry */
+    int computeEnergy;
+    int computeVirial;
+    int computeDhdl;
+    int useGpuFBufferOps;
+} nbnxm_step_workload_t;
+
+/* Caller-owned accumulation targets of gpu_wait_finish_task (gmx_enerdata_t subset,
+ * nbnxm/gpu_common.h:405-435, mdtypes/enerdata.h:123-130). */
+typedef struct
+{
+    double  e_lj;            /* grpp LJSR[0]      += */
+    double  e_el;            /* grpp CoulombSR[0] += */
+    double  dvdl_lin[2];     /* [0]=Coul, [1]=Vdw; used when !haveSoftCore */
+    double  dvdl_nonlin[2];  /* used when haveSoftCore */
+    int     n_lambda;        /* number of foreign lambdas */
+    double* foreign_energies;   /* n_lambda+1: ForeignLambdaTerms::energies_ */
+    double* foreign_dhdl_coul;  /* n_lambda+1: dhdl_[idx][Coul] */
+    double* foreign_dhdl_vdw;   /* n_lambda+1: dhdl_[idx][Vdw]  */
+} nbnxm_enerdata_t;
+
+typedef struct NbnxmGpu NbnxmGpu; /* opaque; nbnxm/cuda/nbnxm_cuda_types.h:67-143 */
+
+/* Kernel-time accounting (gmx_wallclock_gpu_nbnxn_t subset, timing/gpu_timing.h:85-93) */
+typedef struct
+{
+    double nb_k_ms;    int nb_k_count;
+    double fep_k_ms;   int fep_k_count;
+    double prune_k_ms; int prune_k_count;
+} nbnxm_gpu_timings_t;
+
+/* ---- life cycle ---------------------------------------------------------------------------- */
+
+/* Nbnxm::gpu_init — nbnxm/gpu_data_mgmt.h:88-96, nbnxm_gpu_data_mgmt.cpp:538-628.
+ * nbfp: 2*numTypes^2 floats (6*C6, 12*C12); nbfp_comb: 2*numTypes floats or NULL.
+ * localStream/nonLocalStream: hipStream_t to enqueue into, or NULL to let the module create its own
+ * (DeviceStreamManager in the reference). */
+NbnxmGpu* nbnxm_gpu_init(const nbnxm_interaction_params_t* ic, int numTypes, const float* nbfp,
+                         const float* nbfp_comb, int bLocalAndNonlocal, int bFEP, int n_lambda,
+                         void* localStream, void* nonLocalStream);
+
+/* Nbnxm::gpu_free — nbnxm/gpu_data_mgmt.h:115, nbnxm_gpu_data_mgmt.cpp:1540-1654 */
+void nbnxm_gpu_free(NbnxmGpu* nb);
+
+/* Nbnxm::cuda_copy_fepparams — nbnxm/gpu_data_mgmt.h:73-85, nbnxm_gpu_data_mgmt.cpp:491-536.
+ * all_lambda_coul/vdw: n_lambda doubles each (all_lambda[Coul], all_lambda[Vdw]). */
+void nbnxm_gpu_copy_fepparams(NbnxmGpu* nb, int bFEP, float alpha_coul, float alpha_vdw,
+                              int lam_power, float sc_sigma6_def, float sc_sigma6_min,
+                              float lambda_q, float lambda_v, int n_lambda,
+                              const double* all_lambda_coul, const double* all_lambda_vdw);
+
+/* Nbnxm::gpu_pme_loadbal_update_param — nbnxm_gpu_data_mgmt.cpp (cut-off/Ewald update) */
+void nbnxm_gpu_pme_loadbal_update_param(NbnxmGpu* nb, const nbnxm_interaction_params_t* ic);
+
+/* ---- per search step ----------------------------------------------------------------------- */
+
+/* Nbnxm::gpu_init_atomdata — nbnxm/gpu_data_mgmt.h:112-113, nbnxm_gpu_data_mgmt.cpp:873-1045.
+ * Arrays are in nbnxm grid order, numAtoms long (nbat->params()):
+ *   type / lj_comb(2 per atom)           : "normal" parameters, perturbed atoms zeroed by the caller
+ *   qA,qB,typeA,typeB,lj_combA,lj_combB  : A/B-state parameters (FEP only; may be NULL otherwise) */
+void nbnxm_gpu_init_atomdata(NbnxmGpu* nb, int numAtoms, int numAtomsLocal, const int* type,
+                             const float* lj_comb, const float* qA, const float* qB,
+                             const int* typeA, const int* typeB, const float* lj_combA,
+                             const float* lj_combB);
+
+/* Nbnxm::gpu_init_pairlist — nbnxm/gpu_data_mgmt.h:99-101, nbnxm_gpu_data_mgmt.cpp:667-759 */
+void nbnxm_gpu_init_pairlist(NbnxmGpu* nb, int iloc, int na_c, int nsci, const nbnxn_sci_t* sci,
+                             int ncjPacked, const nbnxn_cj_packed_t* cjPacked, int nexcl,
+                             const nbnxn_excl_t* excl);
+
+/* Nbnxm::gpu_init_feppairlist — nbnxm/gpu_data_mgmt.h:104-109, nbnxm_gpu_data_mgmt.cpp:761-871.
+ * The t_nblist (mdtypes/nblist.h:40-54) holds TOPOLOGY atom ids; atomIndices is
+ * gridSet.atomIndices() (grid index -> topology id, -1 for fillers), numAtomIndices long.
+ * Pass atomIndices = NULL if iinr/jjnr are already in grid order. */
+void nbnxm_gpu_init_feppairlist(NbnxmGpu* nb, int iloc, int nri, const int* iinr, const int* shift,
+                                const int* jindex, int nrj, const int* jjnr, const int* excl_fep,
+                                int numAtomIndices, const int* atomIndices);
+
+/* MI355X extension ("shape B"): per-cluster perturbed-atom bits (Grid::fepBits,
+ * nbnxm/grid.h:289-299), one byte per 8-atom cluster in grid order.  When set, the cluster-pair
+ * kernel evaluates perturbed pairs in-line with the soft-core A/B math and the atom-pair
+ * FEP list is not needed; the pair list must then keep the topology exclusion bits of
+ * perturbed pairs (i.e. the host builder does not apply pairlist.cpp:1919). */
+void nbnxm_gpu_init_fep_cluster_bits(NbnxmGpu* nb, int numClusters, const unsigned char* fepBits);
+
+/* ---- per step ------------------------------------------------------------------------------ */
+
+/* Nbnxm::gpu_upload_shiftvec — nbnxm/gpu_data_mgmt.h:123, 45 x 3 floats */
+void nbnxm_gpu_upload_shiftvec(NbnxmGpu* nb, const float* shift_vec);
+
+/* Nbnxm::gpu_copy_xq_to_gpu — nbnxm/nbnxm_gpu.h:93-96.  xq: 4 floats per atom, grid order, host. */
+void nbnxm_gpu_copy_xq_to_gpu(NbnxmGpu* nb, const float* xq, int atomLocality);
+
+/* Nbnxm::gpu_launch_kernel — nbnxm/nbnxm_gpu.h:108-111, nbnxm/cuda/nbnxm_cuda.cu:642-858 */
+void nbnxm_gpu_launch_kernel(NbnxmGpu* nb, const nbnxm_step_workload_t* stepWork, int iloc);
+
+/* Nbnxm::gpu_launch_kernel_pruneonly — nbnxm/nbnxm_gpu.h:148-151, nbnxm_cuda.cu:873-994 */
+void nbnxm_gpu_launch_kernel_pruneonly(NbnxmGpu* nb, int iloc, int numParts);
+
+/* Nbnxm::gpu_launch_cpyback — nbnxm/nbnxm_gpu.h:157-161, nbnxm_gpu_data_mgmt.cpp:1117-1303.
+ * f_out: 3 floats per atom (nbat->out[0].f), host. */
+void nbnxm_gpu_launch_cpyback(NbnxmGpu* nb, float* f_out, const nbnxm_step_workload_t* stepWork,
+                              int atomLocality);
+
+/* Nbnxm::gpu_try_finish_task (Check) / gpu_wait_finish_task (Wait) —
+ * nbnxm/nbnxm_gpu.h:201-236, nbnxm/gpu_common.h:293-435.
+ * shiftForces: 45 x 3 floats accumulated into (may be NULL when !computeVirial).
+ * try returns 1 when the task had finished (and the reduction was done), else 0. */
+int  nbnxm_gpu_try_finish_task(NbnxmGpu* nb, const nbnxm_step_workload_t* stepWork, int atomLocality,
+                               int haveSoftCore, nbnxm_enerdata_t* enerd, float* shiftForces);
+void nbnxm_gpu_wait_finish_task(NbnxmGpu* nb, const nbnxm_step_workload_t* stepWork,
+                                int atomLocality, int haveSoftCore, nbnxm_enerdata_t* enerd,
+                                float* shiftForces);
+
+/* Nbnxm::gpu_clear_outputs — nbnxm/gpu_data_mgmt.h:126, nbnxm_gpu_data_mgmt.cpp:1047-1070.
+ * (Unlike the reference, energies and dV/dl are cleared on every call) */
+void nbnxm_gpu_clear_outputs(NbnxmGpu* nb, int computeVirial);
+
+/* ---- queries / plumbing -------------------------------------------------------------------- */
+
+/* Nbnxm::gpu_get_timings / gpu_reset_timings — nbnxm/gpu_data_mgmt.h:129-132 */
+void nbnxm_gpu_get_timings(NbnxmGpu* nb, nbnxm_gpu_timings_t* out);
+void nbnxm_gpu_reset_timings(NbnxmGpu* nb);
+/* enable/disable hipEvent timing of the kernels (GMX_ENABLE_GPU_TIMING, gpu_utils/gpu_utils.cpp:60-75) */
+void nbnxm_gpu_set_timing(NbnxmGpu* nb, int enable);
+
+/* Nbnxm::gpu_min_ci_balanced — nbnxm/gpu_data_mgmt.h:135, cuda/nbnxm_cuda_data_mgmt.cu:82-109 */
+int nbnxm_gpu_min_ci_balanced(NbnxmGpu* nb);
+/* Nbnxm::gpu_is_kernel_ewald_analytical — nbnxm/gpu_data_mgmt.h:138 */
+int nbnxm_gpu_is_kernel_ewald_analytical(const NbnxmGpu* nb);
+/* Nbnxm::gpu_get_xq / gpu_get_f / gpuGetNBAtomData-style raw device pointers (nbnxm_gpu.h:238-311) */
+void* nbnxm_gpu_get_xq(NbnxmGpu* nb);
+void* nbnxm_gpu_get_f(NbnxmGpu* nb);
+void* nbnxm_gpu_get_fshift(NbnxmGpu* nb);
+/* stream of a locality (hipStream_t), for callers that order their own work after the kernels */
+void* nbnxm_gpu_get_stream(NbnxmGpu* nb, int iloc);
+/* Nbnxm::haveGpuShortRangeWork — nbnxm_gpu.h:300-311 */
+int nbnxm_gpu_have_short_range_work(const NbnxmGpu* nb, int iloc);
+
+/* Selects how perturbed pairs are evaluated (MI355X extension):
+ *   0 = reference shape: cluster kernel + separate atom-pair FEP-list kernels (gpu_feplist);
+ *   1 = fused: perturbed pairs inside the cluster-pair kernel (needs nbnxm_gpu_init_fep_cluster_bits). */
+void nbnxm_gpu_set_fep_mode(NbnxmGpu* nb, int fused);
+
+/* Library/ABI version and a last-error string for diagnostics (never needed on the success path). */
+int         nbnxm_hip_abi_version(void);
+const char* nbnxm_hip_last_error(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NBNXM_HIP_H */

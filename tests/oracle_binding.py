@@ -1,0 +1,183 @@
+"""ctypes binding of the CPU oracle (oracle/build/liboracle.so).
+
+TEST INFRASTRUCTURE: imported only by tests/, __graft_entry__.smoke() and bench.py's
+cpu_baseline leg.  The product (gromacs-fep-gpu_amd) never imports this module.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_DIR = os.path.join(ROOT, "oracle")
+LIB_PATH = os.path.join(ORACLE_DIR, "build", "liboracle.so")
+
+ONE_4PI_EPS0 = 138.93545764438198  # gmx::c_one4PiEps0, api/legacy/include/gromacs/math/units.h:110
+
+DO_FORCE, DO_SHIFTFORCE, DO_POTENTIAL = 1, 2, 4
+SOFTCORE_BEUTLER, SOFTCORE_GAPSYS = 0, 1
+
+
+class FepParams(C.Structure):
+    _fields_ = [
+        ("elecIsEwald", C.c_int), ("vdwIsEwald", C.c_int), ("vdwPotSwitch", C.c_int),
+        ("epsfac", C.c_double),
+        ("rcoulomb", C.c_double), ("rvdw", C.c_double), ("rvdw_switch", C.c_double),
+        ("k_rf", C.c_double), ("c_rf", C.c_double),
+        ("ewaldcoeff_q", C.c_double), ("ewaldcoeff_lj", C.c_double),
+        ("sh_ewald", C.c_double), ("sh_lj_ewald", C.c_double),
+        ("dispersion_shift_cpot", C.c_double), ("repulsion_shift_cpot", C.c_double),
+        ("softcoreType", C.c_int),
+        ("alphaVdw", C.c_double), ("alphaCoulomb", C.c_double),
+        ("lambdaPower", C.c_int),
+        ("sigma6WithInvalidSigma", C.c_double), ("sigma6Minimum", C.c_double),
+        ("gapsysScaleLinpointVdW", C.c_double), ("gapsysScaleLinpointCoul", C.c_double),
+        ("gapsysSigma6VdW", C.c_double),
+    ]
+
+
+class RefParams(C.Structure):
+    _fields_ = [
+        ("elecType", C.c_int), ("vdwType", C.c_int),
+        ("epsfac", C.c_double), ("c_rf", C.c_double), ("k_rf", C.c_double),
+        ("ewaldcoeff_q", C.c_double), ("sh_ewald", C.c_double), ("sh_lj_ewald", C.c_double),
+        ("ewaldcoeff_lj", C.c_double),
+        ("rcoulomb", C.c_double), ("rvdw", C.c_double), ("rvdw_switch", C.c_double),
+        ("rlist", C.c_double),
+        ("disp_c2", C.c_double), ("disp_c3", C.c_double), ("disp_cpot", C.c_double),
+        ("rep_c2", C.c_double), ("rep_c3", C.c_double), ("rep_cpot", C.c_double),
+        ("sw_c3", C.c_double), ("sw_c4", C.c_double), ("sw_c5", C.c_double),
+    ]
+
+
+_lib = None
+
+
+def build():
+    subprocess.check_call(["make", "-s", "-C", ORACLE_DIR])
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            build()
+        _lib = C.CDLL(LIB_PATH)
+        _lib.oracle_calc_ewaldcoeff_q.restype = C.c_double
+        _lib.oracle_calc_ewaldcoeff_q.argtypes = [C.c_double, C.c_double]
+        _lib.oracle_calc_ewaldcoeff_lj.restype = C.c_double
+        _lib.oracle_calc_ewaldcoeff_lj.argtypes = [C.c_double, C.c_double]
+        _lib.oracle_nbnxm_prune.restype = C.c_longlong
+    return _lib
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def _arr(a, dtype):
+    return None if a is None else np.ascontiguousarray(a, dtype=dtype)
+
+
+def softcore_params(p, sc_alpha, sc_power, sc_sigma, sc_sigma_min, sc_coul, softcore_type=SOFTCORE_BEUTLER,
+                    gapsys_lj=0.85, gapsys_q=0.3, gapsys_sigma=0.3):
+    lib().oracle_softcore_from_fepvals(C.byref(p), C.c_double(sc_alpha), C.c_int(sc_power),
+                                       C.c_double(sc_sigma), C.c_double(sc_sigma_min),
+                                       C.c_int(1 if sc_coul else 0), C.c_int(softcore_type),
+                                       C.c_double(gapsys_lj), C.c_double(gapsys_q),
+                                       C.c_double(gapsys_sigma))
+    return p
+
+
+def fep_kernel(nbl, x, ntype, p, shiftvec, nbfp, nbfp_grid, qA, qB, typeA, typeB, flags,
+               lambda_coul, lambda_vdw, precision="f64"):
+    """nbl: dict(iinr, jindex, jjnr, shift, excl_fep|None) with atom ids indexing x (N x 3).
+    Returns dict(f, fshift, Vc, Vv, dvdl_coul, dvdl_vdw)."""
+    rt = np.float64 if precision == "f64" else np.float32
+    fn = getattr(lib(), "oracle_nb_free_energy_kernel_" + precision)
+    iinr = _arr(nbl["iinr"], np.int32)
+    jindex = _arr(nbl["jindex"], np.int32)
+    jjnr = _arr(nbl["jjnr"], np.int32)
+    shift = _arr(nbl["shift"], np.int32)
+    excl = _arr(nbl.get("excl_fep"), np.int32)
+    x = _arr(x, rt)
+    sv = _arr(shiftvec, rt)
+    nbfp_ = _arr(nbfp, rt)
+    grid_ = _arr(nbfp_grid if nbfp_grid is not None else np.zeros_like(nbfp_), rt)
+    qA_, qB_ = _arr(qA, rt), _arr(qB, rt)
+    tA, tB = _arr(typeA, np.int32), _arr(typeB, np.int32)
+    n = x.shape[0]
+    f = np.zeros((n, 3), rt)
+    fshift = np.zeros((sv.reshape(-1, 3).shape[0], 3), rt)
+    Vc, Vv = C.c_double(0), C.c_double(0)
+    dvdl = (C.c_double * 2)(0, 0)
+    fn(C.c_int(len(iinr)), _ptr(iinr), _ptr(jindex), _ptr(jjnr), _ptr(shift), _ptr(excl), _ptr(x),
+       C.c_int(ntype), C.byref(p), _ptr(sv), _ptr(nbfp_), _ptr(grid_), _ptr(qA_), _ptr(qB_),
+       _ptr(tA), _ptr(tB), C.c_int(flags), C.c_double(lambda_coul), C.c_double(lambda_vdw),
+       _ptr(f), _ptr(fshift), C.byref(Vc), C.byref(Vv), dvdl)
+    return dict(f=f, fshift=fshift, Vc=Vc.value, Vv=Vv.value, dvdl_coul=dvdl[0], dvdl_vdw=dvdl[1])
+
+
+def fep_foreign(nbl, x, ntype, p, shiftvec, nbfp, nbfp_grid, qA, qB, typeA, typeB, lambda_coul,
+                lambda_vdw, all_lambda_coul, all_lambda_vdw, precision="f64"):
+    rt = np.float64 if precision == "f64" else np.float32
+    fn = getattr(lib(), "oracle_fep_foreign_" + precision)
+    iinr = _arr(nbl["iinr"], np.int32)
+    jindex = _arr(nbl["jindex"], np.int32)
+    jjnr = _arr(nbl["jjnr"], np.int32)
+    shift = _arr(nbl["shift"], np.int32)
+    excl = _arr(nbl.get("excl_fep"), np.int32)
+    x = _arr(x, rt)
+    sv = _arr(shiftvec, rt)
+    nbfp_ = _arr(nbfp, rt)
+    grid_ = _arr(nbfp_grid if nbfp_grid is not None else np.zeros_like(nbfp_), rt)
+    qA_, qB_ = _arr(qA, rt), _arr(qB, rt)
+    tA, tB = _arr(typeA, np.int32), _arr(typeB, np.int32)
+    alc = _arr(all_lambda_coul, np.float64)
+    alv = _arr(all_lambda_vdw, np.float64)
+    nl = len(alc)
+    out = [np.zeros(nl + 1) for _ in range(4)]
+    fn(C.c_int(len(iinr)), _ptr(iinr), _ptr(jindex), _ptr(jjnr), _ptr(shift), _ptr(excl), _ptr(x),
+       C.c_int(ntype), C.byref(p), _ptr(sv), _ptr(nbfp_), _ptr(grid_), _ptr(qA_), _ptr(qB_),
+       _ptr(tA), _ptr(tB), C.c_double(lambda_coul), C.c_double(lambda_vdw), C.c_int(nl),
+       _ptr(alc), _ptr(alv), _ptr(out[0]), _ptr(out[1]), _ptr(out[2]), _ptr(out[3]))
+    return dict(eVdw=out[0], eCoul=out[1], dvdlVdw=out[2], dvdlCoul=out[3])
+
+
+def nbnxm_ref(sci, cjPacked, excl, xq, atype, ntype, nbfp, p, shiftvec, compute_energy=True,
+              compute_fshift=True, lj_comb=None, nbfp_comb=None, precision="f64"):
+    """sci/cjPacked/excl: numpy structured or raw int32/uint32 arrays with the ABI layout."""
+    rt = np.float64 if precision == "f64" else np.float32
+    fn = getattr(lib(), "oracle_nbnxm_ref_" + precision)
+    sci = np.ascontiguousarray(sci)
+    cjPacked = np.ascontiguousarray(cjPacked)
+    excl = np.ascontiguousarray(excl)
+    xq_ = _arr(xq, rt)
+    n = xq_.reshape(-1, 4).shape[0]
+    t = _arr(atype, np.int32)
+    nbfp_ = _arr(nbfp, rt)
+    ljc = _arr(lj_comb, rt)
+    nbc = _arr(nbfp_comb, rt)
+    sv = _arr(shiftvec, rt)
+    f = np.zeros((n, 3), rt)
+    fshift = np.zeros((45, 3), rt)
+    Vc, Vv = C.c_double(0), C.c_double(0)
+    npair = C.c_longlong(0)
+    nsci = sci.size if sci.dtype.names else sci.reshape(-1, 4).shape[0]
+    fn(C.c_int(nsci), _ptr(sci), _ptr(cjPacked), _ptr(excl), _ptr(xq_), _ptr(t), C.c_int(ntype),
+       _ptr(nbfp_), _ptr(ljc), _ptr(nbc), C.byref(p), _ptr(sv), C.c_int(1 if compute_energy else 0),
+       C.c_int(1 if compute_fshift else 0), _ptr(f), _ptr(fshift), C.byref(Vc), C.byref(Vv),
+       C.byref(npair))
+    return dict(f=f, fshift=fshift, Vc=Vc.value, Vv=Vv.value, npairs=npair.value)
+
+
+def nbnxm_prune(sci, cjPacked, xq, shiftvec, rlist):
+    """Prunes cjPacked IN PLACE (imask bits); returns the number of cluster pairs left."""
+    sci = np.ascontiguousarray(sci)
+    assert cjPacked.flags["C_CONTIGUOUS"]
+    xq_ = _arr(xq, np.float32)
+    sv = _arr(shiftvec, np.float32)
+    nsci = sci.size if sci.dtype.names else sci.reshape(-1, 4).shape[0]
+    return lib().oracle_nbnxm_prune(C.c_int(nsci), _ptr(sci), _ptr(cjPacked), _ptr(xq_), _ptr(sv),
+                                    C.c_double(rlist))

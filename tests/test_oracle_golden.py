@@ -1,0 +1,105 @@
+"""Pins the CPU oracle (oracle/fep_oracle.c) against the reference's own 72 known answers.
+
+Fixture: tests/golden/nb_fep_refdata.json, transcribed from
+/root/reference/src/gromacs/gmxlib/nonbonded/tests/refdata/NBInteraction_NonbondedFepTest_testKernel_*.xml
+by tests/golden/make_nb_fep_golden.py.  Inputs as in gmxlib/nonbonded/tests/nb_free_energy.cpp.
+Tolerance: the reference's own (1e-6 relative in float, 1e-8 in double, nb_free_energy.cpp:504-506)
+with the same absolute floor idea as its FloatingPointTolerance (1e-6 / 1e-11 absolute).
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import oracle_binding as ob
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+with open(os.path.join(HERE, "golden", "nb_fep_refdata.json")) as fh:
+    GOLDEN = json.load(fh)
+SYS = GOLDEN["system"]
+
+
+def build_inputs(case):
+    s = SYS
+    ntype = s["ntype"]
+    lj = np.array(s["lj_c6_c12"], dtype=np.float64)
+    nbfp = np.empty(2 * ntype * ntype)
+    nbfp[0::2] = 6.0 * lj[:, 0]    # makeNonBondedParameterLists, mdlib/forcerec.cpp:115-152
+    nbfp[1::2] = 12.0 * lj[:, 1]
+    grid = np.zeros(2 * ntype * ntype)  # makeLJPmeC6GridCorrectionParameters, forcerec.cpp:154-190 (Geom)
+    for i in range(ntype):
+        for j in range(ntype):
+            c6i = lj[i * (ntype + 1), 0]
+            c6j = lj[j * (ntype + 1), 0]
+            grid[2 * (ntype * i + j)] = 6.0 * np.sqrt(c6i * c6j)
+    p = ob.FepParams()
+    inter = case["interaction"]
+    p.elecIsEwald = 1 if inter["coulomb"] == "Pme" else 0
+    p.vdwIsEwald = 1 if inter["vdw"] == "Pme" else 0
+    p.vdwPotSwitch = 1 if inter["vdw_modifier"] == "PotSwitch" else 0
+    p.epsfac = ob.ONE_4PI_EPS0 * s["epsfac_factor_of_one4pieps0"]
+    p.rcoulomb, p.rvdw, p.rvdw_switch = s["rcoulomb"], s["rvdw"], s["rvdw_switch"]
+    p.k_rf, p.c_rf = s["k_rf"], s["c_rf"]
+    p.ewaldcoeff_q = ob.lib().oracle_calc_ewaldcoeff_q(s["ewald_rc"], s["ewald_rtol"])
+    p.ewaldcoeff_lj = ob.lib().oracle_calc_ewaldcoeff_lj(s["ewald_rc"], s["ewald_rtol"])
+    p.sh_ewald, p.sh_lj_ewald = s["sh_ewald"], s["sh_lj_ewald"]
+    p.dispersion_shift_cpot = s["dispersion_shift_cpot"]
+    p.repulsion_shift_cpot = s["repulsion_shift_cpot"]
+    sc_type = ob.SOFTCORE_BEUTLER if case["softcore"] == "Beutler" else ob.SOFTCORE_GAPSYS
+    # ForcerecHelper::setSoftcoreAlpha sets sc_alpha and both Gapsys linpoint scalings (nb_free_energy.cpp:254-259)
+    a = case["sc_alpha"]
+    ob.softcore_params(p, a, s["sc_power"], s["sc_sigma"], s["sc_sigma_min"], case["sc_coul"], sc_type,
+                       gapsys_lj=a, gapsys_q=a, gapsys_sigma=s["gapsys_sigma_lj"])
+    nbl = dict(iinr=s["iinr"], jindex=s["jindex"], jjnr=s["jjnr"], shift=s["shift"], excl_fep=s["excl_fep"])
+    return nbl, nbfp, grid, p
+
+
+def run_case(case, precision):
+    nbl, nbfp, grid, p = build_inputs(case)
+    lam = case["lambda"]
+    return ob.fep_kernel(nbl, SYS["x"], SYS["ntype"], p, SYS["shiftvec"], nbfp, grid, SYS["chargeA"],
+                         SYS["chargeB"], SYS["typeA"], SYS["typeB"],
+                         ob.DO_FORCE | ob.DO_SHIFTFORCE | ob.DO_POTENTIAL, lam, lam, precision)
+
+
+def check(got, want, rel, abs_):
+    got = np.asarray(got, dtype=np.float64)
+    want = np.asarray(want, dtype=np.float64)
+    err = np.abs(got - want)
+    tol = np.maximum(abs_, rel * np.abs(want))
+    assert np.all(err <= tol), "got %s want %s (err %s tol %s)" % (got, want, err, tol)
+
+
+@pytest.mark.parametrize("case", GOLDEN["cases"], ids=lambda c: "k%02d" % c["index"])
+def test_oracle_f64_matches_reference_known_answers(case):
+    out = run_case(case, "f64")
+    exp = case["expected"]
+    # double build of the reference: 1e-8 relative (nb_free_energy.cpp:374,504); the Ewald cases were
+    # generated with the rational erf approximations (accuracy 1e-11..4e-11 of libm erf, simd_math.h).
+    rel, abs_ = 1e-8, 1e-9
+    check(out["Vv"], exp["EVdw"], rel, abs_)
+    check(out["Vc"], exp["ECoul"], rel, abs_)
+    check(out["dvdl_coul"], exp["dVdlCoul"], rel, abs_)
+    check(out["dvdl_vdw"], exp["dVdlVdw"], rel, abs_)
+    fscale = max(1.0, float(np.max(np.abs(exp["Forces"]))))
+    check(out["f"], exp["Forces"], rel, abs_ * fscale)
+    check(out["fshift"][0], exp["ShiftForceCentral"], rel, abs_ * fscale)
+
+
+@pytest.mark.parametrize("case", GOLDEN["cases"], ids=lambda c: "k%02d" % c["index"])
+def test_oracle_f32_matches_reference_known_answers(case):
+    out = run_case(case, "f32")
+    exp = case["expected"]
+    # float build of the reference: FloatingPointTolerance(1e-6 rel, ..., 10000 ULP) (nb_free_energy.cpp:433-435),
+    # i.e. up to ~6e-4 relative in float; the inputs (0.1 nm separations in float, r^-12) limit an
+    # independent float evaluation to ~1e-5, which is what is asserted here.
+    scale = max(1.0, abs(exp["EVdw"]), abs(exp["ECoul"]), abs(exp["dVdlCoul"]), abs(exp["dVdlVdw"]))
+    rel, abs_ = 1e-5, 1e-5 * scale
+    check(out["Vv"], exp["EVdw"], rel, abs_)
+    check(out["Vc"], exp["ECoul"], rel, abs_)
+    check(out["dvdl_coul"], exp["dVdlCoul"], rel, abs_)
+    check(out["dvdl_vdw"], exp["dVdlVdw"], rel, abs_)
+    fscale = max(1.0, float(np.max(np.abs(exp["Forces"]))))
+    check(out["f"], exp["Forces"], rel, 1e-5 * fscale)
+    check(out["fshift"][0], exp["ShiftForceCentral"], rel, 1e-5 * fscale)
