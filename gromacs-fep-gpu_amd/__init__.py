@@ -1,0 +1,435 @@
+"""Python face of the MI355X non-bonded FEP path.
+
+The product is two in-tree shared libraries with a C ABI:
+  lib/libnbnxm_hip.so   (include/nbnxm_hip.h)   HIP kernels + the Nbnxm GPU API drop-in
+  lib/libnbnxm_host.so  (include/nbnxm_host.h)  synthetic box, cluster grid, pair-list builders
+This module only binds them with ctypes for the tests and bench.py: names and argument
+meaning mirror the reference's Nbnxm functions (nbnxm/nbnxm_gpu.h, nbnxm/gpu_data_mgmt.h).
+There is NO CPU fallback: if libnbnxm_hip.so is missing, or there is no GPU when a GPU entry
+point is called, this fails loudly.  (The directory name has a hyphen, so load it with
+__graft_entry__.load_package(), which registers it as `gromacs_fep_gpu_amd`.)
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+PKG_DIR = os.path.dirname(os.path.abspath(__file__))
+LIB_DIR = os.path.join(PKG_DIR, "lib")
+HIP_LIB_PATH = os.path.join(LIB_DIR, "libnbnxm_hip.so")
+HOST_LIB_PATH = os.path.join(LIB_DIR, "libnbnxm_host.so")
+
+# ---- ABI constants (include/nbnxm_hip.h) ----------------------------------------------------------
+CLUSTER_SIZE = 8
+NUM_CLUSTER_PER_SUPERCLUSTER = 8
+JGROUP_SIZE = 4
+NUM_SHIFT_VECTORS = 45
+CENTRAL_SHIFT_INDEX = 22
+ELEC_CUT, ELEC_RF, ELEC_EWALD_TAB, ELEC_EWALD_TAB_TWIN, ELEC_EWALD_ANA, ELEC_EWALD_ANA_TWIN = range(6)
+VDW_CUT, VDW_CUT_COMB_GEOM, VDW_CUT_COMB_LB, VDW_FSWITCH, VDW_PSWITCH, VDW_EWALD_GEOM, VDW_EWALD_LB = range(7)
+LOCAL, NONLOCAL = 0, 1
+
+SCI_DTYPE = np.dtype([("sci", "<i4"), ("shift", "<i4"), ("cjPackedBegin", "<i4"), ("cjPackedEnd", "<i4")])
+IMEI_DTYPE = np.dtype([("imask", "<u4"), ("excl_ind", "<i4")])
+CJ_PACKED_DTYPE = np.dtype([("cj", "<i4", (4,)), ("imei", IMEI_DTYPE, (2,))])
+EXCL_DTYPE = np.dtype([("pair", "<u4", (32,))])
+assert SCI_DTYPE.itemsize == 16 and CJ_PACKED_DTYPE.itemsize == 32 and EXCL_DTYPE.itemsize == 128
+
+
+class ShiftConsts(C.Structure):
+    _fields_ = [("c2", C.c_float), ("c3", C.c_float), ("cpot", C.c_float)]
+
+
+class SwitchConsts(C.Structure):
+    _fields_ = [("c3", C.c_float), ("c4", C.c_float), ("c5", C.c_float)]
+
+
+class InteractionParams(C.Structure):
+    """nbnxm_interaction_params_t"""
+    _fields_ = [
+        ("elecType", C.c_int), ("vdwType", C.c_int),
+        ("epsfac", C.c_float), ("c_rf", C.c_float), ("k_rf", C.c_float),
+        ("ewaldcoeff_q", C.c_float), ("sh_ewald", C.c_float), ("sh_lj_ewald", C.c_float),
+        ("ewaldcoeff_lj", C.c_float),
+        ("rcoulomb", C.c_float), ("rvdw", C.c_float), ("rvdw_switch", C.c_float),
+        ("rlistOuter", C.c_float), ("rlistInner", C.c_float),
+        ("useDynamicPruning", C.c_int),
+        ("dispersion_shift", ShiftConsts), ("repulsion_shift", ShiftConsts),
+        ("vdw_switch", SwitchConsts),
+        ("coulomb_tab_scale", C.c_float), ("coulomb_tab_size", C.c_int),
+        ("coulomb_tab", C.POINTER(C.c_float)),
+    ]
+
+
+class StepWorkload(C.Structure):
+    """nbnxm_step_workload_t"""
+    _fields_ = [("computeForces", C.c_int), ("computeEnergy", C.c_int), ("computeVirial", C.c_int),
+                ("computeDhdl", C.c_int), ("useGpuFBufferOps", C.c_int)]
+
+
+class EnerData(C.Structure):
+    """nbnxm_enerdata_t"""
+    _fields_ = [("e_lj", C.c_double), ("e_el", C.c_double),
+                ("dvdl_lin", C.c_double * 2), ("dvdl_nonlin", C.c_double * 2),
+                ("n_lambda", C.c_int),
+                ("foreign_energies", C.POINTER(C.c_double)),
+                ("foreign_dhdl_coul", C.POINTER(C.c_double)),
+                ("foreign_dhdl_vdw", C.POINTER(C.c_double))]
+
+
+class GpuTimings(C.Structure):
+    _fields_ = [("nb_k_ms", C.c_double), ("nb_k_count", C.c_int),
+                ("fep_k_ms", C.c_double), ("fep_k_count", C.c_int),
+                ("prune_k_ms", C.c_double), ("prune_k_count", C.c_int)]
+
+
+# Every symbol include/nbnxm_hip.h declares (checked by tests/test_abi_symbols.py).
+HIP_SYMBOLS = [
+    "nbnxm_gpu_init", "nbnxm_gpu_free", "nbnxm_gpu_copy_fepparams", "nbnxm_gpu_pme_loadbal_update_param",
+    "nbnxm_gpu_init_atomdata", "nbnxm_gpu_init_pairlist", "nbnxm_gpu_init_feppairlist",
+    "nbnxm_gpu_init_fep_cluster_bits", "nbnxm_gpu_upload_shiftvec", "nbnxm_gpu_copy_xq_to_gpu",
+    "nbnxm_gpu_launch_kernel", "nbnxm_gpu_launch_kernel_pruneonly", "nbnxm_gpu_launch_cpyback",
+    "nbnxm_gpu_try_finish_task", "nbnxm_gpu_wait_finish_task", "nbnxm_gpu_clear_outputs",
+    "nbnxm_gpu_get_timings", "nbnxm_gpu_reset_timings", "nbnxm_gpu_set_timing",
+    "nbnxm_gpu_min_ci_balanced", "nbnxm_gpu_is_kernel_ewald_analytical", "nbnxm_gpu_get_xq",
+    "nbnxm_gpu_get_f", "nbnxm_gpu_get_fshift", "nbnxm_gpu_get_stream",
+    "nbnxm_gpu_have_short_range_work", "nbnxm_gpu_set_fep_mode", "nbnxm_hip_abi_version",
+    "nbnxm_hip_last_error",
+]
+HOST_SYMBOLS = [
+    "nbnxm_host_make_water_box", "nbnxm_host_grid_create", "nbnxm_host_grid_free",
+    "nbnxm_host_grid_num_atoms", "nbnxm_host_grid_num_clusters", "nbnxm_host_grid_get",
+    "nbnxm_host_grid_update_xq", "nbnxm_host_shift_vectors", "nbnxm_host_pairlist_build",
+    "nbnxm_host_pairlist_free", "nbnxm_host_pairlist_sizes", "nbnxm_host_pairlist_get",
+    "nbnxm_host_pairlist_get_fep", "nbnxm_host_abi_version",
+]
+
+_hip = None
+_host = None
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def _a(a, dt):
+    return None if a is None else np.ascontiguousarray(a, dtype=dt)
+
+
+def hip_lib():
+    """Loads lib/libnbnxm_hip.so.  Raises if it has not been built — there is no fallback."""
+    global _hip
+    if _hip is None:
+        if not os.path.exists(HIP_LIB_PATH):
+            raise RuntimeError("HIP extension missing: %s (run __graft_entry__.build() / make -C %s)"
+                               % (HIP_LIB_PATH, PKG_DIR))
+        lib = C.CDLL(HIP_LIB_PATH)
+        lib.nbnxm_gpu_init.restype = C.c_void_p
+        lib.nbnxm_gpu_get_xq.restype = C.c_void_p
+        lib.nbnxm_gpu_get_f.restype = C.c_void_p
+        lib.nbnxm_gpu_get_fshift.restype = C.c_void_p
+        lib.nbnxm_gpu_get_stream.restype = C.c_void_p
+        lib.nbnxm_hip_last_error.restype = C.c_char_p
+        _hip = lib
+    return _hip
+
+
+def host_lib():
+    global _host
+    if _host is None:
+        if not os.path.exists(HOST_LIB_PATH):
+            raise RuntimeError("host library missing: %s (run __graft_entry__.build())" % HOST_LIB_PATH)
+        lib = C.CDLL(HOST_LIB_PATH)
+        lib.nbnxm_host_grid_create.restype = C.c_void_p
+        lib.nbnxm_host_pairlist_build.restype = C.c_void_p
+        _host = lib
+    return _host
+
+
+# ---- host side: synthetic system, grid, lists -------------------------------------------------------
+
+def make_water_box(nmx, nmy, nmz, spacing=0.310736, jitter=0.03, seed=2026, num_perturbed_molecules=0):
+    """SPC/E-like water box (nbnxm/benchmark/bench_system.cpp recipe, 100 atoms/nm^3 at the default
+    spacing: 3000 atoms in 3.10736 nm = 10 molecules per edge).  Returns a dict of topology-order arrays."""
+    n = 3 * nmx * nmy * nmz
+    out = dict(x=np.zeros((n, 3), np.float32), qA=np.zeros(n, np.float32), qB=np.zeros(n, np.float32),
+               typeA=np.zeros(n, np.int32), typeB=np.zeros(n, np.int32), molId=np.zeros(n, np.int32),
+               box=np.zeros(3, np.float32))
+    host_lib().nbnxm_host_make_water_box(C.c_int(nmx), C.c_int(nmy), C.c_int(nmz), C.c_double(spacing),
+                                         C.c_double(jitter), C.c_uint(seed), C.c_int(num_perturbed_molecules),
+                                         _p(out["x"]), _p(out["qA"]), _p(out["qB"]), _p(out["typeA"]),
+                                         _p(out["typeB"]), _p(out["molId"]), _p(out["box"]))
+    out["ntype"] = 3
+    # 6*C6, 12*C12 (bench_system.cpp:76-84: OW-OW only), ntype x ntype
+    nbfp = np.zeros((3, 3, 2), np.float64)
+    nbfp[0, 0] = (6.0 * 0.0026173456, 12.0 * 2.634129e-6)
+    out["nbfp"] = nbfp.reshape(-1).astype(np.float32)  # the table every consumer sees (float, like nbat)
+    return out
+
+
+def exclusions_from_groups(group_id):
+    """CSR exclusion lists: atoms with the same group id exclude each other (rigid waters)."""
+    group_id = np.asarray(group_id)
+    order = np.argsort(group_id, kind="stable")
+    sorted_ids = group_id[order]
+    starts = np.flatnonzero(np.r_[True, sorted_ids[1:] != sorted_ids[:-1]])
+    ends = np.r_[starts[1:], len(order)]
+    n = len(group_id)
+    counts = np.zeros(n, np.int64)
+    for s, e in zip(starts, ends):
+        counts[order[s:e]] = e - s
+    index = np.zeros(n + 1, np.int32)
+    index[1:] = np.cumsum(counts)
+    atoms = np.zeros(index[-1], np.int32)
+    for s, e in zip(starts, ends):
+        members = order[s:e]
+        for a in members:
+            atoms[index[a]:index[a + 1]] = members
+    return index, atoms
+
+
+class Grid:
+    """Cluster grid of one system (nbnxm/grid.cpp role)."""
+
+    def __init__(self, x, box, qA, qB, typeA, typeB, ntype, perturbed=None):
+        self.natoms = len(qA)
+        self.ntype = int(ntype)
+        self.box = _a(box, np.float32)
+        x = _a(x, np.float32)
+        pert = _a(perturbed, np.uint8)
+        self._h = host_lib().nbnxm_host_grid_create(C.c_int(self.natoms), _p(x), _p(self.box),
+                                                    _p(_a(qA, np.float32)), _p(_a(qB, np.float32)),
+                                                    _p(_a(typeA, np.int32)), _p(_a(typeB, np.int32)),
+                                                    C.c_int(self.ntype), _p(pert))
+        h = C.c_void_p(self._h)
+        self.num_atoms = host_lib().nbnxm_host_grid_num_atoms(h)
+        self.num_clusters = host_lib().nbnxm_host_grid_num_clusters(h)
+        np_ = self.num_atoms
+        self.xq = np.zeros((np_, 4), np.float32)
+        self.type = np.zeros(np_, np.int32)
+        self.qA = np.zeros(np_, np.float32)
+        self.qB = np.zeros(np_, np.float32)
+        self.typeA = np.zeros(np_, np.int32)
+        self.typeB = np.zeros(np_, np.int32)
+        self.atomIndices = np.zeros(np_, np.int32)
+        self.fepBits = np.zeros(self.num_clusters, np.uint8)
+        self.x_wrapped = np.zeros((self.natoms, 3), np.float32)
+        host_lib().nbnxm_host_grid_get(h, _p(self.xq), _p(self.type), _p(self.qA), _p(self.qB), _p(self.typeA),
+                                       _p(self.typeB), _p(self.atomIndices), _p(self.fepBits), _p(self.x_wrapped))
+        self.shift_vec = np.zeros((NUM_SHIFT_VECTORS, 3), np.float32)
+        host_lib().nbnxm_host_shift_vectors(_p(self.box), _p(self.shift_vec))
+
+    @property
+    def num_types(self):
+        """numTypes of the grid-order arrays: topology types + the zero filler type."""
+        return self.ntype + 1
+
+    def nbat_nbfp(self, nbfp):
+        """(ntype+1)^2 x 2 table with a zero last row/column (nbnxn_atomdata_t params().nbfp)."""
+        t = self.ntype
+        out = np.zeros((t + 1, t + 1, 2), np.float32)
+        out[:t, :t] = np.asarray(nbfp, np.float32).reshape(t, t, 2)
+        return out.reshape(-1)
+
+    def update_xq(self, x):
+        xq = self.xq.copy()
+        host_lib().nbnxm_host_grid_update_xq(C.c_void_p(self._h), _p(_a(x, np.float32)), _p(xq))
+        return xq
+
+    def build_pairlist(self, excl_index, excl_atoms, rlist, max_cjpacked_per_sci=0, carve_fep=True,
+                       rlist_fep=None):
+        return Pairlist(self, excl_index, excl_atoms, rlist, max_cjpacked_per_sci, carve_fep,
+                        rlist if rlist_fep is None else rlist_fep)
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            host_lib().nbnxm_host_grid_free(C.c_void_p(self._h))
+            self._h = None
+
+
+class Pairlist:
+    """GPU-layout cluster pair list + atom-pair FEP list (NbnxnPairlistGpu + t_nblist)."""
+
+    def __init__(self, grid, excl_index, excl_atoms, rlist, max_cjpacked_per_sci, carve_fep, rlist_fep):
+        ei = _a(excl_index, np.int32)
+        ea = _a(excl_atoms, np.int32)
+        h = host_lib().nbnxm_host_pairlist_build(C.c_void_p(grid._h), _p(ei), _p(ea), C.c_float(rlist),
+                                                 C.c_int(max_cjpacked_per_sci), C.c_int(1 if carve_fep else 0),
+                                                 C.c_float(rlist_fep))
+        h = C.c_void_p(h)
+        sizes = np.zeros(6, np.int64)
+        host_lib().nbnxm_host_pairlist_sizes(h, _p(sizes))
+        nsci, ncj, nexcl, nri, nrj, self.num_cluster_pairs = [int(v) for v in sizes]
+        self.rlist = float(rlist)
+        self.sci = np.zeros(nsci, SCI_DTYPE)
+        self.cjPacked = np.zeros(ncj, CJ_PACKED_DTYPE)
+        self.excl = np.zeros(nexcl, EXCL_DTYPE)
+        host_lib().nbnxm_host_pairlist_get(h, _p(self.sci), _p(self.cjPacked), _p(self.excl))
+        self.fep = dict(iinr=np.zeros(nri, np.int32), shift=np.zeros(nri, np.int32),
+                        jindex=np.zeros(nri + 1, np.int32), jjnr=np.zeros(nrj, np.int32),
+                        excl_fep=np.zeros(nrj, np.int32))
+        host_lib().nbnxm_host_pairlist_get_fep(h, _p(self.fep["iinr"]), _p(self.fep["shift"]),
+                                               _p(self.fep["jindex"]), _p(self.fep["jjnr"]),
+                                               _p(self.fep["excl_fep"]))
+        host_lib().nbnxm_host_pairlist_free(h)
+
+
+# ---- GPU side: the Nbnxm GPU API ----------------------------------------------------------------------
+
+def make_interaction_params(elec_type, vdw_type, epsfac, rcoulomb, rvdw, rlist_outer, rlist_inner=None,
+                            k_rf=0.0, c_rf=0.0, ewaldcoeff_q=0.0, sh_ewald=0.0, ewaldcoeff_lj=0.0,
+                            sh_lj_ewald=0.0, rvdw_switch=0.0, dispersion_shift=(0, 0, 0),
+                            repulsion_shift=(0, 0, 0), vdw_switch=(0, 0, 0), use_dynamic_pruning=False,
+                            coulomb_tab=None, coulomb_tab_scale=0.0):
+    ic = InteractionParams()
+    ic.elecType, ic.vdwType = int(elec_type), int(vdw_type)
+    ic.epsfac, ic.c_rf, ic.k_rf = epsfac, c_rf, k_rf
+    ic.ewaldcoeff_q, ic.sh_ewald, ic.sh_lj_ewald, ic.ewaldcoeff_lj = ewaldcoeff_q, sh_ewald, sh_lj_ewald, ewaldcoeff_lj
+    ic.rcoulomb, ic.rvdw, ic.rvdw_switch = rcoulomb, rvdw, rvdw_switch
+    ic.rlistOuter = rlist_outer
+    ic.rlistInner = rlist_outer if rlist_inner is None else rlist_inner
+    ic.useDynamicPruning = 1 if use_dynamic_pruning else 0
+    ic.dispersion_shift = ShiftConsts(*dispersion_shift)
+    ic.repulsion_shift = ShiftConsts(*repulsion_shift)
+    ic.vdw_switch = SwitchConsts(*vdw_switch)
+    if coulomb_tab is not None:
+        tab = _a(coulomb_tab, np.float32)
+        ic._tab_keepalive = tab
+        ic.coulomb_tab = tab.ctypes.data_as(C.POINTER(C.c_float))
+        ic.coulomb_tab_size = len(tab)
+        ic.coulomb_tab_scale = coulomb_tab_scale
+    return ic
+
+
+def step_workload(energy=False, virial=False, dhdl=False):
+    return StepWorkload(1, 1 if energy else 0, 1 if virial else 0, 1 if dhdl else 0, 0)
+
+
+class NbnxmGpu:
+    """Owner of one NbnxmGpu object behind the C ABI; method names follow Nbnxm::gpu_* ."""
+
+    def __init__(self, ic, num_types, nbfp, nbfp_comb=None, local_and_nonlocal=False, fep=False, n_lambda=0):
+        lib = hip_lib()
+        self._lib = lib
+        self.n_lambda = int(n_lambda)
+        self._ic = ic
+        nbfp = _a(nbfp, np.float32)
+        assert nbfp.size == 2 * num_types * num_types, "nbfp must hold 2*numTypes^2 floats"
+        comb = _a(nbfp_comb, np.float32)
+        self._h = lib.nbnxm_gpu_init(C.byref(ic), C.c_int(num_types), _p(nbfp), _p(comb),
+                                     C.c_int(1 if local_and_nonlocal else 0), C.c_int(1 if fep else 0),
+                                     C.c_int(n_lambda), None, None)
+        if not self._h:
+            raise RuntimeError("nbnxm_gpu_init failed: %s" % lib.nbnxm_hip_last_error().decode())
+        self.num_atoms = 0
+
+    @property
+    def h(self):
+        return C.c_void_p(self._h)
+
+    def copy_fepparams(self, alpha_coul, alpha_vdw, lam_power, sc_sigma6_def, sc_sigma6_min, lambda_q,
+                       lambda_v, all_lambda_coul=(), all_lambda_vdw=()):
+        alc = _a(all_lambda_coul, np.float64)
+        alv = _a(all_lambda_vdw, np.float64)
+        assert len(alc) == len(alv) == self.n_lambda
+        self._lib.nbnxm_gpu_copy_fepparams(self.h, C.c_int(1), C.c_float(alpha_coul), C.c_float(alpha_vdw),
+                                           C.c_int(lam_power), C.c_float(sc_sigma6_def), C.c_float(sc_sigma6_min),
+                                           C.c_float(lambda_q), C.c_float(lambda_v), C.c_int(self.n_lambda),
+                                           _p(alc), _p(alv))
+
+    def init_atomdata(self, num_atoms, atype, lj_comb=None, qA=None, qB=None, typeA=None, typeB=None,
+                      lj_combA=None, lj_combB=None, num_atoms_local=None):
+        self.num_atoms = int(num_atoms)
+        nl = self.num_atoms if num_atoms_local is None else int(num_atoms_local)
+        self._lib.nbnxm_gpu_init_atomdata(self.h, C.c_int(self.num_atoms), C.c_int(nl), _p(_a(atype, np.int32)),
+                                          _p(_a(lj_comb, np.float32)), _p(_a(qA, np.float32)),
+                                          _p(_a(qB, np.float32)), _p(_a(typeA, np.int32)),
+                                          _p(_a(typeB, np.int32)), _p(_a(lj_combA, np.float32)),
+                                          _p(_a(lj_combB, np.float32)))
+
+    def init_pairlist(self, sci, cjPacked, excl, iloc=LOCAL):
+        sci = np.ascontiguousarray(sci)
+        cjPacked = np.ascontiguousarray(cjPacked)
+        excl = np.ascontiguousarray(excl)
+        assert sci.dtype == SCI_DTYPE and cjPacked.dtype == CJ_PACKED_DTYPE and excl.dtype == EXCL_DTYPE
+        self._lib.nbnxm_gpu_init_pairlist(self.h, C.c_int(iloc), C.c_int(CLUSTER_SIZE), C.c_int(len(sci)), _p(sci),
+                                          C.c_int(len(cjPacked)), _p(cjPacked), C.c_int(len(excl)), _p(excl))
+
+    def init_feppairlist(self, fep, atom_indices, iloc=LOCAL):
+        iinr, shift, jindex = (_a(fep[k], np.int32) for k in ("iinr", "shift", "jindex"))
+        jjnr = _a(fep["jjnr"], np.int32)
+        excl = _a(fep.get("excl_fep"), np.int32)
+        ai = _a(atom_indices, np.int32)
+        self._lib.nbnxm_gpu_init_feppairlist(self.h, C.c_int(iloc), C.c_int(len(iinr)), _p(iinr), _p(shift),
+                                             _p(jindex), C.c_int(len(jjnr)), _p(jjnr), _p(excl),
+                                             C.c_int(0 if ai is None else len(ai)), _p(ai))
+
+    def init_fep_cluster_bits(self, fep_bits):
+        fb = _a(fep_bits, np.uint8)
+        self._lib.nbnxm_gpu_init_fep_cluster_bits(self.h, C.c_int(len(fb)), _p(fb))
+
+    def set_fep_mode(self, fused):
+        self._lib.nbnxm_gpu_set_fep_mode(self.h, C.c_int(1 if fused else 0))
+
+    def upload_shiftvec(self, shift_vec):
+        sv = _a(shift_vec, np.float32)
+        assert sv.size == 3 * NUM_SHIFT_VECTORS
+        self._lib.nbnxm_gpu_upload_shiftvec(self.h, _p(sv))
+
+    def copy_xq_to_gpu(self, xq, aloc=LOCAL):
+        xq = _a(xq, np.float32)
+        assert xq.size == 4 * self.num_atoms, "xq must hold 4 floats for each of the %d atoms" % self.num_atoms
+        self._lib.nbnxm_gpu_copy_xq_to_gpu(self.h, _p(xq), C.c_int(aloc))
+
+    def clear_outputs(self, compute_virial=True):
+        self._lib.nbnxm_gpu_clear_outputs(self.h, C.c_int(1 if compute_virial else 0))
+
+    def launch_kernel(self, step_work, iloc=LOCAL):
+        self._lib.nbnxm_gpu_launch_kernel(self.h, C.byref(step_work), C.c_int(iloc))
+
+    def launch_kernel_pruneonly(self, iloc=LOCAL, num_parts=1):
+        self._lib.nbnxm_gpu_launch_kernel_pruneonly(self.h, C.c_int(iloc), C.c_int(num_parts))
+
+    def launch_cpyback(self, f_out, step_work, aloc=LOCAL):
+        assert f_out.dtype == np.float32 and f_out.size == 3 * self.num_atoms and f_out.flags["C_CONTIGUOUS"]
+        self._lib.nbnxm_gpu_launch_cpyback(self.h, _p(f_out), C.byref(step_work), C.c_int(aloc))
+
+    def wait_finish_task(self, step_work, have_soft_core, aloc=LOCAL):
+        """Returns dict(e_lj, e_el, dvdl_lin, dvdl_nonlin, foreign_energies, foreign_dhdl_coul,
+        foreign_dhdl_vdw, fshift) — the caller-owned accumulators, zero-initialised here."""
+        nl = self.n_lambda
+        fe = np.zeros(nl + 1)
+        fc = np.zeros(nl + 1)
+        fv = np.zeros(nl + 1)
+        ed = EnerData()
+        ed.n_lambda = nl
+        ed.foreign_energies = fe.ctypes.data_as(C.POINTER(C.c_double))
+        ed.foreign_dhdl_coul = fc.ctypes.data_as(C.POINTER(C.c_double))
+        ed.foreign_dhdl_vdw = fv.ctypes.data_as(C.POINTER(C.c_double))
+        fshift = np.zeros((NUM_SHIFT_VECTORS, 3), np.float32)
+        self._lib.nbnxm_gpu_wait_finish_task(self.h, C.byref(step_work), C.c_int(aloc),
+                                             C.c_int(1 if have_soft_core else 0), C.byref(ed), _p(fshift))
+        return dict(e_lj=ed.e_lj, e_el=ed.e_el, dvdl_lin=list(ed.dvdl_lin), dvdl_nonlin=list(ed.dvdl_nonlin),
+                    foreign_energies=fe, foreign_dhdl_coul=fc, foreign_dhdl_vdw=fv, fshift=fshift)
+
+    def set_timing(self, enable):
+        self._lib.nbnxm_gpu_set_timing(self.h, C.c_int(1 if enable else 0))
+
+    def get_timings(self):
+        t = GpuTimings()
+        self._lib.nbnxm_gpu_get_timings(self.h, C.byref(t))
+        return t
+
+    def reset_timings(self):
+        self._lib.nbnxm_gpu_reset_timings(self.h)
+
+    def stream(self, iloc=LOCAL):
+        return self._lib.nbnxm_gpu_get_stream(self.h, C.c_int(iloc))
+
+    def free(self):
+        if getattr(self, "_h", None):
+            self._lib.nbnxm_gpu_free(self.h)
+            self._h = None
+
+    def __del__(self):
+        self.free()

@@ -1,0 +1,321 @@
+"""Shared helpers for the parity tests, smoke() and bench.py.
+
+Builds a synthetic solvated FEP case (SURVEY §8d recipe), runs it through
+  * the CPU oracle (oracle/: nbnxm_ref on the carved cluster list + fep_oracle on the FEP list),
+  * the HIP path through the C ABI (gromacs-fep-gpu_amd),
+  * an O(N^2) numpy evaluation (small N only),
+and compares.  Only test code may import the oracle.
+"""
+import math
+import os
+import sys
+from types import SimpleNamespace
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+for _p in (HERE, ROOT):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
+
+import oracle_binding as ob  # noqa: E402
+from __graft_entry__ import load_package  # noqa: E402
+
+pkg = load_package()
+
+ONE_4PI_EPS0 = ob.ONE_4PI_EPS0
+
+
+def make_case(nm=(8, 8, 8), num_perturbed_molecules=3, elec="rf", vdw="cut", seed=2026, rc=1.0, rlist=1.1,
+              rlist_fep=None, sc_alpha=0.5, sc_power=1, sc_sigma=0.3, sc_coul=True, lambda_coul=0.5,
+              lambda_vdw=0.5, n_lambda=0, max_cjpacked_per_sci=0, identical_states=False, rvdw_switch=0.8,
+              spacing=0.310736, jitter=0.03):
+    """elec: 'rf' | 'cut' | 'ewald' | 'ewald_tab';  vdw: 'cut' | 'pswitch' | 'fswitch'."""
+    sysd = pkg.make_water_box(nm[0], nm[1], nm[2], spacing=spacing, jitter=jitter, seed=seed,
+                              num_perturbed_molecules=num_perturbed_molecules)
+    n = len(sysd["qA"])
+    perturbed = (sysd["qA"] != sysd["qB"]) | (sysd["typeA"] != sysd["typeB"])
+    if identical_states:
+        # keep the perturbed flags but make B == A (oracle cross-check in the non-perturbed limit)
+        sysd["qB"] = sysd["qA"].copy()
+        sysd["typeB"] = sysd["typeA"].copy()
+    ntype = sysd["ntype"]
+    grid = pkg.Grid(sysd["x"], sysd["box"], sysd["qA"], sysd["qB"], sysd["typeA"], sysd["typeB"], ntype,
+                    perturbed=perturbed.astype(np.uint8))
+    excl_index, excl_atoms = pkg.exclusions_from_groups(sysd["molId"])
+    if rlist_fep is None:
+        rlist_fep = rlist + 0.0886  # rlist_fep 1.1886 for rlist 1.1
+    plist = grid.build_pairlist(excl_index, excl_atoms, rlist, max_cjpacked_per_sci, carve_fep=True,
+                                rlist_fep=rlist_fep)
+    plist_fused = grid.build_pairlist(excl_index, excl_atoms, rlist, max_cjpacked_per_sci, carve_fep=False,
+                                      rlist_fep=rlist_fep)
+
+    c = SimpleNamespace()
+    c.sys, c.grid, c.plist, c.plist_fused = sysd, grid, plist, plist_fused
+    c.natoms, c.ntype = n, ntype
+    c.perturbed = perturbed
+    c.excl_index, c.excl_atoms = excl_index, excl_atoms
+    c.rc, c.rlist, c.rlist_fep = rc, rlist, rlist_fep
+    c.elec, c.vdw = elec, vdw
+    c.epsfac = ONE_4PI_EPS0
+    c.k_rf = c.c_rf = c.beta = c.sh_ewald = 0.0
+    if elec == "rf":          # epsilon_rf = infinity
+        c.k_rf = 1.0 / (2.0 * rc ** 3)
+        c.c_rf = 1.0 / rc + c.k_rf * rc * rc
+        c.elec_type = pkg.ELEC_RF
+    elif elec == "cut":
+        c.c_rf = 1.0 / rc
+        c.elec_type = pkg.ELEC_CUT
+    else:
+        c.beta = ob.lib().oracle_calc_ewaldcoeff_q(rc, 1e-5)
+        c.sh_ewald = math.erfc(c.beta * rc) / rc
+        c.elec_type = pkg.ELEC_EWALD_ANA if elec == "ewald" else pkg.ELEC_EWALD_TAB
+    # potential-shift modifier (GROMACS default): V(rc) = 0
+    c.disp_shift = (0.0, 0.0, -rc ** -6)
+    c.rep_shift = (0.0, 0.0, -rc ** -12)
+    c.vdw_switch = (0.0, 0.0, 0.0)
+    c.rvdw_switch = 0.0
+    c.vdw_type = pkg.VDW_CUT
+    if vdw == "pswitch":
+        c.vdw_type = pkg.VDW_PSWITCH
+        c.rvdw_switch = rvdw_switch
+        d = rc - rvdw_switch
+        c.vdw_switch = (-10.0 / d ** 3, 15.0 / d ** 4, -6.0 / d ** 5)   # potential_switch_constants, forcerec/interaction_const
+        c.disp_shift = (0.0, 0.0, 0.0)
+        c.rep_shift = (0.0, 0.0, 0.0)
+    elif vdw == "fswitch":
+        c.vdw_type = pkg.VDW_FSWITCH
+        c.rvdw_switch = rvdw_switch
+        c.disp_shift = force_switch_constants(6.0, rvdw_switch, rc)
+        c.rep_shift = force_switch_constants(12.0, rvdw_switch, rc)
+    c.sc_alpha, c.sc_power, c.sc_sigma, c.sc_coul = sc_alpha, sc_power, sc_sigma, sc_coul
+    c.lambda_coul, c.lambda_vdw = lambda_coul, lambda_vdw
+    c.n_lambda = n_lambda
+    c.all_lambda = np.linspace(0.0, 1.0, n_lambda) if n_lambda > 0 else np.zeros(0)
+    c.have_soft_core = sc_alpha != 0
+    return c
+
+
+def force_switch_constants(p, rsw, rc):
+    """force_switch_constants() of mdtypes/interaction_const.cpp: (c2, c3, cpot)."""
+    c2 = ((p + 1) * rsw - (p + 4) * rc) / (rc ** (p + 2) * (rc - rsw) ** 2)
+    c3 = -((p + 1) * rsw - (p + 3) * rc) / (rc ** (p + 2) * (rc - rsw) ** 3)
+    cpot = -rc ** -p + p * c2 / 3 * (rc - rsw) ** 3 + p * c3 / 4 * (rc - rsw) ** 4
+    return (c2, c3, cpot)
+
+
+# ---- oracle -----------------------------------------------------------------------------------------
+
+def oracle_fep_params(c):
+    p = ob.FepParams()
+    p.elecIsEwald = 1 if c.elec in ("ewald", "ewald_tab") else 0
+    p.vdwIsEwald = 0
+    p.vdwPotSwitch = 1 if c.vdw == "pswitch" else 0
+    p.epsfac = c.epsfac
+    p.rcoulomb = p.rvdw = c.rc
+    p.rvdw_switch = c.rvdw_switch
+    p.k_rf, p.c_rf = c.k_rf, c.c_rf
+    p.ewaldcoeff_q, p.sh_ewald = c.beta, c.sh_ewald
+    p.dispersion_shift_cpot, p.repulsion_shift_cpot = c.disp_shift[2], c.rep_shift[2]
+    ob.softcore_params(p, c.sc_alpha, c.sc_power, c.sc_sigma, c.sc_sigma, c.sc_coul)
+    return p
+
+
+def oracle_ref_params(c):
+    p = ob.RefParams()
+    p.elecType, p.vdwType = c.elec_type, c.vdw_type
+    p.epsfac, p.c_rf, p.k_rf = c.epsfac, c.c_rf, c.k_rf
+    p.ewaldcoeff_q, p.sh_ewald = c.beta, c.sh_ewald
+    p.rcoulomb = p.rvdw = c.rc
+    p.rvdw_switch, p.rlist = c.rvdw_switch, c.rlist
+    p.disp_c2, p.disp_c3, p.disp_cpot = c.disp_shift
+    p.rep_c2, p.rep_c3, p.rep_cpot = c.rep_shift
+    p.sw_c3, p.sw_c4, p.sw_c5 = c.vdw_switch
+    return p
+
+
+def run_oracle(c, energy=True, precision="f64", foreign=False, cjPacked=None):
+    """Reference result of one step: cluster kernel on the carved list + FEP kernel on the FEP list.
+    Forces are returned in GRID order (like nbat->out[0].f)."""
+    g = c.grid
+    flags = ob.DO_FORCE | ob.DO_SHIFTFORCE | (ob.DO_POTENTIAL if energy else 0)
+    ref = ob.nbnxm_ref(c.plist.sci, c.plist.cjPacked if cjPacked is None else cjPacked, c.plist.excl, g.xq,
+                       g.type, g.num_types, g.nbat_nbfp(c.sys["nbfp"]), oracle_ref_params(c), g.shift_vec,
+                       compute_energy=energy, compute_fshift=True, precision=precision)
+    fp = oracle_fep_params(c)
+    fep = ob.fep_kernel(c.plist.fep, g.x_wrapped, c.ntype, fp, g.shift_vec, c.sys["nbfp"], None, c.sys["qA"],
+                        c.sys["qB"], c.sys["typeA"], c.sys["typeB"], flags, c.lambda_coul, c.lambda_vdw, precision)
+    f = np.array(ref["f"], dtype=np.float64)
+    real = g.atomIndices >= 0
+    f[real] += fep["f"][g.atomIndices[real]]
+    fshift = np.array(ref["fshift"], dtype=np.float64)
+    fs_fep = np.array(fep["fshift"], dtype=np.float64)
+    fs_fep[pkg.CENTRAL_SHIFT_INDEX] = 0.0  # the GPU path does not accumulate the central shift
+    fshift += fs_fep
+    out = dict(f=f, fshift=fshift, e_lj=ref["Vv"] + fep["Vv"], e_el=ref["Vc"] + fep["Vc"],
+               dvdl_coul=fep["dvdl_coul"], dvdl_vdw=fep["dvdl_vdw"], npairs=ref["npairs"],
+               parts=dict(ref=ref, fep=fep))
+    if foreign and c.n_lambda > 0:
+        out["foreign"] = ob.fep_foreign(c.plist.fep, g.x_wrapped, c.ntype, fp, g.shift_vec, c.sys["nbfp"], None,
+                                        c.sys["qA"], c.sys["qB"], c.sys["typeA"], c.sys["typeB"], c.lambda_coul,
+                                        c.lambda_vdw, c.all_lambda, c.all_lambda, precision)
+    return out
+
+
+# ---- GPU through the C ABI -----------------------------------------------------------------------------
+
+def gpu_interaction_params(c, use_dynamic_pruning=False):
+    tab, scale = None, 0.0
+    if c.elec == "ewald_tab":
+        tab, scale = ewald_force_table(c.beta, c.rc + 0.3)
+    return pkg.make_interaction_params(c.elec_type, c.vdw_type, c.epsfac, c.rc, c.rc, c.rlist, c.rlist,
+                                       k_rf=c.k_rf, c_rf=c.c_rf, ewaldcoeff_q=c.beta, sh_ewald=c.sh_ewald,
+                                       rvdw_switch=c.rvdw_switch, dispersion_shift=c.disp_shift,
+                                       repulsion_shift=c.rep_shift, vdw_switch=c.vdw_switch,
+                                       use_dynamic_pruning=use_dynamic_pruning, coulomb_tab=tab,
+                                       coulomb_tab_scale=scale)
+
+
+def ewald_force_table(beta, rmax, scale=2000.0):
+    """Ewald correction force table with the meaning the kernels give coulombEwaldTables->tableF
+    (nbnxm_cuda_kernel.cuh:624-628: F/r += qq (int_bit/r^2 - T(r)) / r):
+    T(r) = -d/dr(erf(beta r)/r) = erf(beta r)/r^2 - 2 beta/sqrt(pi) exp(-beta^2 r^2)/r, at r = i/scale."""
+    n = int(rmax * scale) + 2
+    r = np.arange(n) / scale
+    tab = np.zeros(n)
+    r1 = r[1:]
+    tab[1:] = (np.vectorize(math.erf)(beta * r1) / r1 ** 2
+               - 2 * beta / math.sqrt(math.pi) * np.exp(-(beta * r1) ** 2) / r1)
+    return tab.astype(np.float32), scale
+
+
+def setup_gpu(c, fused=False, use_dynamic_pruning=False):
+    g = c.grid
+    ic = gpu_interaction_params(c, use_dynamic_pruning)
+    nb = pkg.NbnxmGpu(ic, g.num_types, g.nbat_nbfp(c.sys["nbfp"]), fep=True, n_lambda=c.n_lambda)
+    sig6 = c.sc_sigma ** 6
+    alpha_coul = c.sc_alpha if c.sc_coul else 0.0
+    sig6_min = sig6 if c.sc_coul else 0.0
+    nb.copy_fepparams(alpha_coul, c.sc_alpha, c.sc_power, sig6, sig6_min, c.lambda_coul, c.lambda_vdw,
+                      c.all_lambda, c.all_lambda)
+    nb.init_atomdata(g.num_atoms, g.type, qA=g.qA, qB=g.qB, typeA=g.typeA, typeB=g.typeB)
+    pl = c.plist_fused if fused else c.plist
+    nb.init_pairlist(pl.sci, pl.cjPacked, pl.excl)
+    if fused:
+        nb.init_fep_cluster_bits(g.fepBits)
+        nb.set_fep_mode(True)
+        # the foreign-lambda kernel still walks the atom-pair list
+        nb.init_feppairlist(c.plist.fep, g.atomIndices)
+    else:
+        nb.init_feppairlist(c.plist.fep, g.atomIndices)
+    nb.upload_shiftvec(g.shift_vec)
+    nb.copy_xq_to_gpu(g.xq)
+    return nb
+
+
+def run_gpu(c, energy=True, fused=False, dhdl=False, nb=None, prune=False):
+    own = nb is None
+    if own:
+        nb = setup_gpu(c, fused=fused, use_dynamic_pruning=prune)
+    sw = pkg.step_workload(energy=energy, virial=True, dhdl=dhdl)
+    nb.clear_outputs(True)
+    nb.launch_kernel(sw)
+    f = np.zeros((c.grid.num_atoms, 3), np.float32)
+    nb.launch_cpyback(f, sw)
+    res = nb.wait_finish_task(sw, c.have_soft_core)
+    dv = res["dvdl_nonlin"] if c.have_soft_core else res["dvdl_lin"]
+    out = dict(f=f.astype(np.float64), fshift=res["fshift"].astype(np.float64), e_lj=res["e_lj"], e_el=res["e_el"],
+               dvdl_coul=dv[0], dvdl_vdw=dv[1], raw=res)
+    if dhdl:
+        out["foreign"] = dict(energies=res["foreign_energies"], dvdlCoul=res["foreign_dhdl_coul"],
+                              dvdlVdw=res["foreign_dhdl_vdw"])
+    if own:
+        nb.free()
+    return out
+
+
+# ---- comparison -------------------------------------------------------------------------------------------
+
+def assert_parity(got, want, rel=1e-4, energy=True, label=""):
+    """Forces: per-component error relative to the RMS force; sums that cancel (energies, dV/dl, fshift):
+    relative to the larger of |value| and a scale of the summed magnitudes (SURVEY §7 'hard parts')."""
+    f_got, f_want = np.asarray(got["f"]), np.asarray(want["f"])
+    frms = math.sqrt(float(np.mean(f_want ** 2))) + 1e-30
+    ferr = float(np.max(np.abs(f_got - f_want)))
+    assert ferr <= rel * max(frms, float(np.max(np.abs(f_want))) * 0.05), \
+        "%s force max err %.3e (rms force %.3e)" % (label, ferr, frms)
+    fs_scale = max(float(np.max(np.abs(want["fshift"]))), frms)
+    fserr = float(np.max(np.abs(np.asarray(got["fshift"]) - np.asarray(want["fshift"]))))
+    assert fserr <= 10 * rel * fs_scale, "%s fshift max err %.3e (scale %.3e)" % (label, fserr, fs_scale)
+    if energy:
+        for k in ("e_lj", "e_el", "dvdl_coul", "dvdl_vdw"):
+            scale = max(abs(want[k]), 1e-3 * (abs(want["e_lj"]) + abs(want["e_el"])), 1.0)
+            assert abs(got[k] - want[k]) <= rel * scale, "%s %s got %.8g want %.8g" % (label, k, got[k], want[k])
+
+
+# ---- O(N^2) evaluation (tiny systems) ------------------------------------------------------------------------
+
+def brute_force(c, use_state="A"):
+    """Minimum-image all-pairs evaluation of the non-perturbed Hamiltonian (state A parameters)
+    with the same functional forms (cut-off/RF/Ewald real space + exclusion corrections + self term,
+    LJ with potential shift / switches).  Returns forces in TOPOLOGY order."""
+    x = c.grid.x_wrapped.astype(np.float64)
+    n = len(x)
+    box = c.grid.box.astype(np.float64)
+    q = c.sys["qA" if use_state == "A" else "qB"].astype(np.float64)
+    t = c.sys["typeA" if use_state == "A" else "typeB"]
+    nbfp = np.asarray(c.sys["nbfp"], np.float64).reshape(c.ntype, c.ntype, 2)
+    mol = c.sys["molId"]
+    f = np.zeros((n, 3))
+    e_lj = e_el = 0.0
+    erf = np.vectorize(math.erf)
+    rc2 = c.rc * c.rc
+    for i in range(n - 1):
+        d = x[i] - x[i + 1:]
+        d -= box * np.rint(d / box)
+        r2 = np.einsum("ij,ij->i", d, d)
+        m = r2 < rc2
+        if not m.any():
+            continue
+        idx = np.flatnonzero(m) + i + 1
+        d, r2 = d[m], r2[m]
+        r = np.sqrt(r2)
+        inc = (mol[idx] != mol[i]).astype(np.float64)
+        qq = c.epsfac * q[i] * q[idx]
+        c6 = nbfp[t[i], t[idx], 0]
+        c12 = nbfp[t[i], t[idx], 1]
+        rinv = 1.0 / r
+        rinv6 = rinv ** 6 * inc
+        F = rinv6 * (c12 * rinv6 - c6) * rinv ** 2
+        E = inc * (c12 * (rinv6 ** 2 + c.rep_shift[2]) / 12 - c6 * (rinv6 + c.disp_shift[2]) / 6)
+        if c.vdw in ("pswitch", "fswitch"):
+            rsw = np.maximum(r - c.rvdw_switch, 0.0)
+            if c.vdw == "fswitch":
+                F += (-c6 * (c.disp_shift[0] + c.disp_shift[1] * rsw) + c12 * (c.rep_shift[0] + c.rep_shift[1] * rsw)) * rsw ** 2 * rinv
+                E += (c6 * (c.disp_shift[0] / 3 + c.disp_shift[1] / 4 * rsw) - c12 * (c.rep_shift[0] / 3 + c.rep_shift[1] / 4 * rsw)) * rsw ** 3
+            else:
+                sw = 1 + (c.vdw_switch[0] + (c.vdw_switch[1] + c.vdw_switch[2] * rsw) * rsw) * rsw ** 3
+                dsw = (3 * c.vdw_switch[0] + (4 * c.vdw_switch[1] + 5 * c.vdw_switch[2] * rsw) * rsw) * rsw ** 2
+                F = F * sw - rinv * E * dsw
+                E = E * sw
+        if c.elec in ("ewald", "ewald_tab"):
+            br = c.beta * r
+            F += qq * (inc * rinv ** 3 + (2 / math.sqrt(math.pi) * br * np.exp(-br * br) - erf(br)) / (br ** 3) * c.beta ** 3)
+            e_el += float(np.sum(qq * (rinv * (inc - erf(br)) - inc * c.sh_ewald)))
+        elif c.elec == "rf":
+            F += qq * (inc * rinv ** 3 - 2 * c.k_rf)
+            e_el += float(np.sum(qq * (inc * rinv + c.k_rf * r2 - c.c_rf)))
+        else:
+            F += qq * inc * rinv ** 3
+            e_el += float(np.sum(qq * (inc * rinv - c.c_rf)))
+        e_lj += float(np.sum(E))
+        fv = d * F[:, None]
+        f[i] += fv.sum(axis=0)
+        np.subtract.at(f, idx, fv)
+    q2 = float(np.sum(q * q)) * c.epsfac
+    if c.elec in ("ewald", "ewald_tab"):
+        e_el += -q2 * c.beta / math.sqrt(math.pi)
+    else:
+        e_el += -0.5 * q2 * c.c_rf
+    return dict(f=f, e_lj=e_lj, e_el=e_el)
