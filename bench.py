@@ -1,0 +1,195 @@
+#!/usr/bin/env python3
+"""Benchmark of the FEP non-bonded hot path on MI355X (driver contract: one JSON line on rank 0).
+
+Workload (BASELINE.json configs[2]): 96,000-atom SPC/E-like water box (the "100k box",
+40x40x20 molecules, 12.43 x 12.43 x 6.21 nm, 100 atoms/nm^3) with a 48-atom perturbed ligand
+(A = coupled, B = decoupled), lambda_coul = lambda_vdw = 0.5, soft-core alpha 0.5 / power 1 /
+sigma 0.3, Ewald real-space electrostatics (analytical correction, beta from rtol 1e-5 at 1.0 nm),
+LJ cut-off with potential shift, rc = rvdw = 1.0 nm, rlist = 1.1 nm, dynamically pruned list.
+
+One "step" = one pass of the hot path over the resident inputs: clear outputs + gpu_launch_kernel
+(fused cluster-pair kernel with in-line perturbed pairs; forces only, as in a normal MD step).
+Inputs (xq, parameters, lists) are in HBM before the timed region.  Synthetic data, seeded.
+
+N > 1 (config 4): one process per GPU, each an independent lambda replica of the same box
+(lambda index = rank mod 11); no data-path collective, RCCL only for init/barrier/timing -> weak scaling.
+"""
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8 TB/s
+FP32_PEAK_TFLOPS = 157.3   # vector fp32
+DT_FS = 2.0                # MD time step for the kernel-bound ns/day figure
+METRIC = "ns/day + pair-interactions/s, 100k-atom FEP box @ λ=0.5, 1/2/4/8 MI355X"
+
+
+def list_statistics(pl):
+    """Counts used for the algorithmic-byte and pair figures."""
+    imask = pl.cjPacked["imei"][:, 0]["imask"]
+    cluster_pairs = int(sum(bin(int(m)).count("1") for m in imask))
+    cj_slots = 0
+    for sh in range(4):
+        cj_slots += int(np.count_nonzero((imask >> (8 * sh)) & 0xFF))
+    used_excl = np.unique(pl.cjPacked["imei"]["excl_ind"])
+    return dict(nsci=len(pl.sci), ncjPacked=len(pl.cjPacked), cj_slots=cj_slots, cluster_pairs=cluster_pairs,
+                nexcl=int(len(used_excl)))
+
+
+def algorithmic_bytes(stats, fused, fep_nri=0, fep_nrj=0):
+    """360 B per (sci, cj) entry + 2,832 B per sci entry (+ 768 B when the A/B
+    parameters of the i atoms are staged, fused kernel) + 128 B per exclusion-mask entry;
+    the atom-pair FEP kernel: 64 B per pair + 68 B per i-entry."""
+    b = 360 * stats["cj_slots"] + (2832 + (768 if fused else 0)) * stats["nsci"] + 128 * stats["nexcl"]
+    b_fep = 64 * fep_nrj + 68 * fep_nri
+    return b, b_fep
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--mode", choices=["fused", "split"], default="fused")
+    ap.add_argument("--atoms", choices=["24k", "96k", "768k"], default="96k")
+    ap.add_argument("--max-cjpacked-per-sci", type=int, default=16)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-prune", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (there is no CPU fallback for the product path)")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl")   # RCCL
+
+    import fep_testlib as tl
+    pkg = tl.pkg
+
+    nm = {"24k": (20, 20, 20), "96k": (40, 40, 20), "768k": (80, 80, 40)}[args.atoms]
+    npert = {"24k": 3, "96k": 16, "768k": 16}[args.atoms]
+    lambdas = np.linspace(0.0, 1.0, 11)
+    lam = 0.5 if world == 1 else float(lambdas[rank % 11])   # replica set, config 4
+    t0 = time.time()
+    case = tl.make_case(nm=nm, num_perturbed_molecules=npert, elec="ewald", seed=2026, n_lambda=11,
+                        lambda_coul=lam, lambda_vdw=lam, max_cjpacked_per_sci=args.max_cjpacked_per_sci)
+    t_build = time.time() - t0
+    fused = args.mode == "fused"
+    nb = tl.setup_gpu(case, fused=fused, use_dynamic_pruning=not args.no_prune)
+    nb.set_timing(True)
+    pl = case.plist_fused if fused else case.plist
+    sw_f = pkg.step_workload(energy=False, virial=False, dhdl=False)
+
+    def one_step():
+        nb.clear_outputs(False)
+        nb.launch_kernel(sw_f)
+
+    # first step prunes the fresh list (not timed), then warm up
+    one_step()
+    torch.cuda.synchronize()
+    cj_dev = pkg.download_cjpacked(nb, len(pl.cjPacked))
+    import copy
+    pruned = copy.copy(pl)
+    pruned.cjPacked = cj_dev
+    stats = list_statistics(pruned)
+    for _ in range(args.warmup):
+        one_step()
+    torch.cuda.synchronize()
+    nb.reset_timings()
+
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t_start = time.perf_counter()
+    for _ in range(args.steps):
+        one_step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t_start
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # kernel durations measured with HIP events on the kernel's own stream (inside the C-ABI library)
+    f = np.zeros((case.grid.num_atoms, 3), np.float32)
+    nb.launch_cpyback(f, sw_f)
+    nb.wait_finish_task(sw_f, case.have_soft_core)
+    tm = nb.get_timings()
+    nb_k_us = 1e3 * tm.nb_k_ms / max(1, tm.nb_k_count)
+    fep_k_us = 1e3 * tm.fep_k_ms / max(1, tm.fep_k_count) if tm.fep_k_count else 0.0
+
+    ms_per_step = 1e3 * elapsed / args.steps
+    pair_evals = 64 * stats["cluster_pairs"]          # atom pairs in the (pruned) list, SURVEY §8d
+    fep_pairs = len(case.plist.fep["jjnr"])
+    pairs_per_step = pair_evals + (0 if fused else fep_pairs)
+    value = world * pairs_per_step / (elapsed / args.steps)
+    ns_per_day = world * 86400.0 / (elapsed / args.steps) * DT_FS * 1e-6
+    bytes_nb, bytes_fep = algorithmic_bytes(stats, fused, len(case.plist.fep["iinr"]), fep_pairs)
+    achieved = bytes_nb / (nb_k_us * 1e-6) / 1e9 if nb_k_us > 0 else 0.0
+
+    out = {
+        "metric": METRIC, "value": value, "unit": "pair-interactions/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+        "data": "synthetic (seeded SPC/E-like water box + 48-atom decoupled ligand)",
+        "config": {"workload": "configs[2]: 96k-atom water + 48 perturbed atoms, Ewald(analytical) + LJ cut, rc 1.0, rlist 1.1, lambda 0.5"
+                   if args.atoms == "96k" else args.atoms,
+                   "mode": args.mode, "atoms": int(case.natoms), "perturbed_atoms": int(case.perturbed.sum()),
+                   "nsci": stats["nsci"], "cj_slots": stats["cj_slots"], "cluster_pairs": stats["cluster_pairs"],
+                   "fep_pairs": fep_pairs, "max_cjpacked_per_sci": args.max_cjpacked_per_sci,
+                   "parallelism": "1 lambda replica per GPU" if world > 1 else "single GPU"},
+        "ns_per_day_kernel_bound": ns_per_day,
+        "kernel_us": {"k_calc_nb": nb_k_us, "k_calc_nb_fep": fep_k_us},
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                     "kernel": "nbnxmKernel<EwaldAna,LJcut,F,%s>" % ("fused" if fused else "plain"),
+                     "algorithmic_bytes_per_launch": bytes_nb,
+                     "fp32_valu_frac_estimate": (pair_evals * 45.0 / (nb_k_us * 1e-6) / 1e12 / FP32_PEAK_TFLOPS)
+                     if nb_k_us > 0 else None},
+        "host_list_build_s": t_build,
+    }
+
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        # CPU baseline (kind "port"): the oracle's single-threaded f32 evaluation of the same step
+        # (cluster kernel on the pruned list + FEP kernel), bounded to ~10-20 s.
+        import oracle_binding as ob
+        cj_pruned_carved = case.plist.cjPacked.copy()
+        ob.nbnxm_prune(case.plist.sci, cj_pruned_carved, case.grid.xq, case.grid.shift_vec, case.rlist)
+        cstats = list_statistics(type("P", (), {"cjPacked": cj_pruned_carved, "sci": case.plist.sci})())
+        n_pass, t_cpu = 0, 0.0
+        while t_cpu < 10.0 and n_pass < 20:
+            t1 = time.perf_counter()
+            tl.run_oracle(case, energy=False, precision="f32", cjPacked=cj_pruned_carved)
+            t_cpu += time.perf_counter() - t1
+            n_pass += 1
+        cpu_pairs = 64 * cstats["cluster_pairs"] + fep_pairs
+        out["cpu_baseline"] = {"value": cpu_pairs * n_pass / t_cpu, "unit": "pair-interactions/s", "cores": 1,
+                               "kind": "port",
+                               "sample": "%d full passes of the same 96k-atom step (pruned cluster list + FEP list), "
+                                         "oracle f32, one thread, %.1f s" % (n_pass, t_cpu)}
+    nb.free()
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

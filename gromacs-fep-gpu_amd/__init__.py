@@ -94,7 +94,7 @@ HIP_SYMBOLS = [
     "nbnxm_gpu_min_ci_balanced", "nbnxm_gpu_is_kernel_ewald_analytical", "nbnxm_gpu_get_xq",
     "nbnxm_gpu_get_f", "nbnxm_gpu_get_fshift", "nbnxm_gpu_get_stream",
     "nbnxm_gpu_have_short_range_work", "nbnxm_gpu_set_fep_mode", "nbnxm_hip_abi_version",
-    "nbnxm_hip_last_error",
+    "nbnxm_hip_last_error", "nbnxm_gpu_debug_get_cjpacked", "nbnxm_gpu_debug_download",
 ]
 HOST_SYMBOLS = [
     "nbnxm_host_make_water_box", "nbnxm_host_grid_create", "nbnxm_host_grid_free",
@@ -433,3 +433,13 @@ class NbnxmGpu:
 
     def __del__(self):
         self.free()
+
+
+def download_cjpacked(nb, ncj, iloc=LOCAL):
+    """Test helper: reads the device copy of the packed j-list back (after pruning)."""
+    lib = hip_lib()
+    lib.nbnxm_gpu_debug_get_cjpacked.restype = C.c_void_p
+    ptr = lib.nbnxm_gpu_debug_get_cjpacked(nb.h, C.c_int(iloc))
+    out = np.zeros(ncj, CJ_PACKED_DTYPE)
+    lib.nbnxm_gpu_debug_download(nb.h, C.c_void_p(ptr), _p(out), C.c_size_t(out.nbytes))
+    return out

@@ -1,0 +1,450 @@
+/*
+ * Device-side building blocks shared by the cluster-pair kernel, the atom-pair FEP kernels and
+ * the foreign-lambda kernel (gfx950, wave64).
+ *
+ * What is computed follows the reference (citations at each function); how it is computed is
+ * CDNA4-specific: DPP row operations for the 8-lane j-force reduction, 64-lane butterflies,
+ * segmented wave reductions, a locally fitted rational Ewald correction.
+ */
+#ifndef NBNXM_DEVICE_HELPERS_H
+#define NBNXM_DEVICE_HELPERS_H
+
+#include <hip/hip_runtime.h>
+
+#include "nbnxm_hip_types.h"
+#include "pme_corr_coeffs.h"
+
+/* kernel flavour tags (compile-time) */
+enum
+{
+    ELK_CUT = 0,
+    ELK_RF,
+    ELK_EWALD_ANA,
+    ELK_EWALD_TAB
+};
+enum
+{
+    VDK_CUT = 0, /* nbfp table */
+    VDK_COMB_GEOM,
+    VDK_COMB_LB,
+    VDK_FSWITCH,
+    VDK_PSWITCH
+};
+
+#define NB_DEVINL __device__ __forceinline__
+
+constexpr float c_oneSixth    = 1.0F / 6.0F;
+constexpr float c_oneTwelfth  = 1.0F / 12.0F;
+constexpr float c_oneOverSqrtPi = 0.564189583547756F;
+
+/* ---- cross-lane ------------------------------------------------------------------------------ */
+
+/* DPP controls (LLVM AMDGPU): quad_perm [1,0,3,2] = 0xB1, [2,3,0,1] = 0x4E, row_half_mirror = 0x141,
+ * row_ror:8 = 0x128 */
+template<int CTRL>
+NB_DEVINL float dppMove(float v)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, false));
+}
+
+/* Sum over the 8 consecutive lanes that share a j atom (same lane >> 3); every lane gets the sum. */
+NB_DEVINL float reduceOver8Lanes(float v)
+{
+    v += dppMove<0xB1>(v);  /* lane ^ 1 */
+    v += dppMove<0x4E>(v);  /* lane ^ 2 */
+    v += dppMove<0x141>(v); /* i <-> 7 - i within each half row */
+    return v;
+}
+
+/* Sum over the 8 lanes with the same (lane & 7), i.e. over tidxj; every lane gets the sum. */
+NB_DEVINL float reduceOverTidxj(float v)
+{
+    v += dppMove<0x128>(v); /* lane ^ 8 (rotate by 8 within the 16-lane row) */
+    v += __shfl_xor(v, 16);
+    v += __shfl_xor(v, 32);
+    return v;
+}
+
+NB_DEVINL float waveSum(float v)
+{
+    v += dppMove<0xB1>(v);
+    v += dppMove<0x4E>(v);
+    v += dppMove<0x141>(v);
+    v += dppMove<0x128>(v);
+    v += __shfl_xor(v, 16);
+    v += __shfl_xor(v, 32);
+    return v;
+}
+
+/* ---- math ------------------------------------------------------------------------------------ */
+
+/* [d/dz (erf z / z)] / z as a function of z^2; definition as gmx::pmeForceCorrection
+ * (simd/simd_math.h:1560-1650), coefficients fitted by tools/fit_pme_corr.py. */
+NB_DEVINL float pmeCorrF(float z2)
+{
+    float num = PME_CORR_P6;
+    num       = fmaf(num, z2, PME_CORR_P5);
+    num       = fmaf(num, z2, PME_CORR_P4);
+    num       = fmaf(num, z2, PME_CORR_P3);
+    num       = fmaf(num, z2, PME_CORR_P2);
+    num       = fmaf(num, z2, PME_CORR_P1);
+    num       = fmaf(num, z2, PME_CORR_P0);
+    float den = PME_CORR_Q5;
+    den       = fmaf(den, z2, PME_CORR_Q4);
+    den       = fmaf(den, z2, PME_CORR_Q3);
+    den       = fmaf(den, z2, PME_CORR_Q2);
+    den       = fmaf(den, z2, PME_CORR_Q1);
+    den       = fmaf(den, z2, PME_CORR_Q0);
+    return num * __frcp_rn(den);
+}
+
+/* Linear interpolation in the Ewald force table (nbnxm_cuda_kernel_utils.cuh:448-459) */
+NB_DEVINL float interpolateCoulombForceR(const NBParamGpu& nbp, float r)
+{
+    const float normalized = nbp.coulomb_tab_scale * r;
+    const int   index      = static_cast<int>(normalized);
+    const float fraction   = normalized - static_cast<float>(index);
+    const float d0         = nbp.coulomb_tab[index];
+    const float d1         = nbp.coulomb_tab[index + 1];
+    return fmaf(fraction, d1, fmaf(-fraction, d0, d0));
+}
+
+/* ---- non-perturbed atom pair (nbnxm_cuda_kernel.cuh:518-645) ---------------------------------- */
+
+template<int ELEC, bool TWIN, int VDW, bool ENERGY, bool EXCL_FORCES>
+NB_DEVINL void nbPair(const NBParamGpu& nbp,
+                      float             r2,
+                      float             int_bit,
+                      float             qq, /* epsfac q_i q_j */
+                      float             c6,
+                      float             c12,
+                      float&            F_invr,
+                      float&            E_lj,
+                      float&            E_el)
+{
+    r2                 = fmaxf(r2, c_nbnxnMinDistanceSquared);
+    const float inv_r  = __frsqrt_rn(r2);
+    const float inv_r2 = inv_r * inv_r;
+    float       inv_r6 = inv_r2 * inv_r2 * inv_r2;
+    const float mask   = EXCL_FORCES ? int_bit : 1.0F;
+    inv_r6 *= mask;
+
+    F_invr       = inv_r6 * (c12 * inv_r6 - c6) * inv_r2;
+    float E_lj_p = 0.0F;
+    if constexpr (ENERGY || VDW == VDK_PSWITCH)
+    {
+        E_lj_p = int_bit
+                 * (c12 * (inv_r6 * inv_r6 + nbp.repulsion_shift.cpot) * c_oneTwelfth
+                    - c6 * (inv_r6 + nbp.dispersion_shift.cpot) * c_oneSixth);
+    }
+    if constexpr (VDW == VDK_FSWITCH)
+    {
+        const float r  = r2 * inv_r;
+        float       rs = r - nbp.rvdw_switch;
+        rs             = rs >= 0.0F ? rs : 0.0F;
+        F_invr += (-c6 * (nbp.dispersion_shift.c2 + nbp.dispersion_shift.c3 * rs)
+                   + c12 * (nbp.repulsion_shift.c2 + nbp.repulsion_shift.c3 * rs))
+                  * rs * rs * inv_r;
+        if constexpr (ENERGY)
+        {
+            E_lj_p += (c6 * (nbp.dispersion_shift.c2 * (1.0F / 3.0F) + nbp.dispersion_shift.c3 * 0.25F * rs)
+                       - c12 * (nbp.repulsion_shift.c2 * (1.0F / 3.0F) + nbp.repulsion_shift.c3 * 0.25F * rs))
+                      * rs * rs * rs;
+        }
+    }
+    if constexpr (VDW == VDK_PSWITCH)
+    {
+        const float r  = r2 * inv_r;
+        float       rs = r - nbp.rvdw_switch;
+        rs             = rs >= 0.0F ? rs : 0.0F;
+        const float sw = 1.0F + (nbp.vdw_switch.c3 + (nbp.vdw_switch.c4 + nbp.vdw_switch.c5 * rs) * rs) * rs * rs * rs;
+        const float dsw = (3.0F * nbp.vdw_switch.c3 + (4.0F * nbp.vdw_switch.c4 + 5.0F * nbp.vdw_switch.c5 * rs) * rs) * rs * rs;
+        F_invr = F_invr * sw - inv_r * E_lj_p * dsw;
+        E_lj_p *= sw;
+    }
+    if constexpr (TWIN)
+    {
+        const float inRange = (r2 < nbp.rvdw_sq) ? 1.0F : 0.0F;
+        F_invr *= inRange;
+        E_lj_p *= inRange;
+    }
+    if constexpr (ENERGY) { E_lj = E_lj_p; }
+
+    if constexpr (ELEC == ELK_CUT)
+    {
+        F_invr += qq * mask * inv_r2 * inv_r;
+        if constexpr (ENERGY) { E_el = qq * (int_bit * inv_r - nbp.c_rf); }
+    }
+    else if constexpr (ELEC == ELK_RF)
+    {
+        F_invr += qq * (mask * inv_r2 * inv_r - nbp.two_k_rf);
+        if constexpr (ENERGY) { E_el = qq * (int_bit * inv_r + 0.5F * nbp.two_k_rf * r2 - nbp.c_rf); }
+    }
+    else
+    {
+        const float beta = nbp.ewald_beta;
+        if constexpr (ELEC == ELK_EWALD_ANA)
+        {
+            const float beta2 = beta * beta;
+            F_invr += qq * (mask * inv_r2 * inv_r + pmeCorrF(beta2 * r2) * beta2 * beta);
+        }
+        else
+        {
+            F_invr += qq * (mask * inv_r2 - interpolateCoulombForceR(nbp, r2 * inv_r)) * inv_r;
+        }
+        if constexpr (ENERGY)
+        {
+            E_el = qq * (inv_r * (int_bit - erff(r2 * inv_r * beta)) - int_bit * nbp.sh_ewald);
+        }
+    }
+}
+
+/* ---- perturbed atom pair ------------------------------------------------------------------------
+ * Semantics: the CPU kernel nb_free_energy_kernel<> (gmxlib/nonbonded/nb_free_energy.cpp:723-1136),
+ * Beutler soft-core or none, RF/cut-off or Ewald, LJ cut-off with optional potential switch;
+ * per-interaction cut-offs on the soft-core radii (:804-812,880-890) and the r^-6 cap (:907) as on the
+ * CPU, which is where the reference's own CUDA kernel deviates.
+ */
+struct FepLambda
+{
+    float LFC[2], LFV[2];       /* lambda factors, state A/B            :420-427 */
+    float scLFC[2], scLFV[2];   /* soft-core lambda factors             :437-449 */
+    float scDLFC[2], scDLFV[2]; /* soft-core dV/dl factors                       */
+    bool  differ;               /* scLambdasOrAlphasDiffer              :1405-1419 */
+};
+
+NB_DEVINL FepLambda makeFepLambda(float lambdaCoul, float lambdaVdw, int lamPower, float alphaCoul, float alphaVdw)
+{
+    FepLambda L;
+    L.LFC[0] = 1.0F - lambdaCoul;
+    L.LFC[1] = lambdaCoul;
+    L.LFV[0] = 1.0F - lambdaVdw;
+    L.LFV[1] = lambdaVdw;
+    const float lp = static_cast<float>(lamPower);
+#pragma unroll
+    for (int k = 0; k < 2; k++)
+    {
+        const float dlf = (k == 0) ? -1.0F : 1.0F;
+        const float oc = 1.0F - L.LFC[k], ov = 1.0F - L.LFV[k];
+        L.scLFC[k]  = (lamPower == 2) ? oc * oc : oc;
+        L.scLFV[k]  = (lamPower == 2) ? ov * ov : ov;
+        L.scDLFC[k] = dlf * lp * c_oneSixth * ((lamPower == 2) ? oc : 1.0F);
+        L.scDLFV[k] = dlf * lp * c_oneSixth * ((lamPower == 2) ? ov : 1.0F);
+    }
+    L.differ = !((alphaCoul == 0.0F && alphaVdw == 0.0F) || (lambdaCoul == lambdaVdw && alphaCoul == alphaVdw));
+    return L;
+}
+
+/* Returns false when the pair is skipped (beyond the cut-off and not an exclusion, :665-678). */
+template<int ELEC, bool PSWITCH, bool FORCE, bool ENERGY>
+NB_DEVINL bool fepPair(const NBParamGpu& nbp,
+                       const FepLambda&  L,
+                       float             r2raw,
+                       bool              included,
+                       bool              iEqJ,
+                       const float (&qq)[2],
+                       const float (&c6)[2],
+                       const float (&c12)[2],
+                       float&            fscal,
+                       float&            eLJ,
+                       float&            eEl,
+                       float&            dvdlLJ,
+                       float&            dvdlEl)
+{
+    const float rcMax2 = fmaxf(nbp.rcoulomb_sq, nbp.rvdw_sq);
+    if (included && !(r2raw < rcMax2)) { return false; }
+
+    const bool  useSoftCore = (nbp.alpha_coul != 0.0F || nbp.alpha_vdw != 0.0F); /* dispatchKernel :1326 */
+    const float r2          = fmaxf(r2raw, c_nbnxnMinDistanceSquared);
+    const float rInv        = __frsqrt_rn(r2);
+    const float r           = r2 * rInv;
+    float       fs          = 0.0F;
+
+    if (included)
+    {
+        float rp, rpm2;
+        if (useSoftCore)
+        {
+            rpm2 = r2 * r2;
+            rp   = rpm2 * r2;
+        }
+        else
+        {
+            rpm2 = rInv * rInv;
+            rp   = 1.0F;
+        }
+        float sigma6[2];
+#pragma unroll
+        for (int k = 0; k < 2; k++)
+        {
+            if (c6[k] > 0.0F && c12[k] > 0.0F)
+            {
+                sigma6[k] = fmaxf(0.5F * c12[k] / c6[k], nbp.sc_sigma6_min);
+            }
+            else { sigma6[k] = nbp.sc_sigma6; }
+        }
+        const bool  hardCore  = (c12[0] > 0.0F && c12[1] > 0.0F);
+        const float alphaVEff = hardCore ? 0.0F : nbp.alpha_vdw;
+        const float alphaCEff = hardCore ? 0.0F : nbp.alpha_coul;
+
+        float fC[2] = { 0.0F, 0.0F }, fV[2] = { 0.0F, 0.0F }, vC[2] = { 0.0F, 0.0F }, vV[2] = { 0.0F, 0.0F };
+#pragma unroll
+        for (int k = 0; k < 2; k++)
+        {
+            if (qq[k] != 0.0F || c6[k] != 0.0F || c12[k] != 0.0F)
+            {
+                float rPInvC, rInvC, rC, rPInvV, rInvV, rV;
+                if (useSoftCore)
+                {
+                    rPInvC          = 1.0F / (alphaCEff * L.scLFC[k] * sigma6[k] + rp);
+                    const float r2C = rcbrtf(rPInvC);
+                    rInvC           = __frsqrt_rn(r2C);
+                    rC              = r2C * rInvC;
+                    if (L.differ)
+                    {
+                        rPInvV          = 1.0F / (alphaVEff * L.scLFV[k] * sigma6[k] + rp);
+                        const float r2V = rcbrtf(rPInvV);
+                        rInvV           = __frsqrt_rn(r2V);
+                        rV              = r2V * rInvV;
+                    }
+                    else
+                    {
+                        rPInvV = rPInvC;
+                        rInvV  = rInvC;
+                        rV     = rC;
+                    }
+                }
+                else
+                {
+                    rPInvC = 1.0F;
+                    rInvC  = rInv;
+                    rC     = r;
+                    rPInvV = 1.0F;
+                    rInvV  = rInv;
+                    rV     = r;
+                }
+
+                const bool doElec = (qq[k] != 0.0F)
+                                    && ((ELEC >= ELK_EWALD_ANA) ? (r2 < nbp.rcoulomb_sq) : (rC < nbp.rcoulomb));
+                if (doElec)
+                {
+                    if constexpr (ELEC >= ELK_EWALD_ANA)
+                    {
+                        vC[k] = qq[k] * (rInvC - nbp.sh_ewald);
+                        fC[k] = qq[k] * rInvC;
+                    }
+                    else
+                    {
+                        /* plain cut-off is reaction-field with k_rf = 0 (:377-386) */
+                        vC[k] = qq[k] * (rInvC + 0.5F * nbp.two_k_rf * rC * rC - nbp.c_rf);
+                        fC[k] = qq[k] * (rInvC - nbp.two_k_rf * rC * rC);
+                    }
+                }
+                const bool doVdw = (c6[k] != 0.0F || c12[k] != 0.0F) && (rV < nbp.rvdw);
+                if (doVdw)
+                {
+                    float rInv6;
+                    if (useSoftCore) { rInv6 = rPInvV; }
+                    else
+                    {
+                        rInv6 = rInvV * rInvV;
+                        rInv6 = rInv6 * rInv6 * rInv6;
+                    }
+                    rInv6           = fminf(rInv6, c_maxRInvSix);
+                    const float v6  = c6[k] * rInv6;
+                    const float v12 = c12[k] * rInv6 * rInv6;
+                    vV[k]           = (v12 + c12[k] * nbp.repulsion_shift.cpot) * c_oneTwelfth
+                            - (v6 + c6[k] * nbp.dispersion_shift.cpot) * c_oneSixth;
+                    fV[k] = v12 - v6;
+                    if constexpr (PSWITCH)
+                    {
+                        float d        = rV - nbp.rvdw_switch;
+                        d              = (0.0F < d) ? d : 0.0F;
+                        const float d2 = d * d;
+                        const float sw = 1.0F + d2 * d * (nbp.vdw_switch.c3 + d * (nbp.vdw_switch.c4 + d * nbp.vdw_switch.c5));
+                        const float dsw = d2 * (3.0F * nbp.vdw_switch.c3 + d * (4.0F * nbp.vdw_switch.c4 + d * 5.0F * nbp.vdw_switch.c5));
+                        fV[k] = fV[k] * sw - rV * vV[k] * dsw;
+                        vV[k] = vV[k] * sw;
+                    }
+                }
+                fC[k] *= rPInvC;
+                fV[k] *= rPInvV;
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 2; k++)
+        {
+            const float dlf = (k == 0) ? -1.0F : 1.0F;
+            if constexpr (FORCE)
+            {
+                fs += (L.LFC[k] * fC[k] + L.LFV[k] * fV[k]) * rpm2;
+            }
+            if constexpr (ENERGY)
+            {
+                eEl += L.LFC[k] * vC[k];
+                eLJ += L.LFV[k] * vV[k];
+                dvdlEl += vC[k] * dlf;
+                dvdlLJ += vV[k] * dlf;
+                if (useSoftCore)
+                {
+                    dvdlEl += L.LFC[k] * alphaCEff * L.scDLFC[k] * fC[k] * sigma6[k];
+                    dvdlLJ += L.LFV[k] * alphaVEff * L.scDLFV[k] * fV[k] * sigma6[k];
+                }
+            }
+        }
+    }
+    else if constexpr (ELEC < ELK_EWALD_ANA)
+    {
+        /* excluded pair, cut-off / reaction-field (:1023-1054) */
+        float VV = 0.5F * nbp.two_k_rf * r2 - nbp.c_rf;
+        if (iEqJ) { VV *= 0.5F; }
+#pragma unroll
+        for (int k = 0; k < 2; k++)
+        {
+            const float dlf = (k == 0) ? -1.0F : 1.0F;
+            if constexpr (FORCE) { fs += L.LFC[k] * qq[k] * (-nbp.two_k_rf); }
+            if constexpr (ENERGY)
+            {
+                eEl += L.LFC[k] * qq[k] * VV;
+                dvdlEl += dlf * qq[k] * VV;
+            }
+        }
+    }
+
+    if constexpr (ELEC >= ELK_EWALD_ANA)
+    {
+        /* remove the reciprocal-space part (:1056-1101) */
+        if (!included || r2 < nbp.rcoulomb_sq)
+        {
+            const float beta = nbp.ewald_beta;
+            float       f_lr = 0.0F;
+            if constexpr (FORCE)
+            {
+                if constexpr (ELEC == ELK_EWALD_ANA) { f_lr = -pmeCorrF(beta * beta * r2) * beta * beta * beta; }
+                else { f_lr = interpolateCoulombForceR(nbp, r) * rInv; }
+            }
+            float v_lr = 0.0F;
+            if constexpr (ENERGY)
+            {
+                /* erf(beta r)/r, with its r -> 0 limit for the self pair */
+                v_lr = (beta * r > 1.0e-4F) ? erff(beta * r) * rInv : 2.0F * beta * c_oneOverSqrtPi;
+                if (iEqJ) { v_lr *= 0.5F; }
+            }
+#pragma unroll
+            for (int k = 0; k < 2; k++)
+            {
+                const float dlf = (k == 0) ? -1.0F : 1.0F;
+                if constexpr (FORCE) { fs -= L.LFC[k] * qq[k] * f_lr; }
+                if constexpr (ENERGY)
+                {
+                    eEl -= L.LFC[k] * qq[k] * v_lr;
+                    dvdlEl -= dlf * qq[k] * v_lr;
+                }
+            }
+        }
+    }
+    fscal = fs;
+    return true;
+}
+
+#endif

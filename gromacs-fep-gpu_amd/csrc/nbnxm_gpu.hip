@@ -1,0 +1,965 @@
+/*
+ * C ABI of the MI355X Nbnxm FEP path (include/nbnxm_hip.h): data management, kernel launch,
+ * copy-back and task completion.  Host-side control flow follows the reference:
+ *   nbnxm/nbnxm_gpu_data_mgmt.cpp   gpu_init :538-628, initNbparam :421-489, cuda_copy_fepparams :491-536,
+ *                                   gpu_init_pairlist :667-759, gpu_init_feppairlist :761-871,
+ *                                   gpu_init_atomdata :873-1045, gpu_clear_outputs :1047-1070,
+ *                                   gpu_launch_cpyback :1117-1303, gpu_free :1540-1654
+ *   nbnxm/cuda/nbnxm_cuda.cu        gpu_launch_kernel :642-858, gpu_launch_kernel_pruneonly :873-994
+ *   nbnxm/gpu_common.h              gpu_reduce_staged_outputs :139-168, gpu_reduce_staged_foreign_term :178-191,
+ *                                   gpu_try_finish_task :293-385, gpu_wait_finish_task :405-435
+ * Deliberate deviations from the reference's quirks are marked "A.4".
+ */
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "device_utils.h"
+#include "nbnxm_hip.h"
+#include "nbnxm_hip_types.h"
+#include "nbnxm_kernels.h"
+
+using namespace nbnxm_hip;
+
+namespace nbnxm_hip
+{
+static thread_local std::string g_lastError;
+void setLastError(const char* msg)
+{
+    g_lastError = msg ? msg : "";
+}
+} // namespace nbnxm_hip
+
+/* nbnxm/gpu_types_common.h:81-98, all pinned */
+struct NBStagingData
+{
+    float* eLJ             = nullptr;
+    float* eElec           = nullptr;
+    float* dvdlLJ          = nullptr;
+    float* dvdlElec        = nullptr;
+    float* fShift          = nullptr; /* 45 x 3 */
+    float* eLJForeign      = nullptr;
+    float* eElecForeign    = nullptr;
+    float* dvdlLJForeign   = nullptr;
+    float* dvdlElecForeign = nullptr;
+};
+
+struct InteractionTimers
+{
+    GpuRegionTimer nb_k, fep_k, prune_k;
+    bool           didPrune = false, didRollingPrune = false;
+};
+
+/* nbnxm/cuda/nbnxm_cuda_types.h:67-143 */
+struct NbnxmGpu
+{
+    bool           bUseTwoStreams = false;
+    NBAtomDataGpu* atdat          = nullptr;
+    NBParamGpu*    nbparam        = nullptr;
+    gpu_plist*     plist[2]       = { nullptr, nullptr };
+    gpu_feplist*   feplist[2]     = { nullptr, nullptr };
+    NBStagingData  nbst;
+    DeviceStream   deviceStreams[2];
+    hipEvent_t     nonlocal_done               = nullptr;
+    hipEvent_t     misc_ops_and_local_H2D_done = nullptr;
+    bool           haveWork[2]                 = { false, false };
+
+    bool                bDoTime = false;
+    InteractionTimers   timers[2];
+    nbnxm_gpu_timings_t timings{};
+
+    int  n_lambda  = 0;
+    bool fusedFep  = false;
+    int  numCUs    = 256;
+
+    /* allocation bookkeeping */
+    int xq_nalloc = 0, f_nalloc = 0, fep_nalloc = 0, fepBits_nalloc = 0;
+    int nbfp_n = 0, nbfp_comb_n = 0, coulomb_tab_n = 0;
+    int iinr_nalloc = 0, jindex_nalloc = 0, shiftIdx_nalloc = 0, jjnr_nalloc = 0, exclFep_nalloc = 0;
+
+    /* pinned staging for every asynchronous upload: stays alive until the next upload of the same
+     * kind (A.4: the reference frees its temporaries right after queuing the copies) */
+    PinnedBuffer<float4> h_q4, h_ljComb4;
+    PinnedBuffer<int4>   h_atomTypes4;
+    PinnedBuffer<int>    h_atomTypes, h_iinr, h_jjnr, h_shift, h_jindex, h_exclFep, h_pairEntry;
+    PinnedBuffer<float2> h_ljComb;
+    PinnedBuffer<float4> h_xq;
+    PinnedBuffer<float>  h_f;
+    PinnedBuffer<nbnxn_sci_t>       h_sci;
+    PinnedBuffer<nbnxn_cj_packed_t> h_cjPacked;
+    PinnedBuffer<nbnxn_excl_t>      h_excl;
+    PinnedBuffer<unsigned char>     h_fepBits;
+    PinnedBuffer<float>             h_shiftVec;
+};
+
+namespace
+{
+
+void setCutoffParameters(NBParamGpu* nbp, const nbnxm_interaction_params_t* ic)
+{
+    /* set_cutoff_parameters, nbnxm_gpu_data_mgmt.cpp:201-223 */
+    nbp->ewald_beta        = ic->ewaldcoeff_q;
+    nbp->sh_ewald          = ic->sh_ewald;
+    nbp->epsfac            = ic->epsfac;
+    nbp->two_k_rf          = 2.0F * ic->k_rf;
+    nbp->c_rf              = ic->c_rf;
+    nbp->rvdw_sq           = ic->rvdw * ic->rvdw;
+    nbp->rcoulomb_sq       = ic->rcoulomb * ic->rcoulomb;
+    nbp->rcoulomb          = ic->rcoulomb;
+    nbp->rvdw              = ic->rvdw;
+    nbp->rlistOuter_sq     = ic->rlistOuter * ic->rlistOuter;
+    nbp->rlistInner_sq     = ic->rlistInner * ic->rlistInner;
+    nbp->useDynamicPruning = ic->useDynamicPruning != 0;
+    nbp->sh_lj_ewald       = ic->sh_lj_ewald;
+    nbp->ewaldcoeff_lj     = ic->ewaldcoeff_lj;
+    nbp->rvdw_switch       = ic->rvdw_switch;
+    nbp->dispersion_shift  = ic->dispersion_shift;
+    nbp->repulsion_shift   = ic->repulsion_shift;
+    nbp->vdw_switch        = ic->vdw_switch;
+}
+
+void uploadCoulombTable(NbnxmGpu* nb, const nbnxm_interaction_params_t* ic)
+{
+    NBParamGpu* nbp = nb->nbparam;
+    if (ic->coulomb_tab != nullptr && ic->coulomb_tab_size > 0)
+    {
+        if (ic->coulomb_tab_size > nb->coulomb_tab_n)
+        {
+            freeDeviceBuffer(&nbp->coulomb_tab);
+            allocateDeviceBuffer(&nbp->coulomb_tab, ic->coulomb_tab_size);
+            nb->coulomb_tab_n = ic->coulomb_tab_size;
+        }
+        copyToDeviceBuffer(&nbp->coulomb_tab, ic->coulomb_tab, 0, ic->coulomb_tab_size, nb->deviceStreams[0].stream, false);
+        nbp->coulomb_tab_scale = ic->coulomb_tab_scale;
+    }
+    const bool tabulated = (nbp->elecType == NBNXM_ELEC_EWALD_TAB || nbp->elecType == NBNXM_ELEC_EWALD_TAB_TWIN);
+    NBNXM_ASSERT(!tabulated || nbp->coulomb_tab != nullptr, "tabulated Ewald kernel selected without a force table");
+}
+
+bool canSkipNonbondedWork(const NbnxmGpu& nb, int iloc)
+{
+    return iloc == NBNXM_NONLOCAL && nb.plist[iloc]->nsci == 0;
+}
+
+void initFeplist(gpu_feplist* l)
+{
+    std::memset(l, 0, sizeof(*l));
+    l->maxnri = l->maxnshift = l->maxnjidx = l->maxnrj = l->maxnexcl = -1;
+}
+
+void accumulateTimings(NbnxmGpu* nb, int iloc)
+{
+    if (!nb->bDoTime) { return; }
+    InteractionTimers& t = nb->timers[iloc];
+    t.nb_k.accumulate();
+    t.fep_k.accumulate();
+    t.prune_k.accumulate();
+    nb->timings.nb_k_ms       = nb->timers[0].nb_k.totalMs + nb->timers[1].nb_k.totalMs;
+    nb->timings.nb_k_count    = nb->timers[0].nb_k.count + nb->timers[1].nb_k.count;
+    nb->timings.fep_k_ms      = nb->timers[0].fep_k.totalMs + nb->timers[1].fep_k.totalMs;
+    nb->timings.fep_k_count   = nb->timers[0].fep_k.count + nb->timers[1].fep_k.count;
+    nb->timings.prune_k_ms    = nb->timers[0].prune_k.totalMs + nb->timers[1].prune_k.totalMs;
+    nb->timings.prune_k_count = nb->timers[0].prune_k.count + nb->timers[1].prune_k.count;
+}
+
+} // namespace
+
+extern "C" {
+
+int nbnxm_hip_abi_version(void)
+{
+    return 1;
+}
+
+const char* nbnxm_hip_last_error(void)
+{
+    return g_lastError.c_str();
+}
+
+NbnxmGpu* nbnxm_gpu_init(const nbnxm_interaction_params_t* ic, int numTypes, const float* nbfp,
+                         const float* nbfp_comb, int bLocalAndNonlocal, int bFEP, int n_lambda,
+                         void* localStream, void* nonLocalStream)
+{
+    NBNXM_ASSERT(ic != nullptr && nbfp != nullptr && numTypes > 0, "gpu_init needs interaction parameters and the nbfp table");
+    int numDevices = 0;
+    if (hipGetDeviceCount(&numDevices) != hipSuccess || numDevices == 0)
+    {
+        fatal(__FILE__, __LINE__, "nbnxm_gpu_init", "no HIP device available: this path has no CPU fallback");
+    }
+    auto* nb           = new NbnxmGpu;
+    nb->bUseTwoStreams = bLocalAndNonlocal != 0;
+    nb->n_lambda       = n_lambda;
+    nb->atdat          = new NBAtomDataGpu;
+    nb->nbparam        = new NBParamGpu;
+    std::memset(nb->atdat, 0, sizeof(NBAtomDataGpu));
+    std::memset(nb->nbparam, 0, sizeof(NBParamGpu));
+    for (int i = 0; i < (nb->bUseTwoStreams ? 2 : 1); i++)
+    {
+        nb->plist[i] = new gpu_plist;
+        std::memset(nb->plist[i], 0, sizeof(gpu_plist));
+        nb->plist[i]->sci_nalloc = nb->plist[i]->cjPacked_nalloc = nb->plist[i]->imask_nalloc = nb->plist[i]->excl_nalloc = -1;
+        nb->feplist[i] = new gpu_feplist;
+        initFeplist(nb->feplist[i]);
+    }
+    nb->deviceStreams[0].init(localStream);
+    if (nb->bUseTwoStreams)
+    {
+        nb->deviceStreams[1].init(nonLocalStream);
+        NBNXM_HIP_CHECK(hipEventCreateWithFlags(&nb->nonlocal_done, hipEventDisableTiming));
+        NBNXM_HIP_CHECK(hipEventCreateWithFlags(&nb->misc_ops_and_local_H2D_done, hipEventDisableTiming));
+    }
+    for (auto& t : nb->timers)
+    {
+        t.nb_k.init();
+        t.fep_k.init();
+        t.prune_k.init();
+    }
+    hipDeviceProp_t prop;
+    int             dev = 0;
+    NBNXM_HIP_CHECK(hipGetDevice(&dev));
+    NBNXM_HIP_CHECK(hipGetDeviceProperties(&prop, dev));
+    nb->numCUs = prop.multiProcessorCount;
+
+    /* pinned staging (gpu_init :573-583) */
+    auto pinned = [](float** p, size_t n) {
+        NBNXM_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(p), n * sizeof(float), hipHostMallocDefault));
+        std::memset(*p, 0, n * sizeof(float));
+    };
+    pinned(&nb->nbst.eLJ, 1);
+    pinned(&nb->nbst.eElec, 1);
+    pinned(&nb->nbst.dvdlLJ, 1);
+    pinned(&nb->nbst.dvdlElec, 1);
+    pinned(&nb->nbst.fShift, 3 * c_numShiftVectors);
+    pinned(&nb->nbst.eLJForeign, n_lambda + 1);
+    pinned(&nb->nbst.eElecForeign, n_lambda + 1);
+    pinned(&nb->nbst.dvdlLJForeign, n_lambda + 1);
+    pinned(&nb->nbst.dvdlElecForeign, n_lambda + 1);
+
+    /* initNbparam :421-489 */
+    NBParamGpu* nbp = nb->nbparam;
+    nbp->elecType   = ic->elecType;
+    nbp->vdwType    = ic->vdwType;
+    nbp->bFEP       = bFEP != 0;
+    setCutoffParameters(nbp, ic);
+    NBNXM_ASSERT(ic->elecType >= 0 && ic->elecType < NBNXM_ELEC_COUNT && ic->vdwType >= 0 && ic->vdwType < NBNXM_VDW_COUNT,
+                 "unknown electrostatics / VdW kernel type");
+    hipStream_t s = nb->deviceStreams[0].stream;
+    allocateDeviceBuffer(&nbp->nbfp, static_cast<size_t>(numTypes) * numTypes);
+    copyToDeviceBuffer(&nbp->nbfp, reinterpret_cast<const float2*>(nbfp), 0, static_cast<size_t>(numTypes) * numTypes, s, false);
+    nb->nbfp_n = numTypes * numTypes;
+    if (nbfp_comb != nullptr)
+    {
+        allocateDeviceBuffer(&nbp->nbfp_comb, numTypes);
+        copyToDeviceBuffer(&nbp->nbfp_comb, reinterpret_cast<const float2*>(nbfp_comb), 0, numTypes, s, false);
+        nb->nbfp_comb_n = numTypes;
+    }
+    uploadCoulombTable(nb, ic);
+    allocateDeviceBuffer(&nbp->allLambdaCoul, std::max(1, n_lambda));
+    allocateDeviceBuffer(&nbp->allLambdaVdw, std::max(1, n_lambda));
+
+    /* initAtomdataFirst :297-339 */
+    NBAtomDataGpu* ad = nb->atdat;
+    ad->numTypes      = numTypes;
+    allocateDeviceBuffer(&ad->shiftVec, c_numShiftVectors);
+    allocateDeviceBuffer(&ad->fShift, c_numShiftVectors);
+    allocateDeviceBuffer(&ad->eLJ, 1);
+    allocateDeviceBuffer(&ad->eElec, 1);
+    allocateDeviceBuffer(&ad->dvdlLJ, 1);
+    allocateDeviceBuffer(&ad->dvdlElec, 1);
+    allocateDeviceBuffer(&ad->eLJForeign, n_lambda + 1);
+    allocateDeviceBuffer(&ad->eElecForeign, n_lambda + 1);
+    allocateDeviceBuffer(&ad->dvdlLJForeign, n_lambda + 1);
+    allocateDeviceBuffer(&ad->dvdlElecForeign, n_lambda + 1);
+    clearDeviceBufferAsync(&ad->fShift, 0, c_numShiftVectors, s);
+    clearDeviceBufferAsync(&ad->eLJ, 0, 1, s);
+    clearDeviceBufferAsync(&ad->eElec, 0, 1, s);
+    clearDeviceBufferAsync(&ad->dvdlLJ, 0, 1, s);
+    clearDeviceBufferAsync(&ad->dvdlElec, 0, 1, s);
+    clearDeviceBufferAsync(&ad->eLJForeign, 0, n_lambda + 1, s);
+    clearDeviceBufferAsync(&ad->eElecForeign, 0, n_lambda + 1, s);
+    clearDeviceBufferAsync(&ad->dvdlLJForeign, 0, n_lambda + 1, s);
+    clearDeviceBufferAsync(&ad->dvdlElecForeign, 0, n_lambda + 1, s);
+    ad->shiftVecUploaded = false;
+    NBNXM_HIP_CHECK(hipStreamSynchronize(s));
+    return nb;
+}
+
+void nbnxm_gpu_free(NbnxmGpu* nb)
+{
+    if (nb == nullptr) { return; }
+    for (auto& st : nb->deviceStreams)
+    {
+        if (st.stream) { (void)hipStreamSynchronize(st.stream); }
+    }
+    NBAtomDataGpu* ad  = nb->atdat;
+    NBParamGpu*    nbp = nb->nbparam;
+    freeDeviceBuffer(&ad->xq);
+    freeDeviceBuffer(&ad->q4);
+    freeDeviceBuffer(&ad->f);
+    freeDeviceBuffer(&ad->eLJ);
+    freeDeviceBuffer(&ad->eElec);
+    freeDeviceBuffer(&ad->dvdlLJ);
+    freeDeviceBuffer(&ad->dvdlElec);
+    freeDeviceBuffer(&ad->eLJForeign);
+    freeDeviceBuffer(&ad->eElecForeign);
+    freeDeviceBuffer(&ad->dvdlLJForeign);
+    freeDeviceBuffer(&ad->dvdlElecForeign);
+    freeDeviceBuffer(&ad->fShift);
+    freeDeviceBuffer(&ad->atomTypes);
+    freeDeviceBuffer(&ad->ljComb);
+    freeDeviceBuffer(&ad->atomTypes4);
+    freeDeviceBuffer(&ad->ljComb4);
+    freeDeviceBuffer(&ad->shiftVec);
+    freeDeviceBuffer(&ad->fepBits);
+    freeDeviceBuffer(&nbp->nbfp);
+    freeDeviceBuffer(&nbp->nbfp_comb);
+    freeDeviceBuffer(&nbp->coulomb_tab);
+    freeDeviceBuffer(&nbp->allLambdaCoul);
+    freeDeviceBuffer(&nbp->allLambdaVdw);
+    for (int i = 0; i < 2; i++)
+    {
+        if (nb->plist[i])
+        {
+            freeDeviceBuffer(&nb->plist[i]->sci);
+            freeDeviceBuffer(&nb->plist[i]->cjPacked);
+            freeDeviceBuffer(&nb->plist[i]->imask);
+            freeDeviceBuffer(&nb->plist[i]->excl);
+            delete nb->plist[i];
+        }
+        if (nb->feplist[i])
+        {
+            freeDeviceBuffer(&nb->feplist[i]->iinr);
+            freeDeviceBuffer(&nb->feplist[i]->shift);
+            freeDeviceBuffer(&nb->feplist[i]->jindex);
+            freeDeviceBuffer(&nb->feplist[i]->jjnr);
+            freeDeviceBuffer(&nb->feplist[i]->excl_fep);
+            freeDeviceBuffer(&nb->feplist[i]->pairEntry);
+            delete nb->feplist[i];
+        }
+    }
+    auto unpin = [](float* p) {
+        if (p) { (void)hipHostFree(p); }
+    };
+    unpin(nb->nbst.eLJ);
+    unpin(nb->nbst.eElec);
+    unpin(nb->nbst.dvdlLJ);
+    unpin(nb->nbst.dvdlElec);
+    unpin(nb->nbst.fShift);
+    unpin(nb->nbst.eLJForeign);
+    unpin(nb->nbst.eElecForeign);
+    unpin(nb->nbst.dvdlLJForeign);
+    unpin(nb->nbst.dvdlElecForeign);
+    for (auto& t : nb->timers)
+    {
+        t.nb_k.destroy();
+        t.fep_k.destroy();
+        t.prune_k.destroy();
+    }
+    if (nb->nonlocal_done) { (void)hipEventDestroy(nb->nonlocal_done); }
+    if (nb->misc_ops_and_local_H2D_done) { (void)hipEventDestroy(nb->misc_ops_and_local_H2D_done); }
+    nb->deviceStreams[0].destroy();
+    nb->deviceStreams[1].destroy();
+    delete nb->atdat;
+    delete nb->nbparam;
+    delete nb;
+}
+
+void nbnxm_gpu_copy_fepparams(NbnxmGpu* nb, int bFEP, float alpha_coul, float alpha_vdw,
+                              int lam_power, float sc_sigma6_def, float sc_sigma6_min,
+                              float lambda_q, float lambda_v, int n_lambda,
+                              const double* all_lambda_coul, const double* all_lambda_vdw)
+{
+    if (!bFEP) { return; }
+    NBNXM_ASSERT(n_lambda == nb->n_lambda, "n_lambda differs from the value given to gpu_init");
+    NBNXM_ASSERT(lam_power == 1 || lam_power == 2, "sc-power must be 1 or 2");
+    NBParamGpu* nbp    = nb->nbparam;
+    nbp->bFEP          = true;
+    nbp->alpha_coul    = alpha_coul;
+    nbp->alpha_vdw     = alpha_vdw;
+    nbp->lam_power     = lam_power;
+    nbp->sc_sigma6     = sc_sigma6_def;
+    nbp->sc_sigma6_min = sc_sigma6_min;
+    nbp->lambda_q      = lambda_q;
+    nbp->lambda_v      = lambda_v;
+    if (n_lambda > 0)
+    {
+        NBNXM_ASSERT(all_lambda_coul && all_lambda_vdw, "foreign lambda arrays missing");
+        std::vector<float> c(n_lambda), v(n_lambda);
+        for (int i = 0; i < n_lambda; i++)
+        {
+            c[i] = static_cast<float>(all_lambda_coul[i]);
+            v[i] = static_cast<float>(all_lambda_vdw[i]);
+        }
+        copyToDeviceBuffer(&nbp->allLambdaCoul, c.data(), 0, n_lambda, nb->deviceStreams[0].stream, false);
+        copyToDeviceBuffer(&nbp->allLambdaVdw, v.data(), 0, n_lambda, nb->deviceStreams[0].stream, false);
+    }
+}
+
+void nbnxm_gpu_pme_loadbal_update_param(NbnxmGpu* nb, const nbnxm_interaction_params_t* ic)
+{
+    nb->nbparam->elecType = ic->elecType;
+    setCutoffParameters(nb->nbparam, ic);
+    uploadCoulombTable(nb, ic);
+}
+
+void nbnxm_gpu_init_atomdata(NbnxmGpu* nb, int numAtoms, int numAtomsLocal, const int* type,
+                             const float* lj_comb, const float* qA, const float* qB,
+                             const int* typeA, const int* typeB, const float* lj_combA,
+                             const float* lj_combB)
+{
+    NBAtomDataGpu* ad = nb->atdat;
+    hipStream_t    s  = nb->deviceStreams[0].stream;
+    NBNXM_ASSERT(numAtoms % c_clSize == 0, "the atom count must be a multiple of the cluster size");
+    const bool useComb = (nb->nbparam->vdwType == NBNXM_VDW_CUT_COMB_GEOM || nb->nbparam->vdwType == NBNXM_VDW_CUT_COMB_LB);
+    NBNXM_ASSERT(type != nullptr, "atom types missing");
+    NBNXM_ASSERT(!useComb || lj_comb != nullptr, "combination-rule kernel selected without per-atom LJ parameters");
+
+    if (numAtoms > ad->numAtomsAlloc)
+    {
+        const int nalloc = static_cast<int>(numAtoms * 1.2) + 1024;
+        freeDeviceBuffer(&ad->f);
+        freeDeviceBuffer(&ad->xq);
+        freeDeviceBuffer(&ad->atomTypes);
+        freeDeviceBuffer(&ad->ljComb);
+        freeDeviceBuffer(&ad->q4);
+        freeDeviceBuffer(&ad->atomTypes4);
+        freeDeviceBuffer(&ad->ljComb4);
+        allocateDeviceBuffer(&ad->f, nalloc);
+        allocateDeviceBuffer(&ad->xq, nalloc);
+        allocateDeviceBuffer(&ad->atomTypes, nalloc);
+        allocateDeviceBuffer(&ad->ljComb, nalloc);
+        allocateDeviceBuffer(&ad->q4, nalloc);
+        allocateDeviceBuffer(&ad->atomTypes4, nalloc);
+        allocateDeviceBuffer(&ad->ljComb4, nalloc);
+        ad->numAtomsAlloc = nalloc;
+        clearDeviceBufferAsync(&ad->f, 0, nalloc, s); /* first use: no stale forces */
+    }
+    ad->numAtoms      = numAtoms;
+    ad->numAtomsLocal = numAtomsLocal;
+
+    nb->h_atomTypes.resize(numAtoms);
+    std::memcpy(nb->h_atomTypes.data, type, sizeof(int) * numAtoms);
+    copyToDeviceBuffer(&ad->atomTypes, nb->h_atomTypes.data, 0, numAtoms, s, true);
+    if (lj_comb != nullptr)
+    {
+        nb->h_ljComb.resize(numAtoms);
+        std::memcpy(nb->h_ljComb.data, lj_comb, sizeof(float2) * numAtoms);
+        copyToDeviceBuffer(&ad->ljComb, nb->h_ljComb.data, 0, numAtoms, s, true);
+    }
+    if (nb->nbparam->bFEP)
+    {
+        /* FEP part, :990-1036: pack qA/qB -> float4, typeA/typeB -> int4 */
+        NBNXM_ASSERT(qA && qB && typeA && typeB, "FEP needs the A/B charges and types");
+        nb->h_q4.resize(numAtoms);
+        nb->h_atomTypes4.resize(numAtoms);
+        for (int i = 0; i < numAtoms; i++)
+        {
+            NBNXM_ASSERT(typeA[i] >= 0 && typeA[i] < ad->numTypes && typeB[i] >= 0 && typeB[i] < ad->numTypes, "atom type out of range");
+            nb->h_q4.data[i]         = make_float4(qA[i], qB[i], 0.0F, 0.0F);
+            nb->h_atomTypes4.data[i] = make_int4(typeA[i], typeB[i], 0, 0);
+        }
+        copyToDeviceBuffer(&ad->q4, nb->h_q4.data, 0, numAtoms, s, true);
+        copyToDeviceBuffer(&ad->atomTypes4, nb->h_atomTypes4.data, 0, numAtoms, s, true);
+        if (lj_combA != nullptr && lj_combB != nullptr)
+        {
+            nb->h_ljComb4.resize(numAtoms);
+            for (int i = 0; i < numAtoms; i++)
+            {
+                nb->h_ljComb4.data[i] = make_float4(lj_combA[2 * i], lj_combA[2 * i + 1], lj_combB[2 * i], lj_combB[2 * i + 1]);
+            }
+            copyToDeviceBuffer(&ad->ljComb4, nb->h_ljComb4.data, 0, numAtoms, s, true);
+        }
+    }
+    for (int i = 0; i < numAtoms; i++)
+    {
+        NBNXM_ASSERT(type[i] >= 0 && type[i] < ad->numTypes, "atom type out of range");
+    }
+}
+
+void nbnxm_gpu_init_pairlist(NbnxmGpu* nb, int iloc, int na_c, int nsci, const nbnxn_sci_t* sci,
+                             int ncjPacked, const nbnxn_cj_packed_t* cjPacked, int nexcl,
+                             const nbnxn_excl_t* excl)
+{
+    NBNXM_ASSERT(iloc == NBNXM_LOCAL || (iloc == NBNXM_NONLOCAL && nb->bUseTwoStreams), "bad locality");
+    NBNXM_ASSERT(na_c == c_clSize, "the pair list cluster size does not match the kernels (8)");
+    gpu_plist*  d = nb->plist[iloc];
+    hipStream_t s = nb->deviceStreams[iloc].stream;
+    const int numAtoms = nb->atdat->numAtoms;
+    /* shape checks: an out-of-range index in the list would fault on the device */
+    for (int i = 0; i < nsci; i++)
+    {
+        NBNXM_ASSERT(sci[i].cjPackedBegin >= 0 && sci[i].cjPackedEnd <= ncjPacked && sci[i].cjPackedBegin <= sci[i].cjPackedEnd,
+                     "sci entry points outside cjPacked");
+        NBNXM_ASSERT(sci[i].sci >= 0 && (sci[i].sci + 1) * c_superClSize <= numAtoms, "sci entry outside the atom range");
+        NBNXM_ASSERT((sci[i].shift & NBNXM_CI_SHIFT_MASK) < c_numShiftVectors, "shift index out of range");
+    }
+    for (int j = 0; j < ncjPacked; j++)
+    {
+        for (int m = 0; m < c_jGroupSize; m++)
+        {
+            NBNXM_ASSERT(cjPacked[j].cj[m] >= 0 && (cjPacked[j].cj[m] + 1) * c_clSize <= numAtoms, "j-cluster outside the atom range");
+        }
+        for (const auto& im : cjPacked[j].imei)
+        {
+            NBNXM_ASSERT(im.excl_ind >= 0 && im.excl_ind < nexcl, "exclusion index out of range");
+        }
+    }
+    d->na_c = na_c;
+    reallocateDeviceBuffer(&d->sci, nsci, &d->nsci, &d->sci_nalloc);
+    reallocateDeviceBuffer(&d->cjPacked, ncjPacked, &d->ncjPacked, &d->cjPacked_nalloc);
+    reallocateDeviceBuffer(&d->imask, static_cast<size_t>(ncjPacked) * NBNXM_GPU_CLUSTERPAIR_SPLIT, &d->nimask, &d->imask_nalloc);
+    reallocateDeviceBuffer(&d->excl, nexcl, &d->nexcl, &d->excl_nalloc);
+    nb->h_sci.resize(nsci);
+    nb->h_cjPacked.resize(ncjPacked);
+    nb->h_excl.resize(nexcl);
+    if (nsci) { std::memcpy(nb->h_sci.data, sci, sizeof(nbnxn_sci_t) * nsci); }
+    if (ncjPacked) { std::memcpy(nb->h_cjPacked.data, cjPacked, sizeof(nbnxn_cj_packed_t) * ncjPacked); }
+    if (nexcl) { std::memcpy(nb->h_excl.data, excl, sizeof(nbnxn_excl_t) * nexcl); }
+    /* pinned copies are per object, not per locality: finish the upload before they can be reused */
+    copyToDeviceBuffer(&d->sci, nb->h_sci.data, 0, nsci, s, true);
+    copyToDeviceBuffer(&d->cjPacked, nb->h_cjPacked.data, 0, ncjPacked, s, true);
+    copyToDeviceBuffer(&d->excl, nb->h_excl.data, 0, nexcl, s, true);
+    NBNXM_HIP_CHECK(hipStreamSynchronize(s));
+    d->haveFreshList          = true;
+    d->rollingPruningNumParts = 0;
+    d->rollingPruningPart     = 0;
+    nb->haveWork[iloc]        = nsci > 0;
+}
+
+void nbnxm_gpu_init_feppairlist(NbnxmGpu* nb, int iloc, int nri, const int* iinr, const int* shift,
+                                const int* jindex, int nrj, const int* jjnr, const int* excl_fep,
+                                int numAtomIndices, const int* atomIndices)
+{
+    NBNXM_ASSERT(iloc == NBNXM_LOCAL || (iloc == NBNXM_NONLOCAL && nb->bUseTwoStreams), "bad locality");
+    NBNXM_ASSERT(nb->nbparam->bFEP, "FEP pair list given to a non-FEP object");
+    gpu_feplist* d = nb->feplist[iloc];
+    hipStream_t  s = nb->deviceStreams[iloc].stream;
+    const int    numAtoms = nb->atdat->numAtoms;
+    NBNXM_ASSERT(nri == 0 || (jindex[0] == 0 && jindex[nri] == nrj), "FEP list jindex does not cover jjnr");
+
+    /* topology id -> grid index (inverse of gridSet.atomIndices(), :766-790) */
+    std::vector<int> inverse;
+    if (atomIndices != nullptr)
+    {
+        int maxId = -1;
+        for (int g = 0; g < numAtomIndices; g++) { maxId = std::max(maxId, atomIndices[g]); }
+        inverse.assign(maxId + 1, -1);
+        for (int g = 0; g < numAtomIndices; g++)
+        {
+            if (atomIndices[g] >= 0) { inverse[atomIndices[g]] = g; }
+        }
+    }
+    auto toGrid = [&](int a) -> int {
+        int g = a;
+        if (atomIndices != nullptr)
+        {
+            NBNXM_ASSERT(a >= 0 && a < static_cast<int>(inverse.size()) && inverse[a] >= 0, "FEP list atom is not on the grid");
+            g = inverse[a];
+        }
+        NBNXM_ASSERT(g >= 0 && g < numAtoms, "FEP list atom outside the atom range");
+        return g;
+    };
+    nb->h_iinr.resize(nri);
+    nb->h_shift.resize(nri);
+    nb->h_jindex.resize(nri + 1);
+    nb->h_jjnr.resize(nrj);
+    nb->h_pairEntry.resize(nrj);
+    nb->h_exclFep.resize(nrj);
+    nb->h_jindex.data[0] = 0;
+    for (int n = 0; n < nri; n++)
+    {
+        nb->h_iinr.data[n]       = toGrid(iinr[n]);
+        nb->h_shift.data[n]      = shift[n];
+        nb->h_jindex.data[n + 1] = jindex[n + 1];
+        NBNXM_ASSERT(shift[n] >= 0 && shift[n] < c_numShiftVectors, "shift index out of range");
+        NBNXM_ASSERT(jindex[n + 1] >= jindex[n], "jindex must not decrease");
+        for (int k = jindex[n]; k < jindex[n + 1]; k++)
+        {
+            nb->h_jjnr.data[k]      = toGrid(jjnr[k]);
+            nb->h_pairEntry.data[k] = n;
+            nb->h_exclFep.data[k]   = (excl_fep != nullptr) ? excl_fep[k] : 1;
+        }
+    }
+    reallocateDeviceBuffer(&d->iinr, nri, &d->nri, &d->maxnri);
+    reallocateDeviceBuffer(&d->shift, nri, &d->nshift, &d->maxnshift);
+    reallocateDeviceBuffer(&d->jindex, nri + 1, &d->njidx, &d->maxnjidx);
+    reallocateDeviceBuffer(&d->jjnr, nrj, &d->nrj, &d->maxnrj);
+    reallocateDeviceBuffer(&d->excl_fep, nrj, &d->nexcl, &d->maxnexcl);
+    int nPairEntry = 0;
+    reallocateDeviceBuffer(&d->pairEntry, nrj, &nPairEntry, &d->pairEntry_nalloc);
+    copyToDeviceBuffer(&d->iinr, nb->h_iinr.data, 0, nri, s, true);
+    copyToDeviceBuffer(&d->shift, nb->h_shift.data, 0, nri, s, true);
+    copyToDeviceBuffer(&d->jindex, nb->h_jindex.data, 0, nri + 1, s, true);
+    copyToDeviceBuffer(&d->jjnr, nb->h_jjnr.data, 0, nrj, s, true);
+    copyToDeviceBuffer(&d->excl_fep, nb->h_exclFep.data, 0, nrj, s, true);
+    copyToDeviceBuffer(&d->pairEntry, nb->h_pairEntry.data, 0, nrj, s, true);
+    NBNXM_HIP_CHECK(hipStreamSynchronize(s));
+}
+
+void nbnxm_gpu_init_fep_cluster_bits(NbnxmGpu* nb, int numClusters, const unsigned char* fepBits)
+{
+    NBAtomDataGpu* ad = nb->atdat;
+    NBNXM_ASSERT(numClusters * c_clSize == ad->numAtoms, "fepBits must hold one byte per 8-atom cluster");
+    NBNXM_ASSERT(numClusters % c_numClPerSupercl == 0, "cluster count must be a multiple of 8");
+    if (numClusters > nb->fepBits_nalloc)
+    {
+        freeDeviceBuffer(&ad->fepBits);
+        nb->fepBits_nalloc = static_cast<int>(numClusters * 1.2) + 64;
+        allocateDeviceBuffer(&ad->fepBits, nb->fepBits_nalloc);
+    }
+    ad->numClusters = numClusters;
+    nb->h_fepBits.resize(numClusters);
+    std::memcpy(nb->h_fepBits.data, fepBits, numClusters);
+    copyToDeviceBuffer(&ad->fepBits, nb->h_fepBits.data, 0, numClusters, nb->deviceStreams[0].stream, true);
+}
+
+void nbnxm_gpu_set_fep_mode(NbnxmGpu* nb, int fused)
+{
+    NBNXM_ASSERT(!fused || nb->atdat->fepBits != nullptr, "fused FEP mode needs nbnxm_gpu_init_fep_cluster_bits first");
+    nb->fusedFep = fused != 0;
+}
+
+void nbnxm_gpu_upload_shiftvec(NbnxmGpu* nb, const float* shift_vec)
+{
+    nb->h_shiftVec.resize(3 * c_numShiftVectors);
+    std::memcpy(nb->h_shiftVec.data, shift_vec, sizeof(float) * 3 * c_numShiftVectors);
+    copyToDeviceBuffer(&nb->atdat->shiftVec, reinterpret_cast<const float3*>(nb->h_shiftVec.data), 0, c_numShiftVectors,
+                       nb->deviceStreams[0].stream, true);
+    nb->atdat->shiftVecUploaded = true;
+}
+
+void nbnxm_gpu_copy_xq_to_gpu(NbnxmGpu* nb, const float* xq, int atomLocality)
+{
+    NBAtomDataGpu* ad   = nb->atdat;
+    const int      iloc = atomLocality;
+    NBNXM_ASSERT(iloc == NBNXM_LOCAL || (iloc == NBNXM_NONLOCAL && nb->bUseTwoStreams), "bad locality");
+    hipStream_t s = nb->deviceStreams[iloc].stream;
+    /* local: atoms [0, numAtomsLocal), non-local: the rest (nbnxm_gpu.h:93-96) */
+    const int begin = (iloc == NBNXM_LOCAL) ? 0 : ad->numAtomsLocal;
+    const int count = (iloc == NBNXM_LOCAL) ? ad->numAtomsLocal : ad->numAtoms - ad->numAtomsLocal;
+    if (count > 0)
+    {
+        NBNXM_HIP_CHECK(hipMemcpyAsync(ad->xq + begin, xq + 4 * static_cast<size_t>(begin), sizeof(float4) * count,
+                                       hipMemcpyHostToDevice, s));
+    }
+    if (iloc == NBNXM_LOCAL && nb->bUseTwoStreams)
+    {
+        NBNXM_HIP_CHECK(hipEventRecord(nb->misc_ops_and_local_H2D_done, s));
+    }
+}
+
+void nbnxm_gpu_clear_outputs(NbnxmGpu* nb, int computeVirial)
+{
+    NBAtomDataGpu* ad = nb->atdat;
+    hipStream_t    s  = nb->deviceStreams[0].stream;
+    clearDeviceBufferAsync(&ad->f, 0, ad->numAtoms, s);
+    if (computeVirial) { clearDeviceBufferAsync(&ad->fShift, 0, c_numShiftVectors, s); }
+    /* A.4: the reference clears E / dV/dl only on virial steps; they are accumulated with atomics,
+     * so they are cleared on every call here. */
+    clearDeviceBufferAsync(&ad->eLJ, 0, 1, s);
+    clearDeviceBufferAsync(&ad->eElec, 0, 1, s);
+    clearDeviceBufferAsync(&ad->dvdlLJ, 0, 1, s);
+    clearDeviceBufferAsync(&ad->dvdlElec, 0, 1, s);
+    if (nb->n_lambda > 0)
+    {
+        clearDeviceBufferAsync(&ad->eLJForeign, 0, nb->n_lambda + 1, s);
+        clearDeviceBufferAsync(&ad->eElecForeign, 0, nb->n_lambda + 1, s);
+        clearDeviceBufferAsync(&ad->dvdlLJForeign, 0, nb->n_lambda + 1, s);
+        clearDeviceBufferAsync(&ad->dvdlElecForeign, 0, nb->n_lambda + 1, s);
+    }
+}
+
+void nbnxm_gpu_launch_kernel_pruneonly(NbnxmGpu* nb, int iloc, int numParts)
+{
+    gpu_plist*  plist = nb->plist[iloc];
+    hipStream_t s     = nb->deviceStreams[iloc].stream;
+    if (plist->haveFreshList)
+    {
+        NBNXM_ASSERT(numParts == 1, "with first pruning we expect 1 part");
+        plist->rollingPruningNumParts = 0;
+    }
+    else
+    {
+        if (plist->rollingPruningNumParts == 0) { plist->rollingPruningNumParts = numParts; }
+        else { NBNXM_ASSERT(numParts == plist->rollingPruningNumParts, "the number of rolling-prune parts may not change between searches"); }
+    }
+    const int part         = plist->haveFreshList ? 0 : plist->rollingPruningPart;
+    const int numSciInPart = (plist->nsci - part + numParts - 1) / numParts;
+    if (numSciInPart <= 0)
+    {
+        plist->haveFreshList = false;
+        return;
+    }
+    InteractionTimers& t = nb->timers[iloc];
+    if (nb->bDoTime) { t.prune_k.openTimingRegion(s); }
+    const PruneKernelPtr kernel = selectPruneKernel(plist->haveFreshList);
+    hipLaunchKernelGGL(kernel, dim3(numSciInPart), dim3(c_waveSize), 0, s, *nb->atdat, *nb->nbparam, *plist, numParts, part);
+    NBNXM_HIP_CHECK(hipGetLastError());
+    if (nb->bDoTime) { t.prune_k.closeTimingRegion(s); }
+    if (plist->haveFreshList)
+    {
+        plist->haveFreshList = false;
+        t.didPrune           = true;
+    }
+    else
+    {
+        plist->rollingPruningPart = (part + 1) % numParts;
+        t.didRollingPrune         = true;
+    }
+}
+
+void nbnxm_gpu_launch_kernel(NbnxmGpu* nb, const nbnxm_step_workload_t* stepWork, int iloc)
+{
+    NBNXM_ASSERT(iloc == NBNXM_LOCAL || (iloc == NBNXM_NONLOCAL && nb->bUseTwoStreams), "bad locality");
+    NBAtomDataGpu*     adat  = nb->atdat;
+    NBParamGpu*        nbp   = nb->nbparam;
+    gpu_plist*         plist = nb->plist[iloc];
+    hipStream_t        s     = nb->deviceStreams[iloc].stream;
+    InteractionTimers& t     = nb->timers[iloc];
+    NBNXM_ASSERT(adat->shiftVecUploaded, "shift vectors have not been uploaded");
+
+    if (canSkipNonbondedWork(*nb, iloc))
+    {
+        plist->haveFreshList = false;
+        return;
+    }
+    if (iloc == NBNXM_NONLOCAL)
+    {
+        /* the non-local kernel must see the local H2D and the output clearing (nbnxm_cuda.cu:625-641) */
+        NBNXM_HIP_CHECK(hipStreamWaitEvent(s, nb->misc_ops_and_local_H2D_done, 0));
+    }
+    if (nbp->useDynamicPruning && plist->haveFreshList)
+    {
+        nbnxm_gpu_launch_kernel_pruneonly(nb, iloc, 1);
+    }
+
+    const bool fused = nb->fusedFep && nbp->bFEP;
+    if (plist->nsci > 0)
+    {
+        const NbKernelPtr kernel = selectNbKernel(nbp->elecType, nbp->vdwType, stepWork->computeEnergy != 0, fused);
+        if (kernel == nullptr)
+        {
+            fatal(__FILE__, __LINE__, "nbnxm_gpu_launch_kernel", "no kernel for this electrostatics / VdW combination (LJ-PME grid flavours are not built)");
+        }
+        if (nb->bDoTime) { t.nb_k.openTimingRegion(s); }
+        hipLaunchKernelGGL(kernel, dim3(plist->nsci), dim3(c_waveSize), 0, s, *adat, *nbp, *plist, stepWork->computeVirial);
+        NBNXM_HIP_CHECK(hipGetLastError());
+        if (nb->bDoTime) { t.nb_k.closeTimingRegion(s); }
+    }
+    plist->haveFreshList = false;
+
+    /* A.4: the reference returns before the FEP launch when the normal list is empty; here the
+     * perturbed pairs are evaluated regardless. */
+    if (nbp->bFEP)
+    {
+        gpu_feplist* feplist = nb->feplist[iloc];
+        if (feplist->nri == 0 || feplist->nrj == 0) { return; }
+        const int  nblock  = (feplist->nrj + 255) / 256;
+        const bool doForce = !fused;
+        const bool doForeign = nb->n_lambda > 0 && stepWork->computeDhdl && (nbp->alpha_coul != 0.0F || nbp->alpha_vdw != 0.0F);
+        if (!doForce && !doForeign) { return; }
+        if (nb->bDoTime) { t.fep_k.openTimingRegion(s); }
+        if (doForce)
+        {
+            const FepKernelPtr k = selectFepKernel(nbp->elecType, nbp->vdwType, stepWork->computeEnergy != 0);
+            NBNXM_ASSERT(k != nullptr, "no FEP kernel for this electrostatics type");
+            hipLaunchKernelGGL(k, dim3(nblock), dim3(256), 0, s, *adat, *nbp, *feplist, stepWork->computeVirial);
+            NBNXM_HIP_CHECK(hipGetLastError());
+        }
+        if (doForeign)
+        {
+            const FepKernelPtr k = selectFepForeignKernel(nbp->elecType, nbp->vdwType);
+            NBNXM_ASSERT(k != nullptr, "no foreign-lambda kernel for this electrostatics type");
+            hipLaunchKernelGGL(k, dim3(nblock), dim3(256), 0, s, *adat, *nbp, *feplist, nb->n_lambda);
+            NBNXM_HIP_CHECK(hipGetLastError());
+        }
+        if (nb->bDoTime) { t.fep_k.closeTimingRegion(s); }
+    }
+}
+
+void nbnxm_gpu_launch_cpyback(NbnxmGpu* nb, float* f_out, const nbnxm_step_workload_t* stepWork,
+                              int atomLocality)
+{
+    NBAtomDataGpu* ad   = nb->atdat;
+    const int      iloc = atomLocality;
+    NBNXM_ASSERT(iloc == NBNXM_LOCAL || (iloc == NBNXM_NONLOCAL && nb->bUseTwoStreams), "bad locality");
+    hipStream_t s = nb->deviceStreams[iloc].stream;
+    if (iloc == NBNXM_NONLOCAL && !nb->haveWork[iloc]) { return; }
+    const int begin = (iloc == NBNXM_LOCAL) ? 0 : ad->numAtomsLocal;
+    const int count = (iloc == NBNXM_LOCAL) ? ad->numAtomsLocal : ad->numAtoms - ad->numAtomsLocal;
+
+    if (iloc == NBNXM_LOCAL && nb->bUseTwoStreams)
+    {
+        /* local forces also receive non-local kernel contributions (:1150-1160) */
+        NBNXM_HIP_CHECK(hipStreamWaitEvent(s, nb->nonlocal_done, 0));
+    }
+    if (!stepWork->useGpuFBufferOps && count > 0)
+    {
+        NBNXM_ASSERT(f_out != nullptr, "force output buffer missing");
+        NBNXM_HIP_CHECK(hipMemcpyAsync(f_out + 3 * static_cast<size_t>(begin), reinterpret_cast<float*>(ad->f) + 3 * static_cast<size_t>(begin),
+                                       sizeof(float) * 3 * count, hipMemcpyDeviceToHost, s));
+    }
+    if (iloc == NBNXM_NONLOCAL)
+    {
+        NBNXM_HIP_CHECK(hipEventRecord(nb->nonlocal_done, s));
+    }
+    if (iloc == NBNXM_LOCAL)
+    {
+        if (stepWork->computeVirial)
+        {
+            NBNXM_HIP_CHECK(hipMemcpyAsync(nb->nbst.fShift, ad->fShift, sizeof(float) * 3 * c_numShiftVectors, hipMemcpyDeviceToHost, s));
+        }
+        if (stepWork->computeEnergy)
+        {
+            NBNXM_HIP_CHECK(hipMemcpyAsync(nb->nbst.eLJ, ad->eLJ, sizeof(float), hipMemcpyDeviceToHost, s));
+            NBNXM_HIP_CHECK(hipMemcpyAsync(nb->nbst.eElec, ad->eElec, sizeof(float), hipMemcpyDeviceToHost, s));
+            NBNXM_HIP_CHECK(hipMemcpyAsync(nb->nbst.dvdlLJ, ad->dvdlLJ, sizeof(float), hipMemcpyDeviceToHost, s));
+            NBNXM_HIP_CHECK(hipMemcpyAsync(nb->nbst.dvdlElec, ad->dvdlElec, sizeof(float), hipMemcpyDeviceToHost, s));
+        }
+        if (nb->n_lambda > 0 && stepWork->computeDhdl)
+        {
+            const size_t n = sizeof(float) * (nb->n_lambda + 1);
+            NBNXM_HIP_CHECK(hipMemcpyAsync(nb->nbst.eLJForeign, ad->eLJForeign, n, hipMemcpyDeviceToHost, s));
+            NBNXM_HIP_CHECK(hipMemcpyAsync(nb->nbst.eElecForeign, ad->eElecForeign, n, hipMemcpyDeviceToHost, s));
+            NBNXM_HIP_CHECK(hipMemcpyAsync(nb->nbst.dvdlLJForeign, ad->dvdlLJForeign, n, hipMemcpyDeviceToHost, s));
+            NBNXM_HIP_CHECK(hipMemcpyAsync(nb->nbst.dvdlElecForeign, ad->dvdlElecForeign, n, hipMemcpyDeviceToHost, s));
+        }
+    }
+}
+
+static int finishTask(NbnxmGpu* nb, const nbnxm_step_workload_t* stepWork, int atomLocality, int haveSoftCore,
+                      nbnxm_enerdata_t* enerd, float* shiftForces, bool wait)
+{
+    const int iloc = atomLocality;
+    NBNXM_ASSERT(iloc == NBNXM_LOCAL || (iloc == NBNXM_NONLOCAL && nb->bUseTwoStreams), "bad locality");
+    if (iloc == NBNXM_LOCAL || nb->haveWork[iloc])
+    {
+        if (!wait)
+        {
+            if (!nb->deviceStreams[iloc].completed()) { return 0; }
+        }
+        else { nb->deviceStreams[iloc].synchronize(); }
+        accumulateTimings(nb, iloc);
+        if (iloc == NBNXM_LOCAL)
+        {
+            /* gpu_reduce_staged_outputs, gpu_common.h:139-168 */
+            if (stepWork->computeEnergy)
+            {
+                NBNXM_ASSERT(enerd != nullptr, "energy step without an energy accumulator");
+                enerd->e_lj += *nb->nbst.eLJ;
+                enerd->e_el += *nb->nbst.eElec;
+                double* dvdl = haveSoftCore ? enerd->dvdl_nonlin : enerd->dvdl_lin; /* gpu_common.h:420-428 */
+                dvdl[0] += *nb->nbst.dvdlElec;
+                dvdl[1] += *nb->nbst.dvdlLJ;
+            }
+            if (stepWork->computeVirial && shiftForces != nullptr)
+            {
+                for (int i = 0; i < 3 * c_numShiftVectors; i++) { shiftForces[i] += nb->nbst.fShift[i]; }
+            }
+            /* gpu_reduce_staged_foreign_term, gpu_common.h:178-191 */
+            if (nb->n_lambda > 0 && stepWork->computeDhdl && enerd != nullptr && enerd->foreign_energies != nullptr)
+            {
+                NBNXM_ASSERT(enerd->n_lambda == nb->n_lambda, "foreign-lambda accumulator has a different n_lambda");
+                for (int idx = 0; idx <= nb->n_lambda; idx++)
+                {
+                    enerd->foreign_energies[idx] += nb->nbst.eLJForeign[idx];
+                    enerd->foreign_dhdl_vdw[idx] += nb->nbst.dvdlLJForeign[idx];
+                    enerd->foreign_energies[idx] += nb->nbst.eElecForeign[idx];
+                    enerd->foreign_dhdl_coul[idx] += nb->nbst.dvdlElecForeign[idx];
+                }
+            }
+        }
+    }
+    nb->timers[iloc].didPrune = nb->timers[iloc].didRollingPrune = false;
+    nb->plist[iloc]->haveFreshList                               = false;
+    return 1;
+}
+
+int nbnxm_gpu_try_finish_task(NbnxmGpu* nb, const nbnxm_step_workload_t* stepWork, int atomLocality,
+                              int haveSoftCore, nbnxm_enerdata_t* enerd, float* shiftForces)
+{
+    return finishTask(nb, stepWork, atomLocality, haveSoftCore, enerd, shiftForces, false);
+}
+
+void nbnxm_gpu_wait_finish_task(NbnxmGpu* nb, const nbnxm_step_workload_t* stepWork,
+                                int atomLocality, int haveSoftCore, nbnxm_enerdata_t* enerd,
+                                float* shiftForces)
+{
+    finishTask(nb, stepWork, atomLocality, haveSoftCore, enerd, shiftForces, true);
+}
+
+void nbnxm_gpu_get_timings(NbnxmGpu* nb, nbnxm_gpu_timings_t* out)
+{
+    *out = nb->timings;
+}
+
+void nbnxm_gpu_reset_timings(NbnxmGpu* nb)
+{
+    for (auto& t : nb->timers)
+    {
+        t.nb_k.reset();
+        t.fep_k.reset();
+        t.prune_k.reset();
+    }
+    nb->timings = nbnxm_gpu_timings_t{};
+}
+
+void nbnxm_gpu_set_timing(NbnxmGpu* nb, int enable)
+{
+    nb->bDoTime = enable != 0;
+}
+
+int nbnxm_gpu_min_ci_balanced(NbnxmGpu* nb)
+{
+    /* enough i-entries to fill every SIMD several times over (role of gpu_min_ci_balanced,
+     * cuda/nbnxm_cuda_data_mgmt.cu:82-109: 44 x #multiprocessors) */
+    return 44 * nb->numCUs;
+}
+
+int nbnxm_gpu_is_kernel_ewald_analytical(const NbnxmGpu* nb)
+{
+    return nb->nbparam->elecType == NBNXM_ELEC_EWALD_ANA || nb->nbparam->elecType == NBNXM_ELEC_EWALD_ANA_TWIN;
+}
+
+void* nbnxm_gpu_get_xq(NbnxmGpu* nb)
+{
+    return nb->atdat->xq;
+}
+
+void* nbnxm_gpu_get_f(NbnxmGpu* nb)
+{
+    return nb->atdat->f;
+}
+
+void* nbnxm_gpu_get_fshift(NbnxmGpu* nb)
+{
+    return nb->atdat->fShift;
+}
+
+void* nbnxm_gpu_get_stream(NbnxmGpu* nb, int iloc)
+{
+    return nb->deviceStreams[iloc].stream;
+}
+
+int nbnxm_gpu_have_short_range_work(const NbnxmGpu* nb, int iloc)
+{
+    return nb->haveWork[iloc] ? 1 : 0;
+}
+
+void* nbnxm_gpu_debug_get_cjpacked(NbnxmGpu* nb, int iloc)
+{
+    return nb->plist[iloc]->cjPacked;
+}
+
+void nbnxm_gpu_debug_download(NbnxmGpu* nb, const void* devicePtr, void* hostPtr, size_t numBytes)
+{
+    NBNXM_HIP_CHECK(hipStreamSynchronize(nb->deviceStreams[0].stream));
+    NBNXM_HIP_CHECK(hipMemcpy(hostPtr, devicePtr, numBytes, hipMemcpyDeviceToHost));
+}
+
+} // extern "C"

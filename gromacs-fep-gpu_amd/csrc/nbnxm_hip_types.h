@@ -1,0 +1,157 @@
+/*
+ * Device-visible data contract of the MI355X Nbnxm path.
+ *
+ * NBAtomDataGpu / NBParamGpu / gpu_plist / gpu_feplist keep the members of the reference's structs
+ * (nbnxm/gpu_types_common.h:103-356) so that a maintainer can map them one to one; texture objects
+ * are dropped (plain global / LDS loads on CDNA4) and a few MI355X-only members are appended at the end
+ * of each struct.  Kernels receive the first three by value, as in the reference
+ * (nbnxm/cuda/nbnxm_cuda.cu:142-144).
+ */
+#ifndef NBNXM_HIP_TYPES_H
+#define NBNXM_HIP_TYPES_H
+
+#include <hip/hip_runtime.h>
+
+#include "nbnxm_hip.h"
+
+constexpr int c_clSize            = NBNXM_GPU_CLUSTER_SIZE;
+constexpr int c_numClPerSupercl   = NBNXM_GPU_NUM_CLUSTER_PER_SUPERCLUSTER;
+constexpr int c_jGroupSize        = NBNXM_GPU_JGROUP_SIZE;
+constexpr int c_superClSize       = c_clSize * c_numClPerSupercl;
+constexpr int c_centralShiftIndex = NBNXM_CENTRAL_SHIFT_INDEX;
+constexpr int c_numShiftVectors   = NBNXM_NUM_SHIFT_VECTORS;
+constexpr int c_waveSize          = 64;
+/* nbnxm/pairlist.h:166: keeps r^-12 finite in fp32 */
+constexpr float c_nbnxnMinDistanceSquared = 3.82e-07F;
+/* nb_free_energy.cpp:107: cap on r^-6 in the perturbed-pair math */
+constexpr float c_maxRInvSix = 1.0e15F;
+
+/* nbnxm/gpu_types_common.h:103-155 */
+struct NBAtomDataGpu
+{
+    int numAtoms;
+    int numAtomsLocal;
+    int numAtomsAlloc;
+
+    float4* xq;  /* x,y,z,q  (q of perturbed atoms is 0) */
+    float4* q4;  /* .x = qA, .y = qB  (FEP only) */
+    float3* f;   /* force output, accumulated with atomics */
+
+    float* eLJ;
+    float* eElec;
+    float* dvdlLJ;
+    float* dvdlElec;
+    float* eLJForeign;      /* n_lambda + 1 */
+    float* eElecForeign;    /* n_lambda + 1 */
+    float* dvdlLJForeign;   /* n_lambda + 1 */
+    float* dvdlElecForeign; /* n_lambda + 1 */
+    float3* fShift;         /* 45 */
+
+    int     numTypes;
+    int*    atomTypes;  /* per atom (perturbed atoms: numTypes-1) */
+    float2* ljComb;     /* per atom, combination-rule kernels */
+    int4*   atomTypes4; /* .x = typeA, .y = typeB (FEP only) */
+    float4* ljComb4;    /* c6A,c12A,c6B,c12B factors (FEP + combination rule) */
+
+    float3* shiftVec; /* 45 */
+    bool    shiftVecUploaded;
+
+    /* MI355X extension: Grid::fepBits per 8-atom cluster (fused kernel), 8 bytes per super-cluster */
+    unsigned char* fepBits;
+    int            numClusters;
+};
+
+/* nbnxm/gpu_types_common.h:160-237 */
+struct NBParamGpu
+{
+    int elecType; /* nbnxm_elec_type */
+    int vdwType;  /* nbnxm_vdw_type */
+
+    float epsfac;
+    float c_rf;
+    float two_k_rf;
+    float ewald_beta;
+    float sh_ewald;
+    float sh_lj_ewald;
+    float ewaldcoeff_lj;
+
+    float rcoulomb_sq;
+    float rvdw_sq;
+    float rvdw_switch;
+    float rlistOuter_sq;
+    float rlistInner_sq;
+    bool  useDynamicPruning;
+
+    nbnxm_shift_consts_t  dispersion_shift;
+    nbnxm_shift_consts_t  repulsion_shift;
+    nbnxm_switch_consts_t vdw_switch;
+
+    float2* nbfp;      /* numTypes^2: (6*C6, 12*C12) */
+    float2* nbfp_comb; /* numTypes: LJ-PME grid parameters */
+
+    float  coulomb_tab_scale;
+    float* coulomb_tab;
+
+    bool  bFEP;
+    float alpha_coul;
+    float alpha_vdw;
+    int   lam_power;
+    float sc_sigma6;
+    float sc_sigma6_min;
+    float lambda_q;
+    float lambda_v;
+    float* allLambdaCoul; /* n_lambda */
+    float* allLambdaVdw;  /* n_lambda */
+
+    /* MI355X extension: rvdw (not squared) and rcoulomb for the per-interaction soft-core cut-offs
+     * of the CPU kernel (nb_free_energy.cpp:804-812,880-890) */
+    float rcoulomb;
+    float rvdw;
+};
+
+/* nbnxm/gpu_types_common.h:297-341 */
+struct gpu_plist
+{
+    int na_c;
+
+    int          nsci;
+    int          sci_nalloc;
+    nbnxn_sci_t* sci;
+
+    int                ncjPacked;
+    int                cjPacked_nalloc;
+    nbnxn_cj_packed_t* cjPacked;
+    int                nimask;
+    int                imask_nalloc;
+    unsigned int*      imask; /* outer-pruned masks, 2 per packed group (rolling pruning source) */
+    nbnxn_excl_t*      excl;
+    int                nexcl;
+    int                excl_nalloc;
+
+    bool haveFreshList;
+    int  rollingPruningNumParts;
+    int  rollingPruningPart;
+};
+
+/* nbnxm/gpu_types_common.h:343-356; iinr/jjnr hold GRID-order atom indices on the device */
+struct gpu_feplist
+{
+    int nri, maxnri;
+    int nshift, maxnshift;
+    int njidx, maxnjidx;
+    int nrj, maxnrj;
+    int nexcl, maxnexcl;
+
+    int* iinr;
+    int* shift;
+    int* jindex;
+    int* jjnr;
+    int* excl_fep;
+
+    /* MI355X extension: i-entry of every j slot, so that the kernel can flatten the ragged list
+     * (one lane per pair, 64 consecutive pairs per wave) */
+    int* pairEntry; /* nrj */
+    int  pairEntry_nalloc;
+};
+
+#endif

@@ -1,0 +1,483 @@
+/*
+ * Cluster-pair non-bonded kernel for gfx950 (wave64), optionally with the perturbed pairs fused in.
+ *
+ * Replaces  nbnxn_kernel_<Elec>_<Vdw>_{F,VF}_cuda  (nbnxm/cuda/nbnxm_cuda_kernel.cuh:141-702) and, in its
+ * FUSED flavour, also  nbnxn_fep_kernel_*  (nbnxm/cuda/nbnxm_fep_cuda_kernel.cuh:87-628) for the force path.
+ *
+ * Mapping (MI355X-first, not the CUDA one):
+ *   - one 64-lane wavefront = one workgroup = one i-super-cluster entry (nbnxn_sci_t);
+ *     lane = tidxj*8 + tidxi covers a complete 8 x (4+4) cluster pair per step, lanes 0-31 read the
+ *     exclusion words of imei[0], lanes 32-63 those of imei[1] (the reference's split-2 list, unchanged);
+ *   - list words (sci, cjPacked) are wave-uniform and come through scalar loads; the imask tests are
+ *     scalar branches, so a skipped cluster pair costs no vector issue;
+ *   - i-atom x/q (+shift, q*epsfac), types or LJ parameters, and for FUSED the A/B charges and types,
+ *     are staged once in LDS and re-read as broadcast ds_read_b128/b32 (8 distinct addresses per wave);
+ *   - j-atom data: one 16-byte load per lane of 128 contiguous bytes per j-cluster;
+ *   - j-forces: 3 DPP adds per component over the 8 lanes that share a j atom, then one no-return
+ *     float atomic per component from 24 lanes (96 contiguous bytes);
+ *   - i-forces: 24 accumulators in registers, reduced over tidxj once per entry and written with
+ *     64-lane coalesced atomics (768 contiguous bytes);
+ *   - FUSED: a cluster pair that touches a perturbed atom (Grid::fepBits) takes a separate,
+ *     non-unrolled path in which perturbed lanes evaluate the soft-core A/B pair (fepPair) and the
+ *     other lanes the plain pair; everything else runs the plain path untouched.
+ */
+#ifndef NBNXM_KERNEL_IMPL_H
+#define NBNXM_KERNEL_IMPL_H
+
+#include "nbnxm_device_helpers.h"
+
+template<int VDW>
+struct VdwTraits
+{
+    static constexpr bool useTable = (VDW == VDK_CUT || VDW == VDK_FSWITCH || VDW == VDK_PSWITCH);
+};
+
+template<int ELEC, bool TWIN, int VDW, bool ENERGY, bool FUSED>
+__launch_bounds__(c_waveSize) __global__
+        void nbnxmKernel(const NBAtomDataGpu atdat, const NBParamGpu nbp, const gpu_plist plist, const int bCalcFshiftIn)
+{
+    constexpr bool EXCL_FORCES = (ELEC != ELK_CUT) || ENERGY; /* nbnxm_cuda_kernel.cuh:69-78 */
+    constexpr bool USE_TABLE   = VdwTraits<VDW>::useTable;
+    constexpr int  FEP_ELEC    = (ELEC == ELK_CUT) ? ELK_RF : ELEC;
+
+    const unsigned lane  = threadIdx.x;
+    const unsigned tidxi = lane & 7U;
+    const unsigned tidxj = lane >> 3;
+    const unsigned half  = lane >> 5;
+
+    __shared__ float4 xqib[c_superClSize];
+    __shared__ int    atib[USE_TABLE ? c_superClSize : 1];
+    __shared__ float2 ljcpib[USE_TABLE ? 1 : c_superClSize];
+    __shared__ float2 qABib[FUSED ? c_superClSize : 1]; /* epsfac * (qA, qB) */
+    __shared__ int2   tABib[FUSED ? c_superClSize : 1];
+
+    const nbnxn_sci_t nb_sci        = plist.sci[blockIdx.x];
+    const int         sci           = nb_sci.sci;
+    const int         shiftIdx      = nb_sci.shift & NBNXM_CI_SHIFT_MASK;
+    const int         cjPackedBegin = nb_sci.cjPackedBegin;
+    const int         cjPackedEnd   = nb_sci.cjPackedEnd;
+    const bool        central       = (shiftIdx == c_centralShiftIndex);
+
+    const float4* __restrict__ xq = atdat.xq;
+    const int* __restrict__ atomTypes = atdat.atomTypes;
+    const float2* __restrict__ ljComb = atdat.ljComb;
+    const float2* __restrict__ nbfp   = nbp.nbfp;
+    float* __restrict__ f             = reinterpret_cast<float*>(atdat.f);
+    const int   numTypes              = atdat.numTypes;
+    const float rcoulomb_sq           = nbp.rcoulomb_sq;
+
+    /* stage the 64 i-atoms: lane l holds atom l of the super-cluster */
+    {
+        const int    ai  = sci * c_superClSize + static_cast<int>(lane);
+        const float3 sh  = atdat.shiftVec[shiftIdx];
+        float4       xqi = xq[ai];
+        xqi.x += sh.x;
+        xqi.y += sh.y;
+        xqi.z += sh.z;
+        xqi.w *= nbp.epsfac;
+        xqib[lane] = xqi;
+        if constexpr (USE_TABLE) { atib[lane] = atomTypes[ai]; }
+        else { ljcpib[lane] = ljComb[ai]; }
+        if constexpr (FUSED)
+        {
+            const float4 q4 = atdat.q4[ai];
+            qABib[lane]     = make_float2(q4.x * nbp.epsfac, q4.y * nbp.epsfac);
+            const int4 t4   = atdat.atomTypes4[ai];
+            tABib[lane]     = make_int2(t4.x, t4.y);
+        }
+    }
+    __syncthreads();
+
+    /* perturbed-atom bits of the 8 i-clusters (FUSED) */
+    unsigned long long iFepBits = 0;
+    FepLambda          L;
+    if constexpr (FUSED)
+    {
+        iFepBits = *reinterpret_cast<const unsigned long long*>(atdat.fepBits + static_cast<size_t>(sci) * c_numClPerSupercl);
+        iFepBits = __builtin_amdgcn_readfirstlane(static_cast<unsigned>(iFepBits))
+                   | (static_cast<unsigned long long>(__builtin_amdgcn_readfirstlane(static_cast<unsigned>(iFepBits >> 32))) << 32);
+        L = makeFepLambda(nbp.lambda_q, nbp.lambda_v, nbp.lam_power, nbp.alpha_coul, nbp.alpha_vdw);
+    }
+
+    float3 fci_buf[c_numClPerSupercl];
+#pragma unroll
+    for (int i = 0; i < c_numClPerSupercl; i++) { fci_buf[i] = make_float3(0.0F, 0.0F, 0.0F); }
+    float3 fSlowShift = make_float3(0.0F, 0.0F, 0.0F); /* i-forces that left through the FUSED path */
+
+    float E_lj = 0.0F, E_el = 0.0F, DVDL_lj = 0.0F, DVDL_el = 0.0F;
+
+    if constexpr (ENERGY && EXCL_FORCES)
+    {
+        /* self terms on the diagonal entry (nbnxm_cuda_kernel.cuh:365-400); lane l owns atom l */
+        if (central && plist.cjPacked[cjPackedBegin].cj[0] == sci * c_numClPerSupercl)
+        {
+            const float coef = (ELEC == ELK_CUT || ELEC == ELK_RF) ? -0.5F * nbp.c_rf : -nbp.ewald_beta * c_oneOverSqrtPi;
+            const float qi   = xqib[lane].w;
+            E_el += qi * qi / nbp.epsfac * coef;
+            if constexpr (FUSED)
+            {
+                /* perturbed atoms carry q = 0 in xq; their lambda-dependent self term is what the i == j
+                 * entry of the atom-pair list contributes (nb_free_energy.cpp:1035-1052,1079-1100) */
+                if ((iFepBits >> lane) & 1ULL)
+                {
+                    const float2 qAB = qABib[lane];
+                    const float  sA  = qAB.x * qAB.x / nbp.epsfac * coef;
+                    const float  sB  = qAB.y * qAB.y / nbp.epsfac * coef;
+                    E_el += L.LFC[0] * sA + L.LFC[1] * sB;
+                    DVDL_el += sB - sA;
+                }
+            }
+        }
+    }
+
+    for (int jPacked = cjPackedBegin; jPacked < cjPackedEnd; jPacked++)
+    {
+        const nbnxn_cj_packed_t* __restrict__ grp = &plist.cjPacked[jPacked];
+        const unsigned imask = grp->imei[0].imask;
+        if (imask == 0U) { continue; }
+        const int      exclInd0 = grp->imei[0].excl_ind;
+        const int      exclInd1 = grp->imei[1].excl_ind;
+        const unsigned wexcl    = plist.excl[half ? exclInd1 : exclInd0].pair[lane & 31U];
+
+#pragma unroll 1
+        for (int jm = 0; jm < c_jGroupSize; jm++)
+        {
+            const unsigned imaskJ = (imask >> (jm * c_numClPerSupercl)) & 0xFFU;
+            if (imaskJ == 0U) { continue; }
+            const unsigned wexclJ = wexcl >> (jm * c_numClPerSupercl);
+
+            const int    cj   = grp->cj[jm];
+            const int    aj   = cj * c_clSize + static_cast<int>(tidxj);
+            const float4 xqj  = xq[aj];
+            int          typej = 0;
+            float2       ljcp_j = make_float2(0.0F, 0.0F);
+            if constexpr (USE_TABLE) { typej = atomTypes[aj]; }
+            else { ljcp_j = ljComb[aj]; }
+
+            float3 fcj_buf = make_float3(0.0F, 0.0F, 0.0F);
+
+            bool slowPath = false;
+            unsigned jFepBits = 0;
+            if constexpr (FUSED)
+            {
+                jFepBits = __builtin_amdgcn_readfirstlane(static_cast<unsigned>(atdat.fepBits[cj]));
+                slowPath = (iFepBits != 0ULL) || (jFepBits != 0U);
+            }
+
+            if (!slowPath)
+            {
+#pragma unroll
+                for (int i = 0; i < c_numClPerSupercl; i++)
+                {
+                    if (imaskJ & (1U << i))
+                    {
+                        const float4 xqi = xqib[i * c_clSize + tidxi];
+                        const float3 rv  = make_float3(xqi.x - xqj.x, xqi.y - xqj.y, xqi.z - xqj.z);
+                        const float  r2  = rv.x * rv.x + rv.y * rv.y + rv.z * rv.z;
+                        const float  int_bit = ((wexclJ >> i) & 1U) ? 1.0F : 0.0F;
+                        bool         active;
+                        if constexpr (EXCL_FORCES)
+                        {
+                            const int ci = sci * c_numClPerSupercl + i;
+                            active       = (r2 < rcoulomb_sq) && (!(central && tidxj <= tidxi) || ci != cj);
+                        }
+                        else { active = (r2 < rcoulomb_sq) && (int_bit != 0.0F); }
+                        if (active)
+                        {
+                            float c6, c12;
+                            if constexpr (USE_TABLE)
+                            {
+                                const float2 c6c12 = nbfp[numTypes * atib[i * c_clSize + tidxi] + typej];
+                                c6                 = c6c12.x;
+                                c12                = c6c12.y;
+                            }
+                            else
+                            {
+                                const float2 ljcp_i = ljcpib[i * c_clSize + tidxi];
+                                if constexpr (VDW == VDK_COMB_GEOM)
+                                {
+                                    c6  = ljcp_i.x * ljcp_j.x;
+                                    c12 = ljcp_i.y * ljcp_j.y;
+                                }
+                                else
+                                {
+                                    const float sigma  = ljcp_i.x + ljcp_j.x;
+                                    const float eps    = ljcp_i.y * ljcp_j.y;
+                                    const float sigma2 = sigma * sigma;
+                                    const float sigma6 = sigma2 * sigma2 * sigma2;
+                                    c6                 = eps * sigma6;
+                                    c12                = c6 * sigma6;
+                                }
+                            }
+                            float F_invr, E_lj_p = 0.0F, E_el_p = 0.0F;
+                            nbPair<ELEC, TWIN, VDW, ENERGY, EXCL_FORCES>(nbp, r2, int_bit, xqi.w * xqj.w, c6, c12,
+                                                                         F_invr, E_lj_p, E_el_p);
+                            if constexpr (ENERGY)
+                            {
+                                E_lj += E_lj_p;
+                                E_el += E_el_p;
+                            }
+                            const float3 f_ij = make_float3(rv.x * F_invr, rv.y * F_invr, rv.z * F_invr);
+                            fcj_buf.x -= f_ij.x;
+                            fcj_buf.y -= f_ij.y;
+                            fcj_buf.z -= f_ij.z;
+                            fci_buf[i].x += f_ij.x;
+                            fci_buf[i].y += f_ij.y;
+                            fci_buf[i].z += f_ij.z;
+                        }
+                    }
+                }
+            }
+            else
+            {
+                if constexpr (FUSED)
+                {
+                    /* rare path: the cluster pair touches a perturbed atom */
+                    const float4 q4j = atdat.q4[aj];
+                    const int4   t4j = atdat.atomTypes4[aj];
+#pragma unroll 1
+                    for (int i = 0; i < c_numClPerSupercl; i++)
+                    {
+                        if (!(imaskJ & (1U << i))) { continue; }
+                        const unsigned iBits = static_cast<unsigned>(iFepBits >> (i * c_clSize)) & 0xFFU;
+                        const float4   xqi   = xqib[i * c_clSize + tidxi];
+                        const float3   rv    = make_float3(xqi.x - xqj.x, xqi.y - xqj.y, xqi.z - xqj.z);
+                        const float    r2    = rv.x * rv.x + rv.y * rv.y + rv.z * rv.z;
+                        const bool     included = ((wexclJ >> i) & 1U) != 0U;
+                        const int      ci       = sci * c_numClPerSupercl + i;
+                        const bool     subDiag  = central && (ci == cj) && (tidxj <= tidxi);
+                        const bool     pert     = (((iBits >> tidxi) | (jFepBits >> tidxj)) & 1U) != 0U;
+                        float          F_invr   = 0.0F;
+                        if (pert)
+                        {
+                            if (!subDiag)
+                            {
+                                const float2 qABi = qABib[i * c_clSize + tidxi];
+                                const int2   tABi = tABib[i * c_clSize + tidxi];
+                                const float  qq[2] = { qABi.x * q4j.x, qABi.y * q4j.y };
+                                const float2 pA    = nbfp[numTypes * tABi.x + t4j.x];
+                                const float2 pB    = nbfp[numTypes * tABi.y + t4j.y];
+                                const float  c6[2]  = { pA.x, pB.x };
+                                const float  c12[2] = { pA.y, pB.y };
+                                float        fscal  = 0.0F;
+                                const bool   done = fepPair<FEP_ELEC, VDW == VDK_PSWITCH, true, ENERGY>(
+                                        nbp, L, r2, included, false, qq, c6, c12, fscal, E_lj, E_el, DVDL_lj, DVDL_el);
+                                F_invr = done ? fscal : 0.0F;
+                            }
+                        }
+                        else
+                        {
+                            const float int_bit = included ? 1.0F : 0.0F;
+                            bool        active;
+                            if constexpr (EXCL_FORCES) { active = (r2 < rcoulomb_sq) && !subDiag; }
+                            else { active = (r2 < rcoulomb_sq) && included; }
+                            if (active)
+                            {
+                                float c6, c12;
+                                if constexpr (USE_TABLE)
+                                {
+                                    const float2 c6c12 = nbfp[numTypes * atib[i * c_clSize + tidxi] + typej];
+                                    c6                 = c6c12.x;
+                                    c12                = c6c12.y;
+                                }
+                                else
+                                {
+                                    const float2 ljcp_i = ljcpib[i * c_clSize + tidxi];
+                                    if constexpr (VDW == VDK_COMB_GEOM)
+                                    {
+                                        c6  = ljcp_i.x * ljcp_j.x;
+                                        c12 = ljcp_i.y * ljcp_j.y;
+                                    }
+                                    else
+                                    {
+                                        const float sigma  = ljcp_i.x + ljcp_j.x;
+                                        const float eps    = ljcp_i.y * ljcp_j.y;
+                                        const float sigma2 = sigma * sigma;
+                                        const float sigma6 = sigma2 * sigma2 * sigma2;
+                                        c6                 = eps * sigma6;
+                                        c12                = c6 * sigma6;
+                                    }
+                                }
+                                float E_lj_p = 0.0F, E_el_p = 0.0F;
+                                nbPair<ELEC, TWIN, VDW, ENERGY, EXCL_FORCES>(nbp, r2, int_bit, xqi.w * xqj.w, c6, c12,
+                                                                             F_invr, E_lj_p, E_el_p);
+                                if constexpr (ENERGY)
+                                {
+                                    E_lj += E_lj_p;
+                                    E_el += E_el_p;
+                                }
+                            }
+                        }
+                        const float3 f_ij = make_float3(rv.x * F_invr, rv.y * F_invr, rv.z * F_invr);
+                        fcj_buf.x -= f_ij.x;
+                        fcj_buf.y -= f_ij.y;
+                        fcj_buf.z -= f_ij.z;
+                        /* i-force of this cluster leaves directly (dynamic i: no register array indexing) */
+                        const float fix = reduceOverTidxj(f_ij.x);
+                        const float fiy = reduceOverTidxj(f_ij.y);
+                        const float fiz = reduceOverTidxj(f_ij.z);
+                        if (tidxj < 3U)
+                        {
+                            const float v = (tidxj == 0U) ? fix : ((tidxj == 1U) ? fiy : fiz);
+                            atomicAdd(&f[3 * (ci * c_clSize + static_cast<int>(tidxi)) + static_cast<int>(tidxj)], v);
+                        }
+                        fSlowShift.x += f_ij.x;
+                        fSlowShift.y += f_ij.y;
+                        fSlowShift.z += f_ij.z;
+                    }
+                }
+            }
+
+            /* j-force: sum over the 8 lanes of a j atom, lanes tidxi 0..2 add x,y,z */
+            const float fjx = reduceOver8Lanes(fcj_buf.x);
+            const float fjy = reduceOver8Lanes(fcj_buf.y);
+            const float fjz = reduceOver8Lanes(fcj_buf.z);
+            if (tidxi < 3U)
+            {
+                const float v = (tidxi == 0U) ? fjx : ((tidxi == 1U) ? fjy : fjz);
+                atomicAdd(&f[3 * aj + static_cast<int>(tidxi)], v);
+            }
+        }
+    }
+
+    /* i-forces: reduce over tidxj; lane (tidxj, tidxi) keeps the sum of cluster tidxj, atom tidxi */
+    float3 mine = make_float3(0.0F, 0.0F, 0.0F);
+#pragma unroll
+    for (int i = 0; i < c_numClPerSupercl; i++)
+    {
+        const float sx = reduceOverTidxj(fci_buf[i].x);
+        const float sy = reduceOverTidxj(fci_buf[i].y);
+        const float sz = reduceOverTidxj(fci_buf[i].z);
+        if (tidxj == static_cast<unsigned>(i)) { mine = make_float3(sx, sy, sz); }
+    }
+    {
+        const int ai = sci * c_superClSize + static_cast<int>(lane);
+        atomicAdd(&f[3 * ai + 0], mine.x);
+        atomicAdd(&f[3 * ai + 1], mine.y);
+        atomicAdd(&f[3 * ai + 2], mine.z);
+    }
+
+    if (bCalcFshiftIn && !central)
+    {
+        float sx = mine.x, sy = mine.y, sz = mine.z;
+        if constexpr (FUSED)
+        {
+            sx += fSlowShift.x;
+            sy += fSlowShift.y;
+            sz += fSlowShift.z;
+        }
+        sx = waveSum(sx);
+        sy = waveSum(sy);
+        sz = waveSum(sz);
+        if (lane < 3U)
+        {
+            const float v = (lane == 0U) ? sx : ((lane == 1U) ? sy : sz);
+            atomicAdd(reinterpret_cast<float*>(atdat.fShift) + 3 * shiftIdx + static_cast<int>(lane), v);
+        }
+    }
+
+    if constexpr (ENERGY)
+    {
+        E_lj = waveSum(E_lj);
+        E_el = waveSum(E_el);
+        if constexpr (FUSED)
+        {
+            DVDL_lj = waveSum(DVDL_lj);
+            DVDL_el = waveSum(DVDL_el);
+        }
+        if (lane == 0U)
+        {
+            atomicAdd(atdat.eLJ, E_lj);
+            atomicAdd(atdat.eElec, E_el);
+            if constexpr (FUSED)
+            {
+                atomicAdd(atdat.dvdlLJ, DVDL_lj);
+                atomicAdd(atdat.dvdlElec, DVDL_el);
+            }
+        }
+    }
+}
+
+/* First-pass / rolling list pruning (nbnxm/cuda/nbnxm_cuda_kernel_pruneonly.cuh:100-316).
+ * One wavefront per i-entry `blockIdx.x * numParts + part`; a cluster pair is kept when any of its 64
+ * atom pairs is within range, and the same mask is written to both halves of the split-2 entry. */
+template<bool haveFreshList>
+__launch_bounds__(c_waveSize) __global__
+        void nbnxmPruneKernel(const NBAtomDataGpu atdat, const NBParamGpu nbp, const gpu_plist plist, const int numParts, const int part)
+{
+    const int entry = static_cast<int>(blockIdx.x) * numParts + part;
+    if (entry >= plist.nsci) { return; }
+    const unsigned lane  = threadIdx.x;
+    const unsigned tidxi = lane & 7U;
+    const unsigned tidxj = lane >> 3;
+
+    __shared__ float4 xib[c_superClSize];
+
+    const nbnxn_sci_t nb_sci   = plist.sci[entry];
+    const int         shiftIdx = nb_sci.shift & NBNXM_CI_SHIFT_MASK;
+    {
+        const float3 sh = atdat.shiftVec[shiftIdx];
+        float4       xi = atdat.xq[nb_sci.sci * c_superClSize + static_cast<int>(lane)];
+        xi.x += sh.x;
+        xi.y += sh.y;
+        xi.z += sh.z;
+        xib[lane] = xi;
+    }
+    __syncthreads();
+
+    const float rlistOuter_sq = nbp.rlistOuter_sq;
+    const float rlistInner_sq = nbp.rlistInner_sq;
+
+    for (int jPacked = nb_sci.cjPackedBegin; jPacked < nb_sci.cjPackedEnd; jPacked++)
+    {
+        unsigned imaskFull, imaskCheck, imaskNew;
+        if constexpr (haveFreshList)
+        {
+            imaskFull  = plist.cjPacked[jPacked].imei[0].imask;
+            imaskCheck = imaskFull;
+            imaskNew   = 0U;
+        }
+        else
+        {
+            imaskFull  = plist.imask[jPacked * NBNXM_GPU_CLUSTERPAIR_SPLIT];
+            imaskNew   = plist.cjPacked[jPacked].imei[0].imask;
+            imaskCheck = imaskNew ^ imaskFull;
+        }
+        if (imaskCheck == 0U) { continue; }
+#pragma unroll 1
+        for (int jm = 0; jm < c_jGroupSize; jm++)
+        {
+            if (!(imaskCheck & (0xFFU << (jm * c_numClPerSupercl)))) { continue; }
+            const int    cj = plist.cjPacked[jPacked].cj[jm];
+            const float4 xj = atdat.xq[cj * c_clSize + static_cast<int>(tidxj)];
+#pragma unroll
+            for (int i = 0; i < c_numClPerSupercl; i++)
+            {
+                const unsigned mask_ji = 1U << (jm * c_numClPerSupercl + i);
+                if (imaskCheck & mask_ji)
+                {
+                    const float4 xi = xib[i * c_clSize + tidxi];
+                    const float  dx = xi.x - xj.x, dy = xi.y - xj.y, dz = xi.z - xj.z;
+                    const float  r2 = dx * dx + dy * dy + dz * dz;
+                    if constexpr (haveFreshList)
+                    {
+                        if (__ballot(r2 < rlistOuter_sq) == 0ULL) { imaskFull &= ~mask_ji; }
+                    }
+                    if (__ballot(r2 < rlistInner_sq) != 0ULL) { imaskNew |= mask_ji; }
+                }
+            }
+        }
+        if (lane == 0U)
+        {
+            if constexpr (haveFreshList)
+            {
+                plist.imask[jPacked * NBNXM_GPU_CLUSTERPAIR_SPLIT]     = imaskFull;
+                plist.imask[jPacked * NBNXM_GPU_CLUSTERPAIR_SPLIT + 1] = imaskFull;
+            }
+            plist.cjPacked[jPacked].imei[0].imask = imaskNew;
+            plist.cjPacked[jPacked].imei[1].imask = imaskNew;
+        }
+    }
+}
+
+#endif

@@ -1,0 +1,28 @@
+/*
+ * Kernel selection tables (the role of select_nbnxn_kernel / select_nbnxn_fep_kernel /
+ * select_nbnxn_foreign_fep_kernel, nbnxm/cuda/nbnxm_cuda.cu:416-591).  Flavours are C++ template
+ * instantiations, one translation unit per electrostatics kind so that they build in parallel.
+ */
+#ifndef NBNXM_KERNELS_H
+#define NBNXM_KERNELS_H
+
+#include "nbnxm_hip_types.h"
+
+using NbKernelPtr    = void (*)(NBAtomDataGpu, NBParamGpu, gpu_plist, int);
+using FepKernelPtr   = void (*)(NBAtomDataGpu, NBParamGpu, gpu_feplist, int);
+using PruneKernelPtr = void (*)(NBAtomDataGpu, NBParamGpu, gpu_plist, int, int);
+
+/* vdwKind: VDK_* of nbnxm_device_helpers.h; returns nullptr for an unsupported flavour */
+NbKernelPtr nbKernelElecCut(int vdwKind, bool energy, bool fused);
+NbKernelPtr nbKernelElecRF(int vdwKind, bool energy, bool fused);
+NbKernelPtr nbKernelElecEwaldAna(int vdwKind, bool energy, bool fused);
+NbKernelPtr nbKernelElecEwaldTab(int vdwKind, bool energy, bool fused);
+NbKernelPtr nbKernelElecEwaldAnaTwin(int vdwKind, bool energy, bool fused);
+NbKernelPtr nbKernelElecEwaldTabTwin(int vdwKind, bool energy, bool fused);
+
+NbKernelPtr    selectNbKernel(int elecType, int vdwType, bool energy, bool fused);
+FepKernelPtr   selectFepKernel(int elecType, int vdwType, bool energy);
+FepKernelPtr   selectFepForeignKernel(int elecType, int vdwType);
+PruneKernelPtr selectPruneKernel(bool haveFreshList);
+
+#endif

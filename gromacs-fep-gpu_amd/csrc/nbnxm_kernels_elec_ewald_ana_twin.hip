@@ -1,0 +1,23 @@
+/* Cluster-pair kernel instantiations, electrostatics flavour: elec_ewald_ana_twin (see nbnxm_kernel_impl.h). */
+#include "nbnxm_kernel_impl.h"
+#include "nbnxm_kernels.h"
+
+template<int VDW>
+static NbKernelPtr pick(bool energy, bool fused)
+{
+    if (energy) { return fused ? nbnxmKernel<ELK_EWALD_ANA, true, VDW, true, true> : nbnxmKernel<ELK_EWALD_ANA, true, VDW, true, false>; }
+    return fused ? nbnxmKernel<ELK_EWALD_ANA, true, VDW, false, true> : nbnxmKernel<ELK_EWALD_ANA, true, VDW, false, false>;
+}
+
+NbKernelPtr nbKernelElecEwaldAnaTwin(int vdwKind, bool energy, bool fused)
+{
+    switch (vdwKind)
+    {
+        case VDK_CUT: return pick<VDK_CUT>(energy, fused);
+        case VDK_COMB_GEOM: return pick<VDK_COMB_GEOM>(energy, fused);
+        case VDK_COMB_LB: return pick<VDK_COMB_LB>(energy, fused);
+        case VDK_FSWITCH: return pick<VDK_FSWITCH>(energy, fused);
+        case VDK_PSWITCH: return pick<VDK_PSWITCH>(energy, fused);
+        default: return nullptr;
+    }
+}

@@ -24,6 +24,8 @@
 #ifndef NBNXM_HIP_H
 #define NBNXM_HIP_H
 
+#include <stddef.h>
+
 #ifdef __cplusplus
 extern "C" {
 #endif
@@ -273,6 +275,11 @@ int nbnxm_gpu_have_short_range_work(const NbnxmGpu* nb, int iloc);
  *   0 = reference shape: cluster kernel + separate atom-pair FEP-list kernels (gpu_feplist);
  *   1 = fused: perturbed pairs inside the cluster-pair kernel (needs nbnxm_gpu_init_fep_cluster_bits). */
 void nbnxm_gpu_set_fep_mode(NbnxmGpu* nb, int fused);
+
+/* Diagnostics for tests: device pointer of the packed j-list of a locality, and a synchronous
+ * device-to-host copy on that object's local stream. */
+void* nbnxm_gpu_debug_get_cjpacked(NbnxmGpu* nb, int iloc);
+void  nbnxm_gpu_debug_download(NbnxmGpu* nb, const void* devicePtr, void* hostPtr, size_t numBytes);
 
 /* Library/ABI version and a last-error string for diagnostics (never needed on the success path). */
 int         nbnxm_hip_abi_version(void);

@@ -1,0 +1,150 @@
+"""GPU parity tests: the HIP path, called through the C ABI, against the CPU oracle on identical
+inputs (same lists, same float coordinates).
+
+Tolerance: 1e-4 relative — the bar the reference's own GPU-vs-CPU acceptance test uses
+(src/programs/mdrun/tests/freeenergy.cpp:115-135) and the one BASELINE.json states.  Forces are
+compared against the RMS force, sums that cancel against the magnitude of their terms (fep_testlib.assert_parity).
+"""
+import numpy as np
+import pytest
+
+import fep_testlib as tl
+
+pytestmark = pytest.mark.gpu
+pkg = tl.pkg
+
+SMALL = dict(nm=(10, 10, 10), num_perturbed_molecules=3)      # 3000 atoms, 9 perturbed
+
+
+@pytest.mark.parametrize("elec", ["rf", "cut", "ewald", "ewald_tab"])
+@pytest.mark.parametrize("energy", [False, True])
+def test_split_path_matches_oracle(elec, energy):
+    c = tl.make_case(elec=elec, seed=21, **SMALL)
+    got = tl.run_gpu(c, energy=energy, fused=False)
+    want = tl.run_oracle(c, energy=True)
+    tl.assert_parity(got, want, rel=1e-4 if elec != "ewald_tab" else 3e-4, energy=energy, label=elec)
+
+
+@pytest.mark.parametrize("elec", ["rf", "cut", "ewald", "ewald_tab"])
+@pytest.mark.parametrize("energy", [False, True])
+def test_fused_path_matches_oracle(elec, energy):
+    c = tl.make_case(elec=elec, seed=22, **SMALL)
+    got = tl.run_gpu(c, energy=energy, fused=True)
+    want = tl.run_oracle(c, energy=True)
+    tl.assert_parity(got, want, rel=1e-4 if elec != "ewald_tab" else 3e-4, energy=energy, label="fused " + elec)
+
+
+@pytest.mark.parametrize("vdw", ["pswitch", "fswitch"])
+@pytest.mark.parametrize("fused", [False, True])
+def test_vdw_modifiers(vdw, fused):
+    # force switch: perturbed pairs use plain shifted LJ on both sides (reference behaviour)
+    c = tl.make_case(elec="rf", vdw=vdw, seed=23, **SMALL)
+    got = tl.run_gpu(c, energy=True, fused=fused)
+    want = tl.run_oracle(c, energy=True)
+    tl.assert_parity(got, want, rel=1e-4, label=vdw)
+
+
+@pytest.mark.parametrize("sc_alpha,sc_power,sc_coul,lam", [(0.0, 1, True, 0.5), (0.5, 2, True, 0.3), (0.5, 1, False, 0.7),
+                                                            (0.5, 1, True, 0.0), (0.5, 1, True, 1.0)])
+@pytest.mark.parametrize("fused", [False, True])
+def test_softcore_settings(sc_alpha, sc_power, sc_coul, lam, fused):
+    c = tl.make_case(elec="ewald", seed=24, sc_alpha=sc_alpha, sc_power=sc_power, sc_coul=sc_coul,
+                     lambda_coul=lam, lambda_vdw=min(1.0, lam + 0.2) if 0 < lam < 1 else lam, **SMALL)
+    got = tl.run_gpu(c, energy=True, fused=fused)
+    want = tl.run_oracle(c, energy=True)
+    tl.assert_parity(got, want, rel=1e-4, label="sc")
+
+
+@pytest.mark.parametrize("elec", ["rf", "ewald"])
+def test_foreign_lambda_energies(elec):
+    c = tl.make_case(elec=elec, seed=25, n_lambda=11, **SMALL)
+    got = tl.run_gpu(c, energy=True, fused=False, dhdl=True)
+    want = tl.run_oracle(c, energy=True, foreign=True)
+    fw = want["foreign"]
+    e_want = fw["eVdw"] + fw["eCoul"]
+    scale = max(1.0, float(np.max(np.abs(fw["eVdw"])) + np.max(np.abs(fw["eCoul"]))))
+    assert np.max(np.abs(got["foreign"]["energies"] - e_want)) <= 1e-4 * scale
+    assert np.max(np.abs(got["foreign"]["dvdlCoul"] - fw["dvdlCoul"])) <= 1e-4 * max(1.0, float(np.max(np.abs(fw["dvdlCoul"]))))
+    assert np.max(np.abs(got["foreign"]["dvdlVdw"] - fw["dvdlVdw"])) <= 1e-4 * max(1.0, float(np.max(np.abs(fw["dvdlVdw"]))))
+    # index 0 is the current lambda: must agree with the FEP part of the force/energy kernels
+    fep = want["parts"]["fep"]
+    assert abs(got["foreign"]["energies"][0] - (fep["Vv"] + fep["Vc"])) <= 1e-4 * scale
+
+
+def test_empty_and_ragged_lists():
+    # no perturbed atoms at all: the FEP list is empty, only the cluster kernel runs
+    c = tl.make_case(elec="rf", seed=26, nm=(10, 10, 10), num_perturbed_molecules=0)
+    assert len(c.plist.fep["jjnr"]) == 0
+    for fused in (False, True):
+        got = tl.run_gpu(c, energy=True, fused=fused)
+        want = tl.run_oracle(c, energy=True)
+        tl.assert_parity(got, want, rel=1e-4, label="no-fep")
+        assert got["dvdl_coul"] == 0.0 and got["dvdl_vdw"] == 0.0
+    # split i-entries (list balancing) and a larger ligand: ragged FEP entries up to the 64-j cap
+    c = tl.make_case(elec="ewald", seed=27, nm=(10, 10, 10), num_perturbed_molecules=16, max_cjpacked_per_sci=4)
+    nj = np.diff(c.plist.fep["jindex"])
+    assert nj.max() == 64 and nj.min() <= 3
+    for fused in (False, True):
+        got = tl.run_gpu(c, energy=True, fused=fused)
+        want = tl.run_oracle(c, energy=True)
+        tl.assert_parity(got, want, rel=1e-4, label="ragged")
+
+
+def test_outputs_accumulate_and_clear():
+    c = tl.make_case(elec="rf", seed=28, **SMALL)
+    nb = tl.setup_gpu(c)
+    a = tl.run_gpu(c, energy=True, nb=nb)
+    b = tl.run_gpu(c, energy=True, nb=nb)   # clear_outputs in between: same result, not doubled
+    assert abs(a["e_el"] - b["e_el"]) <= 1e-5 * abs(a["e_el"])
+    frms = np.sqrt(np.mean(a["f"] ** 2))
+    assert np.max(np.abs(a["f"] - b["f"])) <= 1e-4 * frms   # float atomics: order-dependent round-off only
+    # without clearing, a second launch accumulates (+=) like the reference's kernels
+    sw = pkg.step_workload(energy=True, virial=True)
+    nb.clear_outputs(True)
+    nb.launch_kernel(sw)
+    nb.launch_kernel(sw)
+    f = np.zeros((c.grid.num_atoms, 3), np.float32)
+    nb.launch_cpyback(f, sw)
+    res = nb.wait_finish_task(sw, c.have_soft_core)
+    assert abs(res["e_el"] - 2 * a["e_el"]) <= 1e-4 * abs(2 * a["e_el"])
+    assert np.max(np.abs(f - 2 * a["f"])) <= 2e-4 * frms
+    nb.free()
+
+
+def test_prune_kernel_matches_oracle_and_keeps_forces():
+    import oracle_binding as ob
+    c = tl.make_case(elec="rf", seed=29, **SMALL)
+    want = tl.run_oracle(c, energy=True)
+    nb = tl.setup_gpu(c, use_dynamic_pruning=True)
+    got = tl.run_gpu(c, energy=True, nb=nb)          # first launch prunes the fresh list, then computes
+    tl.assert_parity(got, want, rel=1e-4, label="pruned")
+    # the pruned masks equal the oracle's pruning of the same list
+    cj = c.plist.cjPacked.copy()
+    nleft = ob.nbnxm_prune(c.plist.sci, cj, c.grid.xq, c.grid.shift_vec, c.rlist)
+    assert nleft < c.plist.num_cluster_pairs
+    dev = pkg.download_cjpacked(nb, len(cj))
+    assert np.array_equal(dev["imei"]["imask"], cj["imei"]["imask"])
+    # rolling prune in 4 parts over the already pruned list leaves it unchanged (rlistInner == rlistOuter)
+    for _ in range(4):
+        nb.launch_kernel_pruneonly(num_parts=4)
+    dev2 = pkg.download_cjpacked(nb, len(cj))
+    assert np.array_equal(dev2["imei"]["imask"], cj["imei"]["imask"])
+    nb.free()
+
+
+def test_full_size_properties_100k():
+    """BASELINE size (96k atoms, 48 perturbed): properties that need no full oracle pass —
+    Newton's third law (zero net force incl. shift bookkeeping), fused == split, F-only == VF forces."""
+    c = tl.make_case(elec="ewald", seed=2026, nm=(40, 40, 20), num_perturbed_molecules=16, max_cjpacked_per_sci=16)
+    split = tl.run_gpu(c, energy=True, fused=False)
+    fused = tl.run_gpu(c, energy=True, fused=True)
+    fonly = tl.run_gpu(c, energy=False, fused=True)
+    frms = np.sqrt(np.mean(split["f"] ** 2))
+    assert np.max(np.abs(split["f"].sum(axis=0))) <= 1e-3 * frms * np.sqrt(c.grid.num_atoms)
+    assert np.max(np.abs(split["f"] - fused["f"])) <= 1e-4 * frms
+    assert np.max(np.abs(fonly["f"] - fused["f"])) <= 1e-4 * frms
+    for k in ("e_lj", "e_el", "dvdl_coul", "dvdl_vdw"):
+        assert abs(split[k] - fused[k]) <= 1e-4 * max(abs(split[k]), 1e-3 * abs(split["e_el"]))
+    # and the oracle on the full box (1.6 s of CPU)
+    want = tl.run_oracle(c, energy=True)
+    tl.assert_parity(fused, want, rel=1e-4, label="96k fused")
