@@ -95,7 +95,7 @@ NB_DEVINL float pmeCorrF(float z2)
     den       = fmaf(den, z2, PME_CORR_Q2);
     den       = fmaf(den, z2, PME_CORR_Q1);
     den       = fmaf(den, z2, PME_CORR_Q0);
-    return num * __frcp_rn(den);
+    return num * __builtin_amdgcn_rcpf(den);
 }
 
 /* Linear interpolation in the Ewald force table (nbnxm_cuda_kernel_utils.cuh:448-459) */

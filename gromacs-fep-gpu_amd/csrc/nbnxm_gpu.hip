@@ -15,6 +15,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -77,6 +78,11 @@ struct NbnxmGpu
     bool fusedFep  = false;
     int  numCUs    = 256;
 
+    int nbWavesPerBlock = c_nbWavesPerBlock; /* tunable: NBNXM_HIP_WAVES_PER_BLOCK = 1..4 */
+
+    float* scalarOutputs    = nullptr; /* device block behind atdat->eLJ ... dvdlElecForeign */
+    int    numScalarOutputs = 0;
+
     /* allocation bookkeeping */
     int xq_nalloc = 0, f_nalloc = 0, fep_nalloc = 0, fepBits_nalloc = 0;
     int nbfp_n = 0, nbfp_comb_n = 0, coulomb_tab_n = 0;
@@ -96,6 +102,20 @@ struct NbnxmGpu
     PinnedBuffer<unsigned char>     h_fepBits;
     PinnedBuffer<float>             h_shiftVec;
 };
+
+/* Clears the force array and the block of scalar outputs (energies, dV/dl, foreign terms, shift forces)
+ * in one launch; replaces the 5-10 separate memsets of gpu_clear_outputs (nbnxm_gpu_data_mgmt.cpp:1047-1070). */
+__global__ void nbnxmClearOutputsKernel(float4* __restrict__ f4, int numFloat4, float* __restrict__ tail, int numTail,
+                                        float* __restrict__ scalars, int numScalars, float* __restrict__ fshift, int numFshift)
+{
+    const int    gid    = static_cast<int>(blockIdx.x * blockDim.x + threadIdx.x);
+    const int    stride = static_cast<int>(gridDim.x * blockDim.x);
+    const float4 zero   = make_float4(0.0F, 0.0F, 0.0F, 0.0F);
+    for (int i = gid; i < numFloat4; i += stride) { f4[i] = zero; }
+    if (gid < numTail) { tail[gid] = 0.0F; }
+    if (gid < numScalars) { scalars[gid] = 0.0F; }
+    if (gid < numFshift) { fshift[gid] = 0.0F; }
+}
 
 namespace
 {
@@ -224,6 +244,12 @@ NbnxmGpu* nbnxm_gpu_init(const nbnxm_interaction_params_t* ic, int numTypes, con
     NBNXM_HIP_CHECK(hipGetDevice(&dev));
     NBNXM_HIP_CHECK(hipGetDeviceProperties(&prop, dev));
     nb->numCUs = prop.multiProcessorCount;
+    if (const char* env = std::getenv("NBNXM_HIP_WAVES_PER_BLOCK"))
+    {
+        const int w = std::atoi(env);
+        NBNXM_ASSERT(w >= 1 && w <= c_nbWavesPerBlock, "NBNXM_HIP_WAVES_PER_BLOCK must be 1..4");
+        nb->nbWavesPerBlock = w;
+    }
 
     /* pinned staging (gpu_init :573-583) */
     auto pinned = [](float** p, size_t n) {
@@ -266,24 +292,21 @@ NbnxmGpu* nbnxm_gpu_init(const nbnxm_interaction_params_t* ic, int numTypes, con
     NBAtomDataGpu* ad = nb->atdat;
     ad->numTypes      = numTypes;
     allocateDeviceBuffer(&ad->shiftVec, c_numShiftVectors);
+    /* all scalar outputs live in one block so that one kernel clears them:
+     * [eLJ, eElec, dvdlLJ, dvdlElec, eLJForeign[n+1], eElecForeign[n+1], dvdlLJForeign[n+1], dvdlElecForeign[n+1]] */
+    nb->numScalarOutputs = 4 + 4 * (n_lambda + 1);
+    allocateDeviceBuffer(&nb->scalarOutputs, nb->numScalarOutputs);
+    ad->eLJ             = nb->scalarOutputs + 0;
+    ad->eElec           = nb->scalarOutputs + 1;
+    ad->dvdlLJ          = nb->scalarOutputs + 2;
+    ad->dvdlElec        = nb->scalarOutputs + 3;
+    ad->eLJForeign      = nb->scalarOutputs + 4;
+    ad->eElecForeign    = ad->eLJForeign + (n_lambda + 1);
+    ad->dvdlLJForeign   = ad->eElecForeign + (n_lambda + 1);
+    ad->dvdlElecForeign = ad->dvdlLJForeign + (n_lambda + 1);
     allocateDeviceBuffer(&ad->fShift, c_numShiftVectors);
-    allocateDeviceBuffer(&ad->eLJ, 1);
-    allocateDeviceBuffer(&ad->eElec, 1);
-    allocateDeviceBuffer(&ad->dvdlLJ, 1);
-    allocateDeviceBuffer(&ad->dvdlElec, 1);
-    allocateDeviceBuffer(&ad->eLJForeign, n_lambda + 1);
-    allocateDeviceBuffer(&ad->eElecForeign, n_lambda + 1);
-    allocateDeviceBuffer(&ad->dvdlLJForeign, n_lambda + 1);
-    allocateDeviceBuffer(&ad->dvdlElecForeign, n_lambda + 1);
     clearDeviceBufferAsync(&ad->fShift, 0, c_numShiftVectors, s);
-    clearDeviceBufferAsync(&ad->eLJ, 0, 1, s);
-    clearDeviceBufferAsync(&ad->eElec, 0, 1, s);
-    clearDeviceBufferAsync(&ad->dvdlLJ, 0, 1, s);
-    clearDeviceBufferAsync(&ad->dvdlElec, 0, 1, s);
-    clearDeviceBufferAsync(&ad->eLJForeign, 0, n_lambda + 1, s);
-    clearDeviceBufferAsync(&ad->eElecForeign, 0, n_lambda + 1, s);
-    clearDeviceBufferAsync(&ad->dvdlLJForeign, 0, n_lambda + 1, s);
-    clearDeviceBufferAsync(&ad->dvdlElecForeign, 0, n_lambda + 1, s);
+    clearDeviceBufferAsync(&nb->scalarOutputs, 0, nb->numScalarOutputs, s);
     ad->shiftVecUploaded = false;
     NBNXM_HIP_CHECK(hipStreamSynchronize(s));
     return nb;
@@ -301,14 +324,7 @@ void nbnxm_gpu_free(NbnxmGpu* nb)
     freeDeviceBuffer(&ad->xq);
     freeDeviceBuffer(&ad->q4);
     freeDeviceBuffer(&ad->f);
-    freeDeviceBuffer(&ad->eLJ);
-    freeDeviceBuffer(&ad->eElec);
-    freeDeviceBuffer(&ad->dvdlLJ);
-    freeDeviceBuffer(&ad->dvdlElec);
-    freeDeviceBuffer(&ad->eLJForeign);
-    freeDeviceBuffer(&ad->eElecForeign);
-    freeDeviceBuffer(&ad->dvdlLJForeign);
-    freeDeviceBuffer(&ad->dvdlElecForeign);
+    freeDeviceBuffer(&nb->scalarOutputs);
     freeDeviceBuffer(&ad->fShift);
     freeDeviceBuffer(&ad->atomTypes);
     freeDeviceBuffer(&ad->ljComb);
@@ -657,21 +673,16 @@ void nbnxm_gpu_clear_outputs(NbnxmGpu* nb, int computeVirial)
 {
     NBAtomDataGpu* ad = nb->atdat;
     hipStream_t    s  = nb->deviceStreams[0].stream;
-    clearDeviceBufferAsync(&ad->f, 0, ad->numAtoms, s);
-    if (computeVirial) { clearDeviceBufferAsync(&ad->fShift, 0, c_numShiftVectors, s); }
     /* A.4: the reference clears E / dV/dl only on virial steps; they are accumulated with atomics,
-     * so they are cleared on every call here. */
-    clearDeviceBufferAsync(&ad->eLJ, 0, 1, s);
-    clearDeviceBufferAsync(&ad->eElec, 0, 1, s);
-    clearDeviceBufferAsync(&ad->dvdlLJ, 0, 1, s);
-    clearDeviceBufferAsync(&ad->dvdlElec, 0, 1, s);
-    if (nb->n_lambda > 0)
-    {
-        clearDeviceBufferAsync(&ad->eLJForeign, 0, nb->n_lambda + 1, s);
-        clearDeviceBufferAsync(&ad->eElecForeign, 0, nb->n_lambda + 1, s);
-        clearDeviceBufferAsync(&ad->dvdlLJForeign, 0, nb->n_lambda + 1, s);
-        clearDeviceBufferAsync(&ad->dvdlElecForeign, 0, nb->n_lambda + 1, s);
-    }
+     * so they are cleared on every call here (one launch for everything). */
+    const int numFloats = 3 * ad->numAtoms;
+    const int numFloat4 = numFloats / 4;
+    const int numTail   = numFloats - 4 * numFloat4;
+    const int nblock    = std::max(1, std::min(2048, (numFloat4 + 255) / 256));
+    hipLaunchKernelGGL(nbnxmClearOutputsKernel, dim3(nblock), dim3(256), 0, s, reinterpret_cast<float4*>(ad->f), numFloat4,
+                       reinterpret_cast<float*>(ad->f) + 4 * static_cast<size_t>(numFloat4), numTail, nb->scalarOutputs,
+                       nb->numScalarOutputs, reinterpret_cast<float*>(ad->fShift), computeVirial ? 3 * c_numShiftVectors : 0);
+    NBNXM_HIP_CHECK(hipGetLastError());
 }
 
 void nbnxm_gpu_launch_kernel_pruneonly(NbnxmGpu* nb, int iloc, int numParts)
@@ -747,7 +758,20 @@ void nbnxm_gpu_launch_kernel(NbnxmGpu* nb, const nbnxm_step_workload_t* stepWork
             fatal(__FILE__, __LINE__, "nbnxm_gpu_launch_kernel", "no kernel for this electrostatics / VdW combination (LJ-PME grid flavours are not built)");
         }
         if (nb->bDoTime) { t.nb_k.openTimingRegion(s); }
-        hipLaunchKernelGGL(kernel, dim3(plist->nsci), dim3(c_waveSize), 0, s, *adat, *nbp, *plist, stepWork->computeVirial);
+        /* The LJ table lives in LDS (up to ~140 types in the 160 KB; large tables cost occupancy) */
+        const bool useTable = (nbp->vdwType == NBNXM_VDW_CUT || nbp->vdwType == NBNXM_VDW_FSWITCH || nbp->vdwType == NBNXM_VDW_PSWITCH);
+        int        wavesPerBlock = nb->nbWavesPerBlock;
+        const int  tableBytes    = useTable ? adat->numTypes * adat->numTypes * 8 : 0;
+        if (tableBytes > 8 * 1024) { wavesPerBlock = c_nbWavesPerBlock; } /* one table copy per 4 waves */
+        const int ldsBytes = tableBytes + 16 + (fused ? wavesPerBlock * c_superClSize * 16 : 0) + 16;
+        NBNXM_ASSERT(ldsBytes <= 160 * 1024, "too many atom types: the LJ parameter table does not fit the 160 KB LDS");
+        if (ldsBytes > 64 * 1024)
+        {
+            NBNXM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, ldsBytes));
+        }
+        hipLaunchKernelGGL(kernel, dim3((plist->nsci + wavesPerBlock - 1) / wavesPerBlock), dim3(wavesPerBlock * c_waveSize), ldsBytes, s,
+                           *adat, *nbp, *plist, stepWork->computeVirial, plist->sci, plist->cjPacked, plist->excl, adat->xq,
+                           adat->atomTypes, adat->ljComb);
         NBNXM_HIP_CHECK(hipGetLastError());
         if (nb->bDoTime) { t.nb_k.closeTimingRegion(s); }
     }

@@ -21,6 +21,9 @@ constexpr int c_superClSize       = c_clSize * c_numClPerSupercl;
 constexpr int c_centralShiftIndex = NBNXM_CENTRAL_SHIFT_INDEX;
 constexpr int c_numShiftVectors   = NBNXM_NUM_SHIFT_VECTORS;
 constexpr int c_waveSize          = 64;
+/* launch geometry of the cluster-pair kernel: one wavefront per i-entry, 4 wavefronts per workgroup */
+constexpr int c_nbWavesPerBlock   = 4;
+constexpr int c_nbBlockSize       = c_nbWavesPerBlock * c_waveSize;
 /* nbnxm/pairlist.h:166: keeps r^-12 finite in fp32 */
 constexpr float c_nbnxnMinDistanceSquared = 3.82e-07F;
 /* nb_free_energy.cpp:107: cap on r^-6 in the perturbed-pair math */

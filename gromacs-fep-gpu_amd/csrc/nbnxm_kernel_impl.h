@@ -5,13 +5,15 @@
  * FUSED flavour, also  nbnxn_fep_kernel_*  (nbnxm/cuda/nbnxm_fep_cuda_kernel.cuh:87-628) for the force path.
  *
  * Mapping (MI355X-first, not the CUDA one):
- *   - one 64-lane wavefront = one workgroup = one i-super-cluster entry (nbnxn_sci_t);
+ *   - one 64-lane wavefront = one i-super-cluster entry (nbnxn_sci_t), 4 wavefronts per workgroup;
  *     lane = tidxj*8 + tidxi covers a complete 8 x (4+4) cluster pair per step, lanes 0-31 read the
  *     exclusion words of imei[0], lanes 32-63 those of imei[1] (the reference's split-2 list, unchanged);
  *   - list words (sci, cjPacked) are wave-uniform and come through scalar loads; the imask tests are
  *     scalar branches, so a skipped cluster pair costs no vector issue;
- *   - i-atom x/q (+shift, q*epsfac), types or LJ parameters, and for FUSED the A/B charges and types,
- *     are staged once in LDS and re-read as broadcast ds_read_b128/b32 (8 distinct addresses per wave);
+ *   - the 8 i-atoms a lane meets (x, q*epsfac, +shift, type row / LJ parameters) stay in 40 VGPRs for the
+ *     whole entry (the 512-entry register file makes the CUDA kernel's per-pair LDS round trip unnecessary);
+ *     LDS holds what is indexed at run time: the whole nbfp table (shared by the workgroup's waves, one
+ *     ds_read_b64 per pair instead of a 512-byte global gather) and, for FUSED, the i-atoms' A/B data;
  *   - j-atom data: one 16-byte load per lane of 128 contiguous bytes per j-cluster;
  *   - j-forces: 3 DPP adds per component over the 8 lanes that share a j atom, then one no-return
  *     float atomic per component from 24 lanes (96 contiguous bytes);
@@ -32,59 +34,98 @@ struct VdwTraits
     static constexpr bool useTable = (VDW == VDK_CUT || VDW == VDK_FSWITCH || VDW == VDK_PSWITCH);
 };
 
+
+/* Dynamic LDS bytes of one workgroup of the cluster-pair kernel (must match the carve-up in the kernel). */
+inline int nbLdsBytes(int numTypes, bool useTable, bool fused, int wavesPerBlock)
+{
+    const int tableBytes = useTable ? ((numTypes * numTypes * static_cast<int>(sizeof(float2)) + 15) & ~15) : 0;
+    return tableBytes + (fused ? wavesPerBlock * c_superClSize * static_cast<int>(sizeof(float2) + sizeof(int2)) : 0) + 16;
+}
+
 template<int ELEC, bool TWIN, int VDW, bool ENERGY, bool FUSED>
-__launch_bounds__(c_waveSize) __global__
-        void nbnxmKernel(const NBAtomDataGpu atdat, const NBParamGpu nbp, const gpu_plist plist, const int bCalcFshiftIn)
+__launch_bounds__(c_nbBlockSize) __global__
+        void nbnxmKernel(const NBAtomDataGpu atdat,
+                         const NBParamGpu    nbp,
+                         const gpu_plist     plist,
+                         const int           bCalcFshiftIn,
+                         /* read-only, non-aliased views of members of the structs above: with noalias the
+                          * compiler turns the wave-uniform list reads into scalar (SMEM) loads, which retire
+                          * through lgkmcnt and so never wait behind the force atomics in the vmcnt queue */
+                         const nbnxn_sci_t* __restrict__ sciList,
+                         const nbnxn_cj_packed_t* __restrict__ cjPackedList,
+                         const nbnxn_excl_t* __restrict__ exclList,
+                         const float4* __restrict__ xq,
+                         const int* __restrict__ atomTypes,
+                         const float2* __restrict__ ljComb)
 {
     constexpr bool EXCL_FORCES = (ELEC != ELK_CUT) || ENERGY; /* nbnxm_cuda_kernel.cuh:69-78 */
     constexpr bool USE_TABLE   = VdwTraits<VDW>::useTable;
     constexpr int  FEP_ELEC    = (ELEC == ELK_CUT) ? ELK_RF : ELEC;
 
-    const unsigned lane  = threadIdx.x;
+    /* wave-uniform values are pinned to SGPRs with readfirstlane so that everything derived from them
+     * (list walk, branches, list loads) stays on the scalar unit */
+    const unsigned blockSize = __builtin_amdgcn_readfirstlane(blockDim.x);
+    const unsigned lane  = threadIdx.x & (c_waveSize - 1);
+    const unsigned wave  = __builtin_amdgcn_readfirstlane(threadIdx.x / c_waveSize);
     const unsigned tidxi = lane & 7U;
     const unsigned tidxj = lane >> 3;
     const unsigned half  = lane >> 5;
 
-    __shared__ float4 xqib[c_superClSize];
-    __shared__ int    atib[USE_TABLE ? c_superClSize : 1];
-    __shared__ float2 ljcpib[USE_TABLE ? 1 : c_superClSize];
-    __shared__ float2 qABib[FUSED ? c_superClSize : 1]; /* epsfac * (qA, qB) */
-    __shared__ int2   tABib[FUSED ? c_superClSize : 1];
+    /* LDS (all dynamic, sized by the launcher, see nbLdsBytes()): the LJ parameter table shared by the
+     * waves of the workgroup, then per wave the A/B charges and types of its 64 i-atoms (FUSED). */
+    extern __shared__ __align__(16) unsigned char nbLds[];
+    const int numTypes     = atdat.numTypes;
+    float2*   nbfpLds      = reinterpret_cast<float2*>(nbLds);
+    const int tableBytes   = USE_TABLE ? ((numTypes * numTypes * static_cast<int>(sizeof(float2)) + 15) & ~15) : 0;
+    float2*   qABib        = reinterpret_cast<float2*>(nbLds + tableBytes) + (FUSED ? wave * 2 * c_superClSize : 0);
+    int2*     tABib        = reinterpret_cast<int2*>(qABib + c_superClSize);
+    if constexpr (USE_TABLE)
+    {
+        for (int t = threadIdx.x; t < numTypes * numTypes; t += blockSize) { nbfpLds[t] = nbp.nbfp[t]; }
+    }
 
-    const nbnxn_sci_t nb_sci        = plist.sci[blockIdx.x];
+    const int  entry    = __builtin_amdgcn_readfirstlane(static_cast<int>(blockIdx.x * (blockSize / c_waveSize) + wave));
+    const bool haveWork = entry < plist.nsci;
+
+    const nbnxn_sci_t nb_sci        = sciList[haveWork ? entry : 0];
     const int         sci           = nb_sci.sci;
     const int         shiftIdx      = nb_sci.shift & NBNXM_CI_SHIFT_MASK;
     const int         cjPackedBegin = nb_sci.cjPackedBegin;
-    const int         cjPackedEnd   = nb_sci.cjPackedEnd;
+    const int         cjPackedEnd   = haveWork ? nb_sci.cjPackedEnd : nb_sci.cjPackedBegin;
     const bool        central       = (shiftIdx == c_centralShiftIndex);
 
-    const float4* __restrict__ xq = atdat.xq;
-    const int* __restrict__ atomTypes = atdat.atomTypes;
-    const float2* __restrict__ ljComb = atdat.ljComb;
     const float2* __restrict__ nbfp   = nbp.nbfp;
     float* __restrict__ f             = reinterpret_cast<float*>(atdat.f);
-    const int   numTypes              = atdat.numTypes;
     const float rcoulomb_sq           = nbp.rcoulomb_sq;
 
-    /* stage the 64 i-atoms: lane l holds atom l of the super-cluster */
+    /* the 8 i-atoms this lane meets (cluster i, atom tidxi) live in registers for the whole entry:
+     * 32 + 8 VGPRs out of the 512-entry file instead of an LDS round trip per cluster pair */
+    float4 xqi[c_numClPerSupercl];
+    int    trow[c_numClPerSupercl];   /* numTypes * type_i (table flavours) */
+    float2 ljcpi[c_numClPerSupercl];  /* combination-rule flavours */
     {
-        const int    ai  = sci * c_superClSize + static_cast<int>(lane);
-        const float3 sh  = atdat.shiftVec[shiftIdx];
-        float4       xqi = xq[ai];
-        xqi.x += sh.x;
-        xqi.y += sh.y;
-        xqi.z += sh.z;
-        xqi.w *= nbp.epsfac;
-        xqib[lane] = xqi;
-        if constexpr (USE_TABLE) { atib[lane] = atomTypes[ai]; }
-        else { ljcpib[lane] = ljComb[ai]; }
-        if constexpr (FUSED)
+        const float3 sh = atdat.shiftVec[shiftIdx];
+#pragma unroll
+        for (int i = 0; i < c_numClPerSupercl; i++)
         {
-            const float4 q4 = atdat.q4[ai];
-            qABib[lane]     = make_float2(q4.x * nbp.epsfac, q4.y * nbp.epsfac);
-            const int4 t4   = atdat.atomTypes4[ai];
-            tABib[lane]     = make_int2(t4.x, t4.y);
+            const int ai = (sci * c_numClPerSupercl + i) * c_clSize + static_cast<int>(tidxi);
+            float4    v  = xq[ai];
+            v.x += sh.x;
+            v.y += sh.y;
+            v.z += sh.z;
+            v.w *= nbp.epsfac;
+            xqi[i] = v;
+            if constexpr (USE_TABLE) { trow[i] = numTypes * atomTypes[ai]; }
+            else { ljcpi[i] = ljComb[ai]; }
         }
+    }
+    if constexpr (FUSED)
+    {
+        const int    ai = sci * c_superClSize + static_cast<int>(lane);
+        const float4 q4 = atdat.q4[ai];
+        qABib[lane]     = make_float2(q4.x * nbp.epsfac, q4.y * nbp.epsfac);
+        const int4 t4   = atdat.atomTypes4[ai];
+        tABib[lane]     = make_int2(t4.x, t4.y);
     }
     __syncthreads();
 
@@ -109,10 +150,10 @@ __launch_bounds__(c_waveSize) __global__
     if constexpr (ENERGY && EXCL_FORCES)
     {
         /* self terms on the diagonal entry (nbnxm_cuda_kernel.cuh:365-400); lane l owns atom l */
-        if (central && plist.cjPacked[cjPackedBegin].cj[0] == sci * c_numClPerSupercl)
+        if (haveWork && central && cjPackedList[cjPackedBegin].cj[0] == sci * c_numClPerSupercl)
         {
             const float coef = (ELEC == ELK_CUT || ELEC == ELK_RF) ? -0.5F * nbp.c_rf : -nbp.ewald_beta * c_oneOverSqrtPi;
-            const float qi   = xqib[lane].w;
+            const float qi   = xq[sci * c_superClSize + static_cast<int>(lane)].w * nbp.epsfac;
             E_el += qi * qi / nbp.epsfac * coef;
             if constexpr (FUSED)
             {
@@ -130,70 +171,184 @@ __launch_bounds__(c_waveSize) __global__
         }
     }
 
+    /* LJ parameters of one atom pair */
+    auto ljParams = [&](int i, int typej, const float2& ljcp_j, float& c6, float& c12) {
+        if constexpr (USE_TABLE)
+        {
+            const float2 c6c12 = nbfpLds[trow[i] + typej];
+            c6                 = c6c12.x;
+            c12                = c6c12.y;
+        }
+        else if constexpr (VDW == VDK_COMB_GEOM)
+        {
+            c6  = ljcpi[i].x * ljcp_j.x;
+            c12 = ljcpi[i].y * ljcp_j.y;
+        }
+        else
+        {
+            const float sigma  = ljcpi[i].x + ljcp_j.x;
+            const float eps    = ljcpi[i].y * ljcp_j.y;
+            const float sigma2 = sigma * sigma;
+            const float sigma6 = sigma2 * sigma2 * sigma2;
+            c6                 = eps * sigma6;
+            c12                = c6 * sigma6;
+        }
+    };
+
+    /* Walk over the j-clusters of this entry.  On gfx950 loads and no-return atomics retire through the
+     * same in-order vmcnt counter: a load issued AFTER an atomic cannot be consumed before that atomic
+     * has made its whole memory-side round trip (~1-3 us under load).  So the j-force atomic of a
+     * j-cluster is deferred (value + address carried in two registers) until the loads of the next
+     * j-cluster have been issued; the wait for those loads is then a counted vmcnt(1) that leaves the
+     * atomic in flight. */
+    /* buffer atomics: a lane whose byte offset lies beyond the buffer is dropped by the hardware range
+     * check, so "no atomic for this lane" needs no branch and the vmcnt bookkeeping stays exact */
+    const __amdgpu_buffer_rsrc_t fRsrc =
+            __builtin_amdgcn_make_buffer_rsrc(f, 0, atdat.numAtoms * 3 * static_cast<int>(sizeof(float)), 0x00020000);
+    constexpr int c_dropLane = 0x7FFFFFF0;
+    float pendingF   = 0.0F;
+    int   pendingOff = c_dropLane; /* byte offset into f of the deferred j-force component */
     for (int jPacked = cjPackedBegin; jPacked < cjPackedEnd; jPacked++)
     {
-        const nbnxn_cj_packed_t* __restrict__ grp = &plist.cjPacked[jPacked];
+        const nbnxn_cj_packed_t* __restrict__ grp = &cjPackedList[jPacked];
         const unsigned imask = grp->imei[0].imask;
         if (imask == 0U) { continue; }
         const int      exclInd0 = grp->imei[0].excl_ind;
         const int      exclInd1 = grp->imei[1].excl_ind;
-        const unsigned wexcl    = plist.excl[half ? exclInd1 : exclInd0].pair[lane & 31U];
+        const unsigned wexcl    = exclList[half ? exclInd1 : exclInd0].pair[lane & 31U];
 
 #pragma unroll 1
         for (int jm = 0; jm < c_jGroupSize; jm++)
         {
-            const unsigned imaskJ = (imask >> (jm * c_numClPerSupercl)) & 0xFFU;
-            if (imaskJ == 0U) { continue; }
-            const unsigned wexclJ = wexcl >> (jm * c_numClPerSupercl);
+        const unsigned imaskJ = (imask >> (jm * c_numClPerSupercl)) & 0xFFU;
+        if (imaskJ == 0U) { continue; }
+        const unsigned wexclJ = wexcl >> (jm * c_numClPerSupercl);
+        const int      cj     = grp->cj[jm];
+        const int      aj     = cj * c_clSize + static_cast<int>(tidxj);
+        const float4   xqj    = xq[aj];
+        int            typej  = 0;
+        float2         ljcp_j = make_float2(0.0F, 0.0F);
+        if constexpr (USE_TABLE) { typej = atomTypes[aj]; }
+        else { ljcp_j = ljComb[aj]; }
+        unsigned fepJ = 0U;
+        if constexpr (FUSED) { fepJ = atdat.fepBits[cj]; }
+        /* the previous j-cluster's force leaves now, behind this j-cluster's loads */
+        __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(pendingF, fRsrc, pendingOff, 0, 0);
 
-            const int    cj   = grp->cj[jm];
-            const int    aj   = cj * c_clSize + static_cast<int>(tidxj);
-            const float4 xqj  = xq[aj];
-            int          typej = 0;
-            float2       ljcp_j = make_float2(0.0F, 0.0F);
-            if constexpr (USE_TABLE) { typej = atomTypes[aj]; }
-            else { ljcp_j = ljComb[aj]; }
+        float3 fcj_buf = make_float3(0.0F, 0.0F, 0.0F);
+        /* which i-cluster (if any) is this j-cluster itself on the central image */
+        [[maybe_unused]] const int diagI = (central && (cj >> 3) == sci) ? (cj & 7) : -1;
 
-            float3 fcj_buf = make_float3(0.0F, 0.0F, 0.0F);
+        bool slowPath = false;
+        unsigned jFepBits = 0;
+        if constexpr (FUSED)
+        {
+            jFepBits = __builtin_amdgcn_readfirstlane(fepJ);
+            slowPath = (iFepBits != 0ULL) || (jFepBits != 0U);
+        }
 
-            bool slowPath = false;
-            unsigned jFepBits = 0;
+        if (!slowPath)
+        {
+#pragma unroll
+            for (int i = 0; i < c_numClPerSupercl; i++)
+            {
+                if (imaskJ & (1U << i))
+                {
+                    const float3 rv  = make_float3(xqi[i].x - xqj.x, xqi[i].y - xqj.y, xqi[i].z - xqj.z);
+                    const float  r2  = rv.x * rv.x + rv.y * rv.y + rv.z * rv.z;
+                    const float  int_bit = ((wexclJ >> i) & 1U) ? 1.0F : 0.0F;
+                    bool         active;
+                    if constexpr (EXCL_FORCES)
+                    {
+                        const int ci = sci * c_numClPerSupercl + i;
+                        active       = (r2 < rcoulomb_sq) && (!(central && tidxj <= tidxi) || ci != cj);
+                    }
+                    else { active = (r2 < rcoulomb_sq) && (int_bit != 0.0F); }
+                    if (active)
+                    {
+                        float c6, c12;
+                        ljParams(i, typej, ljcp_j, c6, c12);
+                        float F_invr, E_lj_p = 0.0F, E_el_p = 0.0F;
+                        nbPair<ELEC, TWIN, VDW, ENERGY, EXCL_FORCES>(nbp, r2, int_bit, xqi[i].w * xqj.w, c6, c12,
+                                                                     F_invr, E_lj_p, E_el_p);
+                        if constexpr (ENERGY)
+                        {
+                            E_lj += E_lj_p;
+                            E_el += E_el_p;
+                        }
+                        const float3 f_ij = make_float3(rv.x * F_invr, rv.y * F_invr, rv.z * F_invr);
+                        fcj_buf.x -= f_ij.x;
+                        fcj_buf.y -= f_ij.y;
+                        fcj_buf.z -= f_ij.z;
+                        fci_buf[i].x += f_ij.x;
+                        fci_buf[i].y += f_ij.y;
+                        fci_buf[i].z += f_ij.z;
+                    }
+                }
+            }
+        }
+        else
+        {
             if constexpr (FUSED)
             {
-                jFepBits = __builtin_amdgcn_readfirstlane(static_cast<unsigned>(atdat.fepBits[cj]));
-                slowPath = (iFepBits != 0ULL) || (jFepBits != 0U);
-            }
-
-            if (!slowPath)
-            {
-#pragma unroll
+                /* rare path: the cluster pair touches a perturbed atom; i is a run-time index here, so the
+                 * i-atom data is re-read from memory instead of the register arrays */
+                const float4 q4j = atdat.q4[aj];
+                const int4   t4j = atdat.atomTypes4[aj];
+                const float3 sh  = atdat.shiftVec[shiftIdx];
+#pragma unroll 1
                 for (int i = 0; i < c_numClPerSupercl; i++)
                 {
-                    if (imaskJ & (1U << i))
+                    if (!(imaskJ & (1U << i))) { continue; }
+                    const unsigned iBits = static_cast<unsigned>(iFepBits >> (i * c_clSize)) & 0xFFU;
+                    const int      ci    = sci * c_numClPerSupercl + i;
+                    const int      ai    = ci * c_clSize + static_cast<int>(tidxi);
+                    float4         xi    = xq[ai];
+                    xi.x += sh.x;
+                    xi.y += sh.y;
+                    xi.z += sh.z;
+                    xi.w *= nbp.epsfac;
+                    const float3   rv    = make_float3(xi.x - xqj.x, xi.y - xqj.y, xi.z - xqj.z);
+                    const float    r2    = rv.x * rv.x + rv.y * rv.y + rv.z * rv.z;
+                    const bool     included = ((wexclJ >> i) & 1U) != 0U;
+                    const bool     subDiag  = central && (ci == cj) && (tidxj <= tidxi);
+                    const bool     pert     = (((iBits >> tidxi) | (jFepBits >> tidxj)) & 1U) != 0U;
+                    float          F_invr   = 0.0F;
+                    if (pert)
                     {
-                        const float4 xqi = xqib[i * c_clSize + tidxi];
-                        const float3 rv  = make_float3(xqi.x - xqj.x, xqi.y - xqj.y, xqi.z - xqj.z);
-                        const float  r2  = rv.x * rv.x + rv.y * rv.y + rv.z * rv.z;
-                        const float  int_bit = ((wexclJ >> i) & 1U) ? 1.0F : 0.0F;
-                        bool         active;
-                        if constexpr (EXCL_FORCES)
+                        if (!subDiag)
                         {
-                            const int ci = sci * c_numClPerSupercl + i;
-                            active       = (r2 < rcoulomb_sq) && (!(central && tidxj <= tidxi) || ci != cj);
+                            const float2 qABi = qABib[i * c_clSize + tidxi];
+                            const int2   tABi = tABib[i * c_clSize + tidxi];
+                            const float  qq[2] = { qABi.x * q4j.x, qABi.y * q4j.y };
+                            const float2 pA    = nbfp[numTypes * tABi.x + t4j.x];
+                            const float2 pB    = nbfp[numTypes * tABi.y + t4j.y];
+                            const float  c6[2]  = { pA.x, pB.x };
+                            const float  c12[2] = { pA.y, pB.y };
+                            float        fscal  = 0.0F;
+                            const bool   done = fepPair<FEP_ELEC, VDW == VDK_PSWITCH, true, ENERGY>(
+                                    nbp, L, r2, included, false, qq, c6, c12, fscal, E_lj, E_el, DVDL_lj, DVDL_el);
+                            F_invr = done ? fscal : 0.0F;
                         }
-                        else { active = (r2 < rcoulomb_sq) && (int_bit != 0.0F); }
+                    }
+                    else
+                    {
+                        const float int_bit = included ? 1.0F : 0.0F;
+                        bool        active;
+                        if constexpr (EXCL_FORCES) { active = (r2 < rcoulomb_sq) && !subDiag; }
+                        else { active = (r2 < rcoulomb_sq) && included; }
                         if (active)
                         {
                             float c6, c12;
                             if constexpr (USE_TABLE)
                             {
-                                const float2 c6c12 = nbfp[numTypes * atib[i * c_clSize + tidxi] + typej];
+                                const float2 c6c12 = nbfp[numTypes * atomTypes[ai] + typej];
                                 c6                 = c6c12.x;
                                 c12                = c6c12.y;
                             }
                             else
                             {
-                                const float2 ljcp_i = ljcpib[i * c_clSize + tidxi];
+                                const float2 ljcp_i = ljComb[ai];
                                 if constexpr (VDW == VDK_COMB_GEOM)
                                 {
                                     c6  = ljcp_i.x * ljcp_j.x;
@@ -209,136 +364,47 @@ __launch_bounds__(c_waveSize) __global__
                                     c12                = c6 * sigma6;
                                 }
                             }
-                            float F_invr, E_lj_p = 0.0F, E_el_p = 0.0F;
-                            nbPair<ELEC, TWIN, VDW, ENERGY, EXCL_FORCES>(nbp, r2, int_bit, xqi.w * xqj.w, c6, c12,
+                            float E_lj_p = 0.0F, E_el_p = 0.0F;
+                            nbPair<ELEC, TWIN, VDW, ENERGY, EXCL_FORCES>(nbp, r2, int_bit, xi.w * xqj.w, c6, c12,
                                                                          F_invr, E_lj_p, E_el_p);
                             if constexpr (ENERGY)
                             {
                                 E_lj += E_lj_p;
                                 E_el += E_el_p;
                             }
-                            const float3 f_ij = make_float3(rv.x * F_invr, rv.y * F_invr, rv.z * F_invr);
-                            fcj_buf.x -= f_ij.x;
-                            fcj_buf.y -= f_ij.y;
-                            fcj_buf.z -= f_ij.z;
-                            fci_buf[i].x += f_ij.x;
-                            fci_buf[i].y += f_ij.y;
-                            fci_buf[i].z += f_ij.z;
                         }
                     }
-                }
-            }
-            else
-            {
-                if constexpr (FUSED)
-                {
-                    /* rare path: the cluster pair touches a perturbed atom */
-                    const float4 q4j = atdat.q4[aj];
-                    const int4   t4j = atdat.atomTypes4[aj];
-#pragma unroll 1
-                    for (int i = 0; i < c_numClPerSupercl; i++)
+                    const float3 f_ij = make_float3(rv.x * F_invr, rv.y * F_invr, rv.z * F_invr);
+                    fcj_buf.x -= f_ij.x;
+                    fcj_buf.y -= f_ij.y;
+                    fcj_buf.z -= f_ij.z;
+                    /* i-force of this cluster leaves directly (dynamic i: no register array indexing) */
+                    const float fix = reduceOverTidxj(f_ij.x);
+                    const float fiy = reduceOverTidxj(f_ij.y);
+                    const float fiz = reduceOverTidxj(f_ij.z);
+                    if (tidxj < 3U)
                     {
-                        if (!(imaskJ & (1U << i))) { continue; }
-                        const unsigned iBits = static_cast<unsigned>(iFepBits >> (i * c_clSize)) & 0xFFU;
-                        const float4   xqi   = xqib[i * c_clSize + tidxi];
-                        const float3   rv    = make_float3(xqi.x - xqj.x, xqi.y - xqj.y, xqi.z - xqj.z);
-                        const float    r2    = rv.x * rv.x + rv.y * rv.y + rv.z * rv.z;
-                        const bool     included = ((wexclJ >> i) & 1U) != 0U;
-                        const int      ci       = sci * c_numClPerSupercl + i;
-                        const bool     subDiag  = central && (ci == cj) && (tidxj <= tidxi);
-                        const bool     pert     = (((iBits >> tidxi) | (jFepBits >> tidxj)) & 1U) != 0U;
-                        float          F_invr   = 0.0F;
-                        if (pert)
-                        {
-                            if (!subDiag)
-                            {
-                                const float2 qABi = qABib[i * c_clSize + tidxi];
-                                const int2   tABi = tABib[i * c_clSize + tidxi];
-                                const float  qq[2] = { qABi.x * q4j.x, qABi.y * q4j.y };
-                                const float2 pA    = nbfp[numTypes * tABi.x + t4j.x];
-                                const float2 pB    = nbfp[numTypes * tABi.y + t4j.y];
-                                const float  c6[2]  = { pA.x, pB.x };
-                                const float  c12[2] = { pA.y, pB.y };
-                                float        fscal  = 0.0F;
-                                const bool   done = fepPair<FEP_ELEC, VDW == VDK_PSWITCH, true, ENERGY>(
-                                        nbp, L, r2, included, false, qq, c6, c12, fscal, E_lj, E_el, DVDL_lj, DVDL_el);
-                                F_invr = done ? fscal : 0.0F;
-                            }
-                        }
-                        else
-                        {
-                            const float int_bit = included ? 1.0F : 0.0F;
-                            bool        active;
-                            if constexpr (EXCL_FORCES) { active = (r2 < rcoulomb_sq) && !subDiag; }
-                            else { active = (r2 < rcoulomb_sq) && included; }
-                            if (active)
-                            {
-                                float c6, c12;
-                                if constexpr (USE_TABLE)
-                                {
-                                    const float2 c6c12 = nbfp[numTypes * atib[i * c_clSize + tidxi] + typej];
-                                    c6                 = c6c12.x;
-                                    c12                = c6c12.y;
-                                }
-                                else
-                                {
-                                    const float2 ljcp_i = ljcpib[i * c_clSize + tidxi];
-                                    if constexpr (VDW == VDK_COMB_GEOM)
-                                    {
-                                        c6  = ljcp_i.x * ljcp_j.x;
-                                        c12 = ljcp_i.y * ljcp_j.y;
-                                    }
-                                    else
-                                    {
-                                        const float sigma  = ljcp_i.x + ljcp_j.x;
-                                        const float eps    = ljcp_i.y * ljcp_j.y;
-                                        const float sigma2 = sigma * sigma;
-                                        const float sigma6 = sigma2 * sigma2 * sigma2;
-                                        c6                 = eps * sigma6;
-                                        c12                = c6 * sigma6;
-                                    }
-                                }
-                                float E_lj_p = 0.0F, E_el_p = 0.0F;
-                                nbPair<ELEC, TWIN, VDW, ENERGY, EXCL_FORCES>(nbp, r2, int_bit, xqi.w * xqj.w, c6, c12,
-                                                                             F_invr, E_lj_p, E_el_p);
-                                if constexpr (ENERGY)
-                                {
-                                    E_lj += E_lj_p;
-                                    E_el += E_el_p;
-                                }
-                            }
-                        }
-                        const float3 f_ij = make_float3(rv.x * F_invr, rv.y * F_invr, rv.z * F_invr);
-                        fcj_buf.x -= f_ij.x;
-                        fcj_buf.y -= f_ij.y;
-                        fcj_buf.z -= f_ij.z;
-                        /* i-force of this cluster leaves directly (dynamic i: no register array indexing) */
-                        const float fix = reduceOverTidxj(f_ij.x);
-                        const float fiy = reduceOverTidxj(f_ij.y);
-                        const float fiz = reduceOverTidxj(f_ij.z);
-                        if (tidxj < 3U)
-                        {
-                            const float v = (tidxj == 0U) ? fix : ((tidxj == 1U) ? fiy : fiz);
-                            atomicAdd(&f[3 * (ci * c_clSize + static_cast<int>(tidxi)) + static_cast<int>(tidxj)], v);
-                        }
-                        fSlowShift.x += f_ij.x;
-                        fSlowShift.y += f_ij.y;
-                        fSlowShift.z += f_ij.z;
+                        const float v = (tidxj == 0U) ? fix : ((tidxj == 1U) ? fiy : fiz);
+                        atomicAdd(&f[3 * ai + static_cast<int>(tidxj)], v);
                     }
+                    fSlowShift.x += f_ij.x;
+                    fSlowShift.y += f_ij.y;
+                    fSlowShift.z += f_ij.z;
                 }
-            }
-
-            /* j-force: sum over the 8 lanes of a j atom, lanes tidxi 0..2 add x,y,z */
-            const float fjx = reduceOver8Lanes(fcj_buf.x);
-            const float fjy = reduceOver8Lanes(fcj_buf.y);
-            const float fjz = reduceOver8Lanes(fcj_buf.z);
-            if (tidxi < 3U)
-            {
-                const float v = (tidxi == 0U) ? fjx : ((tidxi == 1U) ? fjy : fjz);
-                atomicAdd(&f[3 * aj + static_cast<int>(tidxi)], v);
             }
         }
+
+        /* j-force: sum over the 8 lanes of a j atom; lanes tidxi 0..2 carry x,y,z to the deferred atomic */
+        const float fjx = reduceOver8Lanes(fcj_buf.x);
+        const float fjy = reduceOver8Lanes(fcj_buf.y);
+        const float fjz = reduceOver8Lanes(fcj_buf.z);
+        pendingF        = (tidxi == 0U) ? fjx : ((tidxi == 1U) ? fjy : fjz);
+        pendingOff      = (tidxi < 3U) ? (3 * aj + static_cast<int>(tidxi)) * static_cast<int>(sizeof(float)) : c_dropLane;
+        }
     }
+    __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(pendingF, fRsrc, pendingOff, 0, 0);
+
+    if (!haveWork) { return; }
 
     /* i-forces: reduce over tidxj; lane (tidxj, tidxi) keeps the sum of cluster tidxj, atom tidxi */
     float3 mine = make_float3(0.0F, 0.0F, 0.0F);

@@ -238,13 +238,17 @@ def run_gpu(c, energy=True, fused=False, dhdl=False, nb=None, prune=False):
 # ---- comparison -------------------------------------------------------------------------------------------
 
 def assert_parity(got, want, rel=1e-4, energy=True, label=""):
-    """Forces: per-component error relative to the RMS force; sums that cancel (energies, dV/dl, fshift):
+    """Forces: per-atom error relative to max(|f_i|, RMS |f|); sums that cancel (energies, dV/dl, fshift):
     relative to the larger of |value| and a scale of the summed magnitudes (SURVEY §7 'hard parts')."""
     f_got, f_want = np.asarray(got["f"]), np.asarray(want["f"])
-    frms = math.sqrt(float(np.mean(f_want ** 2))) + 1e-30
-    ferr = float(np.max(np.abs(f_got - f_want)))
-    assert ferr <= rel * max(frms, float(np.max(np.abs(f_want))) * 0.05), \
-        "%s force max err %.3e (rms force %.3e)" % (label, ferr, frms)
+    frms = math.sqrt(float(np.mean(np.sum(f_want ** 2, axis=1)))) + 1e-30
+    # per atom: |delta f_i| <= rel * max(|f_i|, rms |f|)
+    ferr = np.sqrt(np.sum((f_got - f_want) ** 2, axis=1))
+    ftol = rel * np.maximum(np.sqrt(np.sum(f_want ** 2, axis=1)), frms)
+    worst = int(np.argmax(ferr / ftol))
+    assert ferr[worst] <= ftol[worst], \
+        "%s force err %.3e on atom %d (|f| %.3e, rms |f| %.3e)" % (label, ferr[worst], worst,
+                                                                 math.sqrt(float(np.sum(f_want[worst] ** 2))), frms)
     fs_scale = max(float(np.max(np.abs(want["fshift"]))), frms)
     fserr = float(np.max(np.abs(np.asarray(got["fshift"]) - np.asarray(want["fshift"]))))
     assert fserr <= 10 * rel * fs_scale, "%s fshift max err %.3e (scale %.3e)" % (label, fserr, fs_scale)
