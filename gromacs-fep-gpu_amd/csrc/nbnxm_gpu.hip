@@ -763,7 +763,7 @@ void nbnxm_gpu_launch_kernel(NbnxmGpu* nb, const nbnxm_step_workload_t* stepWork
         int        wavesPerBlock = nb->nbWavesPerBlock;
         const int  tableBytes    = useTable ? adat->numTypes * adat->numTypes * 8 : 0;
         if (tableBytes > 8 * 1024) { wavesPerBlock = c_nbWavesPerBlock; } /* one table copy per 4 waves */
-        const int ldsBytes = tableBytes + 16 + (fused ? wavesPerBlock * c_superClSize * 16 : 0) + 16;
+        const int ldsBytes = tableBytes + 16 + (fused ? wavesPerBlock * c_superClSize * 32 : 0) + 16;
         NBNXM_ASSERT(ldsBytes <= 160 * 1024, "too many atom types: the LJ parameter table does not fit the 160 KB LDS");
         if (ldsBytes > 64 * 1024)
         {

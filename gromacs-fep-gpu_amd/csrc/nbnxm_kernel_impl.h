@@ -39,7 +39,7 @@ struct VdwTraits
 inline int nbLdsBytes(int numTypes, bool useTable, bool fused, int wavesPerBlock)
 {
     const int tableBytes = useTable ? ((numTypes * numTypes * static_cast<int>(sizeof(float2)) + 15) & ~15) : 0;
-    return tableBytes + (fused ? wavesPerBlock * c_superClSize * static_cast<int>(sizeof(float2) + sizeof(int2)) : 0) + 16;
+    return tableBytes + (fused ? wavesPerBlock * c_superClSize * static_cast<int>(sizeof(float4) + sizeof(float2) + sizeof(int2)) : 0) + 16;
 }
 
 template<int ELEC, bool TWIN, int VDW, bool ENERGY, bool FUSED>
@@ -77,7 +77,9 @@ __launch_bounds__(c_nbBlockSize) __global__
     const int numTypes     = atdat.numTypes;
     float2*   nbfpLds      = reinterpret_cast<float2*>(nbLds);
     const int tableBytes   = USE_TABLE ? ((numTypes * numTypes * static_cast<int>(sizeof(float2)) + 15) & ~15) : 0;
-    float2*   qABib        = reinterpret_cast<float2*>(nbLds + tableBytes) + (FUSED ? wave * 2 * c_superClSize : 0);
+    /* per wave (FUSED): 64 x { float4 x,q*epsfac (shifted) ; float2 epsfac*(qA,qB) ; int2 (typeA,typeB) } */
+    float4*   xqib         = reinterpret_cast<float4*>(nbLds + tableBytes) + (FUSED ? wave * 2 * c_superClSize : 0);
+    float2*   qABib        = reinterpret_cast<float2*>(xqib + c_superClSize);
     int2*     tABib        = reinterpret_cast<int2*>(qABib + c_superClSize);
     if constexpr (USE_TABLE)
     {
@@ -122,6 +124,13 @@ __launch_bounds__(c_nbBlockSize) __global__
     if constexpr (FUSED)
     {
         const int    ai = sci * c_superClSize + static_cast<int>(lane);
+        const float3 sh = atdat.shiftVec[shiftIdx];
+        float4       xl = xq[ai];
+        xl.x += sh.x;
+        xl.y += sh.y;
+        xl.z += sh.z;
+        xl.w *= nbp.epsfac;
+        xqib[lane]      = xl;
         const float4 q4 = atdat.q4[ai];
         qABib[lane]     = make_float2(q4.x * nbp.epsfac, q4.y * nbp.epsfac);
         const int4 t4   = atdat.atomTypes4[ai];
@@ -138,6 +147,15 @@ __launch_bounds__(c_nbBlockSize) __global__
         iFepBits = __builtin_amdgcn_readfirstlane(static_cast<unsigned>(iFepBits))
                    | (static_cast<unsigned long long>(__builtin_amdgcn_readfirstlane(static_cast<unsigned>(iFepBits >> 32))) << 32);
         L = makeFepLambda(nbp.lambda_q, nbp.lambda_v, nbp.lam_power, nbp.alpha_coul, nbp.alpha_vdw);
+    }
+    unsigned iFepClusterMask = 0U; /* bit i: i-cluster i holds a perturbed atom */
+    if constexpr (FUSED)
+    {
+#pragma unroll
+        for (int i = 0; i < c_numClPerSupercl; i++)
+        {
+            if ((iFepBits >> (i * c_clSize)) & 0xFFULL) { iFepClusterMask |= (1U << i); }
+        }
     }
 
     float3 fci_buf[c_numClPerSupercl];
@@ -239,20 +257,23 @@ __launch_bounds__(c_nbBlockSize) __global__
         /* which i-cluster (if any) is this j-cluster itself on the central image */
         [[maybe_unused]] const int diagI = (central && (cj >> 3) == sci) ? (cj & 7) : -1;
 
-        bool slowPath = false;
-        unsigned jFepBits = 0;
+        /* FUSED: i-clusters that must take the perturbed-pair path for this j-cluster: all of them when the
+         * j-cluster holds a perturbed atom, otherwise only the i-clusters that hold one */
+        unsigned jFepBits = 0U;
+        unsigned slowMask = 0U;
         if constexpr (FUSED)
         {
             jFepBits = __builtin_amdgcn_readfirstlane(fepJ);
-            slowPath = (iFepBits != 0ULL) || (jFepBits != 0U);
+            slowMask = (jFepBits != 0U) ? imaskJ : (imaskJ & iFepClusterMask);
         }
+        const unsigned fastMask = imaskJ & ~slowMask;
 
-        if (!slowPath)
+        if (fastMask != 0U)
         {
 #pragma unroll
             for (int i = 0; i < c_numClPerSupercl; i++)
             {
-                if (imaskJ & (1U << i))
+                if (fastMask & (1U << i))
                 {
                     const float3 rv  = make_float3(xqi[i].x - xqj.x, xqi[i].y - xqj.y, xqi[i].z - xqj.z);
                     const float  r2  = rv.x * rv.x + rv.y * rv.y + rv.z * rv.z;
@@ -287,27 +308,23 @@ __launch_bounds__(c_nbBlockSize) __global__
                 }
             }
         }
-        else
+        if constexpr (FUSED)
         {
-            if constexpr (FUSED)
+            if (slowMask != 0U)
             {
                 /* rare path: the cluster pair touches a perturbed atom; i is a run-time index here, so the
-                 * i-atom data is re-read from memory instead of the register arrays */
+                 * i-atom data comes from the wave's LDS copy instead of the register arrays.  Nothing in
+                 * the loop below reads global memory, so its i-force atomics never stall a later load. */
                 const float4 q4j = atdat.q4[aj];
                 const int4   t4j = atdat.atomTypes4[aj];
-                const float3 sh  = atdat.shiftVec[shiftIdx];
 #pragma unroll 1
                 for (int i = 0; i < c_numClPerSupercl; i++)
                 {
-                    if (!(imaskJ & (1U << i))) { continue; }
+                    if (!(slowMask & (1U << i))) { continue; }
                     const unsigned iBits = static_cast<unsigned>(iFepBits >> (i * c_clSize)) & 0xFFU;
                     const int      ci    = sci * c_numClPerSupercl + i;
                     const int      ai    = ci * c_clSize + static_cast<int>(tidxi);
-                    float4         xi    = xq[ai];
-                    xi.x += sh.x;
-                    xi.y += sh.y;
-                    xi.z += sh.z;
-                    xi.w *= nbp.epsfac;
+                    const float4   xi    = xqib[i * c_clSize + tidxi];
                     const float3   rv    = make_float3(xi.x - xqj.x, xi.y - xqj.y, xi.z - xqj.z);
                     const float    r2    = rv.x * rv.x + rv.y * rv.y + rv.z * rv.z;
                     const bool     included = ((wexclJ >> i) & 1U) != 0U;
@@ -321,8 +338,8 @@ __launch_bounds__(c_nbBlockSize) __global__
                             const float2 qABi = qABib[i * c_clSize + tidxi];
                             const int2   tABi = tABib[i * c_clSize + tidxi];
                             const float  qq[2] = { qABi.x * q4j.x, qABi.y * q4j.y };
-                            const float2 pA    = nbfp[numTypes * tABi.x + t4j.x];
-                            const float2 pB    = nbfp[numTypes * tABi.y + t4j.y];
+                            const float2 pA    = USE_TABLE ? nbfpLds[numTypes * tABi.x + t4j.x] : nbfp[numTypes * tABi.x + t4j.x];
+                            const float2 pB    = USE_TABLE ? nbfpLds[numTypes * tABi.y + t4j.y] : nbfp[numTypes * tABi.y + t4j.y];
                             const float  c6[2]  = { pA.x, pB.x };
                             const float  c12[2] = { pA.y, pB.y };
                             float        fscal  = 0.0F;
@@ -342,7 +359,8 @@ __launch_bounds__(c_nbBlockSize) __global__
                             float c6, c12;
                             if constexpr (USE_TABLE)
                             {
-                                const float2 c6c12 = nbfp[numTypes * atomTypes[ai] + typej];
+                                /* a non-perturbed atom's type is its A-state type */
+                                const float2 c6c12 = nbfpLds[numTypes * tABib[i * c_clSize + tidxi].x + typej];
                                 c6                 = c6c12.x;
                                 c12                = c6c12.y;
                             }
@@ -382,10 +400,10 @@ __launch_bounds__(c_nbBlockSize) __global__
                     const float fix = reduceOverTidxj(f_ij.x);
                     const float fiy = reduceOverTidxj(f_ij.y);
                     const float fiz = reduceOverTidxj(f_ij.z);
-                    if (tidxj < 3U)
                     {
-                        const float v = (tidxj == 0U) ? fix : ((tidxj == 1U) ? fiy : fiz);
-                        atomicAdd(&f[3 * ai + static_cast<int>(tidxj)], v);
+                        const float v   = (tidxj == 0U) ? fix : ((tidxj == 1U) ? fiy : fiz);
+                        const int   off = (tidxj < 3U) ? (3 * ai + static_cast<int>(tidxj)) * static_cast<int>(sizeof(float)) : c_dropLane;
+                        __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(v, fRsrc, off, 0, 0);
                     }
                     fSlowShift.x += f_ij.x;
                     fSlowShift.y += f_ij.y;

@@ -667,8 +667,13 @@ NbnxmHostPairlist* nbnxm_host_pairlist_build(const NbnxmHostGrid* g, const int* 
                 }
             }
 
-            // close the entry, optionally split into chunks (list balancing)
-            const int chunk = (maxCjPackedPerSci > 0) ? maxCjPackedPerSci : (groupEnd - groupBegin);
+            // close the entry, optionally split into chunks (list balancing); when the perturbed pairs stay
+            // in the cluster list, entries whose i-clusters hold perturbed atoms cost several times more per
+            // j-cluster, so they get quarter-size chunks
+            bool perturbedI = false;
+            for (int cil = 0; cil < NCL; cil++) { perturbedI = perturbedI || (g->fepBits[sci * NCL + cil] != 0); }
+            int chunk = (maxCjPackedPerSci > 0) ? maxCjPackedPerSci : (groupEnd - groupBegin);
+            if (!carveFep && perturbedI && maxCjPackedPerSci > 0) { chunk = std::max(1, chunk / 4); }
             for (int b = groupBegin; b < groupEnd; b += chunk)
             {
                 nbnxn_sci_t e;
@@ -720,10 +725,15 @@ NbnxmHostPairlist* nbnxm_host_pairlist_build(const NbnxmHostGrid* g, const int* 
         pl->numClusterPairs += w.numClusterPairs;
         w = SciWork();
     }
-    // longest entries first (the reference sorts the sci list by work, pairlist.cpp sort_sci)
-    std::stable_sort(pl->sci.begin(), pl->sci.end(), [](const nbnxn_sci_t& a, const nbnxn_sci_t& b) {
-        return (a.cjPackedEnd - a.cjPackedBegin) > (b.cjPackedEnd - b.cjPackedBegin);
-    });
+    // most expensive entries first (the reference sorts the sci list by work, pairlist.cpp sort_sci);
+    // with un-carved lists, entries with perturbed i-clusters count 4x
+    auto cost = [&](const nbnxn_sci_t& e) {
+        int  w          = e.cjPackedEnd - e.cjPackedBegin;
+        bool perturbedI = false;
+        for (int cil = 0; cil < NCL; cil++) { perturbedI = perturbedI || (g->fepBits[e.sci * NCL + cil] != 0); }
+        return (!carveFep && perturbedI) ? 4 * w + 1000000 : w;
+    };
+    std::stable_sort(pl->sci.begin(), pl->sci.end(), [&](const nbnxn_sci_t& a, const nbnxn_sci_t& b) { return cost(a) > cost(b); });
     return pl;
 }
 
