@@ -5,23 +5,29 @@
  * FUSED flavour, also  nbnxn_fep_kernel_*  (nbnxm/cuda/nbnxm_fep_cuda_kernel.cuh:87-628) for the force path.
  *
  * Mapping (MI355X-first, not the CUDA one):
- *   - one 64-lane wavefront = one i-super-cluster entry (nbnxn_sci_t), 4 wavefronts per workgroup;
+ *   - one 64-lane wavefront = one i-super-cluster entry (nbnxn_sci_t), 1-4 wavefronts per workgroup;
  *     lane = tidxj*8 + tidxi covers a complete 8 x (4+4) cluster pair per step, lanes 0-31 read the
  *     exclusion words of imei[0], lanes 32-63 those of imei[1] (the reference's split-2 list, unchanged);
- *   - list words (sci, cjPacked) are wave-uniform and come through scalar loads; the imask tests are
- *     scalar branches, so a skipped cluster pair costs no vector issue;
+ *   - list words (sci, cjPacked) are wave-uniform and come through scalar loads (restrict kernel arguments,
+ *     indices pinned with readfirstlane); the imask tests are scalar branches, so a skipped cluster pair
+ *     costs no vector issue, and list reads retire through lgkmcnt, never behind an atomic;
  *   - the 8 i-atoms a lane meets (x, q*epsfac, +shift, type row / LJ parameters) stay in 40 VGPRs for the
  *     whole entry (the 512-entry register file makes the CUDA kernel's per-pair LDS round trip unnecessary);
  *     LDS holds what is indexed at run time: the whole nbfp table (shared by the workgroup's waves, one
  *     ds_read_b64 per pair instead of a 512-byte global gather) and, for FUSED, the i-atoms' A/B data;
  *   - j-atom data: one 16-byte load per lane of 128 contiguous bytes per j-cluster;
- *   - j-forces: 3 DPP adds per component over the 8 lanes that share a j atom, then one no-return
- *     float atomic per component from 24 lanes (96 contiguous bytes);
+ *   - j-forces: 3 DPP adds per component over the 8 lanes that share a j atom, then one no-return buffer
+ *     atomic from 24 lanes (96 contiguous bytes), deferred behind the next j-cluster's loads: gfx950 retires
+ *     loads and atomics through one in-order vmcnt counter, so the order load -> atomic keeps every wait a
+ *     counted vmcnt(1-2) instead of a full drain behind a ~1-3 us memory-side atomic;
  *   - i-forces: 24 accumulators in registers, reduced over tidxj once per entry and written with
  *     64-lane coalesced atomics (768 contiguous bytes);
- *   - FUSED: a cluster pair that touches a perturbed atom (Grid::fepBits) takes a separate,
- *     non-unrolled path in which perturbed lanes evaluate the soft-core A/B pair (fepPair) and the
- *     other lanes the plain pair; everything else runs the plain path untouched.
+ *   - FUSED: (i-cluster, j-cluster) pairs that touch a perturbed atom (Grid::fepBits) are left out of the
+ *     main pass and evaluated in a second pass of the same wavefront, run only by the ~1 % of entries that
+ *     have any: perturbed lanes take the soft-core A/B pair (fepPair), the other lanes the plain pair.  The
+ *     second pass starts after the main pass's registers are dead, so the common case keeps the register
+ *     budget (and the 5 waves per SIMD) of the plain kernel.
+ *   - built with -fno-slp-vectorize: on gfx950 v_pk_*_f32 issues at half rate and costs v_mov shuffles.
  */
 #ifndef NBNXM_KERNEL_IMPL_H
 #define NBNXM_KERNEL_IMPL_H
@@ -34,7 +40,6 @@ struct VdwTraits
     static constexpr bool useTable = (VDW == VDK_CUT || VDW == VDK_FSWITCH || VDW == VDK_PSWITCH);
 };
 
-
 /* Dynamic LDS bytes of one workgroup of the cluster-pair kernel (must match the carve-up in the kernel). */
 inline int nbLdsBytes(int numTypes, bool useTable, bool fused, int wavesPerBlock)
 {
@@ -42,15 +47,35 @@ inline int nbLdsBytes(int numTypes, bool useTable, bool fused, int wavesPerBlock
     return tableBytes + (fused ? wavesPerBlock * c_superClSize * static_cast<int>(sizeof(float4) + sizeof(float2) + sizeof(int2)) : 0) + 16;
 }
 
+/* lanes whose byte offset lies beyond the buffer are dropped by the hardware range check */
+constexpr int c_dropLane = 0x7FFFFFF0;
+
+NB_DEVINL void ljFromComb(int vdwKind, const float2& a, const float2& b, float& c6, float& c12)
+{
+    if (vdwKind == VDK_COMB_GEOM)
+    {
+        c6  = a.x * b.x;
+        c12 = a.y * b.y;
+    }
+    else
+    {
+        const float sigma  = a.x + b.x;
+        const float eps    = a.y * b.y;
+        const float sigma2 = sigma * sigma;
+        const float sigma6 = sigma2 * sigma2 * sigma2;
+        c6                 = eps * sigma6;
+        c12                = c6 * sigma6;
+    }
+}
+
 template<int ELEC, bool TWIN, int VDW, bool ENERGY, bool FUSED>
-__launch_bounds__(c_nbBlockSize) __global__
+__launch_bounds__(c_nbBlockSize) __attribute__((amdgpu_waves_per_eu(5))) __global__
         void nbnxmKernel(const NBAtomDataGpu atdat,
                          const NBParamGpu    nbp,
                          const gpu_plist     plist,
                          const int           bCalcFshiftIn,
                          /* read-only, non-aliased views of members of the structs above: with noalias the
-                          * compiler turns the wave-uniform list reads into scalar (SMEM) loads, which retire
-                          * through lgkmcnt and so never wait behind the force atomics in the vmcnt queue */
+                          * compiler turns the wave-uniform list reads into scalar (SMEM) loads */
                          const nbnxn_sci_t* __restrict__ sciList,
                          const nbnxn_cj_packed_t* __restrict__ cjPackedList,
                          const nbnxn_excl_t* __restrict__ exclList,
@@ -65,22 +90,22 @@ __launch_bounds__(c_nbBlockSize) __global__
     /* wave-uniform values are pinned to SGPRs with readfirstlane so that everything derived from them
      * (list walk, branches, list loads) stays on the scalar unit */
     const unsigned blockSize = __builtin_amdgcn_readfirstlane(blockDim.x);
-    const unsigned lane  = threadIdx.x & (c_waveSize - 1);
-    const unsigned wave  = __builtin_amdgcn_readfirstlane(threadIdx.x / c_waveSize);
-    const unsigned tidxi = lane & 7U;
-    const unsigned tidxj = lane >> 3;
-    const unsigned half  = lane >> 5;
+    const unsigned lane      = threadIdx.x & (c_waveSize - 1);
+    const unsigned wave      = __builtin_amdgcn_readfirstlane(threadIdx.x / c_waveSize);
+    const unsigned tidxi     = lane & 7U;
+    const unsigned tidxj     = lane >> 3;
+    const unsigned half      = lane >> 5;
 
     /* LDS (all dynamic, sized by the launcher, see nbLdsBytes()): the LJ parameter table shared by the
-     * waves of the workgroup, then per wave the A/B charges and types of its 64 i-atoms (FUSED). */
+     * waves of the workgroup, then per wave (FUSED) its 64 i-atoms:
+     * { float4 x,q*epsfac (shifted) ; float2 epsfac*(qA,qB) ; int2 (typeA,typeB) } */
     extern __shared__ __align__(16) unsigned char nbLds[];
-    const int numTypes     = atdat.numTypes;
-    float2*   nbfpLds      = reinterpret_cast<float2*>(nbLds);
-    const int tableBytes   = USE_TABLE ? ((numTypes * numTypes * static_cast<int>(sizeof(float2)) + 15) & ~15) : 0;
-    /* per wave (FUSED): 64 x { float4 x,q*epsfac (shifted) ; float2 epsfac*(qA,qB) ; int2 (typeA,typeB) } */
-    float4*   xqib         = reinterpret_cast<float4*>(nbLds + tableBytes) + (FUSED ? wave * 2 * c_superClSize : 0);
-    float2*   qABib        = reinterpret_cast<float2*>(xqib + c_superClSize);
-    int2*     tABib        = reinterpret_cast<int2*>(qABib + c_superClSize);
+    const int numTypes   = atdat.numTypes;
+    float2*   nbfpLds    = reinterpret_cast<float2*>(nbLds);
+    const int tableBytes = USE_TABLE ? ((numTypes * numTypes * static_cast<int>(sizeof(float2)) + 15) & ~15) : 0;
+    float4*   xqib       = reinterpret_cast<float4*>(nbLds + tableBytes) + (FUSED ? wave * 2 * c_superClSize : 0);
+    float2*   qABib      = reinterpret_cast<float2*>(xqib + c_superClSize);
+    int2*     tABib      = reinterpret_cast<int2*>(qABib + c_superClSize);
     if constexpr (USE_TABLE)
     {
         for (int t = threadIdx.x; t < numTypes * numTypes; t += blockSize) { nbfpLds[t] = nbp.nbfp[t]; }
@@ -96,15 +121,15 @@ __launch_bounds__(c_nbBlockSize) __global__
     const int         cjPackedEnd   = haveWork ? nb_sci.cjPackedEnd : nb_sci.cjPackedBegin;
     const bool        central       = (shiftIdx == c_centralShiftIndex);
 
-    const float2* __restrict__ nbfp   = nbp.nbfp;
-    float* __restrict__ f             = reinterpret_cast<float*>(atdat.f);
-    const float rcoulomb_sq           = nbp.rcoulomb_sq;
+    float* __restrict__ f   = reinterpret_cast<float*>(atdat.f);
+    const float rcoulomb_sq = nbp.rcoulomb_sq;
+    const __amdgpu_buffer_rsrc_t fRsrc =
+            __builtin_amdgcn_make_buffer_rsrc(f, 0, atdat.numAtoms * 3 * static_cast<int>(sizeof(float)), 0x00020000);
 
-    /* the 8 i-atoms this lane meets (cluster i, atom tidxi) live in registers for the whole entry:
-     * 32 + 8 VGPRs out of the 512-entry file instead of an LDS round trip per cluster pair */
+    /* ---- stage the i-atoms ---------------------------------------------------------------------- */
     float4 xqi[c_numClPerSupercl];
-    int    trow[c_numClPerSupercl];   /* numTypes * type_i (table flavours) */
-    float2 ljcpi[c_numClPerSupercl];  /* combination-rule flavours */
+    int    trow[c_numClPerSupercl];  /* numTypes * type_i (table flavours) */
+    float2 ljcpi[c_numClPerSupercl]; /* combination-rule flavours */
     {
         const float3 sh = atdat.shiftVec[shiftIdx];
 #pragma unroll
@@ -120,48 +145,37 @@ __launch_bounds__(c_nbBlockSize) __global__
             if constexpr (USE_TABLE) { trow[i] = numTypes * atomTypes[ai]; }
             else { ljcpi[i] = ljComb[ai]; }
         }
-    }
-    if constexpr (FUSED)
-    {
-        const int    ai = sci * c_superClSize + static_cast<int>(lane);
-        const float3 sh = atdat.shiftVec[shiftIdx];
-        float4       xl = xq[ai];
-        xl.x += sh.x;
-        xl.y += sh.y;
-        xl.z += sh.z;
-        xl.w *= nbp.epsfac;
-        xqib[lane]      = xl;
-        const float4 q4 = atdat.q4[ai];
-        qABib[lane]     = make_float2(q4.x * nbp.epsfac, q4.y * nbp.epsfac);
-        const int4 t4   = atdat.atomTypes4[ai];
-        tABib[lane]     = make_int2(t4.x, t4.y);
+        if constexpr (FUSED)
+        {
+            const int ai = sci * c_superClSize + static_cast<int>(lane);
+            float4    xl = xq[ai];
+            xl.x += sh.x;
+            xl.y += sh.y;
+            xl.z += sh.z;
+            xl.w *= nbp.epsfac;
+            xqib[lane]      = xl;
+            const float4 q4 = atdat.q4[ai];
+            qABib[lane]     = make_float2(q4.x * nbp.epsfac, q4.y * nbp.epsfac);
+            const int4 t4   = atdat.atomTypes4[ai];
+            tABib[lane]     = make_int2(t4.x, t4.y);
+        }
     }
     __syncthreads();
 
     /* perturbed-atom bits of the 8 i-clusters (FUSED) */
-    unsigned long long iFepBits = 0;
-    FepLambda          L;
+    unsigned long long iFepBits        = 0;
+    unsigned           iFepClusterMask = 0U; /* bit i: i-cluster i holds a perturbed atom */
     if constexpr (FUSED)
     {
         iFepBits = *reinterpret_cast<const unsigned long long*>(atdat.fepBits + static_cast<size_t>(sci) * c_numClPerSupercl);
         iFepBits = __builtin_amdgcn_readfirstlane(static_cast<unsigned>(iFepBits))
                    | (static_cast<unsigned long long>(__builtin_amdgcn_readfirstlane(static_cast<unsigned>(iFepBits >> 32))) << 32);
-        L = makeFepLambda(nbp.lambda_q, nbp.lambda_v, nbp.lam_power, nbp.alpha_coul, nbp.alpha_vdw);
-    }
-    unsigned iFepClusterMask = 0U; /* bit i: i-cluster i holds a perturbed atom */
-    if constexpr (FUSED)
-    {
 #pragma unroll
         for (int i = 0; i < c_numClPerSupercl; i++)
         {
             if ((iFepBits >> (i * c_clSize)) & 0xFFULL) { iFepClusterMask |= (1U << i); }
         }
     }
-
-    float3 fci_buf[c_numClPerSupercl];
-#pragma unroll
-    for (int i = 0; i < c_numClPerSupercl; i++) { fci_buf[i] = make_float3(0.0F, 0.0F, 0.0F); }
-    float3 fSlowShift = make_float3(0.0F, 0.0F, 0.0F); /* i-forces that left through the FUSED path */
 
     float E_lj = 0.0F, E_el = 0.0F, DVDL_lj = 0.0F, DVDL_el = 0.0F;
 
@@ -182,50 +196,21 @@ __launch_bounds__(c_nbBlockSize) __global__
                     const float2 qAB = qABib[lane];
                     const float  sA  = qAB.x * qAB.x / nbp.epsfac * coef;
                     const float  sB  = qAB.y * qAB.y / nbp.epsfac * coef;
-                    E_el += L.LFC[0] * sA + L.LFC[1] * sB;
+                    E_el += (1.0F - nbp.lambda_q) * sA + nbp.lambda_q * sB;
                     DVDL_el += sB - sA;
                 }
             }
         }
     }
 
-    /* LJ parameters of one atom pair */
-    auto ljParams = [&](int i, int typej, const float2& ljcp_j, float& c6, float& c12) {
-        if constexpr (USE_TABLE)
-        {
-            const float2 c6c12 = nbfpLds[trow[i] + typej];
-            c6                 = c6c12.x;
-            c12                = c6c12.y;
-        }
-        else if constexpr (VDW == VDK_COMB_GEOM)
-        {
-            c6  = ljcpi[i].x * ljcp_j.x;
-            c12 = ljcpi[i].y * ljcp_j.y;
-        }
-        else
-        {
-            const float sigma  = ljcpi[i].x + ljcp_j.x;
-            const float eps    = ljcpi[i].y * ljcp_j.y;
-            const float sigma2 = sigma * sigma;
-            const float sigma6 = sigma2 * sigma2 * sigma2;
-            c6                 = eps * sigma6;
-            c12                = c6 * sigma6;
-        }
-    };
+    /* ---- main pass: plain pairs ---------------------------------------------------------------------- */
+    float3 fci_buf[c_numClPerSupercl];
+#pragma unroll
+    for (int i = 0; i < c_numClPerSupercl; i++) { fci_buf[i] = make_float3(0.0F, 0.0F, 0.0F); }
 
-    /* Walk over the j-clusters of this entry.  On gfx950 loads and no-return atomics retire through the
-     * same in-order vmcnt counter: a load issued AFTER an atomic cannot be consumed before that atomic
-     * has made its whole memory-side round trip (~1-3 us under load).  So the j-force atomic of a
-     * j-cluster is deferred (value + address carried in two registers) until the loads of the next
-     * j-cluster have been issued; the wait for those loads is then a counted vmcnt(1) that leaves the
-     * atomic in flight. */
-    /* buffer atomics: a lane whose byte offset lies beyond the buffer is dropped by the hardware range
-     * check, so "no atomic for this lane" needs no branch and the vmcnt bookkeeping stays exact */
-    const __amdgpu_buffer_rsrc_t fRsrc =
-            __builtin_amdgcn_make_buffer_rsrc(f, 0, atdat.numAtoms * 3 * static_cast<int>(sizeof(float)), 0x00020000);
-    constexpr int c_dropLane = 0x7FFFFFF0;
-    float pendingF   = 0.0F;
-    int   pendingOff = c_dropLane; /* byte offset into f of the deferred j-force component */
+    unsigned slowAny    = 0U;         /* FUSED: some (i-cluster, j-cluster) pair of this entry is left for pass 2 */
+    float    pendingF   = 0.0F;       /* deferred j-force component of the previous j-cluster */
+    int      pendingOff = c_dropLane; /* and its byte offset into f */
     for (int jPacked = cjPackedBegin; jPacked < cjPackedEnd; jPacked++)
     {
         const nbnxn_cj_packed_t* __restrict__ grp = &cjPackedList[jPacked];
@@ -238,60 +223,68 @@ __launch_bounds__(c_nbBlockSize) __global__
 #pragma unroll 1
         for (int jm = 0; jm < c_jGroupSize; jm++)
         {
-        const unsigned imaskJ = (imask >> (jm * c_numClPerSupercl)) & 0xFFU;
-        if (imaskJ == 0U) { continue; }
-        const unsigned wexclJ = wexcl >> (jm * c_numClPerSupercl);
-        const int      cj     = grp->cj[jm];
-        const int      aj     = cj * c_clSize + static_cast<int>(tidxj);
-        const float4   xqj    = xq[aj];
-        int            typej  = 0;
-        float2         ljcp_j = make_float2(0.0F, 0.0F);
-        if constexpr (USE_TABLE) { typej = atomTypes[aj]; }
-        else { ljcp_j = ljComb[aj]; }
-        unsigned fepJ = 0U;
-        if constexpr (FUSED) { fepJ = atdat.fepBits[cj]; }
-        /* the previous j-cluster's force leaves now, behind this j-cluster's loads */
-        __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(pendingF, fRsrc, pendingOff, 0, 0);
+            const unsigned imaskJ = (imask >> (jm * c_numClPerSupercl)) & 0xFFU;
+            if (imaskJ == 0U) { continue; }
+            const unsigned wexclJ = wexcl >> (jm * c_numClPerSupercl);
+            const int      cj     = grp->cj[jm];
+            const int      aj     = cj * c_clSize + static_cast<int>(tidxj);
+            const float4   xqj    = xq[aj];
+            int            typej  = 0;
+            float2         ljcp_j = make_float2(0.0F, 0.0F);
+            if constexpr (USE_TABLE) { typej = atomTypes[aj]; }
+            else { ljcp_j = ljComb[aj]; }
+            unsigned fepJ = 0U;
+            if constexpr (FUSED) { fepJ = atdat.fepBits[cj]; }
+            /* the previous j-cluster's force leaves now, behind this j-cluster's loads */
+            __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(pendingF, fRsrc, pendingOff, 0, 0);
 
-        float3 fcj_buf = make_float3(0.0F, 0.0F, 0.0F);
-        /* which i-cluster (if any) is this j-cluster itself on the central image */
-        [[maybe_unused]] const int diagI = (central && (cj >> 3) == sci) ? (cj & 7) : -1;
+            unsigned fastMask = imaskJ;
+            if constexpr (FUSED)
+            {
+                /* pairs for pass 2: every i-cluster when the j-cluster holds a perturbed atom, otherwise the
+                 * i-clusters that hold one */
+                const unsigned jFepBits = __builtin_amdgcn_readfirstlane(fepJ);
+                const unsigned slowMask = (jFepBits != 0U) ? imaskJ : (imaskJ & iFepClusterMask);
+                slowAny |= slowMask;
+                fastMask = imaskJ & ~slowMask;
+            }
+            /* which i-cluster (if any) is this j-cluster itself on the central image */
+            [[maybe_unused]] const int diagI = (central && (cj >> 3) == sci) ? (cj & 7) : -1;
 
-        /* FUSED: i-clusters that must take the perturbed-pair path for this j-cluster: all of them when the
-         * j-cluster holds a perturbed atom, otherwise only the i-clusters that hold one */
-        unsigned jFepBits = 0U;
-        unsigned slowMask = 0U;
-        if constexpr (FUSED)
-        {
-            jFepBits = __builtin_amdgcn_readfirstlane(fepJ);
-            slowMask = (jFepBits != 0U) ? imaskJ : (imaskJ & iFepClusterMask);
-        }
-        const unsigned fastMask = imaskJ & ~slowMask;
-
-        if (fastMask != 0U)
-        {
+            float3 fcj_buf = make_float3(0.0F, 0.0F, 0.0F);
 #pragma unroll
             for (int i = 0; i < c_numClPerSupercl; i++)
             {
                 if (fastMask & (1U << i))
                 {
-                    const float3 rv  = make_float3(xqi[i].x - xqj.x, xqi[i].y - xqj.y, xqi[i].z - xqj.z);
-                    const float  r2  = rv.x * rv.x + rv.y * rv.y + rv.z * rv.z;
+                    const float3 rv      = make_float3(xqi[i].x - xqj.x, xqi[i].y - xqj.y, xqi[i].z - xqj.z);
+                    const float  r2      = rv.x * rv.x + rv.y * rv.y + rv.z * rv.z;
                     const float  int_bit = ((wexclJ >> i) & 1U) ? 1.0F : 0.0F;
-                    bool         active;
+                    bool         active  = (r2 < rcoulomb_sq);
                     if constexpr (EXCL_FORCES)
                     {
-                        const int ci = sci * c_numClPerSupercl + i;
-                        active       = (r2 < rcoulomb_sq) && (!(central && tidxj <= tidxi) || ci != cj);
+                        /* diagonal cluster pair of the central image: only j > i.  The condition is wave-uniform
+                         * and rare; the empty asm keeps it a scalar branch (no per-pair select chain). */
+                        if (diagI == i)
+                        {
+                            asm volatile("" ::: "memory");
+                            active = active && (tidxj > tidxi);
+                        }
                     }
-                    else { active = (r2 < rcoulomb_sq) && (int_bit != 0.0F); }
+                    else { active = active && (int_bit != 0.0F); }
                     if (active)
                     {
                         float c6, c12;
-                        ljParams(i, typej, ljcp_j, c6, c12);
+                        if constexpr (USE_TABLE)
+                        {
+                            const float2 c6c12 = nbfpLds[trow[i] + typej];
+                            c6                 = c6c12.x;
+                            c12                = c6c12.y;
+                        }
+                        else { ljFromComb(VDW, ljcpi[i], ljcp_j, c6, c12); }
                         float F_invr, E_lj_p = 0.0F, E_el_p = 0.0F;
-                        nbPair<ELEC, TWIN, VDW, ENERGY, EXCL_FORCES>(nbp, r2, int_bit, xqi[i].w * xqj.w, c6, c12,
-                                                                     F_invr, E_lj_p, E_el_p);
+                        nbPair<ELEC, TWIN, VDW, ENERGY, EXCL_FORCES>(nbp, r2, int_bit, xqi[i].w * xqj.w, c6, c12, F_invr,
+                                                                     E_lj_p, E_el_p);
                         if constexpr (ENERGY)
                         {
                             E_lj += E_lj_p;
@@ -307,117 +300,13 @@ __launch_bounds__(c_nbBlockSize) __global__
                     }
                 }
             }
-        }
-        if constexpr (FUSED)
-        {
-            if (slowMask != 0U)
-            {
-                /* rare path: the cluster pair touches a perturbed atom; i is a run-time index here, so the
-                 * i-atom data comes from the wave's LDS copy instead of the register arrays.  Nothing in
-                 * the loop below reads global memory, so its i-force atomics never stall a later load. */
-                const float4 q4j = atdat.q4[aj];
-                const int4   t4j = atdat.atomTypes4[aj];
-#pragma unroll 1
-                for (int i = 0; i < c_numClPerSupercl; i++)
-                {
-                    if (!(slowMask & (1U << i))) { continue; }
-                    const unsigned iBits = static_cast<unsigned>(iFepBits >> (i * c_clSize)) & 0xFFU;
-                    const int      ci    = sci * c_numClPerSupercl + i;
-                    const int      ai    = ci * c_clSize + static_cast<int>(tidxi);
-                    const float4   xi    = xqib[i * c_clSize + tidxi];
-                    const float3   rv    = make_float3(xi.x - xqj.x, xi.y - xqj.y, xi.z - xqj.z);
-                    const float    r2    = rv.x * rv.x + rv.y * rv.y + rv.z * rv.z;
-                    const bool     included = ((wexclJ >> i) & 1U) != 0U;
-                    const bool     subDiag  = central && (ci == cj) && (tidxj <= tidxi);
-                    const bool     pert     = (((iBits >> tidxi) | (jFepBits >> tidxj)) & 1U) != 0U;
-                    float          F_invr   = 0.0F;
-                    if (pert)
-                    {
-                        if (!subDiag)
-                        {
-                            const float2 qABi = qABib[i * c_clSize + tidxi];
-                            const int2   tABi = tABib[i * c_clSize + tidxi];
-                            const float  qq[2] = { qABi.x * q4j.x, qABi.y * q4j.y };
-                            const float2 pA    = USE_TABLE ? nbfpLds[numTypes * tABi.x + t4j.x] : nbfp[numTypes * tABi.x + t4j.x];
-                            const float2 pB    = USE_TABLE ? nbfpLds[numTypes * tABi.y + t4j.y] : nbfp[numTypes * tABi.y + t4j.y];
-                            const float  c6[2]  = { pA.x, pB.x };
-                            const float  c12[2] = { pA.y, pB.y };
-                            float        fscal  = 0.0F;
-                            const bool   done = fepPair<FEP_ELEC, VDW == VDK_PSWITCH, true, ENERGY>(
-                                    nbp, L, r2, included, false, qq, c6, c12, fscal, E_lj, E_el, DVDL_lj, DVDL_el);
-                            F_invr = done ? fscal : 0.0F;
-                        }
-                    }
-                    else
-                    {
-                        const float int_bit = included ? 1.0F : 0.0F;
-                        bool        active;
-                        if constexpr (EXCL_FORCES) { active = (r2 < rcoulomb_sq) && !subDiag; }
-                        else { active = (r2 < rcoulomb_sq) && included; }
-                        if (active)
-                        {
-                            float c6, c12;
-                            if constexpr (USE_TABLE)
-                            {
-                                /* a non-perturbed atom's type is its A-state type */
-                                const float2 c6c12 = nbfpLds[numTypes * tABib[i * c_clSize + tidxi].x + typej];
-                                c6                 = c6c12.x;
-                                c12                = c6c12.y;
-                            }
-                            else
-                            {
-                                const float2 ljcp_i = ljComb[ai];
-                                if constexpr (VDW == VDK_COMB_GEOM)
-                                {
-                                    c6  = ljcp_i.x * ljcp_j.x;
-                                    c12 = ljcp_i.y * ljcp_j.y;
-                                }
-                                else
-                                {
-                                    const float sigma  = ljcp_i.x + ljcp_j.x;
-                                    const float eps    = ljcp_i.y * ljcp_j.y;
-                                    const float sigma2 = sigma * sigma;
-                                    const float sigma6 = sigma2 * sigma2 * sigma2;
-                                    c6                 = eps * sigma6;
-                                    c12                = c6 * sigma6;
-                                }
-                            }
-                            float E_lj_p = 0.0F, E_el_p = 0.0F;
-                            nbPair<ELEC, TWIN, VDW, ENERGY, EXCL_FORCES>(nbp, r2, int_bit, xi.w * xqj.w, c6, c12,
-                                                                         F_invr, E_lj_p, E_el_p);
-                            if constexpr (ENERGY)
-                            {
-                                E_lj += E_lj_p;
-                                E_el += E_el_p;
-                            }
-                        }
-                    }
-                    const float3 f_ij = make_float3(rv.x * F_invr, rv.y * F_invr, rv.z * F_invr);
-                    fcj_buf.x -= f_ij.x;
-                    fcj_buf.y -= f_ij.y;
-                    fcj_buf.z -= f_ij.z;
-                    /* i-force of this cluster leaves directly (dynamic i: no register array indexing) */
-                    const float fix = reduceOverTidxj(f_ij.x);
-                    const float fiy = reduceOverTidxj(f_ij.y);
-                    const float fiz = reduceOverTidxj(f_ij.z);
-                    {
-                        const float v   = (tidxj == 0U) ? fix : ((tidxj == 1U) ? fiy : fiz);
-                        const int   off = (tidxj < 3U) ? (3 * ai + static_cast<int>(tidxj)) * static_cast<int>(sizeof(float)) : c_dropLane;
-                        __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(v, fRsrc, off, 0, 0);
-                    }
-                    fSlowShift.x += f_ij.x;
-                    fSlowShift.y += f_ij.y;
-                    fSlowShift.z += f_ij.z;
-                }
-            }
-        }
 
-        /* j-force: sum over the 8 lanes of a j atom; lanes tidxi 0..2 carry x,y,z to the deferred atomic */
-        const float fjx = reduceOver8Lanes(fcj_buf.x);
-        const float fjy = reduceOver8Lanes(fcj_buf.y);
-        const float fjz = reduceOver8Lanes(fcj_buf.z);
-        pendingF        = (tidxi == 0U) ? fjx : ((tidxi == 1U) ? fjy : fjz);
-        pendingOff      = (tidxi < 3U) ? (3 * aj + static_cast<int>(tidxi)) * static_cast<int>(sizeof(float)) : c_dropLane;
+            /* j-force: sum over the 8 lanes of a j atom; lanes tidxi 0..2 carry x,y,z to the deferred atomic */
+            const float fjx = reduceOver8Lanes(fcj_buf.x);
+            const float fjy = reduceOver8Lanes(fcj_buf.y);
+            const float fjz = reduceOver8Lanes(fcj_buf.z);
+            pendingF        = (tidxi == 0U) ? fjx : ((tidxi == 1U) ? fjy : fjz);
+            pendingOff      = (tidxi < 3U) ? (3 * aj + static_cast<int>(tidxi)) * static_cast<int>(sizeof(float)) : c_dropLane;
         }
     }
     __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(pendingF, fRsrc, pendingOff, 0, 0);
@@ -440,19 +329,136 @@ __launch_bounds__(c_nbBlockSize) __global__
         atomicAdd(&f[3 * ai + 1], mine.y);
         atomicAdd(&f[3 * ai + 2], mine.z);
     }
+    float3 fshiftAcc = mine; /* per-lane share of this entry's total i-force */
+
+    /* ---- pass 2 (FUSED, rare): pairs that touch a perturbed atom ------------------------------------ */
+    if constexpr (FUSED)
+    {
+        if (slowAny != 0U)
+        {
+            const FepLambda L = makeFepLambda(nbp.lambda_q, nbp.lambda_v, nbp.lam_power, nbp.alpha_coul, nbp.alpha_vdw);
+            const float2* __restrict__ nbfp = nbp.nbfp;
+            for (int jPacked = cjPackedBegin; jPacked < cjPackedEnd; jPacked++)
+            {
+                const nbnxn_cj_packed_t* __restrict__ grp = &cjPackedList[jPacked];
+                const unsigned imask = grp->imei[0].imask;
+                if (imask == 0U) { continue; }
+                const int      exclInd0 = grp->imei[0].excl_ind;
+                const int      exclInd1 = grp->imei[1].excl_ind;
+                const unsigned wexcl    = exclList[half ? exclInd1 : exclInd0].pair[lane & 31U];
+#pragma unroll 1
+                for (int jm = 0; jm < c_jGroupSize; jm++)
+                {
+                    const unsigned imaskJ = (imask >> (jm * c_numClPerSupercl)) & 0xFFU;
+                    if (imaskJ == 0U) { continue; }
+                    const int      cj       = grp->cj[jm];
+                    const unsigned jFepBits = __builtin_amdgcn_readfirstlane(static_cast<unsigned>(atdat.fepBits[cj]));
+                    const unsigned slowMask = (jFepBits != 0U) ? imaskJ : (imaskJ & iFepClusterMask);
+                    if (slowMask == 0U) { continue; }
+                    const unsigned wexclJ = wexcl >> (jm * c_numClPerSupercl);
+                    const int      aj     = cj * c_clSize + static_cast<int>(tidxj);
+                    const float4   xqj    = xq[aj];
+                    const float4   q4j    = atdat.q4[aj];
+                    const int4     t4j    = atdat.atomTypes4[aj];
+                    int            typej  = 0;
+                    float2         ljcp_j = make_float2(0.0F, 0.0F);
+                    if constexpr (USE_TABLE) { typej = atomTypes[aj]; }
+                    else { ljcp_j = ljComb[aj]; }
+                    float3 fcj_buf = make_float3(0.0F, 0.0F, 0.0F);
+                    /* i is a run-time index here: the i-atom data comes from the wave's LDS copy.  Nothing in
+                     * this loop reads global memory, so its force atomics never stall a later load. */
+#pragma unroll 1
+                    for (int i = 0; i < c_numClPerSupercl; i++)
+                    {
+                        if (!(slowMask & (1U << i))) { continue; }
+                        const unsigned iBits    = static_cast<unsigned>(iFepBits >> (i * c_clSize)) & 0xFFU;
+                        const int      ci       = sci * c_numClPerSupercl + i;
+                        const int      ai       = ci * c_clSize + static_cast<int>(tidxi);
+                        const float4   xi       = xqib[i * c_clSize + tidxi];
+                        const int2     tABi     = tABib[i * c_clSize + tidxi];
+                        const float3   rv       = make_float3(xi.x - xqj.x, xi.y - xqj.y, xi.z - xqj.z);
+                        const float    r2       = rv.x * rv.x + rv.y * rv.y + rv.z * rv.z;
+                        const bool     included = ((wexclJ >> i) & 1U) != 0U;
+                        const bool     subDiag  = central && (ci == cj) && (tidxj <= tidxi);
+                        const bool     pert     = (((iBits >> tidxi) | (jFepBits >> tidxj)) & 1U) != 0U;
+                        float          F_invr   = 0.0F;
+                        if (pert)
+                        {
+                            if (!subDiag)
+                            {
+                                const float2 qABi   = qABib[i * c_clSize + tidxi];
+                                const float  qq[2]  = { qABi.x * q4j.x, qABi.y * q4j.y };
+                                const float2 pA     = USE_TABLE ? nbfpLds[numTypes * tABi.x + t4j.x] : nbfp[numTypes * tABi.x + t4j.x];
+                                const float2 pB     = USE_TABLE ? nbfpLds[numTypes * tABi.y + t4j.y] : nbfp[numTypes * tABi.y + t4j.y];
+                                const float  c6[2]  = { pA.x, pB.x };
+                                const float  c12[2] = { pA.y, pB.y };
+                                float        fscal  = 0.0F;
+                                const bool   done   = fepPair<FEP_ELEC, VDW == VDK_PSWITCH, true, ENERGY>(
+                                        nbp, L, r2, included, false, qq, c6, c12, fscal, E_lj, E_el, DVDL_lj, DVDL_el);
+                                F_invr = done ? fscal : 0.0F;
+                            }
+                        }
+                        else
+                        {
+                            const float int_bit = included ? 1.0F : 0.0F;
+                            bool        active;
+                            if constexpr (EXCL_FORCES) { active = (r2 < rcoulomb_sq) && !subDiag; }
+                            else { active = (r2 < rcoulomb_sq) && included; }
+                            if (active)
+                            {
+                                float c6, c12;
+                                if constexpr (USE_TABLE)
+                                {
+                                    /* a non-perturbed atom's type is its A-state type */
+                                    const float2 c6c12 = nbfpLds[numTypes * tABi.x + typej];
+                                    c6                 = c6c12.x;
+                                    c12                = c6c12.y;
+                                }
+                                else { ljFromComb(VDW, ljComb[ai], ljcp_j, c6, c12); }
+                                float E_lj_p = 0.0F, E_el_p = 0.0F;
+                                nbPair<ELEC, TWIN, VDW, ENERGY, EXCL_FORCES>(nbp, r2, int_bit, xi.w * xqj.w, c6, c12, F_invr,
+                                                                             E_lj_p, E_el_p);
+                                if constexpr (ENERGY)
+                                {
+                                    E_lj += E_lj_p;
+                                    E_el += E_el_p;
+                                }
+                            }
+                        }
+                        const float3 f_ij = make_float3(rv.x * F_invr, rv.y * F_invr, rv.z * F_invr);
+                        fcj_buf.x -= f_ij.x;
+                        fcj_buf.y -= f_ij.y;
+                        fcj_buf.z -= f_ij.z;
+                        const float fix = reduceOverTidxj(f_ij.x);
+                        const float fiy = reduceOverTidxj(f_ij.y);
+                        const float fiz = reduceOverTidxj(f_ij.z);
+                        {
+                            const float v   = (tidxj == 0U) ? fix : ((tidxj == 1U) ? fiy : fiz);
+                            const int   off = (tidxj < 3U) ? (3 * ai + static_cast<int>(tidxj)) * static_cast<int>(sizeof(float)) : c_dropLane;
+                            __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(v, fRsrc, off, 0, 0);
+                        }
+                        fshiftAcc.x += f_ij.x;
+                        fshiftAcc.y += f_ij.y;
+                        fshiftAcc.z += f_ij.z;
+                    }
+                    const float fjx = reduceOver8Lanes(fcj_buf.x);
+                    const float fjy = reduceOver8Lanes(fcj_buf.y);
+                    const float fjz = reduceOver8Lanes(fcj_buf.z);
+                    {
+                        const float v   = (tidxi == 0U) ? fjx : ((tidxi == 1U) ? fjy : fjz);
+                        const int   off = (tidxi < 3U) ? (3 * aj + static_cast<int>(tidxi)) * static_cast<int>(sizeof(float)) : c_dropLane;
+                        __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(v, fRsrc, off, 0, 0);
+                    }
+                }
+            }
+        }
+    }
 
     if (bCalcFshiftIn && !central)
     {
-        float sx = mine.x, sy = mine.y, sz = mine.z;
-        if constexpr (FUSED)
-        {
-            sx += fSlowShift.x;
-            sy += fSlowShift.y;
-            sz += fSlowShift.z;
-        }
-        sx = waveSum(sx);
-        sy = waveSum(sy);
-        sz = waveSum(sz);
+        const float sx = waveSum(fshiftAcc.x);
+        const float sy = waveSum(fshiftAcc.y);
+        const float sz = waveSum(fshiftAcc.z);
         if (lane < 3U)
         {
             const float v = (lane == 0U) ? sx : ((lane == 1U) ? sy : sz);

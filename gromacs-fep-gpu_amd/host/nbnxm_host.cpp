@@ -669,11 +669,11 @@ NbnxmHostPairlist* nbnxm_host_pairlist_build(const NbnxmHostGrid* g, const int* 
 
             // close the entry, optionally split into chunks (list balancing); when the perturbed pairs stay
             // in the cluster list, entries whose i-clusters hold perturbed atoms cost several times more per
-            // j-cluster, so they get quarter-size chunks
+            // j-cluster and are the kernel's critical path: they are cut into single-group entries
             bool perturbedI = false;
             for (int cil = 0; cil < NCL; cil++) { perturbedI = perturbedI || (g->fepBits[sci * NCL + cil] != 0); }
             int chunk = (maxCjPackedPerSci > 0) ? maxCjPackedPerSci : (groupEnd - groupBegin);
-            if (!carveFep && perturbedI && maxCjPackedPerSci > 0) { chunk = std::max(1, chunk / 4); }
+            if (!carveFep && perturbedI && maxCjPackedPerSci > 0) { chunk = 1; }
             for (int b = groupBegin; b < groupEnd; b += chunk)
             {
                 nbnxn_sci_t e;
