@@ -771,7 +771,7 @@ void nbnxm_gpu_launch_kernel(NbnxmGpu* nb, const nbnxm_step_workload_t* stepWork
         }
         hipLaunchKernelGGL(kernel, dim3((plist->nsci + wavesPerBlock - 1) / wavesPerBlock), dim3(wavesPerBlock * c_waveSize), ldsBytes, s,
                            *adat, *nbp, *plist, stepWork->computeVirial, plist->sci, plist->cjPacked, plist->excl, adat->xq,
-                           adat->atomTypes, adat->ljComb);
+                           adat->atomTypes, adat->ljComb, reinterpret_cast<const unsigned*>(adat->fepBits));
         NBNXM_HIP_CHECK(hipGetLastError());
         if (nb->bDoTime) { t.nb_k.closeTimingRegion(s); }
     }

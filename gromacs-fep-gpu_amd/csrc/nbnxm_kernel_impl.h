@@ -81,7 +81,8 @@ __launch_bounds__(c_nbBlockSize) __attribute__((amdgpu_waves_per_eu(5))) __globa
                          const nbnxn_excl_t* __restrict__ exclList,
                          const float4* __restrict__ xq,
                          const int* __restrict__ atomTypes,
-                         const float2* __restrict__ ljComb)
+                         const float2* __restrict__ ljComb,
+                         const unsigned* __restrict__ fepWords /* atdat.fepBits viewed as dwords (scalar loads) */)
 {
     constexpr bool EXCL_FORCES = (ELEC != ELK_CUT) || ENERGY; /* nbnxm_cuda_kernel.cuh:69-78 */
     constexpr bool USE_TABLE   = VdwTraits<VDW>::useTable;
@@ -167,9 +168,7 @@ __launch_bounds__(c_nbBlockSize) __attribute__((amdgpu_waves_per_eu(5))) __globa
     unsigned           iFepClusterMask = 0U; /* bit i: i-cluster i holds a perturbed atom */
     if constexpr (FUSED)
     {
-        iFepBits = *reinterpret_cast<const unsigned long long*>(atdat.fepBits + static_cast<size_t>(sci) * c_numClPerSupercl);
-        iFepBits = __builtin_amdgcn_readfirstlane(static_cast<unsigned>(iFepBits))
-                   | (static_cast<unsigned long long>(__builtin_amdgcn_readfirstlane(static_cast<unsigned>(iFepBits >> 32))) << 32);
+        iFepBits = static_cast<unsigned long long>(fepWords[2 * sci]) | (static_cast<unsigned long long>(fepWords[2 * sci + 1]) << 32);
 #pragma unroll
         for (int i = 0; i < c_numClPerSupercl; i++)
         {
@@ -208,7 +207,10 @@ __launch_bounds__(c_nbBlockSize) __attribute__((amdgpu_waves_per_eu(5))) __globa
 #pragma unroll
     for (int i = 0; i < c_numClPerSupercl; i++) { fci_buf[i] = make_float3(0.0F, 0.0F, 0.0F); }
 
-    unsigned slowAny    = 0U;         /* FUSED: some (i-cluster, j-cluster) pair of this entry is left for pass 2 */
+    /* FUSED: which j-cluster slots of this entry hold pairs left for pass 2: one bit per slot for the first 64
+     * slots (16 packed groups), one flag for everything beyond */
+    unsigned long long slowSlots    = 0ULL;
+    bool               slowOverflow = false;
     float    pendingF   = 0.0F;       /* deferred j-force component of the previous j-cluster */
     int      pendingOff = c_dropLane; /* and its byte offset into f */
     for (int jPacked = cjPackedBegin; jPacked < cjPackedEnd; jPacked++)
@@ -233,8 +235,8 @@ __launch_bounds__(c_nbBlockSize) __attribute__((amdgpu_waves_per_eu(5))) __globa
             float2         ljcp_j = make_float2(0.0F, 0.0F);
             if constexpr (USE_TABLE) { typej = atomTypes[aj]; }
             else { ljcp_j = ljComb[aj]; }
-            unsigned fepJ = 0U;
-            if constexpr (FUSED) { fepJ = atdat.fepBits[cj]; }
+            unsigned fepJ = 0U; /* wave-uniform: comes through a scalar load, off the vmcnt queue */
+            if constexpr (FUSED) { fepJ = (fepWords[cj >> 2] >> ((cj & 3) * 8)) & 0xFFU; }
             /* the previous j-cluster's force leaves now, behind this j-cluster's loads */
             __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(pendingF, fRsrc, pendingOff, 0, 0);
 
@@ -243,9 +245,14 @@ __launch_bounds__(c_nbBlockSize) __attribute__((amdgpu_waves_per_eu(5))) __globa
             {
                 /* pairs for pass 2: every i-cluster when the j-cluster holds a perturbed atom, otherwise the
                  * i-clusters that hold one */
-                const unsigned jFepBits = __builtin_amdgcn_readfirstlane(fepJ);
+                const unsigned jFepBits = fepJ;
                 const unsigned slowMask = (jFepBits != 0U) ? imaskJ : (imaskJ & iFepClusterMask);
-                slowAny |= slowMask;
+                if (slowMask != 0U)
+                {
+                    const int slot = (jPacked - cjPackedBegin) * c_jGroupSize + jm;
+                    if (slot < 64) { slowSlots |= (1ULL << slot); }
+                    else { slowOverflow = true; }
+                }
                 fastMask = imaskJ & ~slowMask;
             }
             /* which i-cluster (if any) is this j-cluster itself on the central image */
@@ -334,12 +341,17 @@ __launch_bounds__(c_nbBlockSize) __attribute__((amdgpu_waves_per_eu(5))) __globa
     /* ---- pass 2 (FUSED, rare): pairs that touch a perturbed atom ------------------------------------ */
     if constexpr (FUSED)
     {
-        if (slowAny != 0U)
+        if (slowSlots != 0ULL || slowOverflow)
         {
             const FepLambda L = makeFepLambda(nbp.lambda_q, nbp.lambda_v, nbp.lam_power, nbp.alpha_coul, nbp.alpha_vdw);
             const float2* __restrict__ nbfp = nbp.nbfp;
             for (int jPacked = cjPackedBegin; jPacked < cjPackedEnd; jPacked++)
             {
+                /* only the slots flagged by the main pass are visited (no list or fepBits reads for the rest) */
+                const int      group     = jPacked - cjPackedBegin;
+                const unsigned groupSlow = (group < 16) ? static_cast<unsigned>(slowSlots >> (group * c_jGroupSize)) & 0xFU
+                                                        : (slowOverflow ? 0xFU : 0U);
+                if (groupSlow == 0U) { continue; }
                 const nbnxn_cj_packed_t* __restrict__ grp = &cjPackedList[jPacked];
                 const unsigned imask = grp->imei[0].imask;
                 if (imask == 0U) { continue; }
@@ -350,9 +362,9 @@ __launch_bounds__(c_nbBlockSize) __attribute__((amdgpu_waves_per_eu(5))) __globa
                 for (int jm = 0; jm < c_jGroupSize; jm++)
                 {
                     const unsigned imaskJ = (imask >> (jm * c_numClPerSupercl)) & 0xFFU;
-                    if (imaskJ == 0U) { continue; }
+                    if (imaskJ == 0U || !((groupSlow >> jm) & 1U)) { continue; }
                     const int      cj       = grp->cj[jm];
-                    const unsigned jFepBits = __builtin_amdgcn_readfirstlane(static_cast<unsigned>(atdat.fepBits[cj]));
+                    const unsigned jFepBits = (fepWords[cj >> 2] >> ((cj & 3) * 8)) & 0xFFU;
                     const unsigned slowMask = (jFepBits != 0U) ? imaskJ : (imaskJ & iFepClusterMask);
                     if (slowMask == 0U) { continue; }
                     const unsigned wexclJ = wexcl >> (jm * c_numClPerSupercl);

@@ -9,7 +9,7 @@
 #include "nbnxm_hip_types.h"
 
 using NbKernelPtr = void (*)(NBAtomDataGpu, NBParamGpu, gpu_plist, int, const nbnxn_sci_t*, const nbnxn_cj_packed_t*,
-                             const nbnxn_excl_t*, const float4*, const int*, const float2*);
+                             const nbnxn_excl_t*, const float4*, const int*, const float2*, const unsigned*);
 using FepKernelPtr   = void (*)(NBAtomDataGpu, NBParamGpu, gpu_feplist, int);
 using PruneKernelPtr = void (*)(NBAtomDataGpu, NBParamGpu, gpu_plist, int, int);
 

@@ -728,10 +728,22 @@ NbnxmHostPairlist* nbnxm_host_pairlist_build(const NbnxmHostGrid* g, const int* 
     // most expensive entries first (the reference sorts the sci list by work, pairlist.cpp sort_sci);
     // with un-carved lists, entries with perturbed i-clusters count 4x
     auto cost = [&](const nbnxn_sci_t& e) {
-        int  w          = e.cjPackedEnd - e.cjPackedBegin;
+        int w = e.cjPackedEnd - e.cjPackedBegin;
+        if (carveFep) { return w; }
         bool perturbedI = false;
         for (int cil = 0; cil < NCL; cil++) { perturbedI = perturbedI || (g->fepBits[e.sci * NCL + cil] != 0); }
-        return (!carveFep && perturbedI) ? 4 * w + 1000000 : w;
+        if (perturbedI) { return 4 * w + 1000000; }
+        // a j-cluster with perturbed atoms costs about as much as four ordinary packed groups
+        int pertJ = 0;
+        for (int jp = e.cjPackedBegin; jp < e.cjPackedEnd; jp++)
+        {
+            for (int jm = 0; jm < JG; jm++)
+            {
+                const unsigned mj = (pl->cjPacked[jp].imei[0].imask >> (jm * NCL)) & 0xFFU;
+                if (mj != 0U && g->fepBits[pl->cjPacked[jp].cj[jm]] != 0) { pertJ++; }
+            }
+        }
+        return w + 4 * pertJ + (pertJ > 0 ? 1000 : 0);
     };
     std::stable_sort(pl->sci.begin(), pl->sci.end(), [&](const nbnxn_sci_t& a, const nbnxn_sci_t& b) { return cost(a) > cost(b); });
     return pl;
