@@ -83,8 +83,9 @@ def main():
 
     nm = {"24k": (20, 20, 20), "96k": (40, 40, 20), "768k": (80, 80, 40)}[args.atoms]
     npert = {"24k": 3, "96k": 16, "768k": 16}[args.atoms]
-    lambdas = np.linspace(0.0, 1.0, 11)
-    lam = 0.5 if world == 1 else float(lambdas[rank % 11])   # replica set, config 4
+    import importlib
+    replica = importlib.import_module("gromacs_fep_gpu_amd.replica")
+    lam = replica.replica_lambda(rank, world)   # 0.5 on one GPU; window rank mod 11 in the replica set (config 4)
     t0 = time.time()
     case = tl.make_case(nm=nm, num_perturbed_molecules=npert, elec="ewald", seed=2026, n_lambda=11,
                         lambda_coul=lam, lambda_vdw=lam, max_cjpacked_per_sci=args.max_cjpacked_per_sci)
@@ -123,9 +124,7 @@ def main():
         dist.barrier()
     elapsed = time.perf_counter() - t_start
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        elapsed = replica.max_over_ranks(elapsed, dist, device="cuda")
 
     # kernel durations measured with HIP events on the kernel's own stream (inside the C-ABI library)
     f = np.zeros((case.grid.num_atoms, 3), np.float32)
@@ -139,7 +138,7 @@ def main():
     pair_evals = 64 * stats["cluster_pairs"]          # atom pairs in the (pruned) list, SURVEY §8d
     fep_pairs = len(case.plist.fep["jjnr"])
     pairs_per_step = pair_evals + (0 if fused else fep_pairs)
-    value = world * pairs_per_step / (elapsed / args.steps)
+    value = replica.aggregate_throughput(pairs_per_step, args.steps, elapsed, world)
     ns_per_day = world * 86400.0 / (elapsed / args.steps) * DT_FS * 1e-6
     bytes_nb, bytes_fep = algorithmic_bytes(stats, fused, len(case.plist.fep["iinr"]), fep_pairs)
     achieved = bytes_nb / (nb_k_us * 1e-6) / 1e9 if nb_k_us > 0 else 0.0
