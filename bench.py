@@ -64,6 +64,7 @@ def main():
     ap.add_argument("--max-cjpacked-per-sci", type=int, default=16)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-prune", action="store_true")
+    ap.add_argument("--perturbed-molecules", type=int, default=-1, help="override the ligand size (diagnostics)")
     args = ap.parse_args()
 
     import torch
@@ -83,6 +84,8 @@ def main():
 
     nm = {"24k": (20, 20, 20), "96k": (40, 40, 20), "768k": (80, 80, 40)}[args.atoms]
     npert = {"24k": 3, "96k": 16, "768k": 16}[args.atoms]
+    if args.perturbed_molecules >= 0:
+        npert = args.perturbed_molecules
     import importlib
     replica = importlib.import_module("gromacs_fep_gpu_amd.replica")
     lam = replica.replica_lambda(rank, world)   # 0.5 on one GPU; window rank mod 11 in the replica set (config 4)

@@ -79,18 +79,17 @@ NB_DEVINL float waveSum(float v)
 /* ---- math ------------------------------------------------------------------------------------ */
 
 /* [d/dz (erf z / z)] / z as a function of z^2; definition as gmx::pmeForceCorrection
- * (simd/simd_math.h:1560-1650), coefficients fitted by tools/fit_pme_corr.py. */
+ * (simd/simd_math.h:1560-1650); own [5/4] rational fit on z^2 <= PME_CORR_XMAX (tools/fit_pme_corr.py,
+ * relative error < 1e-6, the accuracy class of the reference's approximation). */
 NB_DEVINL float pmeCorrF(float z2)
 {
-    float num = PME_CORR_P6;
-    num       = fmaf(num, z2, PME_CORR_P5);
+    float num = PME_CORR_P5;
     num       = fmaf(num, z2, PME_CORR_P4);
     num       = fmaf(num, z2, PME_CORR_P3);
     num       = fmaf(num, z2, PME_CORR_P2);
     num       = fmaf(num, z2, PME_CORR_P1);
     num       = fmaf(num, z2, PME_CORR_P0);
-    float den = PME_CORR_Q5;
-    den       = fmaf(den, z2, PME_CORR_Q4);
+    float den = PME_CORR_Q4;
     den       = fmaf(den, z2, PME_CORR_Q3);
     den       = fmaf(den, z2, PME_CORR_Q2);
     den       = fmaf(den, z2, PME_CORR_Q1);
@@ -111,7 +110,7 @@ NB_DEVINL float interpolateCoulombForceR(const NBParamGpu& nbp, float r)
 
 /* ---- non-perturbed atom pair (nbnxm_cuda_kernel.cuh:518-645) ---------------------------------- */
 
-template<int ELEC, bool TWIN, int VDW, bool ENERGY, bool EXCL_FORCES>
+template<int ELEC, bool TWIN, int VDW, bool ENERGY, bool EXCL_FORCES, bool HAS_EXCL = true>
 NB_DEVINL void nbPair(const NBParamGpu& nbp,
                       float             r2,
                       float             int_bit,
@@ -126,14 +125,15 @@ NB_DEVINL void nbPair(const NBParamGpu& nbp,
     const float inv_r  = __frsqrt_rn(r2);
     const float inv_r2 = inv_r * inv_r;
     float       inv_r6 = inv_r2 * inv_r2 * inv_r2;
-    const float mask   = EXCL_FORCES ? int_bit : 1.0F;
-    inv_r6 *= mask;
+    /* HAS_EXCL == false: the caller guarantees int_bit == 1 for every lane, no masking at all */
+    const float mask = (EXCL_FORCES && HAS_EXCL) ? int_bit : 1.0F;
+    if constexpr (EXCL_FORCES && HAS_EXCL) { inv_r6 *= mask; }
 
     F_invr       = inv_r6 * (c12 * inv_r6 - c6) * inv_r2;
     float E_lj_p = 0.0F;
     if constexpr (ENERGY || VDW == VDK_PSWITCH)
     {
-        E_lj_p = int_bit
+        E_lj_p = (HAS_EXCL ? int_bit : 1.0F)
                  * (c12 * (inv_r6 * inv_r6 + nbp.repulsion_shift.cpot) * c_oneTwelfth
                     - c6 * (inv_r6 + nbp.dispersion_shift.cpot) * c_oneSixth);
     }

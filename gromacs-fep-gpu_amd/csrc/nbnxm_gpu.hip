@@ -285,6 +285,12 @@ NbnxmGpu* nbnxm_gpu_init(const nbnxm_interaction_params_t* ic, int numTypes, con
         nb->nbfp_comb_n = numTypes;
     }
     uploadCoulombTable(nb, ic);
+    if (ic->elecType == NBNXM_ELEC_EWALD_ANA || ic->elecType == NBNXM_ELEC_EWALD_ANA_TWIN)
+    {
+        /* domain of the fitted analytical correction (pme_corr_coeffs.h): (beta r)^2 <= 12 */
+        NBNXM_ASSERT(ic->ewaldcoeff_q * ic->ewaldcoeff_q * ic->rcoulomb * ic->rcoulomb <= 12.0F,
+                     "beta*rc > 3.46: outside the analytical Ewald correction's fitted range, use the tabulated kernel type");
+    }
     allocateDeviceBuffer(&nbp->allLambdaCoul, std::max(1, n_lambda));
     allocateDeviceBuffer(&nbp->allLambdaVdw, std::max(1, n_lambda));
 
