@@ -146,6 +146,16 @@ def main():
     bytes_nb, bytes_fep = algorithmic_bytes(stats, fused, len(case.plist.fep["iinr"]), fep_pairs)
     achieved = bytes_nb / (nb_k_us * 1e-6) / 1e9 if nb_k_us > 0 else 0.0
 
+    # HBM bytes per launch of the dominant kernel from rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE; separate runs of this
+    # same command, tools/gpu_traffic.sh; FETCH_SIZE doubled as MI355X_MICROARCH.md §HBM prescribes for gfx950)
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "r01", "c_traffic_fused.json")
+    if fused and args.atoms == "96k" and args.perturbed_molecules < 0 and os.path.exists(tpath):
+        try:
+            traffic = json.load(open(tpath)).get("hbm_bytes_per_launch_corrected")
+        except Exception:
+            traffic = None
+
     out = {
         "metric": METRIC, "value": value, "unit": "pair-interactions/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
@@ -160,7 +170,7 @@ def main():
         "ns_per_day_kernel_bound": ns_per_day,
         "kernel_us": {"k_calc_nb": nb_k_us, "k_calc_nb_fep": fep_k_us},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                      "kernel": "nbnxmKernel<EwaldAna,LJcut,F,%s>" % ("fused" if fused else "plain"),
                      "algorithmic_bytes_per_launch": bytes_nb,
                      "fp32_valu_frac_estimate": (pair_evals * 45.0 / (nb_k_us * 1e-6) / 1e12 / FP32_PEAK_TFLOPS)
