@@ -30,7 +30,7 @@ ONE_4PI_EPS0 = ob.ONE_4PI_EPS0
 def make_case(nm=(8, 8, 8), num_perturbed_molecules=3, elec="rf", vdw="cut", seed=2026, rc=1.0, rlist=1.1,
               rlist_fep=None, sc_alpha=0.5, sc_power=1, sc_sigma=0.3, sc_coul=True, lambda_coul=0.5,
               lambda_vdw=0.5, n_lambda=0, max_cjpacked_per_sci=0, identical_states=False, rvdw_switch=0.8,
-              spacing=0.310736, jitter=0.03):
+              spacing=0.310736, jitter=0.03, num_extra_types=0):
     """elec: 'rf' | 'cut' | 'ewald' | 'ewald_tab';  vdw: 'cut' | 'pswitch' | 'fswitch'."""
     sysd = pkg.make_water_box(nm[0], nm[1], nm[2], spacing=spacing, jitter=jitter, seed=seed,
                               num_perturbed_molecules=num_perturbed_molecules)
@@ -40,6 +40,8 @@ def make_case(nm=(8, 8, 8), num_perturbed_molecules=3, elec="rf", vdw="cut", see
         # keep the perturbed flags but make B == A (oracle cross-check in the non-perturbed limit)
         sysd["qB"] = sysd["qA"].copy()
         sysd["typeB"] = sysd["typeA"].copy()
+    if num_extra_types > 0:
+        add_oxygen_type_variants(sysd, num_extra_types, seed)
     ntype = sysd["ntype"]
     grid = pkg.Grid(sysd["x"], sysd["box"], sysd["qA"], sysd["qB"], sysd["typeA"], sysd["typeB"], ntype,
                     perturbed=perturbed.astype(np.uint8))
@@ -84,6 +86,8 @@ def make_case(nm=(8, 8, 8), num_perturbed_molecules=3, elec="rf", vdw="cut", see
         c.vdw_switch = (-10.0 / d ** 3, 15.0 / d ** 4, -6.0 / d ** 5)   # potential_switch_constants, forcerec/interaction_const
         c.disp_shift = (0.0, 0.0, 0.0)
         c.rep_shift = (0.0, 0.0, 0.0)
+    elif vdw in ("comb_geom", "comb_lb"):
+        c.vdw_type = pkg.VDW_CUT_COMB_GEOM if vdw == "comb_geom" else pkg.VDW_CUT_COMB_LB
     elif vdw == "fswitch":
         c.vdw_type = pkg.VDW_FSWITCH
         c.rvdw_switch = rvdw_switch
@@ -95,6 +99,52 @@ def make_case(nm=(8, 8, 8), num_perturbed_molecules=3, elec="rf", vdw="cut", see
     c.all_lambda = np.linspace(0.0, 1.0, n_lambda) if n_lambda > 0 else np.zeros(0)
     c.have_soft_core = sc_alpha != 0
     return c
+
+
+def add_oxygen_type_variants(sysd, k, seed):
+    """Gives the water oxygens k extra atom types with slightly different LJ parameters (geometric mixing),
+    to exercise the type-pair table with a realistic number of types (ntype = 3 + k)."""
+    rng = np.random.default_rng(seed)
+    nt_old, nt = sysd["ntype"], sysd["ntype"] + k
+    old = np.asarray(sysd["nbfp"], np.float64).reshape(nt_old, nt_old, 2)
+    c6 = np.zeros(nt)
+    c12 = np.zeros(nt)
+    c6[0], c12[0] = old[0, 0]
+    for t in range(nt_old, nt):
+        c6[t] = old[0, 0, 0] * (1.0 + 0.03 * (t - nt_old + 1))
+        c12[t] = old[0, 0, 1] * (1.0 + 0.05 * (t - nt_old + 1))
+    nbfp = np.zeros((nt, nt, 2))
+    nbfp[..., 0] = np.sqrt(np.outer(c6, c6))
+    nbfp[..., 1] = np.sqrt(np.outer(c12, c12))
+    sysd["nbfp"] = nbfp.reshape(-1).astype(np.float32)
+    sysd["ntype"] = nt
+    ox = np.flatnonzero(sysd["typeA"] == 0)
+    newt = rng.integers(0, k + 1, size=len(ox))
+    newt = np.where(newt == 0, 0, newt + nt_old - 1).astype(np.int32)
+    same = sysd["typeB"][ox] == sysd["typeA"][ox]
+    sysd["typeA"][ox] = newt
+    sysd["typeB"][ox] = np.where(same, newt, sysd["typeB"][ox])
+
+
+def lj_comb_params(c, atype):
+    """Per-atom combination-rule parameters in the kernels' convention (nbnxm_cuda_kernel.cuh:504-516):
+    geometric: (sqrt(6 C6), sqrt(12 C12)); Lorentz-Berthelot: (sigma/2, sqrt(eps)) with
+    c6 = eps sigma^6 = 6 C6 and c12 = c6 sigma^6 = 12 C12.  atype: grid-order (masked) types, numTypes = ntype + 1."""
+    nt = c.ntype
+    tab = np.zeros((nt + 1, 2))
+    diag = np.asarray(c.sys["nbfp"], np.float64).reshape(nt, nt, 2)[np.arange(nt), np.arange(nt)]
+    tab[:nt] = diag
+    out = np.zeros((len(atype), 2), np.float32)
+    c6, c12 = tab[atype, 0], tab[atype, 1]
+    has = (c6 > 0) & (c12 > 0)
+    if c.vdw == "comb_geom":
+        out[:, 0] = np.sqrt(c6)
+        out[:, 1] = np.sqrt(c12)
+    else:
+        sig6 = np.where(has, c12 / np.where(has, c6, 1.0), 0.0)
+        out[:, 0] = 0.5 * sig6 ** (1.0 / 6.0)
+        out[:, 1] = np.where(has, c6 / np.sqrt(np.where(has, c12, 1.0)), 0.0)
+    return out
 
 
 def force_switch_constants(p, rsw, rc):
@@ -140,9 +190,10 @@ def run_oracle(c, energy=True, precision="f64", foreign=False, cjPacked=None):
     Forces are returned in GRID order (like nbat->out[0].f)."""
     g = c.grid
     flags = ob.DO_FORCE | ob.DO_SHIFTFORCE | (ob.DO_POTENTIAL if energy else 0)
+    ljc = lj_comb_params(c, g.type) if c.vdw in ("comb_geom", "comb_lb") else None
     ref = ob.nbnxm_ref(c.plist.sci, c.plist.cjPacked if cjPacked is None else cjPacked, c.plist.excl, g.xq,
                        g.type, g.num_types, g.nbat_nbfp(c.sys["nbfp"]), oracle_ref_params(c), g.shift_vec,
-                       compute_energy=energy, compute_fshift=True, precision=precision)
+                       compute_energy=energy, compute_fshift=True, lj_comb=ljc, precision=precision)
     fp = oracle_fep_params(c)
     fep = ob.fep_kernel(c.plist.fep, g.x_wrapped, c.ntype, fp, g.shift_vec, c.sys["nbfp"], None, c.sys["qA"],
                         c.sys["qB"], c.sys["typeA"], c.sys["typeB"], flags, c.lambda_coul, c.lambda_vdw, precision)
@@ -199,7 +250,8 @@ def setup_gpu(c, fused=False, use_dynamic_pruning=False):
     sig6_min = sig6 if c.sc_coul else 0.0
     nb.copy_fepparams(alpha_coul, c.sc_alpha, c.sc_power, sig6, sig6_min, c.lambda_coul, c.lambda_vdw,
                       c.all_lambda, c.all_lambda)
-    nb.init_atomdata(g.num_atoms, g.type, qA=g.qA, qB=g.qB, typeA=g.typeA, typeB=g.typeB)
+    ljc = lj_comb_params(c, g.type) if c.vdw in ("comb_geom", "comb_lb") else None
+    nb.init_atomdata(g.num_atoms, g.type, lj_comb=ljc, qA=g.qA, qB=g.qB, typeA=g.typeA, typeB=g.typeB)
     pl = c.plist_fused if fused else c.plist
     nb.init_pairlist(pl.sci, pl.cjPacked, pl.excl)
     if fused:

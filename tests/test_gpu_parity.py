@@ -148,3 +148,78 @@ def test_full_size_properties_100k():
     # and the oracle on the full box (1.6 s of CPU)
     want = tl.run_oracle(c, energy=True)
     tl.assert_parity(fused, want, rel=1e-4, label="96k fused")
+
+
+@pytest.mark.parametrize("vdw", ["comb_geom", "comb_lb"])
+@pytest.mark.parametrize("fused", [False, True])
+def test_combination_rule_kernels(vdw, fused):
+    # the cluster kernel takes per-atom LJ parameters; perturbed pairs still use the type table (both agree)
+    c = tl.make_case(elec="ewald", vdw=vdw, seed=41, **SMALL)
+    got = tl.run_gpu(c, energy=True, fused=fused)
+    want = tl.run_oracle(c, energy=True)
+    tl.assert_parity(got, want, rel=1e-4, label=vdw)
+
+
+@pytest.mark.parametrize("extra", [13, 37])
+def test_many_atom_types_table_in_lds(extra):
+    c = tl.make_case(elec="rf", seed=42, num_extra_types=extra, **SMALL)
+    assert c.grid.num_types == 4 + extra
+    for fused in (False, True):
+        got = tl.run_gpu(c, energy=True, fused=fused)
+        want = tl.run_oracle(c, energy=True)
+        tl.assert_parity(got, want, rel=1e-4, label="types %d" % extra)
+
+
+def test_local_and_nonlocal_streams():
+    """Two localities as with domain decomposition: the sci entries are dealt to a Local and a NonLocal list,
+    both kernels accumulate into the same force buffer, copy-back order NonLocal then Local (sim_util.cpp:1914-1924)."""
+    c = tl.make_case(elec="rf", seed=43, **SMALL)
+    g = c.grid
+    nb = pkg.NbnxmGpu(tl.gpu_interaction_params(c), g.num_types, g.nbat_nbfp(c.sys["nbfp"]), local_and_nonlocal=True,
+                      fep=True, n_lambda=0)
+    sig6 = c.sc_sigma ** 6
+    nb.copy_fepparams(c.sc_alpha, c.sc_alpha, c.sc_power, sig6, sig6, c.lambda_coul, c.lambda_vdw)
+    nb.init_atomdata(g.num_atoms, g.type, qA=g.qA, qB=g.qB, typeA=g.typeA, typeB=g.typeB)
+    sci = c.plist.sci
+    nb.init_pairlist(sci[0::2], c.plist.cjPacked, c.plist.excl, iloc=pkg.LOCAL)
+    nb.init_pairlist(sci[1::2], c.plist.cjPacked, c.plist.excl, iloc=pkg.NONLOCAL)
+    fep = c.plist.fep
+    empty = dict(iinr=np.zeros(0, np.int32), shift=np.zeros(0, np.int32), jindex=np.zeros(1, np.int32),
+                 jjnr=np.zeros(0, np.int32), excl_fep=np.zeros(0, np.int32))
+    nb.init_feppairlist(fep, g.atomIndices, iloc=pkg.LOCAL)
+    nb.init_feppairlist(empty, g.atomIndices, iloc=pkg.NONLOCAL)
+    nb.upload_shiftvec(g.shift_vec)
+    sw = pkg.step_workload(energy=True, virial=True)
+    nb.clear_outputs(True)
+    nb.copy_xq_to_gpu(g.xq, pkg.LOCAL)
+    nb.launch_kernel(sw, pkg.LOCAL)
+    nb.copy_xq_to_gpu(g.xq, pkg.NONLOCAL)
+    nb.launch_kernel(sw, pkg.NONLOCAL)
+    f = np.zeros((g.num_atoms, 3), np.float32)
+    nb.launch_cpyback(f, sw, pkg.NONLOCAL)
+    nb.launch_cpyback(f, sw, pkg.LOCAL)
+    nb.wait_finish_task(sw, c.have_soft_core, pkg.NONLOCAL)
+    res = nb.wait_finish_task(sw, c.have_soft_core, pkg.LOCAL)
+    dv = res["dvdl_nonlin"]
+    got = dict(f=f.astype(np.float64), fshift=res["fshift"].astype(np.float64), e_lj=res["e_lj"], e_el=res["e_el"],
+               dvdl_coul=dv[0], dvdl_vdw=dv[1])
+    want = tl.run_oracle(c, energy=True)
+    tl.assert_parity(got, want, rel=1e-4, label="two localities")
+    nb.free()
+
+
+def test_timing_and_query_entry_points():
+    c = tl.make_case(elec="ewald", seed=44, n_lambda=3, **SMALL)
+    nb = tl.setup_gpu(c)
+    nb.set_timing(True)
+    tl.run_gpu(c, energy=True, dhdl=True, nb=nb)
+    t = nb.get_timings()
+    assert t.nb_k_count == 1 and t.fep_k_count == 1 and t.nb_k_ms > 0 and t.fep_k_ms > 0
+    nb.reset_timings()
+    assert nb.get_timings().nb_k_count == 0
+    lib = pkg.hip_lib()
+    assert lib.nbnxm_gpu_is_kernel_ewald_analytical(nb.h) == 1
+    assert lib.nbnxm_gpu_min_ci_balanced(nb.h) >= 44 * 64
+    assert lib.nbnxm_gpu_have_short_range_work(nb.h, pkg.LOCAL) == 1
+    assert nb.stream() is not None
+    nb.free()
