@@ -137,6 +137,21 @@ def main():
     nb_k_us = 1e3 * tm.nb_k_ms / max(1, tm.nb_k_count)
     fep_k_us = 1e3 * tm.fep_k_ms / max(1, tm.fep_k_count) if tm.fep_k_count else 0.0
 
+    # secondary figures (not part of `value`): an energy+virial step and a dH/dlambda step with 11 foreign lambdas
+    def timed(sw, n=20):
+        for _ in range(3):
+            nb.clear_outputs(True)
+            nb.launch_kernel(sw)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(n):
+            nb.clear_outputs(True)
+            nb.launch_kernel(sw)
+        torch.cuda.synchronize()
+        return 1e3 * (time.perf_counter() - t1) / n
+    ms_energy_step = timed(pkg.step_workload(energy=True, virial=True, dhdl=False))
+    ms_dhdl_step = timed(pkg.step_workload(energy=True, virial=True, dhdl=True))
+
     ms_per_step = 1e3 * elapsed / args.steps
     pair_evals = 64 * stats["cluster_pairs"]          # atom pairs in the (pruned) list, SURVEY §8d
     fep_pairs = len(case.plist.fep["jjnr"])
@@ -169,6 +184,7 @@ def main():
                    "parallelism": "1 lambda replica per GPU" if world > 1 else "single GPU"},
         "ns_per_day_kernel_bound": ns_per_day,
         "kernel_us": {"k_calc_nb": nb_k_us, "k_calc_nb_fep": fep_k_us},
+        "ms_per_energy_step": ms_energy_step, "ms_per_dhdl_step_11_foreign_lambdas": ms_dhdl_step,
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                      "kernel": "nbnxmKernel<EwaldAna,LJcut,F,%s>" % ("fused" if fused else "plain"),

@@ -113,7 +113,7 @@ NB_DEVINL float interpolateCoulombForceR(const NBParamGpu& nbp, float r)
 template<int ELEC, bool TWIN, int VDW, bool ENERGY, bool EXCL_FORCES, bool HAS_EXCL = true>
 NB_DEVINL void nbPair(const NBParamGpu& nbp,
                       float             r2,
-                      float             int_bit,
+                      int               intMask, /* all ones if the pair interacts, 0 if it is excluded */
                       float             qq, /* epsfac q_i q_j */
                       float             c6,
                       float             c12,
@@ -125,15 +125,20 @@ NB_DEVINL void nbPair(const NBParamGpu& nbp,
     const float inv_r  = __frsqrt_rn(r2);
     const float inv_r2 = inv_r * inv_r;
     float       inv_r6 = inv_r2 * inv_r2 * inv_r2;
-    /* HAS_EXCL == false: the caller guarantees int_bit == 1 for every lane, no masking at all */
-    const float mask = (EXCL_FORCES && HAS_EXCL) ? int_bit : 1.0F;
-    if constexpr (EXCL_FORCES && HAS_EXCL) { inv_r6 *= mask; }
+    /* The exclusion bit is applied as a bit mask on the float (x & ~0 = x, x & 0 = +0): one full-rate v_and
+     * per masked term instead of the compare + select + multiply chain (half-rate ops on gfx950).
+     * HAS_EXCL == false: the caller guarantees that every pair interacts, no masking at all. */
+    auto masked = [intMask](float v) { return __builtin_bit_cast(float, __builtin_bit_cast(int, v) & intMask); };
+    [[maybe_unused]] const float int_bit = HAS_EXCL ? masked(1.0F) : 1.0F;
+    constexpr bool MASK_FORCES = EXCL_FORCES && HAS_EXCL;
+    if constexpr (MASK_FORCES) { inv_r6 = masked(inv_r6); }
+    const float inv_r3m = MASK_FORCES ? masked(inv_r2 * inv_r) : inv_r2 * inv_r; /* masked 1/r^3 */
 
     F_invr       = inv_r6 * (c12 * inv_r6 - c6) * inv_r2;
     float E_lj_p = 0.0F;
     if constexpr (ENERGY || VDW == VDK_PSWITCH)
     {
-        E_lj_p = (HAS_EXCL ? int_bit : 1.0F)
+        E_lj_p = int_bit
                  * (c12 * (inv_r6 * inv_r6 + nbp.repulsion_shift.cpot) * c_oneTwelfth
                     - c6 * (inv_r6 + nbp.dispersion_shift.cpot) * c_oneSixth);
     }
@@ -172,12 +177,12 @@ NB_DEVINL void nbPair(const NBParamGpu& nbp,
 
     if constexpr (ELEC == ELK_CUT)
     {
-        F_invr += qq * mask * inv_r2 * inv_r;
+        F_invr += qq * inv_r3m;
         if constexpr (ENERGY) { E_el = qq * (int_bit * inv_r - nbp.c_rf); }
     }
     else if constexpr (ELEC == ELK_RF)
     {
-        F_invr += qq * (mask * inv_r2 * inv_r - nbp.two_k_rf);
+        F_invr += qq * (inv_r3m - nbp.two_k_rf);
         if constexpr (ENERGY) { E_el = qq * (int_bit * inv_r + 0.5F * nbp.two_k_rf * r2 - nbp.c_rf); }
     }
     else
@@ -186,11 +191,11 @@ NB_DEVINL void nbPair(const NBParamGpu& nbp,
         if constexpr (ELEC == ELK_EWALD_ANA)
         {
             const float beta2 = beta * beta;
-            F_invr += qq * (mask * inv_r2 * inv_r + pmeCorrF(beta2 * r2) * beta2 * beta);
+            F_invr += qq * (inv_r3m + pmeCorrF(beta2 * r2) * beta2 * beta);
         }
         else
         {
-            F_invr += qq * (mask * inv_r2 - interpolateCoulombForceR(nbp, r2 * inv_r)) * inv_r;
+            F_invr += qq * (inv_r3m - interpolateCoulombForceR(nbp, r2 * inv_r) * inv_r);
         }
         if constexpr (ENERGY)
         {

@@ -80,11 +80,11 @@ NB_DEVINL void ljFromComb(int vdwKind, const float2& a, const float2& b, float& 
                         { \
                             const float3 rv      = make_float3(xqi[i].x - xqj.x, xqi[i].y - xqj.y, xqi[i].z - xqj.z); \
                             const float  r2      = rv.x * rv.x + rv.y * rv.y + rv.z * rv.z; \
-                            float        int_bit = 1.0F; \
+                            int          intMask = -1; \
                             bool         active  = (r2 < rcoulomb_sq); \
                             if constexpr (HAS_EXCL) \
                             { \
-                                int_bit = ((wexclJ >> i) & 1U) ? 1.0F : 0.0F; \
+                                intMask = __builtin_amdgcn_sbfe(static_cast<int>(wexclJ), i, 1); \
                                 if constexpr (EXCL_FORCES) \
                                 { \
                                     if (diagI == i) \
@@ -93,7 +93,7 @@ NB_DEVINL void ljFromComb(int vdwKind, const float2& a, const float2& b, float& 
                                         active = active && (tidxj > tidxi); \
                                     } \
                                 } \
-                                else { active = active && (int_bit != 0.0F); } \
+                                else { active = active && (intMask != 0); } \
                             } \
                             if (active) \
                             { \
@@ -106,7 +106,7 @@ NB_DEVINL void ljFromComb(int vdwKind, const float2& a, const float2& b, float& 
                                 } \
                                 else { ljFromComb(VDW, ljcpi[i], ljcp_j, c6, c12); } \
                                 float F_invr, E_lj_p = 0.0F, E_el_p = 0.0F; \
-                                nbPair<ELEC, TWIN, VDW, ENERGY, EXCL_FORCES, HAS_EXCL>(nbp, r2, int_bit, xqi[i].w * xqj.w, c6, c12, \
+                                nbPair<ELEC, TWIN, VDW, ENERGY, EXCL_FORCES, HAS_EXCL>(nbp, r2, intMask, xqi[i].w * xqj.w, c6, c12, \
                                                                                        F_invr, E_lj_p, E_el_p); \
                                 if constexpr (ENERGY) \
                                 { \
@@ -427,7 +427,7 @@ __launch_bounds__(c_nbBlockSize) __attribute__((amdgpu_waves_per_eu(5))) __globa
                         }
                         else
                         {
-                            const float int_bit = included ? 1.0F : 0.0F;
+                            const int intMask = included ? -1 : 0;
                             bool        active;
                             if constexpr (EXCL_FORCES) { active = (r2 < rcoulomb_sq) && !subDiag; }
                             else { active = (r2 < rcoulomb_sq) && included; }
@@ -443,7 +443,7 @@ __launch_bounds__(c_nbBlockSize) __attribute__((amdgpu_waves_per_eu(5))) __globa
                                 }
                                 else { ljFromComb(VDW, ljComb[ai], ljcp_j, c6, c12); }
                                 float E_lj_p = 0.0F, E_el_p = 0.0F;
-                                nbPair<ELEC, TWIN, VDW, ENERGY, EXCL_FORCES>(nbp, r2, int_bit, xi.w * xqj.w, c6, c12, F_invr,
+                                nbPair<ELEC, TWIN, VDW, ENERGY, EXCL_FORCES>(nbp, r2, intMask, xi.w * xqj.w, c6, c12, F_invr,
                                                                              E_lj_p, E_el_p);
                                 if constexpr (ENERGY)
                                 {
