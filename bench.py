@@ -151,6 +151,8 @@ def main():
         return 1e3 * (time.perf_counter() - t1) / n
     ms_energy_step = timed(pkg.step_workload(energy=True, virial=True, dhdl=False))
     ms_dhdl_step = timed(pkg.step_workload(energy=True, virial=True, dhdl=True))
+    ms_virial_only = timed(pkg.step_workload(energy=False, virial=True, dhdl=False))
+    ms_energy_only = timed(pkg.step_workload(energy=True, virial=False, dhdl=False))
 
     ms_per_step = 1e3 * elapsed / args.steps
     pair_evals = 64 * stats["cluster_pairs"]          # atom pairs in the (pruned) list, SURVEY §8d
@@ -185,6 +187,7 @@ def main():
         "ns_per_day_kernel_bound": ns_per_day,
         "kernel_us": {"k_calc_nb": nb_k_us, "k_calc_nb_fep": fep_k_us},
         "ms_per_energy_step": ms_energy_step, "ms_per_dhdl_step_11_foreign_lambdas": ms_dhdl_step,
+        "ms_per_virial_only_step": ms_virial_only, "ms_per_energy_only_step": ms_energy_only,
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                      "kernel": "nbnxmKernel<EwaldAna,LJcut,F,%s>" % ("fused" if fused else "plain"),

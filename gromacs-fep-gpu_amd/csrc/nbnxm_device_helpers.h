@@ -97,6 +97,24 @@ NB_DEVINL float pmeCorrF(float z2)
     return num * __builtin_amdgcn_rcpf(den);
 }
 
+/* erf(z)/z as a function of z^2 (definition as gmx::pmePotentialCorrection, simd/simd_math.h:1660-1760); own
+ * [5/4] rational fit on z^2 <= PME_CORR_XMAX (tools/fit_pme_corr.py, relative error < 5e-7 in fp32). */
+NB_DEVINL float pmeCorrV(float z2)
+{
+    float num = PME_CORR_V_P5;
+    num       = fmaf(num, z2, PME_CORR_V_P4);
+    num       = fmaf(num, z2, PME_CORR_V_P3);
+    num       = fmaf(num, z2, PME_CORR_V_P2);
+    num       = fmaf(num, z2, PME_CORR_V_P1);
+    num       = fmaf(num, z2, PME_CORR_V_P0);
+    float den = PME_CORR_V_Q4;
+    den       = fmaf(den, z2, PME_CORR_V_Q3);
+    den       = fmaf(den, z2, PME_CORR_V_Q2);
+    den       = fmaf(den, z2, PME_CORR_V_Q1);
+    den       = fmaf(den, z2, PME_CORR_V_Q0);
+    return num * __builtin_amdgcn_rcpf(den);
+}
+
 /* Linear interpolation in the Ewald force table (nbnxm_cuda_kernel_utils.cuh:448-459) */
 NB_DEVINL float interpolateCoulombForceR(const NBParamGpu& nbp, float r)
 {
@@ -197,7 +215,13 @@ NB_DEVINL void nbPair(const NBParamGpu& nbp,
         {
             F_invr += qq * (inv_r3m - interpolateCoulombForceR(nbp, r2 * inv_r) * inv_r);
         }
-        if constexpr (ENERGY)
+        if constexpr (ENERGY && ELEC == ELK_EWALD_ANA)
+        {
+            /* erf(beta r)/r = beta V(beta^2 r^2): branch-free, shares z^2 with the force correction (the libm
+             * erff costs two divergent branches per pair) */
+            E_el = qq * (int_bit * (inv_r - nbp.sh_ewald) - beta * pmeCorrV(beta * beta * r2));
+        }
+        else if constexpr (ENERGY)
         {
             E_el = qq * (inv_r * (int_bit - erff(r2 * inv_r * beta)) - int_bit * nbp.sh_ewald);
         }

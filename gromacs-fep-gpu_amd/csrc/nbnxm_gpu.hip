@@ -48,6 +48,10 @@ struct NBStagingData
     float* eElecForeign    = nullptr;
     float* dvdlLJForeign   = nullptr;
     float* dvdlElecForeign = nullptr;
+    /* MI355X: one pinned mirror of the device's scalar-output block (the pointers above, except fShift, point
+     * into it) so that one D2H copy brings everything back; energySlots: see NBAtomDataGpu::energySlots */
+    float* scalars     = nullptr;
+    float* energySlots = nullptr;
 };
 
 struct InteractionTimers
@@ -66,6 +70,12 @@ struct NbnxmGpu
     gpu_feplist*   feplist[2]     = { nullptr, nullptr };
     NBStagingData  nbst;
     DeviceStream   deviceStreams[2];
+    /* MI355X extension: the atom-pair FEP kernels of a locality run on their own stream, concurrently with
+     * the cluster-pair kernel (forked / joined with events inside gpu_launch_kernel; both only += into f) */
+    DeviceStream   fepStreams[2];
+    hipEvent_t     fepFork[2]                  = { nullptr, nullptr };
+    hipEvent_t     fepJoin[2]                  = { nullptr, nullptr };
+    bool           fepConcurrent               = true;
     hipEvent_t     nonlocal_done               = nullptr;
     hipEvent_t     misc_ops_and_local_H2D_done = nullptr;
     bool           haveWork[2]                 = { false, false };
@@ -80,7 +90,9 @@ struct NbnxmGpu
 
     int nbWavesPerBlock = c_nbWavesPerBlock; /* tunable: NBNXM_HIP_WAVES_PER_BLOCK = 1..4 */
 
-    float* scalarOutputs    = nullptr; /* device block behind atdat->eLJ ... dvdlElecForeign */
+    float* scalarOutputs    = nullptr; /* device block behind atdat->eLJ ... dvdlElecForeign, energySlots */
+    int    numHeadScalars   = 0;       /* scalars + foreign arrays */
+    int    slotOffset       = 0;       /* first float of the energy slots */
     int    numScalarOutputs = 0;
 
     /* allocation bookkeeping */
@@ -113,7 +125,7 @@ __global__ void nbnxmClearOutputsKernel(float4* __restrict__ f4, int numFloat4, 
     const float4 zero   = make_float4(0.0F, 0.0F, 0.0F, 0.0F);
     for (int i = gid; i < numFloat4; i += stride) { f4[i] = zero; }
     if (gid < numTail) { tail[gid] = 0.0F; }
-    if (gid < numScalars) { scalars[gid] = 0.0F; }
+    for (int i = gid; i < numScalars; i += stride) { scalars[i] = 0.0F; }
     if (gid < numFshift) { fshift[gid] = 0.0F; }
 }
 
@@ -227,6 +239,20 @@ NbnxmGpu* nbnxm_gpu_init(const nbnxm_interaction_params_t* ic, int numTypes, con
         initFeplist(nb->feplist[i]);
     }
     nb->deviceStreams[0].init(localStream);
+    if (const char* env = std::getenv("NBNXM_HIP_FEP_CONCURRENT")) { nb->fepConcurrent = (std::atoi(env) != 0); }
+    if (bFEP && nb->fepConcurrent)
+    {
+        for (int i = 0; i < (nb->bUseTwoStreams ? 2 : 1); i++)
+        {
+            int lo = 0, hi = 0;
+            NBNXM_HIP_CHECK(hipDeviceGetStreamPriorityRange(&lo, &hi));
+            /* few, long-latency waves: give them priority over the throughput kernel they overlap with */
+            NBNXM_HIP_CHECK(hipStreamCreateWithPriority(&nb->fepStreams[i].stream, hipStreamNonBlocking, hi));
+            nb->fepStreams[i].owned = true;
+            NBNXM_HIP_CHECK(hipEventCreateWithFlags(&nb->fepFork[i], hipEventDisableTiming));
+            NBNXM_HIP_CHECK(hipEventCreateWithFlags(&nb->fepJoin[i], hipEventDisableTiming));
+        }
+    }
     if (nb->bUseTwoStreams)
     {
         nb->deviceStreams[1].init(nonLocalStream);
@@ -256,15 +282,23 @@ NbnxmGpu* nbnxm_gpu_init(const nbnxm_interaction_params_t* ic, int numTypes, con
         NBNXM_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(p), n * sizeof(float), hipHostMallocDefault));
         std::memset(*p, 0, n * sizeof(float));
     };
-    pinned(&nb->nbst.eLJ, 1);
-    pinned(&nb->nbst.eElec, 1);
-    pinned(&nb->nbst.dvdlLJ, 1);
-    pinned(&nb->nbst.dvdlElec, 1);
+    /* scalar-output block, device and pinned mirror:
+     * [eLJ, eElec, dvdlLJ, dvdlElec, eLJForeign[n+1], eElecForeign[n+1], dvdlLJForeign[n+1], dvdlElecForeign[n+1],
+     *  pad to a 128-byte line, energySlots[c_numEnergySlots][c_energySlotStride]] */
+    nb->numHeadScalars   = 4 + 4 * (n_lambda + 1);
+    nb->slotOffset       = (nb->numHeadScalars + c_energySlotStride - 1) / c_energySlotStride * c_energySlotStride;
+    nb->numScalarOutputs = nb->slotOffset + c_numEnergySlots * c_energySlotStride;
+    pinned(&nb->nbst.scalars, nb->numScalarOutputs);
     pinned(&nb->nbst.fShift, 3 * c_numShiftVectors);
-    pinned(&nb->nbst.eLJForeign, n_lambda + 1);
-    pinned(&nb->nbst.eElecForeign, n_lambda + 1);
-    pinned(&nb->nbst.dvdlLJForeign, n_lambda + 1);
-    pinned(&nb->nbst.dvdlElecForeign, n_lambda + 1);
+    nb->nbst.eLJ             = nb->nbst.scalars + 0;
+    nb->nbst.eElec           = nb->nbst.scalars + 1;
+    nb->nbst.dvdlLJ          = nb->nbst.scalars + 2;
+    nb->nbst.dvdlElec        = nb->nbst.scalars + 3;
+    nb->nbst.eLJForeign      = nb->nbst.scalars + 4;
+    nb->nbst.eElecForeign    = nb->nbst.eLJForeign + (n_lambda + 1);
+    nb->nbst.dvdlLJForeign   = nb->nbst.eElecForeign + (n_lambda + 1);
+    nb->nbst.dvdlElecForeign = nb->nbst.dvdlLJForeign + (n_lambda + 1);
+    nb->nbst.energySlots     = nb->nbst.scalars + nb->slotOffset;
 
     /* initNbparam :421-489 */
     NBParamGpu* nbp = nb->nbparam;
@@ -298,9 +332,7 @@ NbnxmGpu* nbnxm_gpu_init(const nbnxm_interaction_params_t* ic, int numTypes, con
     NBAtomDataGpu* ad = nb->atdat;
     ad->numTypes      = numTypes;
     allocateDeviceBuffer(&ad->shiftVec, c_numShiftVectors);
-    /* all scalar outputs live in one block so that one kernel clears them:
-     * [eLJ, eElec, dvdlLJ, dvdlElec, eLJForeign[n+1], eElecForeign[n+1], dvdlLJForeign[n+1], dvdlElecForeign[n+1]] */
-    nb->numScalarOutputs = 4 + 4 * (n_lambda + 1);
+    /* all scalar outputs live in one block (layout above) so that one kernel clears them */
     allocateDeviceBuffer(&nb->scalarOutputs, nb->numScalarOutputs);
     ad->eLJ             = nb->scalarOutputs + 0;
     ad->eElec           = nb->scalarOutputs + 1;
@@ -310,6 +342,7 @@ NbnxmGpu* nbnxm_gpu_init(const nbnxm_interaction_params_t* ic, int numTypes, con
     ad->eElecForeign    = ad->eLJForeign + (n_lambda + 1);
     ad->dvdlLJForeign   = ad->eElecForeign + (n_lambda + 1);
     ad->dvdlElecForeign = ad->dvdlLJForeign + (n_lambda + 1);
+    ad->energySlots     = nb->scalarOutputs + nb->slotOffset;
     allocateDeviceBuffer(&ad->fShift, c_numShiftVectors);
     clearDeviceBufferAsync(&ad->fShift, 0, c_numShiftVectors, s);
     clearDeviceBufferAsync(&nb->scalarOutputs, 0, nb->numScalarOutputs, s);
@@ -367,15 +400,8 @@ void nbnxm_gpu_free(NbnxmGpu* nb)
     auto unpin = [](float* p) {
         if (p) { (void)hipHostFree(p); }
     };
-    unpin(nb->nbst.eLJ);
-    unpin(nb->nbst.eElec);
-    unpin(nb->nbst.dvdlLJ);
-    unpin(nb->nbst.dvdlElec);
+    unpin(nb->nbst.scalars);
     unpin(nb->nbst.fShift);
-    unpin(nb->nbst.eLJForeign);
-    unpin(nb->nbst.eElecForeign);
-    unpin(nb->nbst.dvdlLJForeign);
-    unpin(nb->nbst.dvdlElecForeign);
     for (auto& t : nb->timers)
     {
         t.nb_k.destroy();
@@ -384,6 +410,13 @@ void nbnxm_gpu_free(NbnxmGpu* nb)
     }
     if (nb->nonlocal_done) { (void)hipEventDestroy(nb->nonlocal_done); }
     if (nb->misc_ops_and_local_H2D_done) { (void)hipEventDestroy(nb->misc_ops_and_local_H2D_done); }
+    for (int i = 0; i < 2; i++)
+    {
+        if (nb->fepStreams[i].stream) { (void)hipStreamSynchronize(nb->fepStreams[i].stream); }
+        nb->fepStreams[i].destroy();
+        if (nb->fepFork[i]) { (void)hipEventDestroy(nb->fepFork[i]); }
+        if (nb->fepJoin[i]) { (void)hipEventDestroy(nb->fepJoin[i]); }
+    }
     nb->deviceStreams[0].destroy();
     nb->deviceStreams[1].destroy();
     delete nb->atdat;
@@ -750,12 +783,53 @@ void nbnxm_gpu_launch_kernel(NbnxmGpu* nb, const nbnxm_step_workload_t* stepWork
         /* the non-local kernel must see the local H2D and the output clearing (nbnxm_cuda.cu:625-641) */
         NBNXM_HIP_CHECK(hipStreamWaitEvent(s, nb->misc_ops_and_local_H2D_done, 0));
     }
+    /* A.4: the reference returns before the FEP launch when the normal list is empty; here the
+     * perturbed pairs are evaluated regardless.
+     * The atom-pair kernels are few, latency-bound waves: they go first, on the locality's FEP stream, and
+     * overlap with the cluster-pair kernel (the reference queues them behind it, nbnxm_cuda.cu:762-857). */
+    const bool fused = nb->fusedFep && nbp->bFEP;
+    bool       fepForked = false;
+    if (nbp->bFEP)
+    {
+        gpu_feplist* feplist   = nb->feplist[iloc];
+        const bool   doForce   = !fused;
+        const bool   doForeign = nb->n_lambda > 0 && stepWork->computeDhdl && (nbp->alpha_coul != 0.0F || nbp->alpha_vdw != 0.0F);
+        if (feplist->nri > 0 && feplist->nrj > 0 && (doForce || doForeign))
+        {
+            hipStream_t fs = s;
+            if (nb->fepConcurrent && nb->fepStreams[iloc].stream != nullptr && plist->nsci > 0)
+            {
+                fs = nb->fepStreams[iloc].stream;
+                NBNXM_HIP_CHECK(hipEventRecord(nb->fepFork[iloc], s));
+                NBNXM_HIP_CHECK(hipStreamWaitEvent(fs, nb->fepFork[iloc], 0));
+                fepForked = true;
+            }
+            const int nblock = (feplist->nrj + 255) / 256;
+            if (nb->bDoTime) { t.fep_k.openTimingRegion(fs); }
+            if (doForce)
+            {
+                const FepKernelPtr k = selectFepKernel(nbp->elecType, nbp->vdwType, stepWork->computeEnergy != 0);
+                NBNXM_ASSERT(k != nullptr, "no FEP kernel for this electrostatics type");
+                hipLaunchKernelGGL(k, dim3(nblock), dim3(256), 0, fs, *adat, *nbp, *feplist, stepWork->computeVirial);
+                NBNXM_HIP_CHECK(hipGetLastError());
+            }
+            if (doForeign)
+            {
+                const FepKernelPtr k = selectFepForeignKernel(nbp->elecType, nbp->vdwType);
+                NBNXM_ASSERT(k != nullptr, "no foreign-lambda kernel for this electrostatics type");
+                hipLaunchKernelGGL(k, dim3(nblock), dim3(256), 0, fs, *adat, *nbp, *feplist, nb->n_lambda);
+                NBNXM_HIP_CHECK(hipGetLastError());
+            }
+            if (nb->bDoTime) { t.fep_k.closeTimingRegion(fs); }
+            if (fepForked) { NBNXM_HIP_CHECK(hipEventRecord(nb->fepJoin[iloc], fs)); }
+        }
+    }
+
     if (nbp->useDynamicPruning && plist->haveFreshList)
     {
         nbnxm_gpu_launch_kernel_pruneonly(nb, iloc, 1);
     }
 
-    const bool fused = nb->fusedFep && nbp->bFEP;
     if (plist->nsci > 0)
     {
         const NbKernelPtr kernel = selectNbKernel(nbp->elecType, nbp->vdwType, stepWork->computeEnergy != 0, fused);
@@ -783,33 +857,7 @@ void nbnxm_gpu_launch_kernel(NbnxmGpu* nb, const nbnxm_step_workload_t* stepWork
     }
     plist->haveFreshList = false;
 
-    /* A.4: the reference returns before the FEP launch when the normal list is empty; here the
-     * perturbed pairs are evaluated regardless. */
-    if (nbp->bFEP)
-    {
-        gpu_feplist* feplist = nb->feplist[iloc];
-        if (feplist->nri == 0 || feplist->nrj == 0) { return; }
-        const int  nblock  = (feplist->nrj + 255) / 256;
-        const bool doForce = !fused;
-        const bool doForeign = nb->n_lambda > 0 && stepWork->computeDhdl && (nbp->alpha_coul != 0.0F || nbp->alpha_vdw != 0.0F);
-        if (!doForce && !doForeign) { return; }
-        if (nb->bDoTime) { t.fep_k.openTimingRegion(s); }
-        if (doForce)
-        {
-            const FepKernelPtr k = selectFepKernel(nbp->elecType, nbp->vdwType, stepWork->computeEnergy != 0);
-            NBNXM_ASSERT(k != nullptr, "no FEP kernel for this electrostatics type");
-            hipLaunchKernelGGL(k, dim3(nblock), dim3(256), 0, s, *adat, *nbp, *feplist, stepWork->computeVirial);
-            NBNXM_HIP_CHECK(hipGetLastError());
-        }
-        if (doForeign)
-        {
-            const FepKernelPtr k = selectFepForeignKernel(nbp->elecType, nbp->vdwType);
-            NBNXM_ASSERT(k != nullptr, "no foreign-lambda kernel for this electrostatics type");
-            hipLaunchKernelGGL(k, dim3(nblock), dim3(256), 0, s, *adat, *nbp, *feplist, nb->n_lambda);
-            NBNXM_HIP_CHECK(hipGetLastError());
-        }
-        if (nb->bDoTime) { t.fep_k.closeTimingRegion(s); }
-    }
+    if (fepForked) { NBNXM_HIP_CHECK(hipStreamWaitEvent(s, nb->fepJoin[iloc], 0)); }
 }
 
 void nbnxm_gpu_launch_cpyback(NbnxmGpu* nb, float* f_out, const nbnxm_step_workload_t* stepWork,
@@ -844,20 +892,13 @@ void nbnxm_gpu_launch_cpyback(NbnxmGpu* nb, float* f_out, const nbnxm_step_workl
         {
             NBNXM_HIP_CHECK(hipMemcpyAsync(nb->nbst.fShift, ad->fShift, sizeof(float) * 3 * c_numShiftVectors, hipMemcpyDeviceToHost, s));
         }
-        if (stepWork->computeEnergy)
+        /* one copy of the scalar-output block instead of the reference's 4 + 4 small ones (:1263-1294):
+         * energy steps need the accumulator slots too, dH/dl-only steps just the head */
+        const bool wantForeign = nb->n_lambda > 0 && stepWork->computeDhdl;
+        if (stepWork->computeEnergy || wantForeign)
         {
-            NBNXM_HIP_CHECK(hipMemcpyAsync(nb->nbst.eLJ, ad->eLJ, sizeof(float), hipMemcpyDeviceToHost, s));
-            NBNXM_HIP_CHECK(hipMemcpyAsync(nb->nbst.eElec, ad->eElec, sizeof(float), hipMemcpyDeviceToHost, s));
-            NBNXM_HIP_CHECK(hipMemcpyAsync(nb->nbst.dvdlLJ, ad->dvdlLJ, sizeof(float), hipMemcpyDeviceToHost, s));
-            NBNXM_HIP_CHECK(hipMemcpyAsync(nb->nbst.dvdlElec, ad->dvdlElec, sizeof(float), hipMemcpyDeviceToHost, s));
-        }
-        if (nb->n_lambda > 0 && stepWork->computeDhdl)
-        {
-            const size_t n = sizeof(float) * (nb->n_lambda + 1);
-            NBNXM_HIP_CHECK(hipMemcpyAsync(nb->nbst.eLJForeign, ad->eLJForeign, n, hipMemcpyDeviceToHost, s));
-            NBNXM_HIP_CHECK(hipMemcpyAsync(nb->nbst.eElecForeign, ad->eElecForeign, n, hipMemcpyDeviceToHost, s));
-            NBNXM_HIP_CHECK(hipMemcpyAsync(nb->nbst.dvdlLJForeign, ad->dvdlLJForeign, n, hipMemcpyDeviceToHost, s));
-            NBNXM_HIP_CHECK(hipMemcpyAsync(nb->nbst.dvdlElecForeign, ad->dvdlElecForeign, n, hipMemcpyDeviceToHost, s));
+            const int n = stepWork->computeEnergy ? nb->numScalarOutputs : nb->numHeadScalars;
+            NBNXM_HIP_CHECK(hipMemcpyAsync(nb->nbst.scalars, nb->scalarOutputs, sizeof(float) * n, hipMemcpyDeviceToHost, s));
         }
     }
 }
@@ -881,11 +922,17 @@ static int finishTask(NbnxmGpu* nb, const nbnxm_step_workload_t* stepWork, int a
             if (stepWork->computeEnergy)
             {
                 NBNXM_ASSERT(enerd != nullptr, "energy step without an energy accumulator");
-                enerd->e_lj += *nb->nbst.eLJ;
-                enerd->e_el += *nb->nbst.eElec;
+                /* staged scalars (atom-pair kernels) + the cluster-pair kernel's accumulator slots */
+                double sum[4] = { *nb->nbst.eLJ, *nb->nbst.eElec, *nb->nbst.dvdlLJ, *nb->nbst.dvdlElec };
+                for (int k = 0; k < c_numEnergySlots; k++)
+                {
+                    for (int c = 0; c < 4; c++) { sum[c] += nb->nbst.energySlots[k * c_energySlotStride + c]; }
+                }
+                enerd->e_lj += sum[0];
+                enerd->e_el += sum[1];
                 double* dvdl = haveSoftCore ? enerd->dvdl_nonlin : enerd->dvdl_lin; /* gpu_common.h:420-428 */
-                dvdl[0] += *nb->nbst.dvdlElec;
-                dvdl[1] += *nb->nbst.dvdlLJ;
+                dvdl[0] += sum[3];
+                dvdl[1] += sum[2];
             }
             if (stepWork->computeVirial && shiftForces != nullptr)
             {

@@ -28,6 +28,8 @@ constexpr int c_nbBlockSize       = c_nbWavesPerBlock * c_waveSize;
 constexpr float c_nbnxnMinDistanceSquared = 3.82e-07F;
 /* nb_free_energy.cpp:107: cap on r^-6 in the perturbed-pair math */
 constexpr float c_maxRInvSix = 1.0e15F;
+constexpr int c_numEnergySlots   = 128;
+constexpr int c_energySlotStride = 32;
 
 /* nbnxm/gpu_types_common.h:103-155 */
 struct NBAtomDataGpu
@@ -62,6 +64,12 @@ struct NBAtomDataGpu
     /* MI355X extension: Grid::fepBits per 8-atom cluster (fused kernel), 8 bytes per super-cluster */
     unsigned char* fepBits;
     int            numClusters;
+
+    /* MI355X extension: the cluster-pair kernel spreads its energy / dV/dl atomics over c_numEnergySlots
+     * accumulators of c_energySlotStride floats ([eLJ, eElec, dvdlLJ, dvdlElec, pad...], one 128-byte line each):
+     * thousands of waves adding to ONE address serialise in L2 at ~10 ns per atomic (measured: +0.25 ms per
+     * energy step at 96k atoms).  The slots are summed on the host with the staged scalars (gpu_try_finish_task). */
+    float* energySlots;
 };
 
 /* nbnxm/gpu_types_common.h:160-237 */

@@ -124,8 +124,13 @@ NB_DEVINL void ljFromComb(int vdwKind, const float2& a, const float2& b, float& 
                         } \
                     }
 
+/* 5 waves per SIMD (<= 96 VGPRs) for the flavours that fit without scratch; the energy, combination-rule and
+ * switch flavours carry more live values and run at 4 waves (<= 128 VGPRs) instead of spilling. */
+template<int VDW, bool ENERGY>
+constexpr int c_nbWavesPerEu = (VDW == VDK_CUT && !ENERGY) ? 5 : 4;
+
 template<int ELEC, bool TWIN, int VDW, bool ENERGY, bool FUSED>
-__launch_bounds__(c_nbBlockSize) __attribute__((amdgpu_waves_per_eu(5))) __global__
+__launch_bounds__(c_nbBlockSize) __attribute__((amdgpu_waves_per_eu(c_nbWavesPerEu<VDW, ENERGY>))) __global__
         void nbnxmKernel(const NBAtomDataGpu atdat,
                          const NBParamGpu    nbp,
                          const gpu_plist     plist,
@@ -502,16 +507,11 @@ __launch_bounds__(c_nbBlockSize) __attribute__((amdgpu_waves_per_eu(5))) __globa
             DVDL_lj = waveSum(DVDL_lj);
             DVDL_el = waveSum(DVDL_el);
         }
-        if (lane == 0U)
-        {
-            atomicAdd(atdat.eLJ, E_lj);
-            atomicAdd(atdat.eElec, E_el);
-            if constexpr (FUSED)
-            {
-                atomicAdd(atdat.dvdlLJ, DVDL_lj);
-                atomicAdd(atdat.dvdlElec, DVDL_el);
-            }
-        }
+        /* lanes 0..3 add the four sums to this wave's accumulator slot (see NBAtomDataGpu::energySlots) */
+        const int slot = entry & (c_numEnergySlots - 1);
+        float          v    = (lane == 0U) ? E_lj : E_el;
+        if constexpr (FUSED) { v = (lane == 2U) ? DVDL_lj : ((lane == 3U) ? DVDL_el : v); }
+        if (lane < (FUSED ? 4U : 2U)) { atomicAdd(atdat.energySlots + slot * c_energySlotStride + static_cast<int>(lane), v); }
     }
 }
 
