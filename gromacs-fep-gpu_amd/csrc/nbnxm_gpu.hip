@@ -24,6 +24,7 @@
 #include "nbnxm_hip.h"
 #include "nbnxm_hip_types.h"
 #include "nbnxm_kernels.h"
+#include "nbnxm_work_partition.h"
 
 using namespace nbnxm_hip;
 
@@ -89,6 +90,13 @@ struct NbnxmGpu
     int  numCUs    = 256;
 
     int nbWavesPerBlock = c_nbWavesPerBlock; /* tunable: NBNXM_HIP_WAVES_PER_BLOCK = 1..4 */
+    /* work partition (gpu_plist::work*): SIMDs of the device, weight of a perturbed cluster pair relative to a
+     * plain one (NBNXM_HIP_FEP_PAIR_WEIGHT), smallest range worth a wave (NBNXM_HIP_MIN_GROUPS_PER_WAVE) */
+    int numSimds          = 1024;
+    int fepPairWeight     = 8;
+    int minGroupsPerWave  = 2;
+    int numWorkRangesOverride = 0; /* experiments: NBNXM_HIP_NUM_WORK_RANGES */
+    PinnedBuffer<nbnxn_sci_t> h_sciSorted;
 
     float* scalarOutputs    = nullptr; /* device block behind atdat->eLJ ... dvdlElecForeign, energySlots */
     int    numHeadScalars   = 0;       /* scalars + foreign arrays */
@@ -235,10 +243,22 @@ NbnxmGpu* nbnxm_gpu_init(const nbnxm_interaction_params_t* ic, int numTypes, con
         nb->plist[i] = new gpu_plist;
         std::memset(nb->plist[i], 0, sizeof(gpu_plist));
         nb->plist[i]->sci_nalloc = nb->plist[i]->cjPacked_nalloc = nb->plist[i]->imask_nalloc = nb->plist[i]->excl_nalloc = -1;
+        nb->plist[i]->sciSorted_nalloc = nb->plist[i]->groupWeight_nalloc = nb->plist[i]->weightBlockSum_nalloc = -1;
+        nb->plist[i]->work_nalloc[0] = nb->plist[i]->work_nalloc[1] = -1;
         nb->feplist[i] = new gpu_feplist;
         initFeplist(nb->feplist[i]);
     }
     nb->deviceStreams[0].init(localStream);
+    {
+        int device = 0;
+        hipDeviceProp_t prop;
+        NBNXM_HIP_CHECK(hipGetDevice(&device));
+        NBNXM_HIP_CHECK(hipGetDeviceProperties(&prop, device));
+        nb->numSimds = prop.multiProcessorCount * 4; /* CDNA: 4 SIMDs per CU */
+        if (const char* env = std::getenv("NBNXM_HIP_FEP_PAIR_WEIGHT")) { nb->fepPairWeight = std::max(0, std::atoi(env)); }
+        if (const char* env = std::getenv("NBNXM_HIP_NUM_WORK_RANGES")) { nb->numWorkRangesOverride = std::atoi(env); }
+        if (const char* env = std::getenv("NBNXM_HIP_MIN_GROUPS_PER_WAVE")) { nb->minGroupsPerWave = std::max(1, std::atoi(env)); }
+    }
     if (const char* env = std::getenv("NBNXM_HIP_FEP_CONCURRENT")) { nb->fepConcurrent = (std::atoi(env) != 0); }
     if (bFEP && nb->fepConcurrent)
     {
@@ -384,6 +404,14 @@ void nbnxm_gpu_free(NbnxmGpu* nb)
             freeDeviceBuffer(&nb->plist[i]->cjPacked);
             freeDeviceBuffer(&nb->plist[i]->imask);
             freeDeviceBuffer(&nb->plist[i]->excl);
+            freeDeviceBuffer(&nb->plist[i]->sciSorted);
+            freeDeviceBuffer(&nb->plist[i]->groupWeight);
+            freeDeviceBuffer(&nb->plist[i]->weightBlockSum);
+            for (int p = 0; p < 2; p++)
+            {
+                freeDeviceBuffer(&nb->plist[i]->workRangeStart[p]);
+                freeDeviceBuffer(&nb->plist[i]->workFirstSci[p]);
+            }
             delete nb->plist[i];
         }
         if (nb->feplist[i])
@@ -579,7 +607,24 @@ void nbnxm_gpu_init_pairlist(NbnxmGpu* nb, int iloc, int na_c, int nsci, const n
     copyToDeviceBuffer(&d->sci, nb->h_sci.data, 0, nsci, s, true);
     copyToDeviceBuffer(&d->cjPacked, nb->h_cjPacked.data, 0, ncjPacked, s, true);
     copyToDeviceBuffer(&d->excl, nb->h_excl.data, 0, nexcl, s, true);
+    /* the i-entries ordered by their j-group range, for the work partition (empty entries first among equals) */
+    {
+        int dummy = 0;
+        reallocateDeviceBuffer(&d->sciSorted, nsci, &dummy, &d->sciSorted_nalloc);
+        nb->h_sciSorted.resize(nsci);
+        if (nsci) { std::memcpy(nb->h_sciSorted.data, sci, sizeof(nbnxn_sci_t) * nsci); }
+        std::sort(nb->h_sciSorted.data, nb->h_sciSorted.data + nsci, [](const nbnxn_sci_t& a, const nbnxn_sci_t& b) {
+            return a.cjPackedBegin != b.cjPackedBegin ? a.cjPackedBegin < b.cjPackedBegin : a.cjPackedEnd < b.cjPackedEnd;
+        });
+        for (int i = 1; i < nsci; i++)
+        {
+            NBNXM_ASSERT(nb->h_sciSorted.data[i].cjPackedBegin >= nb->h_sciSorted.data[i - 1].cjPackedEnd,
+                         "the j-group ranges of two sci entries overlap");
+        }
+        copyToDeviceBuffer(&d->sciSorted, nb->h_sciSorted.data, 0, nsci, s, true);
+    }
     NBNXM_HIP_CHECK(hipStreamSynchronize(s));
+    d->workRangesDirty        = true;
     d->haveFreshList          = true;
     d->rollingPruningNumParts = 0;
     d->rollingPruningPart     = 0;
@@ -671,12 +716,20 @@ void nbnxm_gpu_init_fep_cluster_bits(NbnxmGpu* nb, int numClusters, const unsign
     nb->h_fepBits.resize(numClusters);
     std::memcpy(nb->h_fepBits.data, fepBits, numClusters);
     copyToDeviceBuffer(&ad->fepBits, nb->h_fepBits.data, 0, numClusters, nb->deviceStreams[0].stream, true);
+    for (gpu_plist* pl : nb->plist)
+    {
+        if (pl) { pl->workRangesDirty = true; }
+    }
 }
 
 void nbnxm_gpu_set_fep_mode(NbnxmGpu* nb, int fused)
 {
     NBNXM_ASSERT(!fused || nb->atdat->fepBits != nullptr, "fused FEP mode needs nbnxm_gpu_init_fep_cluster_bits first");
     nb->fusedFep = fused != 0;
+    for (gpu_plist* pl : nb->plist)
+    {
+        if (pl) { pl->workRangesDirty = true; }
+    }
 }
 
 void nbnxm_gpu_upload_shiftvec(NbnxmGpu* nb, const float* shift_vec)
@@ -724,6 +777,51 @@ void nbnxm_gpu_clear_outputs(NbnxmGpu* nb, int computeVirial)
     NBNXM_HIP_CHECK(hipGetLastError());
 }
 
+/* (Re)computes the work partition of a list on its stream; cheap (three launches over ncjPacked ints). */
+static void updateWorkPartition(NbnxmGpu* nb, int iloc)
+{
+    gpu_plist*  d = nb->plist[iloc];
+    hipStream_t s = nb->deviceStreams[iloc].stream;
+    d->workRangesDirty = false;
+    if (d->nsci == 0 || d->ncjPacked == 0)
+    {
+        d->numWorkRanges[0] = d->numWorkRanges[1] = 0;
+        return;
+    }
+    const int numBlocks = (d->ncjPacked + c_workBlockSize - 1) / c_workBlockSize;
+    int       dummy     = 0;
+    reallocateDeviceBuffer(&d->groupWeight, d->ncjPacked, &dummy, &d->groupWeight_nalloc);
+    reallocateDeviceBuffer(&d->weightBlockSum, numBlocks + 1, &dummy, &d->weightBlockSum_nalloc);
+    WorkPartitionOut out[2];
+    for (int p = 0; p < 2; p++)
+    {
+        const int slots     = nb->numSimds * (4 + p);
+        d->numWorkRanges[p] = std::max(1, std::min(slots, d->ncjPacked / nb->minGroupsPerWave));
+        if (nb->numWorkRangesOverride > 0) { d->numWorkRanges[p] = std::min(nb->numWorkRangesOverride, d->ncjPacked); }
+        reallocateDeviceBuffer(&d->workRangeStart[p], d->numWorkRanges[p] + 1, &dummy, &d->work_nalloc[p]);
+        out[p].numRanges = d->numWorkRanges[p];
+    }
+    /* workFirstSci shares work_nalloc with workRangeStart: reallocate when that one grew */
+    for (int p = 0; p < 2; p++)
+    {
+        if (d->workFirstSciAlloc[p] < d->work_nalloc[p])
+        {
+            freeDeviceBuffer(&d->workFirstSci[p]);
+            allocateDeviceBuffer(&d->workFirstSci[p], d->work_nalloc[p]);
+            d->workFirstSciAlloc[p] = d->work_nalloc[p];
+        }
+        out[p].rangeStart = d->workRangeStart[p];
+        out[p].firstSci   = d->workFirstSci[p];
+    }
+    const bool weighFep = nb->fusedFep && nb->nbparam->bFEP && nb->atdat->fepBits != nullptr && nb->fepPairWeight > 0;
+    hipLaunchKernelGGL(nbnxmWorkWeightKernel, dim3(numBlocks), dim3(c_workBlockSize), 0, s, d->cjPacked, d->ncjPacked, d->sciSorted,
+                       d->nsci, weighFep ? nb->atdat->fepBits : nullptr, nb->fepPairWeight, d->groupWeight, d->weightBlockSum);
+    hipLaunchKernelGGL(nbnxmWorkScanKernel, dim3(1), dim3(c_workBlockSize), 0, s, d->weightBlockSum, numBlocks);
+    hipLaunchKernelGGL(nbnxmWorkRangesKernel, dim3(numBlocks), dim3(c_workBlockSize), 0, s, d->groupWeight, d->weightBlockSum,
+                       d->ncjPacked, numBlocks, d->sciSorted, d->nsci, out[0], out[1]);
+    NBNXM_HIP_CHECK(hipGetLastError());
+}
+
 void nbnxm_gpu_launch_kernel_pruneonly(NbnxmGpu* nb, int iloc, int numParts)
 {
     gpu_plist*  plist = nb->plist[iloc];
@@ -753,13 +851,16 @@ void nbnxm_gpu_launch_kernel_pruneonly(NbnxmGpu* nb, int iloc, int numParts)
     if (nb->bDoTime) { t.prune_k.closeTimingRegion(s); }
     if (plist->haveFreshList)
     {
-        plist->haveFreshList = false;
-        t.didPrune           = true;
+        plist->haveFreshList   = false;
+        plist->workRangesDirty = true; /* the masks changed: re-balance */
+        t.didPrune             = true;
     }
     else
     {
         plist->rollingPruningPart = (part + 1) % numParts;
-        t.didRollingPrune         = true;
+        /* a rolling pass changes a part of the masks, by little: re-balance once per full cycle */
+        if (plist->rollingPruningPart == 0) { plist->workRangesDirty = true; }
+        t.didRollingPrune = true;
     }
 }
 
@@ -837,6 +938,7 @@ void nbnxm_gpu_launch_kernel(NbnxmGpu* nb, const nbnxm_step_workload_t* stepWork
         {
             fatal(__FILE__, __LINE__, "nbnxm_gpu_launch_kernel", "no kernel for this electrostatics / VdW combination (LJ-PME grid flavours are not built)");
         }
+        if (plist->workRangesDirty) { updateWorkPartition(nb, iloc); }
         if (nb->bDoTime) { t.nb_k.openTimingRegion(s); }
         /* The LJ table lives in LDS (up to ~140 types in the 160 KB; large tables cost occupancy) */
         const bool useTable = (nbp->vdwType == NBNXM_VDW_CUT || nbp->vdwType == NBNXM_VDW_FSWITCH || nbp->vdwType == NBNXM_VDW_PSWITCH);
@@ -849,9 +951,14 @@ void nbnxm_gpu_launch_kernel(NbnxmGpu* nb, const nbnxm_step_workload_t* stepWork
         {
             NBNXM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, ldsBytes));
         }
-        hipLaunchKernelGGL(kernel, dim3((plist->nsci + wavesPerBlock - 1) / wavesPerBlock), dim3(wavesPerBlock * c_waveSize), ldsBytes, s,
-                           *adat, *nbp, *plist, stepWork->computeVirial, plist->sci, plist->cjPacked, plist->excl, adat->xq,
-                           adat->atomTypes, adat->ljComb, reinterpret_cast<const unsigned*>(adat->fepBits));
+        /* one wave per resident wave slot, each with an equal share of the list (see updateWorkPartition) */
+        const int p         = nbKernelWavesPerEu(nbp->vdwType, stepWork->computeEnergy != 0) - 4;
+        const int numRanges = plist->numWorkRanges[p];
+        NBNXM_ASSERT(numRanges > 0, "work partition missing");
+        hipLaunchKernelGGL(kernel, dim3((numRanges + wavesPerBlock - 1) / wavesPerBlock), dim3(wavesPerBlock * c_waveSize), ldsBytes, s,
+                           *adat, *nbp, *plist, stepWork->computeVirial, plist->sciSorted, plist->cjPacked, plist->excl, adat->xq,
+                           adat->atomTypes, adat->ljComb, reinterpret_cast<const unsigned*>(adat->fepBits),
+                           plist->workRangeStart[p], plist->workFirstSci[p], numRanges);
         NBNXM_HIP_CHECK(hipGetLastError());
         if (nb->bDoTime) { t.nb_k.closeTimingRegion(s); }
     }

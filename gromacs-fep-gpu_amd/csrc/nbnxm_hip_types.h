@@ -142,6 +142,25 @@ struct gpu_plist
     bool haveFreshList;
     int  rollingPruningNumParts;
     int  rollingPruningPart;
+
+    /* MI355X extension: work partition of the cluster-pair kernel.  The launch has one wave per resident wave
+     * slot of the device; wave w evaluates the packed j-groups [workRangeStart[p][w], workRangeStart[p][w+1]),
+     * cut so that every wave gets the same weight (set imask bits, perturbed cluster pairs counted several
+     * times), starting in i-entry workFirstSci[p][w] of sciSorted (the i-entries ordered by cjPackedBegin).
+     * Two partitions: p = 0 for the 4-waves-per-SIMD flavours, p = 1 for the 5-waves-per-SIMD ones.
+     * Recomputed on the device after every (re)prune of the list. */
+    nbnxn_sci_t* sciSorted;
+    int          sciSorted_nalloc;
+    int*         groupWeight;     /* ncjPacked, scratch */
+    int          groupWeight_nalloc;
+    int*         weightBlockSum;  /* per 256 groups, then its exclusive scan; last entry = total */
+    int          weightBlockSum_nalloc;
+    int*         workRangeStart[2];
+    int*         workFirstSci[2];
+    int          numWorkRanges[2];
+    int          work_nalloc[2];
+    int          workFirstSciAlloc[2];
+    bool         workRangesDirty;
 };
 
 /* nbnxm/gpu_types_common.h:343-356; iinr/jjnr hold GRID-order atom indices on the device */

@@ -143,7 +143,13 @@ __launch_bounds__(c_nbBlockSize) __attribute__((amdgpu_waves_per_eu(c_nbWavesPer
                          const float4* __restrict__ xq,
                          const int* __restrict__ atomTypes,
                          const float2* __restrict__ ljComb,
-                         const unsigned* __restrict__ fepWords /* atdat.fepBits viewed as dwords (scalar loads) */)
+                         const unsigned* __restrict__ fepWords, /* atdat.fepBits viewed as dwords (scalar loads) */
+                         /* work partition (gpu_plist::work*): wave w owns the packed j-groups
+                          * [workRangeStart[w], workRangeStart[w+1]) and starts in entry workFirstSci[w] of sciList,
+                          * which is the list's i-entries ordered by cjPackedBegin */
+                         const int* __restrict__ workRangeStart,
+                         const int* __restrict__ workFirstSci,
+                         const int numWorkRanges)
 {
     constexpr bool EXCL_FORCES = (ELEC != ELK_CUT) || ENERGY; /* nbnxm_cuda_kernel.cuh:69-78 */
     constexpr bool USE_TABLE   = VdwTraits<VDW>::useTable;
@@ -173,20 +179,37 @@ __launch_bounds__(c_nbBlockSize) __attribute__((amdgpu_waves_per_eu(c_nbWavesPer
         for (int t = threadIdx.x; t < numTypes * numTypes; t += blockSize) { nbfpLds[t] = nbp.nbfp[t]; }
     }
 
-    const int  entry    = __builtin_amdgcn_readfirstlane(static_cast<int>(blockIdx.x * (blockSize / c_waveSize) + wave));
-    const bool haveWork = entry < plist.nsci;
+    __syncthreads(); /* the table is in place; from here on the waves of the workgroup are independent */
 
-    const nbnxn_sci_t nb_sci        = sciList[haveWork ? entry : 0];
-    const int         sci           = nb_sci.sci;
-    const int         shiftIdx      = nb_sci.shift & NBNXM_CI_SHIFT_MASK;
-    const int         cjPackedBegin = nb_sci.cjPackedBegin;
-    const int         cjPackedEnd   = haveWork ? nb_sci.cjPackedEnd : nb_sci.cjPackedBegin;
-    const bool        central       = (shiftIdx == c_centralShiftIndex);
+    /* Every wave of the launch gets the same amount of pair work: a contiguous range of packed j-groups cut
+     * out of the list by weight (nbnxmWorkRangesKernel), regardless of i-entry borders.  The launch has one
+     * wave per resident wave slot, so all waves start together and finish together; with one wave per
+     * i-entry a 96k-atom list (1.2 x the slots) lost 25-35 % to the second, nearly empty round. */
+    const int workItem = __builtin_amdgcn_readfirstlane(static_cast<int>(blockIdx.x * (blockSize / c_waveSize) + wave));
+    if (workItem >= numWorkRanges) { return; }
+    const int rangeBegin = workRangeStart[workItem];
+    const int rangeEnd   = workRangeStart[workItem + 1];
+    int       sciIdx     = workFirstSci[workItem];
 
     float* __restrict__ f   = reinterpret_cast<float*>(atdat.f);
     const float rcoulomb_sq = nbp.rcoulomb_sq;
     const __amdgpu_buffer_rsrc_t fRsrc =
             __builtin_amdgcn_make_buffer_rsrc(f, 0, atdat.numAtoms * 3 * static_cast<int>(sizeof(float)), 0x00020000);
+
+    float E_lj = 0.0F, E_el = 0.0F, DVDL_lj = 0.0F, DVDL_el = 0.0F;
+
+    /* ---- the pieces of this wave's range: one per i-entry it touches ---------------------------------- */
+#pragma unroll 1
+    for (; rangeBegin < rangeEnd && sciIdx < plist.nsci; sciIdx++)
+    {
+    const nbnxn_sci_t nb_sci        = sciList[sciIdx];
+    const int         cjPackedBegin = max(rangeBegin, nb_sci.cjPackedBegin);
+    const int         cjPackedEnd   = min(rangeEnd, nb_sci.cjPackedEnd);
+    if (nb_sci.cjPackedBegin >= rangeEnd) { break; }
+    if (cjPackedBegin >= cjPackedEnd) { continue; }
+    const int         sci           = nb_sci.sci;
+    const int         shiftIdx      = nb_sci.shift & NBNXM_CI_SHIFT_MASK;
+    const bool        central       = (shiftIdx == c_centralShiftIndex);
 
     /* ---- stage the i-atoms ---------------------------------------------------------------------- */
     float4 xqi[c_numClPerSupercl];
@@ -220,9 +243,10 @@ __launch_bounds__(c_nbBlockSize) __attribute__((amdgpu_waves_per_eu(c_nbWavesPer
             qABib[lane]     = make_float2(q4.x * nbp.epsfac, q4.y * nbp.epsfac);
             const int4 t4   = atdat.atomTypes4[ai];
             tABib[lane]     = make_int2(t4.x, t4.y);
+            /* the staged copy is private to this wave: LDS operations of one wave complete in order */
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         }
     }
-    __syncthreads();
 
     /* perturbed-atom bits of the 8 i-clusters (FUSED) */
     unsigned long long iFepBits        = 0;
@@ -237,12 +261,11 @@ __launch_bounds__(c_nbBlockSize) __attribute__((amdgpu_waves_per_eu(c_nbWavesPer
         }
     }
 
-    float E_lj = 0.0F, E_el = 0.0F, DVDL_lj = 0.0F, DVDL_el = 0.0F;
-
     if constexpr (ENERGY && EXCL_FORCES)
     {
-        /* self terms on the diagonal entry (nbnxm_cuda_kernel.cuh:365-400); lane l owns atom l */
-        if (haveWork && central && cjPackedList[cjPackedBegin].cj[0] == sci * c_numClPerSupercl)
+        /* self terms on the diagonal entry (nbnxm_cuda_kernel.cuh:365-400); lane l owns atom l.  The
+         * cluster's own j-cluster is the first one of the entry, so exactly one piece sees it. */
+        if (central && cjPackedList[cjPackedBegin].cj[0] == sci * c_numClPerSupercl)
         {
             const float coef = (ELEC == ELK_CUT || ELEC == ELK_RF) ? -0.5F * nbp.c_rf : -nbp.ewald_beta * c_oneOverSqrtPi;
             const float qi   = xq[sci * c_superClSize + static_cast<int>(lane)].w * nbp.epsfac;
@@ -337,8 +360,6 @@ __launch_bounds__(c_nbBlockSize) __attribute__((amdgpu_waves_per_eu(c_nbWavesPer
         }
     }
     __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(pendingF, fRsrc, pendingOff, 0, 0);
-
-    if (!haveWork) { return; }
 
     /* i-forces: reduce over tidxj; lane (tidxj, tidxi) keeps the sum of cluster tidxj, atom tidxi */
     float3 mine = make_float3(0.0F, 0.0F, 0.0F);
@@ -497,6 +518,7 @@ __launch_bounds__(c_nbBlockSize) __attribute__((amdgpu_waves_per_eu(c_nbWavesPer
             atomicAdd(reinterpret_cast<float*>(atdat.fShift) + 3 * shiftIdx + static_cast<int>(lane), v);
         }
     }
+    } /* pieces */
 
     if constexpr (ENERGY)
     {
@@ -508,7 +530,7 @@ __launch_bounds__(c_nbBlockSize) __attribute__((amdgpu_waves_per_eu(c_nbWavesPer
             DVDL_el = waveSum(DVDL_el);
         }
         /* lanes 0..3 add the four sums to this wave's accumulator slot (see NBAtomDataGpu::energySlots) */
-        const int slot = entry & (c_numEnergySlots - 1);
+        const int slot = workItem & (c_numEnergySlots - 1);
         float          v    = (lane == 0U) ? E_lj : E_el;
         if constexpr (FUSED) { v = (lane == 2U) ? DVDL_lj : ((lane == 3U) ? DVDL_el : v); }
         if (lane < (FUSED ? 4U : 2U)) { atomicAdd(atdat.energySlots + slot * c_energySlotStride + static_cast<int>(lane), v); }

@@ -9,7 +9,8 @@
 #include "nbnxm_hip_types.h"
 
 using NbKernelPtr = void (*)(NBAtomDataGpu, NBParamGpu, gpu_plist, int, const nbnxn_sci_t*, const nbnxn_cj_packed_t*,
-                             const nbnxn_excl_t*, const float4*, const int*, const float2*, const unsigned*);
+                             const nbnxn_excl_t*, const float4*, const int*, const float2*, const unsigned*, const int*,
+                             const int*, int);
 using FepKernelPtr   = void (*)(NBAtomDataGpu, NBParamGpu, gpu_feplist, int);
 using PruneKernelPtr = void (*)(NBAtomDataGpu, NBParamGpu, gpu_plist, int, int);
 
@@ -25,5 +26,7 @@ NbKernelPtr    selectNbKernel(int elecType, int vdwType, bool energy, bool fused
 FepKernelPtr   selectFepKernel(int elecType, int vdwType, bool energy);
 FepKernelPtr   selectFepForeignKernel(int elecType, int vdwType);
 PruneKernelPtr selectPruneKernel(bool haveFreshList);
+/* waves per SIMD the flavour is compiled for (c_nbWavesPerEu): decides which work partition it runs on */
+int nbKernelWavesPerEu(int vdwType, bool energy);
 
 #endif

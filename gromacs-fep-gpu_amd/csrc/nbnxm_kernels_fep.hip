@@ -74,6 +74,11 @@ FepKernelPtr selectFepForeignKernel(int elecType, int vdwType)
     }
 }
 
+int nbKernelWavesPerEu(int vdwType, bool energy)
+{
+    return (vdwKindOf(vdwType) == VDK_CUT && !energy) ? c_nbWavesPerEu<VDK_CUT, false> : c_nbWavesPerEu<VDK_PSWITCH, true>;
+}
+
 PruneKernelPtr selectPruneKernel(bool haveFreshList)
 {
     return haveFreshList ? nbnxmPruneKernel<true> : nbnxmPruneKernel<false>;

@@ -1,0 +1,167 @@
+/*
+ * Work partition of the cluster-pair kernel (MI355X extension, no counterpart in the reference, whose
+ * balancing is the host-side sci splitting of nbnxm/pairlist.cpp:2283-2400 against gpu_min_ci_balanced).
+ *
+ * The list is cut into as many contiguous ranges of packed j-groups as the device has resident wave slots,
+ * all of the same weight: weight(group) = set imask bits (+ fepPairWeight x cluster pairs that hold a perturbed
+ * atom when the fused kernel evaluates them in its second pass).  Three small kernels, run on the list's own
+ * stream after every (re)prune, because pruning changes the masks on the device:
+ *   nbnxmWorkWeightKernel  one thread per group: weight + per-256-group sums
+ *   nbnxmWorkScanKernel    one workgroup: exclusive scan of the sums
+ *   nbnxmWorkRangesKernel  one thread per group: global prefix -> the range borders that fall on this group,
+ *                          for both partitions (4 and 5 waves per SIMD), plus the i-entry each range starts in
+ */
+#ifndef NBNXM_WORK_PARTITION_H
+#define NBNXM_WORK_PARTITION_H
+
+#include "nbnxm_hip_types.h"
+
+constexpr int c_workBlockSize = 256;
+
+/* largest k with sciSorted[k].cjPackedBegin <= group (entries ordered by (cjPackedBegin, cjPackedEnd)); -1 if none */
+__device__ __forceinline__ int findSciOfGroup(const nbnxn_sci_t* __restrict__ sciSorted, int nsci, int group)
+{
+    int lo = 0, hi = nsci; /* first k with begin > group */
+    while (lo < hi)
+    {
+        const int mid = (lo + hi) >> 1;
+        if (sciSorted[mid].cjPackedBegin <= group) { lo = mid + 1; }
+        else { hi = mid; }
+    }
+    return lo - 1;
+}
+
+/* inclusive scan over the workgroup; returns this thread's inclusive prefix, total in *blockTotal */
+__device__ __forceinline__ int blockInclusiveScan(int v, int* lds, int* blockTotal)
+{
+    const int t = static_cast<int>(threadIdx.x);
+    lds[t]      = v;
+    __syncthreads();
+    for (int d = 1; d < c_workBlockSize; d <<= 1)
+    {
+        const int add = (t >= d) ? lds[t - d] : 0;
+        __syncthreads();
+        lds[t] += add;
+        __syncthreads();
+    }
+    const int incl = lds[t];
+    *blockTotal    = lds[c_workBlockSize - 1];
+    __syncthreads();
+    return incl;
+}
+
+__launch_bounds__(c_workBlockSize) __global__
+        void nbnxmWorkWeightKernel(const nbnxn_cj_packed_t* __restrict__ cjPacked,
+                                   const int                             ncjPacked,
+                                   const nbnxn_sci_t* __restrict__       sciSorted,
+                                   const int                             nsci,
+                                   const unsigned char* __restrict__     fepBits, /* nullptr: no perturbed-pair weighting */
+                                   const int                             fepPairWeight,
+                                   int* __restrict__                     groupWeight,
+                                   int* __restrict__                     blockSum)
+{
+    __shared__ int lds[c_workBlockSize];
+    const int      g = static_cast<int>(blockIdx.x) * c_workBlockSize + static_cast<int>(threadIdx.x);
+    int            w = 0;
+    if (g < ncjPacked)
+    {
+        const unsigned imask = cjPacked[g].imei[0].imask;
+        w                    = __popc(imask);
+        if (fepBits != nullptr && imask != 0U)
+        {
+            const int k = findSciOfGroup(sciSorted, nsci, g);
+            if (k >= 0 && g < sciSorted[k].cjPackedEnd)
+            {
+                const int sci          = sciSorted[k].sci;
+                unsigned  iClusterMask = 0U;
+                for (int i = 0; i < c_numClPerSupercl; i++)
+                {
+                    if (fepBits[sci * c_numClPerSupercl + i] != 0) { iClusterMask |= (1U << i); }
+                }
+                for (int jm = 0; jm < c_jGroupSize; jm++)
+                {
+                    const unsigned imaskJ = (imask >> (jm * c_numClPerSupercl)) & 0xFFU;
+                    if (imaskJ == 0U) { continue; }
+                    const unsigned slow = (fepBits[cjPacked[g].cj[jm]] != 0) ? imaskJ : (imaskJ & iClusterMask);
+                    w += fepPairWeight * __popc(slow);
+                }
+            }
+        }
+        groupWeight[g] = w;
+    }
+    int total;
+    (void)blockInclusiveScan(w, lds, &total);
+    if (threadIdx.x == 0) { blockSum[blockIdx.x] = total; }
+}
+
+/* in place: blockSum[b] <- sum of blockSum[0..b), blockSum[numBlocks] <- total */
+__launch_bounds__(c_workBlockSize) __global__ void nbnxmWorkScanKernel(int* __restrict__ blockSum, const int numBlocks)
+{
+    __shared__ int lds[c_workBlockSize];
+    int            carry = 0;
+    for (int base = 0; base < numBlocks; base += c_workBlockSize)
+    {
+        const int idx = base + static_cast<int>(threadIdx.x);
+        const int v   = (idx < numBlocks) ? blockSum[idx] : 0;
+        int       total;
+        const int incl = blockInclusiveScan(v, lds, &total);
+        if (idx < numBlocks) { blockSum[idx] = carry + incl - v; }
+        carry += total;
+    }
+    if (threadIdx.x == 0) { blockSum[numBlocks] = carry; }
+}
+
+struct WorkPartitionOut
+{
+    int  numRanges;
+    int* rangeStart; /* numRanges + 1 */
+    int* firstSci;   /* numRanges */
+};
+
+__launch_bounds__(c_workBlockSize) __global__
+        void nbnxmWorkRangesKernel(const int* __restrict__         groupWeight,
+                                   const int* __restrict__         blockPrefix,
+                                   const int                       ncjPacked,
+                                   const int                       numBlocks,
+                                   const nbnxn_sci_t* __restrict__ sciSorted,
+                                   const int                       nsci,
+                                   const WorkPartitionOut          out0,
+                                   const WorkPartitionOut          out1)
+{
+    __shared__ int lds[c_workBlockSize];
+    const int      g = static_cast<int>(blockIdx.x) * c_workBlockSize + static_cast<int>(threadIdx.x);
+    const int      w = (g < ncjPacked) ? groupWeight[g] : 0;
+    int            blockTotal;
+    const int      incl = blockInclusiveScan(w, lds, &blockTotal);
+    if (g >= ncjPacked) { return; }
+    const long long total = max(1, blockPrefix[numBlocks]);
+    const long long e     = blockPrefix[blockIdx.x] + incl - w;         /* weight before this group */
+    const long long ePrev = (g == 0) ? -1 : e - groupWeight[g - 1];     /* ... and before the previous one */
+    int             sciOfGroup = -2;
+#pragma unroll
+    for (int p = 0; p < 2; p++)
+    {
+        const WorkPartitionOut& out = (p == 0) ? out0 : out1;
+        const int               nW  = out.numRanges;
+        if (nW <= 0) { continue; }
+        /* range a owns the groups whose preceding weight lies in [a total / nW, (a + 1) total / nW) */
+        const int a  = static_cast<int>(min(static_cast<long long>(nW - 1), e * nW / total));
+        const int lo = (g == 0) ? 0 : static_cast<int>(min(static_cast<long long>(nW - 1), ePrev * nW / total)) + 1;
+        if (lo <= a && sciOfGroup == -2) { sciOfGroup = max(0, findSciOfGroup(sciSorted, nsci, g)); }
+        for (int r = lo; r <= a; r++)
+        {
+            out.rangeStart[r] = g;
+            out.firstSci[r]   = sciOfGroup;
+        }
+        if (g == ncjPacked - 1)
+        {
+            for (int r = a + 1; r <= nW; r++)
+            {
+                out.rangeStart[r] = ncjPacked; /* empty ranges behind the last group, and the end sentinel */
+                if (r < nW) { out.firstSci[r] = nsci; }
+            }
+        }
+    }
+}
+
+#endif
