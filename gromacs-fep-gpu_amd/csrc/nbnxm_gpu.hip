@@ -93,7 +93,7 @@ struct NbnxmGpu
     /* work partition (gpu_plist::work*): SIMDs of the device, weight of a perturbed cluster pair relative to a
      * plain one (NBNXM_HIP_FEP_PAIR_WEIGHT), smallest range worth a wave (NBNXM_HIP_MIN_GROUPS_PER_WAVE) */
     int numSimds          = 1024;
-    int fepPairWeight     = 8;
+    int fepPairWeight     = 16;
     int minGroupsPerWave  = 2;
     int numWorkRangesOverride = 0; /* experiments: NBNXM_HIP_NUM_WORK_RANGES */
     PinnedBuffer<nbnxn_sci_t> h_sciSorted;
@@ -406,6 +406,7 @@ void nbnxm_gpu_free(NbnxmGpu* nb)
             freeDeviceBuffer(&nb->plist[i]->excl);
             freeDeviceBuffer(&nb->plist[i]->sciSorted);
             freeDeviceBuffer(&nb->plist[i]->groupWeight);
+            freeDeviceBuffer(&nb->plist[i]->groupFepJ);
             freeDeviceBuffer(&nb->plist[i]->weightBlockSum);
             for (int p = 0; p < 2; p++)
             {
@@ -783,6 +784,9 @@ static void updateWorkPartition(NbnxmGpu* nb, int iloc)
     gpu_plist*  d = nb->plist[iloc];
     hipStream_t s = nb->deviceStreams[iloc].stream;
     d->workRangesDirty = false;
+#ifdef NBNXM_WAVE_TIMELINE
+    if (d->debugTimeline == nullptr) { allocateDeviceBuffer(&d->debugTimeline, 4 * 16384); }
+#endif
     if (d->nsci == 0 || d->ncjPacked == 0)
     {
         d->numWorkRanges[0] = d->numWorkRanges[1] = 0;
@@ -790,7 +794,13 @@ static void updateWorkPartition(NbnxmGpu* nb, int iloc)
     }
     const int numBlocks = (d->ncjPacked + c_workBlockSize - 1) / c_workBlockSize;
     int       dummy     = 0;
+    const int oldAlloc = d->groupWeight_nalloc;
     reallocateDeviceBuffer(&d->groupWeight, d->ncjPacked, &dummy, &d->groupWeight_nalloc);
+    if (d->groupWeight_nalloc != oldAlloc)
+    {
+        freeDeviceBuffer(&d->groupFepJ);
+        allocateDeviceBuffer(&d->groupFepJ, d->groupWeight_nalloc);
+    }
     reallocateDeviceBuffer(&d->weightBlockSum, numBlocks + 1, &dummy, &d->weightBlockSum_nalloc);
     WorkPartitionOut out[2];
     for (int p = 0; p < 2; p++)
@@ -813,9 +823,9 @@ static void updateWorkPartition(NbnxmGpu* nb, int iloc)
         out[p].rangeStart = d->workRangeStart[p];
         out[p].firstSci   = d->workFirstSci[p];
     }
-    const bool weighFep = nb->fusedFep && nb->nbparam->bFEP && nb->atdat->fepBits != nullptr && nb->fepPairWeight > 0;
+    const bool fused = nb->fusedFep && nb->nbparam->bFEP && nb->atdat->fepBits != nullptr;
     hipLaunchKernelGGL(nbnxmWorkWeightKernel, dim3(numBlocks), dim3(c_workBlockSize), 0, s, d->cjPacked, d->ncjPacked, d->sciSorted,
-                       d->nsci, weighFep ? nb->atdat->fepBits : nullptr, nb->fepPairWeight, d->groupWeight, d->weightBlockSum);
+                       d->nsci, fused ? nb->atdat->fepBits : nullptr, nb->fepPairWeight, d->groupFepJ, d->groupWeight, d->weightBlockSum);
     hipLaunchKernelGGL(nbnxmWorkScanKernel, dim3(1), dim3(c_workBlockSize), 0, s, d->weightBlockSum, numBlocks);
     hipLaunchKernelGGL(nbnxmWorkRangesKernel, dim3(numBlocks), dim3(c_workBlockSize), 0, s, d->groupWeight, d->weightBlockSum,
                        d->ncjPacked, numBlocks, d->sciSorted, d->nsci, out[0], out[1]);
@@ -945,20 +955,20 @@ void nbnxm_gpu_launch_kernel(NbnxmGpu* nb, const nbnxm_step_workload_t* stepWork
         int        wavesPerBlock = nb->nbWavesPerBlock;
         const int  tableBytes    = useTable ? adat->numTypes * adat->numTypes * 8 : 0;
         if (tableBytes > 8 * 1024) { wavesPerBlock = c_nbWavesPerBlock; } /* one table copy per 4 waves */
-        const int ldsBytes = tableBytes + 16 + (fused ? wavesPerBlock * c_superClSize * 32 : 0) + 16;
+        const int ldsBytes = nbLdsBytes(adat->numTypes, useTable, fused, wavesPerBlock);
         NBNXM_ASSERT(ldsBytes <= 160 * 1024, "too many atom types: the LJ parameter table does not fit the 160 KB LDS");
         if (ldsBytes > 64 * 1024)
         {
             NBNXM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, ldsBytes));
         }
         /* one wave per resident wave slot, each with an equal share of the list (see updateWorkPartition) */
-        const int p         = nbKernelWavesPerEu(nbp->vdwType, stepWork->computeEnergy != 0) - 4;
+        const int p         = nbKernelWavesPerEu(nbp->vdwType, stepWork->computeEnergy != 0, fused) - 4;
         const int numRanges = plist->numWorkRanges[p];
         NBNXM_ASSERT(numRanges > 0, "work partition missing");
         hipLaunchKernelGGL(kernel, dim3((numRanges + wavesPerBlock - 1) / wavesPerBlock), dim3(wavesPerBlock * c_waveSize), ldsBytes, s,
                            *adat, *nbp, *plist, stepWork->computeVirial, plist->sciSorted, plist->cjPacked, plist->excl, adat->xq,
                            adat->atomTypes, adat->ljComb, reinterpret_cast<const unsigned*>(adat->fepBits),
-                           plist->workRangeStart[p], plist->workFirstSci[p], numRanges);
+                           plist->workRangeStart[p], plist->workFirstSci[p], numRanges, plist->groupFepJ);
         NBNXM_HIP_CHECK(hipGetLastError());
         if (nb->bDoTime) { t.nb_k.closeTimingRegion(s); }
     }
@@ -1139,6 +1149,16 @@ void* nbnxm_gpu_debug_get_cjpacked(NbnxmGpu* nb, int iloc)
 {
     return nb->plist[iloc]->cjPacked;
 }
+
+#ifdef NBNXM_WAVE_TIMELINE
+/* diagnostics build only: copies the per-wave timeline of the last cluster-pair kernel launch */
+void nbnxm_gpu_debug_timeline(NbnxmGpu* nb, unsigned long long* out, int numWaves)
+{
+    NBNXM_HIP_CHECK(hipStreamSynchronize(nb->deviceStreams[0].stream));
+    NBNXM_ASSERT(nb->plist[0]->debugTimeline != nullptr, "no timeline buffer");
+    NBNXM_HIP_CHECK(hipMemcpy(out, nb->plist[0]->debugTimeline, sizeof(unsigned long long) * 4 * numWaves, hipMemcpyDeviceToHost));
+}
+#endif
 
 void nbnxm_gpu_debug_download(NbnxmGpu* nb, const void* devicePtr, void* hostPtr, size_t numBytes)
 {

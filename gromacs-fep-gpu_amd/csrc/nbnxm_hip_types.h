@@ -151,6 +151,7 @@ struct gpu_plist
      * Recomputed on the device after every (re)prune of the list. */
     nbnxn_sci_t* sciSorted;
     int          sciSorted_nalloc;
+    unsigned*    groupFepJ;       /* ncjPacked: Grid::fepBits of each group's 4 j-clusters, one byte each (fused kernel) */
     int*         groupWeight;     /* ncjPacked, scratch */
     int          groupWeight_nalloc;
     int*         weightBlockSum;  /* per 256 groups, then its exclusive scan; last entry = total */
@@ -161,6 +162,7 @@ struct gpu_plist
     int          work_nalloc[2];
     int          workFirstSciAlloc[2];
     bool         workRangesDirty;
+    unsigned long long* debugTimeline; /* diagnostics builds (NBNXM_WAVE_TIMELINE) only, else nullptr */
 };
 
 /* nbnxm/gpu_types_common.h:343-356; iinr/jjnr hold GRID-order atom indices on the device */
@@ -183,5 +185,25 @@ struct gpu_feplist
     int* pairEntry; /* nrj */
     int  pairEntry_nalloc;
 };
+
+/* Per-wave LDS staging of the j-side of one packed group (4 j-clusters):
+ *   [0, 512)     float4 xq of the 32 atoms
+ *   [512, 768)   table flavours: int type[32]; combination-rule flavours: float c.x[32], c.y[32]
+ *   [768, 1024)  unsigned exclusion word of each of the 64 lanes
+ * two such buffers per wave; FUSED adds the 64 i-atoms' A/B data (32 bytes per atom). */
+constexpr int c_jStageBytes      = 1024;
+constexpr int c_jStageLjOffset   = 512;
+constexpr int c_jStageExclOffset = 768;
+constexpr int c_iStageBytes      = c_superClSize * static_cast<int>(sizeof(float4) + sizeof(float2) + sizeof(int2));
+/* ring of 4 list-word records per wave (32 bytes of nbnxn_cj_packed_t + 4 bytes of fepBits, padded) */
+constexpr int c_ringRecordBytes  = 64;
+constexpr int c_jRingBytes       = 4 * c_ringRecordBytes;
+
+/* Dynamic LDS bytes of one workgroup of the cluster-pair kernel (must match the carve-up in the kernel). */
+inline int nbLdsBytes(int numTypes, bool useTable, bool fused, int wavesPerBlock)
+{
+    const int tableBytes = useTable ? ((numTypes * numTypes * static_cast<int>(sizeof(float2)) + 15) & ~15) : 0;
+    return tableBytes + wavesPerBlock * (2 * c_jStageBytes + c_jRingBytes + (fused ? c_iStageBytes : 0));
+}
 
 #endif

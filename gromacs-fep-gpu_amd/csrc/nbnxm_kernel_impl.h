@@ -40,11 +40,29 @@ struct VdwTraits
     static constexpr bool useTable = (VDW == VDK_CUT || VDW == VDK_FSWITCH || VDW == VDK_PSWITCH);
 };
 
-/* Dynamic LDS bytes of one workgroup of the cluster-pair kernel (must match the carve-up in the kernel). */
-inline int nbLdsBytes(int numTypes, bool useTable, bool fused, int wavesPerBlock)
+/* LDS-direct loads (global -> LDS without VGPRs; completion is counted by vmcnt): every active lane moves 16
+ * (4) bytes from base + offset to LDS address ldsBase + 16 (4) * lane.  ldsBase is wave-uniform and travels in
+ * M0 (semantics checked on MI355X by tools/ubench/lds_dma_test.hip).  Written as asm so that the compiler
+ * neither adds its own waits for these loads nor reorders them: the waits are the counted s_waitcnt vmcnt in
+ * the group loop. */
+NB_DEVINL void ldsDirectLoad16(unsigned ldsBase, unsigned offset, const void* base)
 {
-    const int tableBytes = useTable ? ((numTypes * numTypes * static_cast<int>(sizeof(float2)) + 15) & ~15) : 0;
-    return tableBytes + (fused ? wavesPerBlock * c_superClSize * static_cast<int>(sizeof(float4) + sizeof(float2) + sizeof(int2)) : 0) + 16;
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(ldsBase), "v"(offset), "s"(base) : "memory");
+}
+NB_DEVINL void ldsDirectLoad4(unsigned ldsBase, unsigned offset, const void* base)
+{
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dword %1, %2" ::"s"(ldsBase), "v"(offset), "s"(base) : "memory");
+}
+
+typedef int nb_int4 __attribute__((ext_vector_type(4)));
+
+/* lane index within the wave, recomputed in place (2 VALU ops, no live register): volatile so that it is
+ * neither hoisted out of a loop nor merged with an earlier copy */
+NB_DEVINL unsigned laneIdNow()
+{
+    unsigned l;
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
+    return l;
 }
 
 /* lanes whose byte offset lies beyond the buffer are dropped by the hardware range check */
@@ -126,11 +144,11 @@ NB_DEVINL void ljFromComb(int vdwKind, const float2& a, const float2& b, float& 
 
 /* 5 waves per SIMD (<= 96 VGPRs) for the flavours that fit without scratch; the energy, combination-rule and
  * switch flavours carry more live values and run at 4 waves (<= 128 VGPRs) instead of spilling. */
-template<int VDW, bool ENERGY>
-constexpr int c_nbWavesPerEu = (VDW == VDK_CUT && !ENERGY) ? 5 : 4;
+template<int VDW, bool ENERGY, bool FUSED>
+constexpr int c_nbWavesPerEu = (VDW == VDK_CUT && !ENERGY && !FUSED) ? 5 : 4;
 
 template<int ELEC, bool TWIN, int VDW, bool ENERGY, bool FUSED>
-__launch_bounds__(c_nbBlockSize) __attribute__((amdgpu_waves_per_eu(c_nbWavesPerEu<VDW, ENERGY>))) __global__
+__launch_bounds__(c_nbBlockSize) __attribute__((amdgpu_waves_per_eu(c_nbWavesPerEu<VDW, ENERGY, FUSED>))) __global__
         void nbnxmKernel(const NBAtomDataGpu atdat,
                          const NBParamGpu    nbp,
                          const gpu_plist     plist,
@@ -149,7 +167,8 @@ __launch_bounds__(c_nbBlockSize) __attribute__((amdgpu_waves_per_eu(c_nbWavesPer
                           * which is the list's i-entries ordered by cjPackedBegin */
                          const int* __restrict__ workRangeStart,
                          const int* __restrict__ workFirstSci,
-                         const int numWorkRanges)
+                         const int numWorkRanges,
+                         const unsigned* __restrict__ groupFepJ /* FUSED: fepBits bytes of each group's 4 j-clusters */)
 {
     constexpr bool EXCL_FORCES = (ELEC != ELK_CUT) || ENERGY; /* nbnxm_cuda_kernel.cuh:69-78 */
     constexpr bool USE_TABLE   = VdwTraits<VDW>::useTable;
@@ -164,14 +183,16 @@ __launch_bounds__(c_nbBlockSize) __attribute__((amdgpu_waves_per_eu(c_nbWavesPer
     const unsigned tidxj     = lane >> 3;
     const unsigned half      = lane >> 5;
 
-    /* LDS (all dynamic, sized by the launcher, see nbLdsBytes()): the LJ parameter table shared by the
-     * waves of the workgroup, then per wave (FUSED) its 64 i-atoms:
+    /* LDS (all dynamic, sized by nbLdsBytes()): the LJ parameter table shared by the waves of the workgroup,
+     * then per wave: two staging buffers for the j-side of a packed group (filled by LDS-direct loads, see the
+     * group loop) and (FUSED) its 64 i-atoms:
      * { float4 x,q*epsfac (shifted) ; float2 epsfac*(qA,qB) ; int2 (typeA,typeB) } */
     extern __shared__ __align__(16) unsigned char nbLds[];
     const int numTypes   = atdat.numTypes;
     float2*   nbfpLds    = reinterpret_cast<float2*>(nbLds);
     const int tableBytes = USE_TABLE ? ((numTypes * numTypes * static_cast<int>(sizeof(float2)) + 15) & ~15) : 0;
-    float4*   xqib       = reinterpret_cast<float4*>(nbLds + tableBytes) + (FUSED ? wave * 2 * c_superClSize : 0);
+    unsigned char* jStage = nbLds + tableBytes + wave * (2 * c_jStageBytes + c_jRingBytes + (FUSED ? c_iStageBytes : 0));
+    float4*   xqib       = reinterpret_cast<float4*>(jStage + 2 * c_jStageBytes + c_jRingBytes);
     float2*   qABib      = reinterpret_cast<float2*>(xqib + c_superClSize);
     int2*     tABib      = reinterpret_cast<int2*>(qABib + c_superClSize);
     if constexpr (USE_TABLE)
@@ -182,11 +203,16 @@ __launch_bounds__(c_nbBlockSize) __attribute__((amdgpu_waves_per_eu(c_nbWavesPer
     __syncthreads(); /* the table is in place; from here on the waves of the workgroup are independent */
 
     /* Every wave of the launch gets the same amount of pair work: a contiguous range of packed j-groups cut
-     * out of the list by weight (nbnxmWorkRangesKernel), regardless of i-entry borders.  The launch has one
-     * wave per resident wave slot, so all waves start together and finish together; with one wave per
-     * i-entry a 96k-atom list (1.2 x the slots) lost 25-35 % to the second, nearly empty round. */
+     * out of the list by weight (nbnxmWorkRangesKernel), regardless of i-entry borders; the launch has one
+     * wave per resident wave slot.  Inside its range the wave walks "pieces": the part of an i-entry's j-list
+     * that lies in the range. */
     const int workItem = __builtin_amdgcn_readfirstlane(static_cast<int>(blockIdx.x * (blockSize / c_waveSize) + wave));
     if (workItem >= numWorkRanges) { return; }
+#ifdef NBNXM_WAVE_TIMELINE
+    /* diagnostics build only (tools/gpu_timeline.sh): per wave {start, end of main loops, end, HW_ID} in 100 MHz ticks */
+    const unsigned long long tlStart = wall_clock64();
+    unsigned long long       tlMain  = 0;
+#endif
     const int rangeBegin = workRangeStart[workItem];
     const int rangeEnd   = workRangeStart[workItem + 1];
     int       sciIdx     = workFirstSci[workItem];
@@ -195,6 +221,78 @@ __launch_bounds__(c_nbBlockSize) __attribute__((amdgpu_waves_per_eu(c_nbWavesPer
     const float rcoulomb_sq = nbp.rcoulomb_sq;
     const __amdgpu_buffer_rsrc_t fRsrc =
             __builtin_amdgcn_make_buffer_rsrc(f, 0, atdat.numAtoms * 3 * static_cast<int>(sizeof(float)), 0x00020000);
+
+    /* ---- j-side pipeline -----------------------------------------------------------------------------------
+     * Measured on MI355X: with the list words and j-atom data loaded where they are used, the loop skeleton
+     * without any pair arithmetic took half of the kernel's time (5 waves per SIMD cannot cover ~1 us loads, and
+     * every scalar load in flight turns the next LDS wait into a full lgkmcnt(0)).  So nothing in the group
+     * loop is loaded through registers.  With LDS-direct loads (global -> LDS, no VGPRs, counted by vmcnt),
+     * while group g is computed:
+     *   W(g+2): the list words of group g+2 (32 bytes; FUSED: + the fepBits bytes of its j-clusters) go to a ring
+     *           of 4 records, and
+     *   J(g+1): the j-side of group g+1 (32 x float4 xq, 32 types or LJ parameters, 64 exclusion words), addressed
+     *           with the words of g+1 read back from the ring, goes to the other one of two staging buffers.
+     * Loads and atomics retire through ONE in-order vmcnt counter, so every group issues exactly c_vmOpsPerGroup
+     * VMEM operations (W + 3 J loads + 4 j-force atomics, dummies for skipped slots): both waits of an iteration,
+     * for W(g+1) and for J(g), are counted vmcnt(c_vmOpsPerGroup) and never wait for an atomic.  The pipeline
+     * runs across piece borders (the groups of a range are contiguous). */
+    constexpr int  c_vmOpsPerGroup = (FUSED ? 2 : 1) + 3 + 4;
+    const unsigned jStageLds = __builtin_amdgcn_readfirstlane(static_cast<unsigned>(reinterpret_cast<size_t>(jStage)));
+    const unsigned ringLds   = jStageLds + 2U * c_jStageBytes;
+    const unsigned char* ring = jStage + 2 * c_jStageBytes;
+    const int      lastGroup = plist.ncjPacked - 1;
+    const void*    ljBase    = USE_TABLE ? static_cast<const void*>(atomTypes) : static_cast<const void*>(ljComb);
+
+/* W(g): list words of group g -> ring record g & 3 (lanes 0-7: the 8 dwords of nbnxn_cj_packed_t; FUSED: lane 8 adds
+ * groupFepJ[g] behind them).  The lane id is recomputed in place on purpose: hoisted out of the loops it would be
+ * spilled, and a scratch reload in this loop is a VMEM load that drains the pipeline. */
+#define NBNXM_STAGE_WORDS(g)                                                                                    \
+    {                                                                                                          \
+        const unsigned lane = laneIdNow();                                                                     \
+        const unsigned gw   = static_cast<unsigned>(min((g), lastGroup));                                      \
+        const unsigned rec  = ringLds + (static_cast<unsigned>(g) & 3U) * c_ringRecordBytes;                   \
+        if (lane < 8U) { ldsDirectLoad4(rec, gw * 32U + lane * 4U, cjPackedList); }                            \
+        if constexpr (FUSED)                                                                                   \
+        {                                                                                                      \
+            if (lane == 8U) { ldsDirectLoad4(rec, gw * 4U, groupFepJ); }                                       \
+        }                                                                                                      \
+    }
+/* J(g): the three staging loads of group g into buffer buf; each lane reads the list words it needs from the ring */
+#define NBNXM_STAGE_GROUP(g, buf)                                                                               \
+    {                                                                                                          \
+        const unsigned lane  = laneIdNow();                                                                    \
+        const unsigned half  = lane >> 5;                                                                      \
+        const unsigned char* rec = ring + (static_cast<unsigned>(g) & 3U) * c_ringRecordBytes;                 \
+        const int      cjl   = *reinterpret_cast<const int*>(rec + ((lane >> 3) & 3U) * 4U);                   \
+        const int      exl   = *reinterpret_cast<const int*>(rec + 20U + half * 8U);                           \
+        const unsigned ajl   = static_cast<unsigned>(cjl) * c_clSize + (lane & 7U);                            \
+        const unsigned base  = jStageLds + static_cast<unsigned>(buf) * c_jStageBytes;                         \
+        if constexpr (USE_TABLE)                                                                               \
+        {                                                                                                      \
+            if (lane < 32U)                                                                                    \
+            {                                                                                                  \
+                ldsDirectLoad16(base, ajl * 16U, xq);                                                          \
+                ldsDirectLoad4(base + c_jStageLjOffset, ajl * 4U, ljBase);                                     \
+            }                                                                                                  \
+        }                                                                                                      \
+        else                                                                                                   \
+        {                                                                                                      \
+            if (lane < 32U) { ldsDirectLoad16(base, ajl * 16U, xq); }                                          \
+            /* lanes 0-31: c.x of the 32 atoms, lanes 32-63: c.y */                                            \
+            ldsDirectLoad4(base + c_jStageLjOffset, ajl * 8U + half * 4U, ljBase);                             \
+        }                                                                                                      \
+        ldsDirectLoad4(base + c_jStageExclOffset, static_cast<unsigned>(exl) * 128U + (lane & 31U) * 4U, exclList); \
+    }
+#define NBNXM_DUMMY_ATOMIC() __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(0.0F, fRsrc, c_dropLane, 0, 0)
+#define NBNXM_WAIT_VMEM(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory")
+
+    const int prioStep1 = rangeBegin + ((rangeEnd - rangeBegin) >> 2);
+    const int prioStep2 = rangeBegin + ((rangeEnd - rangeBegin) >> 1);
+    const int prioStep3 = rangeBegin + (((rangeEnd - rangeBegin) * 3) >> 2);
+    __builtin_amdgcn_s_setprio(3);
+
+    int curBuf      = 0;  /* staging buffer that holds (or receives) the j-side of group stagedGroup */
+    int stagedGroup = -1;
 
     float E_lj = 0.0F, E_el = 0.0F, DVDL_lj = 0.0F, DVDL_el = 0.0F;
 
@@ -210,6 +308,22 @@ __launch_bounds__(c_nbBlockSize) __attribute__((amdgpu_waves_per_eu(c_nbWavesPer
     const int         sci           = nb_sci.sci;
     const int         shiftIdx      = nb_sci.shift & NBNXM_CI_SHIFT_MASK;
     const bool        central       = (shiftIdx == c_centralShiftIndex);
+
+#ifdef NBNXM_WAVE_TIMELINE
+    tlMain -= wall_clock64();
+#endif
+    if (stagedGroup != cjPackedBegin)
+    {
+        /* (re)start the pipeline: at the first piece, or behind groups that belong to no i-entry */
+        NBNXM_STAGE_WORDS(cjPackedBegin)
+        NBNXM_STAGE_WORDS(cjPackedBegin + 1)
+        NBNXM_WAIT_VMEM(0);
+        NBNXM_STAGE_GROUP(cjPackedBegin, curBuf)
+        NBNXM_DUMMY_ATOMIC();
+        NBNXM_DUMMY_ATOMIC();
+        NBNXM_DUMMY_ATOMIC();
+        NBNXM_DUMMY_ATOMIC();
+    }
 
     /* ---- stage the i-atoms ---------------------------------------------------------------------- */
     float4 xqi[c_numClPerSupercl];
@@ -229,22 +343,6 @@ __launch_bounds__(c_nbBlockSize) __attribute__((amdgpu_waves_per_eu(c_nbWavesPer
             xqi[i] = v;
             if constexpr (USE_TABLE) { trow[i] = numTypes * atomTypes[ai] * static_cast<int>(sizeof(float2)); }
             else { ljcpi[i] = ljComb[ai]; }
-        }
-        if constexpr (FUSED)
-        {
-            const int ai = sci * c_superClSize + static_cast<int>(lane);
-            float4    xl = xq[ai];
-            xl.x += sh.x;
-            xl.y += sh.y;
-            xl.z += sh.z;
-            xl.w *= nbp.epsfac;
-            xqib[lane]      = xl;
-            const float4 q4 = atdat.q4[ai];
-            qABib[lane]     = make_float2(q4.x * nbp.epsfac, q4.y * nbp.epsfac);
-            const int4 t4   = atdat.atomTypes4[ai];
-            tABib[lane]     = make_int2(t4.x, t4.y);
-            /* the staged copy is private to this wave: LDS operations of one wave complete in order */
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         }
     }
 
@@ -276,7 +374,8 @@ __launch_bounds__(c_nbBlockSize) __attribute__((amdgpu_waves_per_eu(c_nbWavesPer
                  * entry of the atom-pair list contributes (nb_free_energy.cpp:1035-1052,1079-1100) */
                 if ((iFepBits >> lane) & 1ULL)
                 {
-                    const float2 qAB = qABib[lane];
+                    const float4 q4l = atdat.q4[sci * c_superClSize + static_cast<int>(lane)];
+                    const float2 qAB = make_float2(q4l.x * nbp.epsfac, q4l.y * nbp.epsfac);
                     const float  sA  = qAB.x * qAB.x / nbp.epsfac * coef;
                     const float  sB  = qAB.y * qAB.y / nbp.epsfac * coef;
                     E_el += (1.0F - nbp.lambda_q) * sA + nbp.lambda_q * sB;
@@ -291,75 +390,105 @@ __launch_bounds__(c_nbBlockSize) __attribute__((amdgpu_waves_per_eu(c_nbWavesPer
 #pragma unroll
     for (int i = 0; i < c_numClPerSupercl; i++) { fci_buf[i] = make_float3(0.0F, 0.0F, 0.0F); }
 
-    /* FUSED: which j-cluster slots of this entry hold pairs left for pass 2: one bit per slot for the first 64
+    /* FUSED: which j-cluster slots of this piece hold pairs left for pass 2: one bit per slot for the first 64
      * slots (16 packed groups), one flag for everything beyond */
     unsigned long long slowSlots    = 0ULL;
     bool               slowOverflow = false;
-    float    pendingF   = 0.0F;       /* deferred j-force component of the previous j-cluster */
-    int      pendingOff = c_dropLane; /* and its byte offset into f */
+#pragma unroll 1
     for (int jPacked = cjPackedBegin; jPacked < cjPackedEnd; jPacked++)
     {
-        const nbnxn_cj_packed_t* __restrict__ grp = &cjPackedList[jPacked];
-        const unsigned imask = grp->imei[0].imask;
-        if (imask == 0U) { continue; }
-        const int      exclInd0 = grp->imei[0].excl_ind;
-        const int      exclInd1 = grp->imei[1].excl_ind;
-        const bool     groupHasExcl = (exclInd0 | exclInd1) != 0; /* entry 0 = shared "all pairs interact" mask */
-        const unsigned wexcl    = exclList[half ? exclInd1 : exclInd0].pair[lane & 31U];
+        /* The SIMD's arbiter serves the oldest wave first: left alone, the 5 waves of a SIMD finish one after the
+         * other and the last one runs alone, latency-bound, for the last ~10 % of the kernel (measured with a
+         * per-wave timeline).  Each wave therefore lowers its own priority as it advances through its range, so
+         * that the waves that are behind get the issue slots and all of them finish together. */
+        if (jPacked == prioStep1) { __builtin_amdgcn_s_setprio(2); }
+        else if (jPacked == prioStep2) { __builtin_amdgcn_s_setprio(1); }
+        else if (jPacked == prioStep3) { __builtin_amdgcn_s_setprio(0); }
 
-#pragma unroll 1
-        for (int jm = 0; jm < c_jGroupSize; jm++)
+        /* pipeline step (see above): W(g+2); wait for W(g+1); J(g+1); wait for J(g) */
+        NBNXM_STAGE_WORDS(jPacked + 2)
+        NBNXM_WAIT_VMEM(c_vmOpsPerGroup);
+        NBNXM_STAGE_GROUP(jPacked + 1, curBuf ^ 1)
+        NBNXM_WAIT_VMEM(c_vmOpsPerGroup);
+
+        /* this group's list words, from the ring (the same address for all lanes) to SGPRs */
+        const unsigned char* rec  = ring + (static_cast<unsigned>(jPacked) & 3U) * c_ringRecordBytes;
+        const nb_int4        recA = *reinterpret_cast<const nb_int4*>(rec);
+        const nb_int4 curA = { __builtin_amdgcn_readfirstlane(recA.x), __builtin_amdgcn_readfirstlane(recA.y),
+                               __builtin_amdgcn_readfirstlane(recA.z), __builtin_amdgcn_readfirstlane(recA.w) };
+        const unsigned imask = __builtin_amdgcn_readfirstlane(*reinterpret_cast<const unsigned*>(rec + 16U));
+        [[maybe_unused]] unsigned fepJCur = 0U; /* FUSED: fepBits of the 4 j-clusters, one byte each */
+        if constexpr (FUSED) { fepJCur = __builtin_amdgcn_readfirstlane(*reinterpret_cast<const unsigned*>(rec + 32U)); }
+        const unsigned char* jData = jStage + curBuf * c_jStageBytes;
+        /* FUSED: can any pair of this group touch a perturbed atom?  (one scalar test for the common "no") */
+        [[maybe_unused]] const bool groupMaySkipPairs = FUSED && ((fepJCur | iFepClusterMask) != 0U);
         {
-            const unsigned imaskJ = (imask >> (jm * c_numClPerSupercl)) & 0xFFU;
-            if (imaskJ == 0U) { continue; }
-            const unsigned wexclJ = wexcl >> (jm * c_numClPerSupercl);
-            const int      cj     = grp->cj[jm];
-            const int      aj     = cj * c_clSize + static_cast<int>(tidxj);
-            const float4   xqj    = xq[aj];
-            int            typej  = 0;
-            float2         ljcp_j = make_float2(0.0F, 0.0F);
-            if constexpr (USE_TABLE) { typej = atomTypes[aj]; }
-            else { ljcp_j = ljComb[aj]; }
-            unsigned fepJ = 0U; /* wave-uniform: comes through a scalar load, off the vmcnt queue */
-            if constexpr (FUSED) { fepJ = (fepWords[cj >> 2] >> ((cj & 3) * 8)) & 0xFFU; }
-            /* the previous j-cluster's force leaves now, behind this j-cluster's loads */
-            __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(pendingF, fRsrc, pendingOff, 0, 0);
-
-            unsigned fastMask = imaskJ;
-            if constexpr (FUSED)
+            const unsigned laneG = laneIdNow(); /* see NBNXM_STAGE_GROUP */
+            const unsigned wexcl = *reinterpret_cast<const unsigned*>(jData + c_jStageExclOffset + laneG * 4U);
+#pragma unroll 1
+            for (int jm = 0; jm < c_jGroupSize; jm++)
             {
-                /* pairs for pass 2: every i-cluster when the j-cluster holds a perturbed atom, otherwise the
-                 * i-clusters that hold one */
-                const unsigned jFepBits = fepJ;
-                const unsigned slowMask = (jFepBits != 0U) ? imaskJ : (imaskJ & iFepClusterMask);
-                if (slowMask != 0U)
+                /* every slot ends in exactly one VMEM atomic: a skipped slot sends nothing (all lanes out of range) */
+                float          fjv    = 0.0F;
+                int            fjOff  = c_dropLane;
+                const unsigned imaskJ = (imask >> (jm * c_numClPerSupercl)) & 0xFFU;
+                if (imaskJ != 0U)
                 {
-                    const int slot = (jPacked - cjPackedBegin) * c_jGroupSize + jm;
-                    if (slot < 64) { slowSlots |= (1ULL << slot); }
-                    else { slowOverflow = true; }
+                const unsigned wexclJ = wexcl >> (jm * c_numClPerSupercl);
+                const int      cj     = (jm == 0) ? curA.x : ((jm == 1) ? curA.y : ((jm == 2) ? curA.z : curA.w));
+                const int      aj     = cj * c_clSize + static_cast<int>(tidxj);
+                const unsigned jAtom  = static_cast<unsigned>(jm) * c_clSize + (laneG >> 3);
+                const float4   xqj    = *reinterpret_cast<const float4*>(jData + jAtom * 16U);
+                int            typej  = 0;
+                float2         ljcp_j = make_float2(0.0F, 0.0F);
+                if constexpr (USE_TABLE) { typej = *reinterpret_cast<const int*>(jData + c_jStageLjOffset + jAtom * 4U); }
+                else
+                {
+                    ljcp_j.x = *reinterpret_cast<const float*>(jData + c_jStageLjOffset + jAtom * 4U);
+                    ljcp_j.y = *reinterpret_cast<const float*>(jData + c_jStageLjOffset + 128U + jAtom * 4U);
                 }
-                fastMask = imaskJ & ~slowMask;
+
+                unsigned fastMask = imaskJ;
+                if (FUSED && groupMaySkipPairs)
+                {
+                    /* pairs for pass 2: every i-cluster when the j-cluster holds a perturbed atom, otherwise the
+                     * i-clusters that hold one */
+                    const unsigned jFepBits = (fepJCur >> (jm * 8)) & 0xFFU;
+                    const unsigned slowMask = (jFepBits != 0U) ? imaskJ : (imaskJ & iFepClusterMask);
+                    if (slowMask != 0U)
+                    {
+                        const int slot = (jPacked - cjPackedBegin) * c_jGroupSize + jm;
+                        if (slot < 64) { slowSlots |= (1ULL << slot); }
+                        else { slowOverflow = true; }
+                    }
+                    fastMask = imaskJ & ~slowMask;
+                }
+                /* which i-cluster (if any) is this j-cluster itself on the central image */
+                [[maybe_unused]] const int diagI = (central && (cj >> 3) == sci) ? (cj & 7) : -1;
+
+                float3    fcj_buf    = make_float3(0.0F, 0.0F, 0.0F);
+                const int typejBytes = typej * static_cast<int>(sizeof(float2));
+                /* (A second instance of the loop without exclusion handling for groups with excl_ind 0 was tried:
+                 * it saves ~6 of ~55 issue slots per pair step on 80 % of the groups but costs 20 VGPRs, i.e. a
+                 * wave per SIMD, and measured 19 % slower on MI355X.) */
+                NBNXM_PAIR_LOOP(true)
+
+                /* j-force: sum over the 8 lanes of a j atom; lanes tidxi 0..2 carry x,y,z (96 contiguous bytes) */
+                const float fjx = reduceOver8Lanes(fcj_buf.x);
+                const float fjy = reduceOver8Lanes(fcj_buf.y);
+                const float fjz = reduceOver8Lanes(fcj_buf.z);
+                fjv   = (tidxi == 0U) ? fjx : ((tidxi == 1U) ? fjy : fjz);
+                fjOff = (tidxi < 3U) ? (3 * aj + static_cast<int>(tidxi)) * static_cast<int>(sizeof(float)) : c_dropLane;
+                }
+                __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(fjv, fRsrc, fjOff, 0, 0);
             }
-            /* which i-cluster (if any) is this j-cluster itself on the central image */
-            [[maybe_unused]] const int diagI = (central && (cj >> 3) == sci) ? (cj & 7) : -1;
-
-            float3 fcj_buf = make_float3(0.0F, 0.0F, 0.0F);
-            const int typejBytes = typej * static_cast<int>(sizeof(float2));
-            /* (A second instance of the loop without exclusion handling for groups with excl_ind 0 was tried:
-             * it saves ~6 of ~55 issue slots per pair step on 80 % of the groups but costs 20 VGPRs, i.e. a
-             * wave per SIMD, and measured 19 % slower on MI355X.) */
-            (void)groupHasExcl;
-            NBNXM_PAIR_LOOP(true)
-
-            /* j-force: sum over the 8 lanes of a j atom; lanes tidxi 0..2 carry x,y,z to the deferred atomic */
-            const float fjx = reduceOver8Lanes(fcj_buf.x);
-            const float fjy = reduceOver8Lanes(fcj_buf.y);
-            const float fjz = reduceOver8Lanes(fcj_buf.z);
-            pendingF        = (tidxi == 0U) ? fjx : ((tidxi == 1U) ? fjy : fjz);
-            pendingOff      = (tidxi < 3U) ? (3 * aj + static_cast<int>(tidxi)) * static_cast<int>(sizeof(float)) : c_dropLane;
         }
+        curBuf ^= 1;
     }
-    __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(pendingF, fRsrc, pendingOff, 0, 0);
+    stagedGroup = cjPackedEnd;
+#ifdef NBNXM_WAVE_TIMELINE
+    tlMain += wall_clock64();
+#endif
 
     /* i-forces: reduce over tidxj; lane (tidxj, tidxi) keeps the sum of cluster tidxj, atom tidxi */
     float3 mine = make_float3(0.0F, 0.0F, 0.0F);
@@ -386,6 +515,24 @@ __launch_bounds__(c_nbBlockSize) __attribute__((amdgpu_waves_per_eu(c_nbWavesPer
         {
             const FepLambda L = makeFepLambda(nbp.lambda_q, nbp.lambda_v, nbp.lam_power, nbp.alpha_coul, nbp.alpha_vdw);
             const float2* __restrict__ nbfp = nbp.nbfp;
+            {
+                /* only now, for the ~1 % of the pieces that get here: the 64 i-atoms' A/B data, staged in LDS
+                 * because pass 2 indexes the i-clusters at run time */
+                const float3 sh = atdat.shiftVec[shiftIdx];
+                const int    ai = sci * c_superClSize + static_cast<int>(lane);
+                float4       xl = xq[ai];
+                xl.x += sh.x;
+                xl.y += sh.y;
+                xl.z += sh.z;
+                xl.w *= nbp.epsfac;
+                xqib[lane]      = xl;
+                const float4 q4 = atdat.q4[ai];
+                qABib[lane]     = make_float2(q4.x * nbp.epsfac, q4.y * nbp.epsfac);
+                const int4 t4   = atdat.atomTypes4[ai];
+                tABib[lane]     = make_int2(t4.x, t4.y);
+                /* the staged copy is private to this wave: LDS operations of one wave complete in order */
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            }
             for (int jPacked = cjPackedBegin; jPacked < cjPackedEnd; jPacked++)
             {
                 /* only the slots flagged by the main pass are visited (no list or fepBits reads for the rest) */
@@ -519,6 +666,25 @@ __launch_bounds__(c_nbBlockSize) __attribute__((amdgpu_waves_per_eu(c_nbWavesPer
         }
     }
     } /* pieces */
+#undef NBNXM_STAGE_GROUP
+#undef NBNXM_STAGE_WORDS
+#undef NBNXM_WAIT_VMEM
+#undef NBNXM_DUMMY_ATOMIC
+
+#ifdef NBNXM_WAVE_TIMELINE
+    if (lane == 0U && workItem < 16384 && plist.debugTimeline != nullptr)
+    {
+        unsigned long long* g_nbTimeline = plist.debugTimeline;
+        unsigned hwId;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwId));
+        unsigned xccId;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xccId));
+        g_nbTimeline[4 * workItem + 0] = tlStart;
+        g_nbTimeline[4 * workItem + 1] = tlMain; /* ticks inside the group loops (incl. pipeline start) */
+        g_nbTimeline[4 * workItem + 2] = wall_clock64();
+        g_nbTimeline[4 * workItem + 3] = (static_cast<unsigned long long>(xccId) << 32) | hwId;
+    }
+#endif
 
     if constexpr (ENERGY)
     {

@@ -10,7 +10,7 @@
 
 using NbKernelPtr = void (*)(NBAtomDataGpu, NBParamGpu, gpu_plist, int, const nbnxn_sci_t*, const nbnxn_cj_packed_t*,
                              const nbnxn_excl_t*, const float4*, const int*, const float2*, const unsigned*, const int*,
-                             const int*, int);
+                             const int*, int, const unsigned*);
 using FepKernelPtr   = void (*)(NBAtomDataGpu, NBParamGpu, gpu_feplist, int);
 using PruneKernelPtr = void (*)(NBAtomDataGpu, NBParamGpu, gpu_plist, int, int);
 
@@ -27,6 +27,6 @@ FepKernelPtr   selectFepKernel(int elecType, int vdwType, bool energy);
 FepKernelPtr   selectFepForeignKernel(int elecType, int vdwType);
 PruneKernelPtr selectPruneKernel(bool haveFreshList);
 /* waves per SIMD the flavour is compiled for (c_nbWavesPerEu): decides which work partition it runs on */
-int nbKernelWavesPerEu(int vdwType, bool energy);
+int nbKernelWavesPerEu(int vdwType, bool energy, bool fused);
 
 #endif

@@ -74,9 +74,9 @@ FepKernelPtr selectFepForeignKernel(int elecType, int vdwType)
     }
 }
 
-int nbKernelWavesPerEu(int vdwType, bool energy)
+int nbKernelWavesPerEu(int vdwType, bool energy, bool fused)
 {
-    return (vdwKindOf(vdwType) == VDK_CUT && !energy) ? c_nbWavesPerEu<VDK_CUT, false> : c_nbWavesPerEu<VDK_PSWITCH, true>;
+    return (vdwKindOf(vdwType) == VDK_CUT && !energy && !fused) ? c_nbWavesPerEu<VDK_CUT, false, false> : c_nbWavesPerEu<VDK_PSWITCH, true, true>;
 }
 
 PruneKernelPtr selectPruneKernel(bool haveFreshList)

@@ -6,7 +6,8 @@
  * all of the same weight: weight(group) = set imask bits (+ fepPairWeight x cluster pairs that hold a perturbed
  * atom when the fused kernel evaluates them in its second pass).  Three small kernels, run on the list's own
  * stream after every (re)prune, because pruning changes the masks on the device:
- *   nbnxmWorkWeightKernel  one thread per group: weight + per-256-group sums
+ *   nbnxmWorkWeightKernel  one thread per group: weight + per-256-group sums (+ the fepBits bytes of the group's
+ *                          j-clusters, which the fused kernel stages together with the list words)
  *   nbnxmWorkScanKernel    one workgroup: exclusive scan of the sums
  *   nbnxmWorkRangesKernel  one thread per group: global prefix -> the range borders that fall on this group,
  *                          for both partitions (4 and 5 waves per SIMD), plus the i-entry each range starts in
@@ -17,6 +18,10 @@
 #include "nbnxm_hip_types.h"
 
 constexpr int c_workBlockSize = 256;
+constexpr int c_weightPair    = 8;
+constexpr int c_weightSlot    = 6;
+constexpr int c_weightGroup   = 8;
+constexpr int c_weightEntry   = 80;
 
 /* largest k with sciSorted[k].cjPackedBegin <= group (entries ordered by (cjPackedBegin, cjPackedEnd)); -1 if none */
 __device__ __forceinline__ int findSciOfGroup(const nbnxn_sci_t* __restrict__ sciSorted, int nsci, int group)
@@ -56,7 +61,8 @@ __launch_bounds__(c_workBlockSize) __global__
                                    const nbnxn_sci_t* __restrict__       sciSorted,
                                    const int                             nsci,
                                    const unsigned char* __restrict__     fepBits, /* nullptr: no perturbed-pair weighting */
-                                   const int                             fepPairWeight,
+                                   const int                             fepPairWeight, /* 0: count plain pairs only */
+                                   unsigned* __restrict__                groupFepJ,
                                    int* __restrict__                     groupWeight,
                                    int* __restrict__                     blockSum)
 {
@@ -65,11 +71,23 @@ __launch_bounds__(c_workBlockSize) __global__
     int            w = 0;
     if (g < ncjPacked)
     {
+        /* cost model in units of 1/8 cluster pair (instruction counts of the kernel's loop levels): a cluster pair,
+         * a non-empty j-cluster slot (staged reads, j-force reduction, atomic), a group (staging loads), and the
+         * start of an i-entry (i-atom loads, i-force reduction and atomics) */
         const unsigned imask = cjPacked[g].imei[0].imask;
-        w                    = __popc(imask);
-        if (fepBits != nullptr && imask != 0U)
+        int            slots = 0;
+        for (int jm = 0; jm < c_jGroupSize; jm++) { slots += ((imask >> (jm * c_numClPerSupercl)) & 0xFFU) != 0U ? 1 : 0; }
+        w                    = c_weightPair * __popc(imask) + c_weightSlot * slots + (imask != 0U ? c_weightGroup : 0);
+        const int k          = findSciOfGroup(sciSorted, nsci, g);
+        if (k >= 0 && sciSorted[k].cjPackedBegin == g) { w += c_weightEntry; }
+        unsigned fepJ        = 0U;
+        if (fepBits != nullptr)
         {
-            const int k = findSciOfGroup(sciSorted, nsci, g);
+            for (int jm = 0; jm < c_jGroupSize; jm++) { fepJ |= static_cast<unsigned>(fepBits[cjPacked[g].cj[jm]]) << (8 * jm); }
+        }
+        groupFepJ[g] = fepJ;
+        if (fepBits != nullptr && fepPairWeight > 0 && imask != 0U)
+        {
             if (k >= 0 && g < sciSorted[k].cjPackedEnd)
             {
                 const int sci          = sciSorted[k].sci;
@@ -83,7 +101,7 @@ __launch_bounds__(c_workBlockSize) __global__
                     const unsigned imaskJ = (imask >> (jm * c_numClPerSupercl)) & 0xFFU;
                     if (imaskJ == 0U) { continue; }
                     const unsigned slow = (fepBits[cjPacked[g].cj[jm]] != 0) ? imaskJ : (imaskJ & iClusterMask);
-                    w += fepPairWeight * __popc(slow);
+                    w += c_weightPair * fepPairWeight * __popc(slow);
                 }
             }
         }
