@@ -130,6 +130,7 @@ NB_DEVINL float interpolateCoulombForceR(const NBParamGpu& nbp, float r)
 
 template<int ELEC, bool TWIN, int VDW, bool ENERGY, bool EXCL_FORCES, bool HAS_EXCL = true>
 NB_DEVINL void nbPair(const NBParamGpu& nbp,
+                      const float2*     ewaldCorrLds, /* analytical Ewald: NBParamGpu::ewaldCorrTab in LDS */
                       float             r2,
                       int               intMask, /* all ones if the pair interacts, 0 if it is excluded */
                       float             qq, /* epsfac q_i q_j */
@@ -208,8 +209,12 @@ NB_DEVINL void nbPair(const NBParamGpu& nbp,
         const float beta = nbp.ewald_beta;
         if constexpr (ELEC == ELK_EWALD_ANA)
         {
-            const float beta2 = beta * beta;
-            F_invr += qq * (inv_r3m + pmeCorrF(beta2 * r2) * beta2 * beta);
+            /* beta^3 F((beta r)^2) by linear interpolation in the LDS table; only pairs within rcoulomb get here,
+             * which is what bounds the index */
+            const float    xs   = r2 * nbp.ewaldCorrTabScale;
+            const unsigned idx  = static_cast<unsigned>(xs);
+            const float2   t    = ewaldCorrLds[idx];
+            F_invr += qq * (inv_r3m + fmaf(__builtin_amdgcn_fractf(xs), t.y, t.x));
         }
         else
         {

@@ -97,6 +97,7 @@ struct NbnxmGpu
     int minGroupsPerWave  = 2;
     int numWorkRangesOverride = 0; /* experiments: NBNXM_HIP_NUM_WORK_RANGES */
     PinnedBuffer<nbnxn_sci_t> h_sciSorted;
+    PinnedBuffer<float2>      h_ewaldCorrTab;
 
     float* scalarOutputs    = nullptr; /* device block behind atdat->eLJ ... dvdlElecForeign, energySlots */
     int    numHeadScalars   = 0;       /* scalars + foreign arrays */
@@ -179,6 +180,44 @@ void uploadCoulombTable(NbnxmGpu* nb, const nbnxm_interaction_params_t* ic)
     }
     const bool tabulated = (nbp->elecType == NBNXM_ELEC_EWALD_TAB || nbp->elecType == NBNXM_ELEC_EWALD_TAB_TWIN);
     NBNXM_ASSERT(!tabulated || nbp->coulomb_tab != nullptr, "tabulated Ewald kernel selected without a force table");
+}
+
+/* beta^3 F((beta r)^2), F(x) = (2/sqrt(pi) z exp(-z^2) - erf z) / z^3 with x = z^2 (definition as gmx::pmeForceCorrection,
+ * simd/simd_math.h:1560-1650), tabulated for the cluster kernel: see NBParamGpu::ewaldCorrTab */
+void uploadEwaldCorrectionTable(NbnxmGpu* nb)
+{
+    NBParamGpu* nbp = nb->nbparam;
+    if (nbp->elecType != NBNXM_ELEC_EWALD_ANA && nbp->elecType != NBNXM_ELEC_EWALD_ANA_TWIN) { return; }
+    const double beta = nbp->ewald_beta;
+    const double xMax = beta * beta * nbp->rcoulomb_sq * (1.0 + 1.0e-5);
+    const int    n    = c_ewaldCorrTabSize;
+    auto         F    = [](double x) {
+        if (x < 1.0e-2)
+        {
+            /* series: 2/sqrt(pi) sum_k (-1)^k 2k x^(k-1) / ((2k+1) k!) , k >= 1 */
+            double s = 0, xp = 1, kf = 1;
+            for (int k = 1; k < 10; k++)
+            {
+                kf *= k;
+                const double term = xp * 2.0 * k / ((2.0 * k + 1.0) * kf);
+                s += (k & 1) ? -term : term;
+                xp *= x;
+            }
+            return 2.0 / std::sqrt(M_PI) * s;
+        }
+        const double z = std::sqrt(x);
+        return (2.0 / std::sqrt(M_PI) * z * std::exp(-x) - std::erf(z)) / (x * z);
+    };
+    nb->h_ewaldCorrTab.resize(n);
+    const double b3 = beta * beta * beta;
+    for (int k = 0; k < n; k++)
+    {
+        const double t0 = b3 * F(xMax * k / n), t1 = b3 * F(xMax * (k + 1) / n);
+        nb->h_ewaldCorrTab.data[k] = make_float2(static_cast<float>(t0), static_cast<float>(t1 - t0));
+    }
+    if (nbp->ewaldCorrTab == nullptr) { allocateDeviceBuffer(&nbp->ewaldCorrTab, n); }
+    copyToDeviceBuffer(&nbp->ewaldCorrTab, nb->h_ewaldCorrTab.data, 0, n, nb->deviceStreams[0].stream, true);
+    nbp->ewaldCorrTabScale = static_cast<float>(beta * beta * n / xMax);
 }
 
 bool canSkipNonbondedWork(const NbnxmGpu& nb, int iloc)
@@ -339,6 +378,7 @@ NbnxmGpu* nbnxm_gpu_init(const nbnxm_interaction_params_t* ic, int numTypes, con
         nb->nbfp_comb_n = numTypes;
     }
     uploadCoulombTable(nb, ic);
+    uploadEwaldCorrectionTable(nb);
     if (ic->elecType == NBNXM_ELEC_EWALD_ANA || ic->elecType == NBNXM_ELEC_EWALD_ANA_TWIN)
     {
         /* domain of the fitted analytical correction (pme_corr_coeffs.h): (beta r)^2 <= 12 */
@@ -394,6 +434,7 @@ void nbnxm_gpu_free(NbnxmGpu* nb)
     freeDeviceBuffer(&nbp->nbfp);
     freeDeviceBuffer(&nbp->nbfp_comb);
     freeDeviceBuffer(&nbp->coulomb_tab);
+    freeDeviceBuffer(&nbp->ewaldCorrTab);
     freeDeviceBuffer(&nbp->allLambdaCoul);
     freeDeviceBuffer(&nbp->allLambdaVdw);
     for (int i = 0; i < 2; i++)
@@ -489,6 +530,7 @@ void nbnxm_gpu_pme_loadbal_update_param(NbnxmGpu* nb, const nbnxm_interaction_pa
     nb->nbparam->elecType = ic->elecType;
     setCutoffParameters(nb->nbparam, ic);
     uploadCoulombTable(nb, ic);
+    uploadEwaldCorrectionTable(nb);
 }
 
 void nbnxm_gpu_init_atomdata(NbnxmGpu* nb, int numAtoms, int numAtomsLocal, const int* type,
@@ -955,7 +997,8 @@ void nbnxm_gpu_launch_kernel(NbnxmGpu* nb, const nbnxm_step_workload_t* stepWork
         int        wavesPerBlock = nb->nbWavesPerBlock;
         const int  tableBytes    = useTable ? adat->numTypes * adat->numTypes * 8 : 0;
         if (tableBytes > 8 * 1024) { wavesPerBlock = c_nbWavesPerBlock; } /* one table copy per 4 waves */
-        const int ldsBytes = nbLdsBytes(adat->numTypes, useTable, fused, wavesPerBlock);
+        const bool ewaldCorrTable = (nbp->elecType == NBNXM_ELEC_EWALD_ANA || nbp->elecType == NBNXM_ELEC_EWALD_ANA_TWIN);
+        const int  ldsBytes       = nbLdsBytes(adat->numTypes, useTable, ewaldCorrTable, fused, wavesPerBlock);
         NBNXM_ASSERT(ldsBytes <= 160 * 1024, "too many atom types: the LJ parameter table does not fit the 160 KB LDS");
         if (ldsBytes > 64 * 1024)
         {

@@ -118,7 +118,17 @@ struct NBParamGpu
      * of the CPU kernel (nb_free_energy.cpp:804-812,880-890) */
     float rcoulomb;
     float rvdw;
+
+    /* MI355X extension, analytical Ewald flavours: the real-space force correction beta^3 F((beta r)^2) on a
+     * uniform grid in x = (beta r)^2 over [0, (beta rc)^2], c_ewaldCorrTabSize intervals, as {value, step to the
+     * next value}; the cluster kernel keeps it in LDS (one ds_read_b64 + one FMA per pair instead of a [5/4]
+     * rational with a reciprocal, ~5 instead of ~14 issue slots).  Linear interpolation error <= 1.2e-6 relative,
+     * the class of the rational fit (pme_corr_coeffs.h).  ewaldCorrTabScale = intervals per unit of r^2. */
+    float2* ewaldCorrTab;
+    float   ewaldCorrTabScale;
 };
+
+constexpr int c_ewaldCorrTabSize = 2048;
 
 /* nbnxm/gpu_types_common.h:297-341 */
 struct gpu_plist
@@ -200,9 +210,10 @@ constexpr int c_ringRecordBytes  = 64;
 constexpr int c_jRingBytes       = 4 * c_ringRecordBytes;
 
 /* Dynamic LDS bytes of one workgroup of the cluster-pair kernel (must match the carve-up in the kernel). */
-inline int nbLdsBytes(int numTypes, bool useTable, bool fused, int wavesPerBlock)
+inline int nbLdsBytes(int numTypes, bool useTable, bool ewaldCorrTable, bool fused, int wavesPerBlock)
 {
-    const int tableBytes = useTable ? ((numTypes * numTypes * static_cast<int>(sizeof(float2)) + 15) & ~15) : 0;
+    const int tableBytes = (useTable ? ((numTypes * numTypes * static_cast<int>(sizeof(float2)) + 15) & ~15) : 0)
+                           + (ewaldCorrTable ? c_ewaldCorrTabSize * static_cast<int>(sizeof(float2)) : 0);
     return tableBytes + wavesPerBlock * (2 * c_jStageBytes + c_jRingBytes + (fused ? c_iStageBytes : 0));
 }
 

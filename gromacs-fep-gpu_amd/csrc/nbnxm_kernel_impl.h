@@ -124,7 +124,7 @@ NB_DEVINL void ljFromComb(int vdwKind, const float2& a, const float2& b, float& 
                                 } \
                                 else { ljFromComb(VDW, ljcpi[i], ljcp_j, c6, c12); } \
                                 float F_invr, E_lj_p = 0.0F, E_el_p = 0.0F; \
-                                nbPair<ELEC, TWIN, VDW, ENERGY, EXCL_FORCES, HAS_EXCL>(nbp, r2, intMask, xqi[i].w * xqj.w, c6, c12, \
+                                nbPair<ELEC, TWIN, VDW, ENERGY, EXCL_FORCES, HAS_EXCL>(nbp, ewaldCorrLds, r2, intMask, xqi[i].w * xqj.w, c6, c12, \
                                                                                        F_invr, E_lj_p, E_el_p); \
                                 if constexpr (ENERGY) \
                                 { \
@@ -190,7 +190,10 @@ __launch_bounds__(c_nbBlockSize) __attribute__((amdgpu_waves_per_eu(c_nbWavesPer
     extern __shared__ __align__(16) unsigned char nbLds[];
     const int numTypes   = atdat.numTypes;
     float2*   nbfpLds    = reinterpret_cast<float2*>(nbLds);
-    const int tableBytes = USE_TABLE ? ((numTypes * numTypes * static_cast<int>(sizeof(float2)) + 15) & ~15) : 0;
+    constexpr bool EWALD_CORR_TABLE = (ELEC == ELK_EWALD_ANA);
+    const int      nbfpBytes  = USE_TABLE ? ((numTypes * numTypes * static_cast<int>(sizeof(float2)) + 15) & ~15) : 0;
+    const int      tableBytes = nbfpBytes + (EWALD_CORR_TABLE ? c_ewaldCorrTabSize * static_cast<int>(sizeof(float2)) : 0);
+    [[maybe_unused]] const float2* ewaldCorrLds = reinterpret_cast<const float2*>(nbLds + nbfpBytes);
     unsigned char* jStage = nbLds + tableBytes + wave * (2 * c_jStageBytes + c_jRingBytes + (FUSED ? c_iStageBytes : 0));
     float4*   xqib       = reinterpret_cast<float4*>(jStage + 2 * c_jStageBytes + c_jRingBytes);
     float2*   qABib      = reinterpret_cast<float2*>(xqib + c_superClSize);
@@ -198,6 +201,12 @@ __launch_bounds__(c_nbBlockSize) __attribute__((amdgpu_waves_per_eu(c_nbWavesPer
     if constexpr (USE_TABLE)
     {
         for (int t = threadIdx.x; t < numTypes * numTypes; t += blockSize) { nbfpLds[t] = nbp.nbfp[t]; }
+    }
+    if constexpr (EWALD_CORR_TABLE)
+    {
+        const float4* __restrict__ src = reinterpret_cast<const float4*>(nbp.ewaldCorrTab);
+        float4*                    dst = reinterpret_cast<float4*>(nbLds + nbfpBytes);
+        for (int t = threadIdx.x; t < c_ewaldCorrTabSize / 2; t += blockSize) { dst[t] = src[t]; }
     }
 
     __syncthreads(); /* the table is in place; from here on the waves of the workgroup are independent */
@@ -212,6 +221,7 @@ __launch_bounds__(c_nbBlockSize) __attribute__((amdgpu_waves_per_eu(c_nbWavesPer
     /* diagnostics build only (tools/gpu_timeline.sh): per wave {start, end of main loops, end, HW_ID} in 100 MHz ticks */
     const unsigned long long tlStart = wall_clock64();
     unsigned long long       tlMain  = 0;
+    unsigned long long       tlFirst = 0; /* first group's data has arrived */
 #endif
     const int rangeBegin = workRangeStart[workItem];
     const int rangeEnd   = workRangeStart[workItem + 1];
@@ -411,6 +421,9 @@ __launch_bounds__(c_nbBlockSize) __attribute__((amdgpu_waves_per_eu(c_nbWavesPer
         NBNXM_STAGE_GROUP(jPacked + 1, curBuf ^ 1)
         NBNXM_WAIT_VMEM(c_vmOpsPerGroup);
 
+#ifdef NBNXM_WAVE_TIMELINE
+        if (tlFirst == 0) { tlFirst = wall_clock64(); }
+#endif
         /* this group's list words, from the ring (the same address for all lanes) to SGPRs */
         const unsigned char* rec  = ring + (static_cast<unsigned>(jPacked) & 3U) * c_ringRecordBytes;
         const nb_int4        recA = *reinterpret_cast<const nb_int4*>(rec);
@@ -616,7 +629,7 @@ __launch_bounds__(c_nbBlockSize) __attribute__((amdgpu_waves_per_eu(c_nbWavesPer
                                 }
                                 else { ljFromComb(VDW, ljComb[ai], ljcp_j, c6, c12); }
                                 float E_lj_p = 0.0F, E_el_p = 0.0F;
-                                nbPair<ELEC, TWIN, VDW, ENERGY, EXCL_FORCES>(nbp, r2, intMask, xi.w * xqj.w, c6, c12, F_invr,
+                                nbPair<ELEC, TWIN, VDW, ENERGY, EXCL_FORCES>(nbp, ewaldCorrLds, r2, intMask, xi.w * xqj.w, c6, c12, F_invr,
                                                                              E_lj_p, E_el_p);
                                 if constexpr (ENERGY)
                                 {
@@ -680,7 +693,7 @@ __launch_bounds__(c_nbBlockSize) __attribute__((amdgpu_waves_per_eu(c_nbWavesPer
         unsigned xccId;
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xccId));
         g_nbTimeline[4 * workItem + 0] = tlStart;
-        g_nbTimeline[4 * workItem + 1] = tlMain; /* ticks inside the group loops (incl. pipeline start) */
+        g_nbTimeline[4 * workItem + 1] = tlFirst;
         g_nbTimeline[4 * workItem + 2] = wall_clock64();
         g_nbTimeline[4 * workItem + 3] = (static_cast<unsigned long long>(xccId) << 32) | hwId;
     }

@@ -9,7 +9,8 @@ import torch
 import fep_testlib as tl
 pkg = tl.pkg
 mode = sys.argv[1] if len(sys.argv) > 1 else "split"
-case = tl.make_case(nm=(40, 40, 20), num_perturbed_molecules=16, elec="ewald", seed=2026, n_lambda=11, max_cjpacked_per_sci=16)
+nm = {"24k": (20, 20, 20), "96k": (40, 40, 20)}[sys.argv[2] if len(sys.argv) > 2 else "96k"]
+case = tl.make_case(nm=nm, num_perturbed_molecules=16, elec="ewald", seed=2026, n_lambda=11, max_cjpacked_per_sci=16)
 nb = tl.setup_gpu(case, fused=(mode == "fused"))
 sw = pkg.step_workload(energy=False, virial=False, dhdl=False)
 for _ in range(5):
@@ -24,14 +25,15 @@ a = np.frombuffer(buf, dtype=np.uint64).reshape(n, 4)
 t0 = a[:, 0].min()
 start = (a[:, 0] - t0).astype(np.float64) / 100.0
 end = (a[:, 2] - t0).astype(np.float64) / 100.0
-main = a[:, 1].astype(np.int64).astype(np.float64) / 100.0
+main = (a[:, 1] - t0).astype(np.float64) / 100.0
 hw = a[:, 3] & np.uint64(0xFFFFFFFF)
 xcc = (a[:, 3] >> np.uint64(32)) & np.uint64(0xF)
 simd = (hw >> np.uint64(4)) & np.uint64(3); cu = (hw >> np.uint64(8)) & np.uint64(0xF); sh = (hw >> np.uint64(12)) & np.uint64(1); se = (hw >> np.uint64(13)) & np.uint64(7)
 key = (((xcc * 8 + se) * 2 + sh) * 16 + cu) * 4 + simd
 print("waves %d  start us: min %.1f p50 %.1f p99 %.1f max %.1f" % (n, start.min(), np.median(start), np.percentile(start, 99), start.max()))
 print("end us:   min %.1f p10 %.1f p50 %.1f p90 %.1f p99 %.1f max %.1f" % (end.min(), np.percentile(end, 10), np.median(end), np.percentile(end, 90), np.percentile(end, 99), end.max()))
-print("duration us: p10 %.1f p50 %.1f p90 %.1f max %.1f; in group loops p50 %.1f" % (tuple(np.percentile(end - start, [10, 50, 90, 100])) + (np.median(main),)))
+print("first group data at us: p10 %.1f p50 %.1f p90 %.1f max %.1f" % tuple(np.percentile(main, [10, 50, 90, 100])))
+print("duration us: p10 %.1f p50 %.1f p90 %.1f max %.1f; first group data at p50 %.1f" % (tuple(np.percentile(end - start, [10, 50, 90, 100])) + (np.median(main),)))
 uk, cnt = np.unique(key, return_counts=True)
 print("distinct SIMDs %d, waves per SIMD: min %d max %d, histogram %s" % (len(uk), cnt.min(), cnt.max(), np.bincount(cnt).tolist()))
 simd_end = np.array([end[key == k].max() for k in uk])
