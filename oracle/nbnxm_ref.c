@@ -3,6 +3,9 @@
  */
 #include "nbnxm_ref.h"
 
+#include <omp.h>
+#include <stdlib.h>
+
 #include <math.h>
 #include <stddef.h>
 #include <string.h>
@@ -262,6 +265,67 @@ void FN(oracle_nbnxm_ref)(int nsci, const nbnxn_sci_t* sci, const nbnxn_cj_packe
         }
     }
     if (npairsWithinCutoff) { *npairsWithinCutoff = npair; }
+}
+
+/* The same kernel on nthreads OpenMP threads: contiguous blocks of i-entries per thread, one private force /
+ * shift-force buffer per thread, summed afterwards (how the reference's CPU path threads its non-bonded
+ * kernels, nbnxm/atomdata.cpp reduce step).  Used for the CPU baseline of bench.py. */
+void FN(oracle_nbnxm_ref_mt)(int nthreads, int natoms, int nsci, const nbnxn_sci_t* sci, const nbnxn_cj_packed_t* cjPacked,
+                             const nbnxn_excl_t* excl, const real* xq, const int* type, int ntype,
+                             const real* nbfp, const real* lj_comb, const real* nbfp_comb,
+                             const nbnxm_ref_params_t* p, const real* shiftvec, int computeEnergy,
+                             int computeFshift, real* f, real* fshift, double* Vc, double* Vvdw,
+                             long long* npairsWithinCutoff)
+{
+    if (nthreads < 1) { nthreads = 1; }
+    real*      fT   = (real*)calloc((size_t)nthreads * 3 * natoms, sizeof(real));
+    real*      fsT  = (real*)calloc((size_t)nthreads * 3 * NBNXM_NUM_SHIFT_VECTORS, sizeof(real));
+    double*    vcT  = (double*)calloc((size_t)nthreads * 2, sizeof(double));
+    long long* npT  = (long long*)calloc((size_t)nthreads, sizeof(long long));
+#pragma omp parallel num_threads(nthreads)
+    {
+        const int t  = omp_get_thread_num();
+        const int nt = omp_get_num_threads();
+        /* blocks of equal j-list length rather than equal i-entry count */
+        long long total = 0;
+        for (int s = 0; s < nsci; s++) { total += sci[s].cjPackedEnd - sci[s].cjPackedBegin; }
+        int       s0 = nsci, s1 = nsci;
+        long long acc = 0;
+        for (int s = 0, found0 = 0; s <= nsci; s++)
+        {
+            if (!found0 && acc >= total * t / nt) { s0 = s; found0 = 1; }
+            if (acc >= total * (t + 1) / nt) { s1 = s; break; }
+            if (s < nsci) { acc += sci[s].cjPackedEnd - sci[s].cjPackedBegin; }
+        }
+        if (t == nt - 1) { s1 = nsci; }
+        if (s0 < s1)
+        {
+            FN(oracle_nbnxm_ref)(s1 - s0, sci + s0, cjPacked, excl, xq, type, ntype, nbfp, lj_comb, nbfp_comb, p, shiftvec,
+                                 computeEnergy, computeFshift, fT + (size_t)t * 3 * natoms,
+                                 fsT + (size_t)t * 3 * NBNXM_NUM_SHIFT_VECTORS, &vcT[2 * t], &vcT[2 * t + 1], &npT[t]);
+        }
+#pragma omp barrier
+#pragma omp for schedule(static)
+        for (int i = 0; i < 3 * natoms; i++)
+        {
+            real sum = 0;
+            for (int k = 0; k < nt; k++) { sum += fT[(size_t)k * 3 * natoms + i]; }
+            f[i] += sum;
+        }
+    }
+    long long np = 0;
+    for (int t = 0; t < nthreads; t++)
+    {
+        for (int i = 0; i < 3 * NBNXM_NUM_SHIFT_VECTORS; i++) { fshift[i] += fsT[(size_t)t * 3 * NBNXM_NUM_SHIFT_VECTORS + i]; }
+        *Vc += vcT[2 * t];
+        *Vvdw += vcT[2 * t + 1];
+        np += npT[t];
+    }
+    if (npairsWithinCutoff) { *npairsWithinCutoff = np; }
+    free(fT);
+    free(fsT);
+    free(vcT);
+    free(npT);
 }
 
 #ifdef ORACLE_IS_PRIMARY

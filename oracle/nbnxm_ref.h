@@ -44,7 +44,15 @@ typedef struct
                                    const REAL* lj_comb, const REAL* nbfp_comb,                     \
                                    const nbnxm_ref_params_t* p, const REAL* shiftvec,              \
                                    int computeEnergy, int computeFshift, REAL* f, REAL* fshift,    \
-                                   double* Vc, double* Vvdw, long long* npairsWithinCutoff);
+                                   double* Vc, double* Vvdw, long long* npairsWithinCutoff);        \
+    /* the same on nthreads OpenMP threads (blocks of i-entries, per-thread force buffers summed at the end) */ \
+    void oracle_nbnxm_ref_mt_##SUFFIX(int nthreads, int natoms, int nsci, const nbnxn_sci_t* sci,  \
+                                      const nbnxn_cj_packed_t* cjPacked, const nbnxn_excl_t* excl, \
+                                      const REAL* xq, const int* type, int ntype, const REAL* nbfp, \
+                                      const REAL* lj_comb, const REAL* nbfp_comb,                  \
+                                      const nbnxm_ref_params_t* p, const REAL* shiftvec,           \
+                                      int computeEnergy, int computeFshift, REAL* f, REAL* fshift, \
+                                      double* Vc, double* Vvdw, long long* npairsWithinCutoff);
 
 NBNXM_REF_DECL(f64, double)
 NBNXM_REF_DECL(f32, float)

@@ -185,7 +185,7 @@ def oracle_ref_params(c):
     return p
 
 
-def run_oracle(c, energy=True, precision="f64", foreign=False, cjPacked=None):
+def run_oracle(c, energy=True, precision="f64", foreign=False, cjPacked=None, num_threads=1):
     """Reference result of one step: cluster kernel on the carved list + FEP kernel on the FEP list.
     Forces are returned in GRID order (like nbat->out[0].f)."""
     g = c.grid
@@ -193,7 +193,7 @@ def run_oracle(c, energy=True, precision="f64", foreign=False, cjPacked=None):
     ljc = lj_comb_params(c, g.type) if c.vdw in ("comb_geom", "comb_lb") else None
     ref = ob.nbnxm_ref(c.plist.sci, c.plist.cjPacked if cjPacked is None else cjPacked, c.plist.excl, g.xq,
                        g.type, g.num_types, g.nbat_nbfp(c.sys["nbfp"]), oracle_ref_params(c), g.shift_vec,
-                       compute_energy=energy, compute_fshift=True, lj_comb=ljc, precision=precision)
+                       compute_energy=energy, compute_fshift=True, lj_comb=ljc, precision=precision, num_threads=num_threads)
     fp = oracle_fep_params(c)
     fep = ob.fep_kernel(c.plist.fep, g.x_wrapped, c.ntype, fp, g.shift_vec, c.sys["nbfp"], None, c.sys["qA"],
                         c.sys["qB"], c.sys["typeA"], c.sys["typeB"], flags, c.lambda_coul, c.lambda_vdw, precision)

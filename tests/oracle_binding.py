@@ -146,10 +146,11 @@ def fep_foreign(nbl, x, ntype, p, shiftvec, nbfp, nbfp_grid, qA, qB, typeA, type
 
 
 def nbnxm_ref(sci, cjPacked, excl, xq, atype, ntype, nbfp, p, shiftvec, compute_energy=True,
-              compute_fshift=True, lj_comb=None, nbfp_comb=None, precision="f64"):
-    """sci/cjPacked/excl: numpy structured or raw int32/uint32 arrays with the ABI layout."""
+              compute_fshift=True, lj_comb=None, nbfp_comb=None, precision="f64", num_threads=1):
+    """sci/cjPacked/excl: numpy structured or raw int32/uint32 arrays with the ABI layout.
+    num_threads > 1: the OpenMP variant (bench.py's CPU baseline)."""
     rt = np.float64 if precision == "f64" else np.float32
-    fn = getattr(lib(), "oracle_nbnxm_ref_" + precision)
+    fn = getattr(lib(), ("oracle_nbnxm_ref_mt_" if num_threads > 1 else "oracle_nbnxm_ref_") + precision)
     sci = np.ascontiguousarray(sci)
     cjPacked = np.ascontiguousarray(cjPacked)
     excl = np.ascontiguousarray(excl)
@@ -165,7 +166,8 @@ def nbnxm_ref(sci, cjPacked, excl, xq, atype, ntype, nbfp, p, shiftvec, compute_
     Vc, Vv = C.c_double(0), C.c_double(0)
     npair = C.c_longlong(0)
     nsci = sci.size if sci.dtype.names else sci.reshape(-1, 4).shape[0]
-    fn(C.c_int(nsci), _ptr(sci), _ptr(cjPacked), _ptr(excl), _ptr(xq_), _ptr(t), C.c_int(ntype),
+    lead = (C.c_int(num_threads), C.c_int(n)) if num_threads > 1 else ()
+    fn(*lead, C.c_int(nsci), _ptr(sci), _ptr(cjPacked), _ptr(excl), _ptr(xq_), _ptr(t), C.c_int(ntype),
        _ptr(nbfp_), _ptr(ljc), _ptr(nbc), C.byref(p), _ptr(sv), C.c_int(1 if compute_energy else 0),
        C.c_int(1 if compute_fshift else 0), _ptr(f), _ptr(fshift), C.byref(Vc), C.byref(Vv),
        C.byref(npair))

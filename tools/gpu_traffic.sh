@@ -20,7 +20,9 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
             if row['Counter_Name'] == c:
                 vals[row['Kernel_Name']].append(float(row['Counter_Value']))
         for k, v in vals.items():
-            if 'nbnxmKernel' in k:
+            # the force-only flavour: nbnxmKernel<ELEC, TWIN, VDW, ENERGY = false, FUSED>
+            import re
+            if re.search(r'nbnxmKernel<\d+, (false|true), \d+, false, ', k):
                 res[c] = sum(v) / len(v)
                 res['kernel'] = k[:70]
                 res['n_' + c] = len(v)
