@@ -941,12 +941,15 @@ void nbnxm_gpu_launch_kernel(NbnxmGpu* nb, const nbnxm_step_workload_t* stepWork
      * The atom-pair kernels are few, latency-bound waves: they go first, on the locality's FEP stream, and
      * overlap with the cluster-pair kernel (the reference queues them behind it, nbnxm_cuda.cu:762-857). */
     const bool fused = nb->fusedFep && nbp->bFEP;
+    /* foreign-lambda energies are wanted on dH/dl steps of soft-core runs (nbnxm_cuda.cu:817-856).  In fused mode
+     * the cluster kernel's second pass accumulates them itself: no atom-pair list is needed at all. */
+    const bool wantForeign = nbp->bFEP && nb->n_lambda > 0 && stepWork->computeDhdl && (nbp->alpha_coul != 0.0F || nbp->alpha_vdw != 0.0F);
     bool       fepForked = false;
-    if (nbp->bFEP)
+    if (nbp->bFEP && !fused)
     {
         gpu_feplist* feplist   = nb->feplist[iloc];
-        const bool   doForce   = !fused;
-        const bool   doForeign = nb->n_lambda > 0 && stepWork->computeDhdl && (nbp->alpha_coul != 0.0F || nbp->alpha_vdw != 0.0F);
+        const bool   doForce   = true;
+        const bool   doForeign = wantForeign;
         if (feplist->nri > 0 && feplist->nrj > 0 && (doForce || doForeign))
         {
             hipStream_t fs = s;
@@ -985,7 +988,9 @@ void nbnxm_gpu_launch_kernel(NbnxmGpu* nb, const nbnxm_step_workload_t* stepWork
 
     if (plist->nsci > 0)
     {
-        const NbKernelPtr kernel = selectNbKernel(nbp->elecType, nbp->vdwType, stepWork->computeEnergy != 0, fused);
+        /* fused dH/dl steps run the energy flavour (the foreign terms are energies of its second pass) */
+        const bool        energyFlavour = stepWork->computeEnergy != 0 || (fused && wantForeign);
+        const NbKernelPtr kernel        = selectNbKernel(nbp->elecType, nbp->vdwType, energyFlavour, fused, fused && wantForeign);
         if (kernel == nullptr)
         {
             fatal(__FILE__, __LINE__, "nbnxm_gpu_launch_kernel", "no kernel for this electrostatics / VdW combination (LJ-PME grid flavours are not built)");
@@ -1005,13 +1010,14 @@ void nbnxm_gpu_launch_kernel(NbnxmGpu* nb, const nbnxm_step_workload_t* stepWork
             NBNXM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, ldsBytes));
         }
         /* one wave per resident wave slot, each with an equal share of the list (see updateWorkPartition) */
-        const int p         = nbKernelWavesPerEu(nbp->vdwType, stepWork->computeEnergy != 0, fused) - 4;
+        const int p         = nbKernelWavesPerEu(nbp->vdwType, energyFlavour, fused) - 4;
         const int numRanges = plist->numWorkRanges[p];
         NBNXM_ASSERT(numRanges > 0, "work partition missing");
         hipLaunchKernelGGL(kernel, dim3((numRanges + wavesPerBlock - 1) / wavesPerBlock), dim3(wavesPerBlock * c_waveSize), ldsBytes, s,
                            *adat, *nbp, *plist, stepWork->computeVirial, plist->sciSorted, plist->cjPacked, plist->excl, adat->xq,
                            adat->atomTypes, adat->ljComb, reinterpret_cast<const unsigned*>(adat->fepBits),
-                           plist->workRangeStart[p], plist->workFirstSci[p], numRanges, plist->groupFepJ);
+                           plist->workRangeStart[p], plist->workFirstSci[p], numRanges, plist->groupFepJ,
+                           (fused && wantForeign) ? nb->n_lambda : -1);
         NBNXM_HIP_CHECK(hipGetLastError());
         if (nb->bDoTime) { t.nb_k.closeTimingRegion(s); }
     }

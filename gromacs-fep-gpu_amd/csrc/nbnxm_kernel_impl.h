@@ -147,7 +147,9 @@ NB_DEVINL void ljFromComb(int vdwKind, const float2& a, const float2& b, float& 
 template<int VDW, bool ENERGY, bool FUSED>
 constexpr int c_nbWavesPerEu = (VDW == VDK_CUT && !ENERGY && !FUSED) ? 5 : 4;
 
-template<int ELEC, bool TWIN, int VDW, bool ENERGY, bool FUSED>
+/* FOREIGN (only with ENERGY && FUSED): the flavour of dH/dl steps, whose second pass also accumulates the perturbed
+ * pairs' energies at the foreign lambdas; a flavour of its own so that the plain energy kernel keeps its registers */
+template<int ELEC, bool TWIN, int VDW, bool ENERGY, bool FUSED, bool FOREIGN = false>
 __launch_bounds__(c_nbBlockSize) __attribute__((amdgpu_waves_per_eu(c_nbWavesPerEu<VDW, ENERGY, FUSED>))) __global__
         void nbnxmKernel(const NBAtomDataGpu atdat,
                          const NBParamGpu    nbp,
@@ -168,7 +170,11 @@ __launch_bounds__(c_nbBlockSize) __attribute__((amdgpu_waves_per_eu(c_nbWavesPer
                          const int* __restrict__ workRangeStart,
                          const int* __restrict__ workFirstSci,
                          const int numWorkRanges,
-                         const unsigned* __restrict__ groupFepJ /* FUSED: fepBits bytes of each group's 4 j-clusters */)
+                         const unsigned* __restrict__ groupFepJ, /* FUSED: fepBits bytes of each group's 4 j-clusters */
+                         /* FUSED energy flavours: >= 0: also accumulate the perturbed pairs' energies and dV/dl at
+                          * lambda index 0 (current) .. numForeignLambda (allLambdaCoul/Vdw[k-1]) into the foreign
+                          * arrays, what nbnxn_foreign_fep_kernel_* does on the atom-pair list; -1: not this step */
+                         const int numForeignLambda)
 {
     constexpr bool EXCL_FORCES = (ELEC != ELK_CUT) || ENERGY; /* nbnxm_cuda_kernel.cuh:69-78 */
     constexpr bool USE_TABLE   = VdwTraits<VDW>::useTable;
@@ -369,11 +375,13 @@ __launch_bounds__(c_nbBlockSize) __attribute__((amdgpu_waves_per_eu(c_nbWavesPer
         }
     }
 
+    [[maybe_unused]] bool diagPiece = false; /* this piece holds the i-entry's own clusters as j-clusters */
     if constexpr (ENERGY && EXCL_FORCES)
     {
         /* self terms on the diagonal entry (nbnxm_cuda_kernel.cuh:365-400); lane l owns atom l.  The
          * cluster's own j-cluster is the first one of the entry, so exactly one piece sees it. */
-        if (central && cjPackedList[cjPackedBegin].cj[0] == sci * c_numClPerSupercl)
+        diagPiece = central && cjPackedList[cjPackedBegin].cj[0] == sci * c_numClPerSupercl;
+        if (diagPiece)
         {
             const float coef = (ELEC == ELK_CUT || ELEC == ELK_RF) ? -0.5F * nbp.c_rf : -nbp.ewald_beta * c_oneOverSqrtPi;
             const float qi   = xq[sci * c_superClSize + static_cast<int>(lane)].w * nbp.epsfac;
@@ -524,7 +532,9 @@ __launch_bounds__(c_nbBlockSize) __attribute__((amdgpu_waves_per_eu(c_nbWavesPer
     /* ---- pass 2 (FUSED, rare): pairs that touch a perturbed atom ------------------------------------ */
     if constexpr (FUSED)
     {
-        if (slowSlots != 0ULL || slowOverflow)
+        /* (a piece can hold the diagonal of an i-entry with perturbed atoms without holding any of its perturbed
+         * cluster pairs: it still owes the atoms' self terms at the foreign lambdas) */
+        if (slowSlots != 0ULL || slowOverflow || (FOREIGN && numForeignLambda >= 0 && diagPiece && iFepBits != 0ULL))
         {
             const FepLambda L = makeFepLambda(nbp.lambda_q, nbp.lambda_v, nbp.lam_power, nbp.alpha_coul, nbp.alpha_vdw);
             const float2* __restrict__ nbfp = nbp.nbfp;
@@ -661,6 +671,113 @@ __launch_bounds__(c_nbBlockSize) __attribute__((amdgpu_waves_per_eu(c_nbWavesPer
                         const float v   = (tidxi == 0U) ? fjx : ((tidxi == 1U) ? fjy : fjz);
                         const int   off = (tidxi < 3U) ? (3 * aj + static_cast<int>(tidxi)) * static_cast<int>(sizeof(float)) : c_dropLane;
                         __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(v, fRsrc, off, 0, 0);
+                    }
+                }
+            }
+
+            /* ---- foreign lambdas (dH/dl steps): energies of this piece's perturbed pairs at every lambda index,
+             * one more walk over the flagged slots per index; the role of nbnxn_foreign_fep_kernel_*
+             * (nbnxm/cuda/nbnxm_foreign_fep_cuda_kernel.cuh:88-583), without an atom-pair list */
+            if constexpr (FOREIGN)
+            {
+                static_assert(!FOREIGN || (ENERGY && FUSED), "the foreign-lambda flavour is an energy flavour of the fused kernel");
+                /* c_foreignChunk lambda indices per walk: the pair's geometry and parameters are loaded once for them */
+                constexpr int c_foreignChunk = 4;
+                for (int fbase = 0; fbase <= numForeignLambda; fbase += c_foreignChunk)
+                {
+                    FepLambda Lf[c_foreignChunk];
+                    float     fE_lj[c_foreignChunk], fE_el[c_foreignChunk], fDVDL_lj[c_foreignChunk], fDVDL_el[c_foreignChunk];
+#pragma unroll
+                    for (int q = 0; q < c_foreignChunk; q++)
+                    {
+                        const int   fidx = min(fbase + q, numForeignLambda);
+                        const float lc   = (fidx == 0) ? nbp.lambda_q : nbp.allLambdaCoul[fidx - 1];
+                        const float lv   = (fidx == 0) ? nbp.lambda_v : nbp.allLambdaVdw[fidx - 1];
+                        Lf[q]            = makeFepLambda(lc, lv, nbp.lam_power, nbp.alpha_coul, nbp.alpha_vdw);
+                        fE_lj[q] = fE_el[q] = fDVDL_lj[q] = fDVDL_el[q] = 0.0F;
+                        if constexpr (EXCL_FORCES)
+                        {
+                            if (diagPiece && ((iFepBits >> lane) & 1ULL))
+                            {
+                                const float  coef = (ELEC == ELK_CUT || ELEC == ELK_RF) ? -0.5F * nbp.c_rf : -nbp.ewald_beta * c_oneOverSqrtPi;
+                                const float2 qAB  = qABib[lane];
+                                const float  sA   = qAB.x * qAB.x / nbp.epsfac * coef;
+                                const float  sB   = qAB.y * qAB.y / nbp.epsfac * coef;
+                                fE_el[q] += (1.0F - lc) * sA + lc * sB;
+                                fDVDL_el[q] += sB - sA;
+                            }
+                        }
+                    }
+                    for (int jPacked = cjPackedBegin; jPacked < cjPackedEnd; jPacked++)
+                    {
+                        const int      group     = jPacked - cjPackedBegin;
+                        const unsigned groupSlow = (group < 16) ? static_cast<unsigned>(slowSlots >> (group * c_jGroupSize)) & 0xFU
+                                                                : (slowOverflow ? 0xFU : 0U);
+                        if (groupSlow == 0U) { continue; }
+                        const nbnxn_cj_packed_t* __restrict__ grp = &cjPackedList[jPacked];
+                        const unsigned imask = grp->imei[0].imask;
+                        if (imask == 0U) { continue; }
+                        const unsigned wexcl = exclList[half ? grp->imei[1].excl_ind : grp->imei[0].excl_ind].pair[lane & 31U];
+#pragma unroll 1
+                        for (int jm = 0; jm < c_jGroupSize; jm++)
+                        {
+                            const unsigned imaskJ = (imask >> (jm * c_numClPerSupercl)) & 0xFFU;
+                            if (imaskJ == 0U || !((groupSlow >> jm) & 1U)) { continue; }
+                            const int      cj       = grp->cj[jm];
+                            const unsigned jFepBits = (fepWords[cj >> 2] >> ((cj & 3) * 8)) & 0xFFU;
+                            const unsigned slowMask = (jFepBits != 0U) ? imaskJ : (imaskJ & iFepClusterMask);
+                            if (slowMask == 0U) { continue; }
+                            const unsigned wexclJ = wexcl >> (jm * c_numClPerSupercl);
+                            const int      aj     = cj * c_clSize + static_cast<int>(tidxj);
+                            const float4   xqj    = xq[aj];
+                            const float4   q4j    = atdat.q4[aj];
+                            const int4     t4j    = atdat.atomTypes4[aj];
+#pragma unroll 1
+                            for (int i = 0; i < c_numClPerSupercl; i++)
+                            {
+                                if (!(slowMask & (1U << i))) { continue; }
+                                const unsigned iBits   = static_cast<unsigned>(iFepBits >> (i * c_clSize)) & 0xFFU;
+                                const int      ci      = sci * c_numClPerSupercl + i;
+                                const bool     subDiag = central && (ci == cj) && (tidxj <= tidxi);
+                                const bool     pert    = (((iBits >> tidxi) | (jFepBits >> tidxj)) & 1U) != 0U;
+                                if (pert && !subDiag)
+                                {
+                                    const float4 xi     = xqib[i * c_clSize + tidxi];
+                                    const int2   tABi   = tABib[i * c_clSize + tidxi];
+                                    const float3 rv     = make_float3(xi.x - xqj.x, xi.y - xqj.y, xi.z - xqj.z);
+                                    const float  r2     = rv.x * rv.x + rv.y * rv.y + rv.z * rv.z;
+                                    const float2 qABi   = qABib[i * c_clSize + tidxi];
+                                    const float  qq[2]  = { qABi.x * q4j.x, qABi.y * q4j.y };
+                                    const float2 pA     = USE_TABLE ? nbfpLds[numTypes * tABi.x + t4j.x] : nbfp[numTypes * tABi.x + t4j.x];
+                                    const float2 pB     = USE_TABLE ? nbfpLds[numTypes * tABi.y + t4j.y] : nbfp[numTypes * tABi.y + t4j.y];
+                                    const float  c6[2]  = { pA.x, pB.x };
+                                    const float  c12[2] = { pA.y, pB.y };
+                                    float        fscal  = 0.0F;
+#pragma unroll
+                                    for (int q = 0; q < c_foreignChunk; q++)
+                                    {
+                                        fepPair<FEP_ELEC, VDW == VDK_PSWITCH, false, true>(nbp, Lf[q], r2, ((wexclJ >> i) & 1U) != 0U, false, qq, c6,
+                                                                                           c12, fscal, fE_lj[q], fE_el[q], fDVDL_lj[q], fDVDL_el[q]);
+                                    }
+                                }
+                            }
+                        }
+                    }
+#pragma unroll
+                    for (int q = 0; q < c_foreignChunk; q++)
+                    {
+                        const float s0 = waveSum(fE_lj[q]);
+                        const float s1 = waveSum(fE_el[q]);
+                        const float s2 = waveSum(fDVDL_lj[q]);
+                        const float s3 = waveSum(fDVDL_el[q]);
+                        if (lane < 4U && fbase + q <= numForeignLambda)
+                        {
+                            const float v   = (lane == 0U) ? s0 : ((lane == 1U) ? s1 : ((lane == 2U) ? s2 : s3));
+                            float*      out = (lane == 0U) ? atdat.eLJForeign
+                                                           : ((lane == 1U) ? atdat.eElecForeign
+                                                                           : ((lane == 2U) ? atdat.dvdlLJForeign : atdat.dvdlElecForeign));
+                            if (v != 0.0F) { atomicAdd(out + fbase + q, v); }
+                        }
                     }
                 }
             }

@@ -10,19 +10,20 @@
 
 using NbKernelPtr = void (*)(NBAtomDataGpu, NBParamGpu, gpu_plist, int, const nbnxn_sci_t*, const nbnxn_cj_packed_t*,
                              const nbnxn_excl_t*, const float4*, const int*, const float2*, const unsigned*, const int*,
-                             const int*, int, const unsigned*);
+                             const int*, int, const unsigned*, int);
 using FepKernelPtr   = void (*)(NBAtomDataGpu, NBParamGpu, gpu_feplist, int);
 using PruneKernelPtr = void (*)(NBAtomDataGpu, NBParamGpu, gpu_plist, int, int);
 
 /* vdwKind: VDK_* of nbnxm_device_helpers.h; returns nullptr for an unsupported flavour */
-NbKernelPtr nbKernelElecCut(int vdwKind, bool energy, bool fused);
-NbKernelPtr nbKernelElecRF(int vdwKind, bool energy, bool fused);
-NbKernelPtr nbKernelElecEwaldAna(int vdwKind, bool energy, bool fused);
-NbKernelPtr nbKernelElecEwaldTab(int vdwKind, bool energy, bool fused);
-NbKernelPtr nbKernelElecEwaldAnaTwin(int vdwKind, bool energy, bool fused);
-NbKernelPtr nbKernelElecEwaldTabTwin(int vdwKind, bool energy, bool fused);
+NbKernelPtr nbKernelElecCut(int vdwKind, bool energy, bool fused, bool foreign);
+NbKernelPtr nbKernelElecRF(int vdwKind, bool energy, bool fused, bool foreign);
+NbKernelPtr nbKernelElecEwaldAna(int vdwKind, bool energy, bool fused, bool foreign);
+NbKernelPtr nbKernelElecEwaldTab(int vdwKind, bool energy, bool fused, bool foreign);
+NbKernelPtr nbKernelElecEwaldAnaTwin(int vdwKind, bool energy, bool fused, bool foreign);
+NbKernelPtr nbKernelElecEwaldTabTwin(int vdwKind, bool energy, bool fused, bool foreign);
 
-NbKernelPtr    selectNbKernel(int elecType, int vdwType, bool energy, bool fused);
+/* foreign: the dH/dl-step flavour of the fused energy kernel (implies energy and fused) */
+NbKernelPtr    selectNbKernel(int elecType, int vdwType, bool energy, bool fused, bool foreign = false);
 FepKernelPtr   selectFepKernel(int elecType, int vdwType, bool energy);
 FepKernelPtr   selectFepForeignKernel(int elecType, int vdwType);
 PruneKernelPtr selectPruneKernel(bool haveFreshList);

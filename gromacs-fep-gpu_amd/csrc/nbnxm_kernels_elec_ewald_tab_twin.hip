@@ -3,21 +3,22 @@
 #include "nbnxm_kernels.h"
 
 template<int VDW>
-static NbKernelPtr pick(bool energy, bool fused)
+static NbKernelPtr pick(bool energy, bool fused, bool foreign)
 {
+    if (foreign) { return nbnxmKernel<ELK_EWALD_TAB, true, VDW, true, true, true>; }
     if (energy) { return fused ? nbnxmKernel<ELK_EWALD_TAB, true, VDW, true, true> : nbnxmKernel<ELK_EWALD_TAB, true, VDW, true, false>; }
     return fused ? nbnxmKernel<ELK_EWALD_TAB, true, VDW, false, true> : nbnxmKernel<ELK_EWALD_TAB, true, VDW, false, false>;
 }
 
-NbKernelPtr nbKernelElecEwaldTabTwin(int vdwKind, bool energy, bool fused)
+NbKernelPtr nbKernelElecEwaldTabTwin(int vdwKind, bool energy, bool fused, bool foreign)
 {
     switch (vdwKind)
     {
-        case VDK_CUT: return pick<VDK_CUT>(energy, fused);
-        case VDK_COMB_GEOM: return pick<VDK_COMB_GEOM>(energy, fused);
-        case VDK_COMB_LB: return pick<VDK_COMB_LB>(energy, fused);
-        case VDK_FSWITCH: return pick<VDK_FSWITCH>(energy, fused);
-        case VDK_PSWITCH: return pick<VDK_PSWITCH>(energy, fused);
+        case VDK_CUT: return pick<VDK_CUT>(energy, fused, foreign);
+        case VDK_COMB_GEOM: return pick<VDK_COMB_GEOM>(energy, fused, foreign);
+        case VDK_COMB_LB: return pick<VDK_COMB_LB>(energy, fused, foreign);
+        case VDK_FSWITCH: return pick<VDK_FSWITCH>(energy, fused, foreign);
+        case VDK_PSWITCH: return pick<VDK_PSWITCH>(energy, fused, foreign);
         default: return nullptr;
     }
 }

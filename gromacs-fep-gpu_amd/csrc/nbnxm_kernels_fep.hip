@@ -16,18 +16,18 @@ static int vdwKindOf(int vdwType)
     }
 }
 
-NbKernelPtr selectNbKernel(int elecType, int vdwType, bool energy, bool fused)
+NbKernelPtr selectNbKernel(int elecType, int vdwType, bool energy, bool fused, bool foreign)
 {
     const int vdwKind = vdwKindOf(vdwType);
     if (vdwKind < 0) { return nullptr; }
     switch (elecType)
     {
-        case NBNXM_ELEC_CUT: return nbKernelElecCut(vdwKind, energy, fused);
-        case NBNXM_ELEC_RF: return nbKernelElecRF(vdwKind, energy, fused);
-        case NBNXM_ELEC_EWALD_ANA: return nbKernelElecEwaldAna(vdwKind, energy, fused);
-        case NBNXM_ELEC_EWALD_TAB: return nbKernelElecEwaldTab(vdwKind, energy, fused);
-        case NBNXM_ELEC_EWALD_ANA_TWIN: return nbKernelElecEwaldAnaTwin(vdwKind, energy, fused);
-        case NBNXM_ELEC_EWALD_TAB_TWIN: return nbKernelElecEwaldTabTwin(vdwKind, energy, fused);
+        case NBNXM_ELEC_CUT: return nbKernelElecCut(vdwKind, energy, fused, foreign);
+        case NBNXM_ELEC_RF: return nbKernelElecRF(vdwKind, energy, fused, foreign);
+        case NBNXM_ELEC_EWALD_ANA: return nbKernelElecEwaldAna(vdwKind, energy, fused, foreign);
+        case NBNXM_ELEC_EWALD_TAB: return nbKernelElecEwaldTab(vdwKind, energy, fused, foreign);
+        case NBNXM_ELEC_EWALD_ANA_TWIN: return nbKernelElecEwaldAnaTwin(vdwKind, energy, fused, foreign);
+        case NBNXM_ELEC_EWALD_TAB_TWIN: return nbKernelElecEwaldTabTwin(vdwKind, energy, fused, foreign);
         default: return nullptr;
     }
 }

@@ -255,10 +255,9 @@ def setup_gpu(c, fused=False, use_dynamic_pruning=False):
     pl = c.plist_fused if fused else c.plist
     nb.init_pairlist(pl.sci, pl.cjPacked, pl.excl)
     if fused:
+        # no atom-pair list at all: the cluster kernel's second pass covers forces, energies and foreign lambdas
         nb.init_fep_cluster_bits(g.fepBits)
         nb.set_fep_mode(True)
-        # the foreign-lambda kernel still walks the atom-pair list
-        nb.init_feppairlist(c.plist.fep, g.atomIndices)
     else:
         nb.init_feppairlist(c.plist.fep, g.atomIndices)
     nb.upload_shiftvec(g.shift_vec)

@@ -55,10 +55,12 @@ def test_softcore_settings(sc_alpha, sc_power, sc_coul, lam, fused):
     tl.assert_parity(got, want, rel=1e-4, label="sc")
 
 
-@pytest.mark.parametrize("elec", ["rf", "ewald"])
-def test_foreign_lambda_energies(elec):
-    c = tl.make_case(elec=elec, seed=25, n_lambda=11, **SMALL)
-    got = tl.run_gpu(c, energy=True, fused=False, dhdl=True)
+@pytest.mark.parametrize("fused", [False, True])
+@pytest.mark.parametrize("elec,vdw", [("rf", "cut"), ("ewald", "cut"), ("ewald", "pswitch"), ("cut", "cut")])
+def test_foreign_lambda_energies(elec, vdw, fused):
+    # split: nbnxmFepForeignKernel on the atom-pair list; fused: the cluster kernel's second pass, no atom-pair list
+    c = tl.make_case(elec=elec, vdw=vdw, seed=25, n_lambda=11, **SMALL)
+    got = tl.run_gpu(c, energy=True, fused=fused, dhdl=True)
     want = tl.run_oracle(c, energy=True, foreign=True)
     fw = want["foreign"]
     e_want = fw["eVdw"] + fw["eCoul"]
