@@ -95,6 +95,9 @@ HIP_SYMBOLS = [
     "nbnxm_gpu_get_f", "nbnxm_gpu_get_fshift", "nbnxm_gpu_get_stream",
     "nbnxm_gpu_have_short_range_work", "nbnxm_gpu_set_fep_mode", "nbnxm_hip_abi_version",
     "nbnxm_hip_last_error", "nbnxm_gpu_debug_get_cjpacked", "nbnxm_gpu_debug_download",
+    "nbnxm_gpu_init_x_to_nbat_x", "nbnxm_gpu_x_to_nbat_x", "nbnxm_gpu_insert_nonlocal_dependency",
+    "nbnxm_gpu_setup_short_range_work", "nbnxm_gpu_force_reduction_reinit", "nbnxm_gpu_force_reduction_execute",
+    "nbnxm_gpu_halo_pack_x", "nbnxm_gpu_halo_unpack_f",
 ]
 HOST_SYMBOLS = [
     "nbnxm_host_make_water_box", "nbnxm_host_grid_create", "nbnxm_host_grid_free",
@@ -381,6 +384,29 @@ class NbnxmGpu:
         assert xq.size == 4 * self.num_atoms, "xq must hold 4 floats for each of the %d atoms" % self.num_atoms
         self._lib.nbnxm_gpu_copy_xq_to_gpu(self.h, _p(xq), C.c_int(aloc))
 
+    # ---- coordinate / force buffer operations (device pointers: ints, e.g. torch.Tensor.data_ptr()) ----
+    def init_x_to_nbat_x(self, atom_indices):
+        ai = _a(atom_indices, np.int32)
+        self._lib.nbnxm_gpu_init_x_to_nbat_x(self.h, C.c_int(ai.size), _p(ai))
+
+    def x_to_nbat_x(self, d_x, slot_begin, slot_end, aloc=LOCAL, x_ready_event=None, insert_nonlocal_dependency=False):
+        self._lib.nbnxm_gpu_x_to_nbat_x(self.h, C.c_void_p(d_x), C.c_void_p(x_ready_event), C.c_int(aloc),
+                                        C.c_int(slot_begin), C.c_int(slot_end), C.c_int(1 if insert_nonlocal_dependency else 0))
+
+    def insert_nonlocal_dependency(self, iloc=LOCAL):
+        self._lib.nbnxm_gpu_insert_nonlocal_dependency(self.h, C.c_int(iloc))
+
+    def setup_short_range_work(self, have_listed_forces=False, iloc=LOCAL):
+        self._lib.nbnxm_gpu_setup_short_range_work(self.h, C.c_int(1 if have_listed_forces else 0), C.c_int(iloc))
+
+    def force_reduction_reinit(self, cell, atom_start=0, accumulate=False):
+        cell = _a(cell, np.int32)
+        self._lib.nbnxm_gpu_force_reduction_reinit(self.h, C.c_int(cell.size), _p(cell), C.c_int(atom_start),
+                                                   C.c_int(1 if accumulate else 0))
+
+    def force_reduction_execute(self, d_base_force, d_rvec_force=None, stream=None):
+        self._lib.nbnxm_gpu_force_reduction_execute(self.h, C.c_void_p(d_base_force), C.c_void_p(d_rvec_force), C.c_void_p(stream))
+
     def clear_outputs(self, compute_virial=True):
         self._lib.nbnxm_gpu_clear_outputs(self.h, C.c_int(1 if compute_virial else 0))
 
@@ -443,3 +469,16 @@ def download_cjpacked(nb, ncj, iloc=LOCAL):
     out = np.zeros(ncj, CJ_PACKED_DTYPE)
     lib.nbnxm_gpu_debug_download(nb.h, C.c_void_p(ptr), _p(out), C.c_size_t(out.nbytes))
     return out
+
+
+def halo_pack_x(stream, d_x, d_map, map_size, d_send_buf, coordinate_shift=None):
+    """sendBuf[i] = x[map[i]] (+ shift); all buffers are device pointers (ints), stream a hipStream_t value (int or None)."""
+    sh = _a(coordinate_shift, np.float32) if coordinate_shift is not None else None
+    hip_lib().nbnxm_gpu_halo_pack_x(C.c_void_p(stream), C.c_void_p(d_x), C.c_void_p(d_map), C.c_int(map_size),
+                                    _p(sh) if sh is not None else None, C.c_void_p(d_send_buf))
+
+
+def halo_unpack_f(stream, d_f, d_map, map_size, d_recv_buf, accumulate=True):
+    """f[map[i]] (+)= recvBuf[i]; device pointers as in halo_pack_x."""
+    hip_lib().nbnxm_gpu_halo_unpack_f(C.c_void_p(stream), C.c_void_p(d_f), C.c_void_p(d_map), C.c_int(map_size),
+                                      C.c_void_p(d_recv_buf), C.c_int(1 if accumulate else 0))

@@ -20,13 +20,9 @@
 #include <string>
 #include <vector>
 
-#include "device_utils.h"
-#include "nbnxm_hip.h"
-#include "nbnxm_hip_types.h"
+#include "nbnxm_gpu_internal.h"
 #include "nbnxm_kernels.h"
 #include "nbnxm_work_partition.h"
-
-using namespace nbnxm_hip;
 
 namespace nbnxm_hip
 {
@@ -37,92 +33,6 @@ void setLastError(const char* msg)
 }
 } // namespace nbnxm_hip
 
-/* nbnxm/gpu_types_common.h:81-98, all pinned */
-struct NBStagingData
-{
-    float* eLJ             = nullptr;
-    float* eElec           = nullptr;
-    float* dvdlLJ          = nullptr;
-    float* dvdlElec        = nullptr;
-    float* fShift          = nullptr; /* 45 x 3 */
-    float* eLJForeign      = nullptr;
-    float* eElecForeign    = nullptr;
-    float* dvdlLJForeign   = nullptr;
-    float* dvdlElecForeign = nullptr;
-    /* MI355X: one pinned mirror of the device's scalar-output block (the pointers above, except fShift, point
-     * into it) so that one D2H copy brings everything back; energySlots: see NBAtomDataGpu::energySlots */
-    float* scalars     = nullptr;
-    float* energySlots = nullptr;
-};
-
-struct InteractionTimers
-{
-    GpuRegionTimer nb_k, fep_k, prune_k;
-    bool           didPrune = false, didRollingPrune = false;
-};
-
-/* nbnxm/cuda/nbnxm_cuda_types.h:67-143 */
-struct NbnxmGpu
-{
-    bool           bUseTwoStreams = false;
-    NBAtomDataGpu* atdat          = nullptr;
-    NBParamGpu*    nbparam        = nullptr;
-    gpu_plist*     plist[2]       = { nullptr, nullptr };
-    gpu_feplist*   feplist[2]     = { nullptr, nullptr };
-    NBStagingData  nbst;
-    DeviceStream   deviceStreams[2];
-    /* MI355X extension: the atom-pair FEP kernels of a locality run on their own stream, concurrently with
-     * the cluster-pair kernel (forked / joined with events inside gpu_launch_kernel; both only += into f) */
-    DeviceStream   fepStreams[2];
-    hipEvent_t     fepFork[2]                  = { nullptr, nullptr };
-    hipEvent_t     fepJoin[2]                  = { nullptr, nullptr };
-    bool           fepConcurrent               = true;
-    hipEvent_t     nonlocal_done               = nullptr;
-    hipEvent_t     misc_ops_and_local_H2D_done = nullptr;
-    bool           haveWork[2]                 = { false, false };
-
-    bool                bDoTime = false;
-    InteractionTimers   timers[2];
-    nbnxm_gpu_timings_t timings{};
-
-    int  n_lambda  = 0;
-    bool fusedFep  = false;
-    int  numCUs    = 256;
-
-    int nbWavesPerBlock = c_nbWavesPerBlock; /* tunable: NBNXM_HIP_WAVES_PER_BLOCK = 1..4 */
-    /* work partition (gpu_plist::work*): SIMDs of the device, weight of a perturbed cluster pair relative to a
-     * plain one (NBNXM_HIP_FEP_PAIR_WEIGHT), smallest range worth a wave (NBNXM_HIP_MIN_GROUPS_PER_WAVE) */
-    int numSimds          = 1024;
-    int fepPairWeight     = 16;
-    int minGroupsPerWave  = 2;
-    int numWorkRangesOverride = 0; /* experiments: NBNXM_HIP_NUM_WORK_RANGES */
-    PinnedBuffer<nbnxn_sci_t> h_sciSorted;
-    PinnedBuffer<float2>      h_ewaldCorrTab;
-
-    float* scalarOutputs    = nullptr; /* device block behind atdat->eLJ ... dvdlElecForeign, energySlots */
-    int    numHeadScalars   = 0;       /* scalars + foreign arrays */
-    int    slotOffset       = 0;       /* first float of the energy slots */
-    int    numScalarOutputs = 0;
-
-    /* allocation bookkeeping */
-    int xq_nalloc = 0, f_nalloc = 0, fep_nalloc = 0, fepBits_nalloc = 0;
-    int nbfp_n = 0, nbfp_comb_n = 0, coulomb_tab_n = 0;
-    int iinr_nalloc = 0, jindex_nalloc = 0, shiftIdx_nalloc = 0, jjnr_nalloc = 0, exclFep_nalloc = 0;
-
-    /* pinned staging for every asynchronous upload: stays alive until the next upload of the same
-     * kind (A.4: the reference frees its temporaries right after queuing the copies) */
-    PinnedBuffer<float4> h_q4, h_ljComb4;
-    PinnedBuffer<int4>   h_atomTypes4;
-    PinnedBuffer<int>    h_atomTypes, h_iinr, h_jjnr, h_shift, h_jindex, h_exclFep, h_pairEntry;
-    PinnedBuffer<float2> h_ljComb;
-    PinnedBuffer<float4> h_xq;
-    PinnedBuffer<float>  h_f;
-    PinnedBuffer<nbnxn_sci_t>       h_sci;
-    PinnedBuffer<nbnxn_cj_packed_t> h_cjPacked;
-    PinnedBuffer<nbnxn_excl_t>      h_excl;
-    PinnedBuffer<unsigned char>     h_fepBits;
-    PinnedBuffer<float>             h_shiftVec;
-};
 
 /* Clears the force array and the block of scalar outputs (energies, dV/dl, foreign terms, shift forces)
  * in one launch; replaces the 5-10 separate memsets of gpu_clear_outputs (nbnxm_gpu_data_mgmt.cpp:1047-1070). */
@@ -435,6 +345,8 @@ void nbnxm_gpu_free(NbnxmGpu* nb)
     freeDeviceBuffer(&nbp->nbfp_comb);
     freeDeviceBuffer(&nbp->coulomb_tab);
     freeDeviceBuffer(&nbp->ewaldCorrTab);
+    freeDeviceBuffer(&nb->atomIndices);
+    freeDeviceBuffer(&nb->cell);
     freeDeviceBuffer(&nbp->allLambdaCoul);
     freeDeviceBuffer(&nbp->allLambdaVdw);
     for (int i = 0; i < 2; i++)

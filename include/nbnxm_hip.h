@@ -271,6 +271,42 @@ void* nbnxm_gpu_get_stream(NbnxmGpu* nb, int iloc);
 /* Nbnxm::haveGpuShortRangeWork — nbnxm_gpu.h:300-311 */
 int nbnxm_gpu_have_short_range_work(const NbnxmGpu* nb, int iloc);
 
+/* ---- coordinate / force buffer operations (GPU update, GPU halo exchange schedules) ----------------- */
+
+/* Nbnxm::nbnxn_gpu_init_x_to_nbat_x — nbnxm/nbnxm_gpu.h:255-262, nbnxm_gpu_data_mgmt.cpp:1400-1500.
+ * atomIndices = gridSet.atomIndices(): grid slot -> atom index, -1 for filler slots, one entry per grid slot
+ * (numAtomIndices == numAtoms of nbnxm_gpu_init_atomdata).  Call after every search. */
+void nbnxm_gpu_init_x_to_nbat_x(NbnxmGpu* nb, int numAtomIndices, const int* atomIndices);
+
+/* Nbnxm::nbnxn_gpu_x_to_nbat_x — nbnxm/nbnxm_gpu.h:264-287, nbnxm_gpu_buffer_ops.cpp:62-98 and
+ * cuda/nbnxm_gpu_buffer_ops_internal.cu:66-147.  d_x: device float3[] in atom order; [slotBegin, slotEnd): the
+ * grid slots to convert (a grid's cellOffset*numAtomsPerCell .. its end); xReadyOnDevice: hipEvent_t the locality's
+ * stream waits for first, or NULL.  Filler slots and the charges (xq.w) are left untouched. */
+void nbnxm_gpu_x_to_nbat_x(NbnxmGpu* nb, const void* d_x, void* xReadyOnDevice, int atomLocality,
+                           int slotBegin, int slotEnd, int mustInsertNonLocalDependency);
+
+/* Nbnxm::nbnxnInsertNonlocalGpuDependency — nbnxm_gpu_data_mgmt.cpp:1305-1327 */
+void nbnxm_gpu_insert_nonlocal_dependency(NbnxmGpu* nb, int iloc);
+
+/* Nbnxm::setupGpuShortRangeWork — nbnxm_gpu_data_mgmt.cpp:1093-1104 */
+void nbnxm_gpu_setup_short_range_work(NbnxmGpu* nb, int haveListedForcesGpuInteractions, int iloc);
+
+/* gmx::GpuForceReduction::reinit / execute — mdlib/gpuforcereduction.h:96-118, gpuforcereduction_impl.cpp:97-190,
+ * kernel mdlib/gpuforcereduction_impl_internal.cu:57-127: for atom i in [0, numAtoms):
+ *   f[atomStart + i] = (accumulate ? f[atomStart + i] : 0) + nbnxmForce[cell[i]] (+ rvecForceToAdd[atomStart + i]).
+ * cell = atom index -> grid slot (gridSet.cells()).  stream NULL: the local non-bonded stream. */
+void nbnxm_gpu_force_reduction_reinit(NbnxmGpu* nb, int numAtoms, const int* cell, int atomStart, int accumulate);
+void nbnxm_gpu_force_reduction_execute(NbnxmGpu* nb, void* d_baseForce, const void* d_rvecForceToAdd, void* stream);
+
+/* Pack / unpack kernels of gmx::GpuHaloExchange — domdec/gpuhaloexchange_impl_gpu.cu:62-116,118-183:
+ *   pack:    sendBuf[i] = x[map[i]] (+ coordinateShift when not NULL)
+ *   unpack:  f[map[i]] (+)= recvBuf[i]
+ * Device pointers; stream is a hipStream_t.  The exchange itself (RCCL send/recv over xGMI) is driven by the caller
+ * (gromacs-fep-gpu_amd/halo.py for the tests and the bench). */
+void nbnxm_gpu_halo_pack_x(void* stream, const void* d_x, const int* d_map, int mapSize, const float* coordinateShift,
+                           void* d_sendBuf);
+void nbnxm_gpu_halo_unpack_f(void* stream, void* d_f, const int* d_map, int mapSize, const void* d_recvBuf, int accumulate);
+
 /* Selects how perturbed pairs are evaluated (MI355X extension):
  *   0 = reference shape: cluster kernel + separate atom-pair FEP-list kernels (gpu_feplist);
  *   1 = fused: perturbed pairs inside the cluster-pair kernel (needs nbnxm_gpu_init_fep_cluster_bits). */

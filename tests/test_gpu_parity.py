@@ -5,6 +5,8 @@ Tolerance: 1e-4 relative — the bar the reference's own GPU-vs-CPU acceptance t
 (src/programs/mdrun/tests/freeenergy.cpp:115-135) and the one BASELINE.json states.  Forces are
 compared against the RMS force, sums that cancel against the magnitude of their terms (fep_testlib.assert_parity).
 """
+import ctypes as C
+
 import numpy as np
 import pytest
 
@@ -225,3 +227,97 @@ def test_timing_and_query_entry_points():
     assert lib.nbnxm_gpu_have_short_range_work(nb.h, pkg.LOCAL) == 1
     assert nb.stream() is not None
     nb.free()
+
+
+# ---- coordinate / force buffer operations and the halo pack / unpack kernels ----
+def _dev(arr):
+    import torch
+    return torch.from_numpy(np.ascontiguousarray(arr)).cuda()
+
+
+def test_x_to_nbat_x_and_force_reduction():
+    """nbnxn_gpu_x_to_nbat_x and GpuForceReduction against their index definitions: bit-exact."""
+    import torch
+    c = tl.make_case(elec="rf", seed=41, **SMALL)
+    g = c.grid
+    nb = tl.setup_gpu(c, fused=True)
+    ai = g.atomIndices
+    nb.init_x_to_nbat_x(ai)
+    rng = np.random.default_rng(5)
+    x_new = (c.sys["x"] + rng.normal(0, 0.01, c.sys["x"].shape)).astype(np.float32)   # atom order
+    d_x = _dev(x_new)
+    nslots = g.num_atoms
+    # two calls, as the reference does per grid / locality
+    nb.x_to_nbat_x(d_x.data_ptr(), 0, nslots // 2)
+    nb.x_to_nbat_x(d_x.data_ptr(), nslots // 2, nslots)
+    xq_dev = np.zeros((nslots, 4), np.float32)
+    pkg.hip_lib().nbnxm_gpu_debug_download(nb.h, C.c_void_p(pkg.hip_lib().nbnxm_gpu_get_xq(nb.h)), xq_dev.ctypes.data_as(C.c_void_p),
+                                           C.c_size_t(xq_dev.nbytes))
+    want = g.xq.reshape(-1, 4).copy()
+    real = ai >= 0
+    want[real, :3] = x_new[ai[real]]
+    assert np.array_equal(xq_dev, want)          # fillers and charges untouched, real atoms replaced
+
+    # force reduction: f_total[a] (+)= f_nbnxm[cell[a]] (+ f_rvec[a])
+    sw = pkg.step_workload(energy=False, virial=False, dhdl=False)
+    nb.clear_outputs(False)
+    nb.launch_kernel(sw)
+    f_grid = np.zeros((nslots, 3), np.float32)
+    nb.launch_cpyback(f_grid, sw)
+    nb.wait_finish_task(sw, c.have_soft_core)
+    natoms = c.natoms
+    cell = np.full(natoms, -1, np.int32)
+    cell[ai[real]] = np.nonzero(real)[0]
+    assert (cell >= 0).all()
+    base = rng.normal(0, 1, (natoms, 3)).astype(np.float32)
+    rvec = rng.normal(0, 1, (natoms, 3)).astype(np.float32)
+    for accumulate in (False, True):
+        for add_rvec in (False, True):
+            nb.force_reduction_reinit(cell, atom_start=0, accumulate=accumulate)
+            d_base, d_rvec = _dev(base), _dev(rvec)
+            nb.force_reduction_execute(d_base.data_ptr(), d_rvec.data_ptr() if add_rvec else None)
+            torch.cuda.synchronize()
+            want_f = f_grid[cell]
+            if accumulate:
+                want_f = base + want_f
+            if add_rvec:
+                want_f = want_f + rvec
+            assert np.array_equal(d_base.cpu().numpy(), want_f.astype(np.float32))
+    # a sub-range (atomStart) as used for the non-local atoms
+    start = natoms // 3
+    nb.force_reduction_reinit(cell[start:], atom_start=start, accumulate=True)
+    d_base = _dev(base)
+    nb.force_reduction_execute(d_base.data_ptr(), None)
+    torch.cuda.synchronize()
+    want_f = base.copy()
+    want_f[start:] += f_grid[cell[start:]]
+    assert np.array_equal(d_base.cpu().numpy(), want_f)
+    nb.free()
+
+
+def test_halo_pack_unpack_kernels():
+    import torch
+    rng = np.random.default_rng(9)
+    n, m = 5000, 1777
+    x = rng.normal(0, 1, (n, 3)).astype(np.float32)
+    idx = rng.choice(n, m, replace=False).astype(np.int32)     # a halo atom is sent once per pulse
+    shift = np.array([1.5, -2.25, 0.125], np.float32)
+    d_x, d_map = _dev(x), _dev(idx)
+    d_send = torch.zeros((m, 3), dtype=torch.float32, device="cuda")
+    s = torch.cuda.current_stream().cuda_stream
+    pkg.halo_pack_x(s, d_x.data_ptr(), d_map.data_ptr(), m, d_send.data_ptr(), shift)
+    assert np.array_equal(d_send.cpu().numpy(), x[idx] + shift)
+    pkg.halo_pack_x(s, d_x.data_ptr(), d_map.data_ptr(), m, d_send.data_ptr(), None)
+    assert np.array_equal(d_send.cpu().numpy(), x[idx])
+    f = rng.normal(0, 1, (n, 3)).astype(np.float32)
+    recv = rng.normal(0, 1, (m, 3)).astype(np.float32)
+    d_f, d_recv = _dev(f), _dev(recv)
+    pkg.halo_unpack_f(s, d_f.data_ptr(), d_map.data_ptr(), m, d_recv.data_ptr(), True)
+    want = f.copy()
+    want[idx] += recv
+    assert np.array_equal(d_f.cpu().numpy(), want)
+    pkg.halo_unpack_f(s, d_f.data_ptr(), d_map.data_ptr(), m, d_recv.data_ptr(), False)
+    want[idx] = recv
+    assert np.array_equal(d_f.cpu().numpy(), want)
+    # empty map: no launch
+    pkg.halo_pack_x(s, d_x.data_ptr(), d_map.data_ptr(), 0, d_send.data_ptr(), None)
