@@ -384,6 +384,10 @@ class NbnxmGpu:
         assert xq.size == 4 * self.num_atoms, "xq must hold 4 floats for each of the %d atoms" % self.num_atoms
         self._lib.nbnxm_gpu_copy_xq_to_gpu(self.h, _p(xq), C.c_int(aloc))
 
+    def stream(self, iloc=LOCAL):
+        """hipStream_t of a locality as an integer (e.g. for torch.cuda.ExternalStream)."""
+        return int(self._lib.nbnxm_gpu_get_stream(self.h, C.c_int(iloc)) or 0)
+
     # ---- coordinate / force buffer operations (device pointers: ints, e.g. torch.Tensor.data_ptr()) ----
     def init_x_to_nbat_x(self, atom_indices):
         ai = _a(atom_indices, np.int32)

@@ -241,7 +241,8 @@ def ewald_force_table(beta, rmax, scale=2000.0):
     return tab.astype(np.float32), scale
 
 
-def setup_gpu(c, fused=False, use_dynamic_pruning=False):
+def setup_gpu(c, fused=False, use_dynamic_pruning=False, list_override=None):
+    """list_override: (sci, cjPacked, excl) to upload instead of the case's own list (domain decomposition)."""
     g = c.grid
     ic = gpu_interaction_params(c, use_dynamic_pruning)
     nb = pkg.NbnxmGpu(ic, g.num_types, g.nbat_nbfp(c.sys["nbfp"]), fep=True, n_lambda=c.n_lambda)
@@ -253,7 +254,10 @@ def setup_gpu(c, fused=False, use_dynamic_pruning=False):
     ljc = lj_comb_params(c, g.type) if c.vdw in ("comb_geom", "comb_lb") else None
     nb.init_atomdata(g.num_atoms, g.type, lj_comb=ljc, qA=g.qA, qB=g.qB, typeA=g.typeA, typeB=g.typeB)
     pl = c.plist_fused if fused else c.plist
-    nb.init_pairlist(pl.sci, pl.cjPacked, pl.excl)
+    if list_override is not None:
+        nb.init_pairlist(*list_override)
+    else:
+        nb.init_pairlist(pl.sci, pl.cjPacked, pl.excl)
     if fused:
         # no atom-pair list at all: the cluster kernel's second pass covers forces, energies and foreign lambdas
         nb.init_fep_cluster_bits(g.fepBits)

@@ -321,3 +321,61 @@ def test_halo_pack_unpack_kernels():
     assert np.array_equal(d_f.cpu().numpy(), want)
     # empty map: no launch
     pkg.halo_pack_x(s, d_x.data_ptr(), d_map.data_ptr(), 0, d_send.data_ptr(), None)
+
+
+@pytest.mark.parametrize("num_ranks", [2, 3])
+def test_domain_decomposition_virtual_ranks(num_ranks):
+    """All ranks of a slab decomposition in one process on one GPU (LoopbackComm): HIP pack / unpack, x -> xq, the fused
+    cluster kernel on each rank's share of the list, force reduction, force halo.  Owners must end up with the forces of
+    the single-domain evaluation (and of the CPU oracle)."""
+    import importlib
+    import torch
+    domdec = importlib.import_module("gromacs_fep_gpu_amd.domdec")
+    c = tl.make_case(nm=(12, 8, 8), num_perturbed_molecules=3, elec="ewald", seed=78)
+    g = c.grid
+    full = c.plist_fused
+    dd = domdec.SlabDecomposition(g, full, num_ranks)
+    plans = [dd.plan(r) for r in range(num_ranks)]
+    ai = g.atomIndices
+    real = ai >= 0
+    x_true = np.zeros((c.natoms, 3), np.float32)
+    x_true[ai[real]] = g.xq.reshape(-1, 4)[real, :3]
+    sw = pkg.step_workload(energy=False, virial=False, dhdl=False)
+    steps = []
+    for p in plans:
+        nb = tl.setup_gpu(c, fused=True, list_override=(p.sci, p.cjPacked, full.excl))
+        # start from garbage coordinates everywhere but at home: the halo and x -> xq must supply the rest
+        xq_bad = g.xq.reshape(-1, 4).copy()
+        xq_bad[real, :3] = 1.0e5
+        nb.copy_xq_to_gpu(xq_bad)
+        st = domdec.DomainStep(nb, g, p, domdec.HaloExchange(p, "cuda"))
+        x0 = np.full((c.natoms, 3), 1.0e5, np.float32)
+        x0[p.home_atoms] = x_true[p.home_atoms]
+        st.d_x.copy_(torch.from_numpy(x0))
+        steps.append(st)
+    torch.cuda.synchronize()
+    comm = domdec.LoopbackComm([s.halo for s in steps])
+    for s in steps:
+        s.pack_x()
+    torch.cuda.synchronize()
+    comm.exchange_all_x()
+    torch.cuda.synchronize()
+    for s in steps:
+        s.compute(sw)
+    torch.cuda.synchronize()
+    comm.exchange_all_f()
+    torch.cuda.synchronize()
+    for s in steps:
+        s.unpack_f()
+    torch.cuda.synchronize()
+    f_dd = np.zeros((c.natoms, 3), np.float32)
+    for s, p in zip(steps, plans):
+        f_dd[p.home_atoms] = s.d_f.cpu().numpy()[p.home_atoms]
+    want = tl.run_oracle(c, energy=False)
+    f_ref = np.zeros((c.natoms, 3))
+    f_ref[ai[real]] = want["f"][real]
+    rms = np.sqrt((f_ref ** 2).sum(axis=1).mean())
+    err = np.abs(f_dd - f_ref)
+    assert (err <= 1e-4 * np.maximum(np.linalg.norm(f_ref, axis=1, keepdims=True), rms)).all()
+    for s in steps:
+        s.nb.free()
