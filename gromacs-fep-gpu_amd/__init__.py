@@ -99,6 +99,11 @@ HIP_SYMBOLS = [
     "nbnxm_gpu_setup_short_range_work", "nbnxm_gpu_force_reduction_reinit", "nbnxm_gpu_force_reduction_execute",
     "nbnxm_gpu_halo_pack_x", "nbnxm_gpu_halo_unpack_f",
 ]
+LISTED_SYMBOLS = [
+    "listed_gpu_create", "listed_gpu_free", "listed_gpu_set_force_params", "listed_gpu_update_interaction_list",
+    "listed_gpu_have_interactions", "listed_gpu_launch_kernel", "listed_gpu_launch_energy_transfer",
+    "listed_gpu_wait_accumulate_energy_terms", "listed_gpu_clear_energies",
+]
 HOST_SYMBOLS = [
     "nbnxm_host_make_water_box", "nbnxm_host_grid_create", "nbnxm_host_grid_free",
     "nbnxm_host_grid_num_atoms", "nbnxm_host_grid_num_clusters", "nbnxm_host_grid_get",
@@ -486,3 +491,65 @@ def halo_unpack_f(stream, d_f, d_map, map_size, d_recv_buf, accumulate=True):
     """f[map[i]] (+)= recvBuf[i]; device pointers as in halo_pack_x."""
     hip_lib().nbnxm_gpu_halo_unpack_f(C.c_void_p(stream), C.c_void_p(d_f), C.c_void_p(d_map), C.c_int(map_size),
                                       C.c_void_p(d_recv_buf), C.c_int(1 if accumulate else 0))
+
+
+# ---- listed (bonded) interactions with FEP: include/listed_hip.h ---------------------------------------------
+LISTED_TYPES = {"bonds": 0, "angles": 1, "urey_bradley": 2, "pdihs": 3, "rbdihs": 4, "idihs": 5}
+LISTED_NRAL = {"bonds": 2, "angles": 3, "urey_bradley": 3, "pdihs": 4, "rbdihs": 4, "idihs": 4}
+LISTED_IPARAMS = np.dtype([("p", np.float32, 12), ("mult", np.int32)])
+
+
+class ListedGpu:
+    """ctypes mirror of gmx::ListedForcesGpu for the perturbed function types (listed_forces_gpu.h:120-190)."""
+
+    def __init__(self, stream=None):
+        self._lib = hip_lib()
+        self._lib.listed_gpu_create.restype = C.c_void_p
+        self._h = self._lib.listed_gpu_create(C.c_void_p(stream))
+        if not self._h:
+            raise RuntimeError("listed_gpu_create failed")
+
+    @property
+    def h(self):
+        return C.c_void_p(self._h)
+
+    def set_force_params(self, params):
+        prm = np.ascontiguousarray(params, dtype=LISTED_IPARAMS)
+        self._lib.listed_gpu_set_force_params(self.h, C.c_int(prm.size), _p(prm))
+
+    def update_interaction_list(self, type_name, iatoms, num_atoms):
+        ia = _a(iatoms, np.int32)
+        n = ia.size // (1 + LISTED_NRAL[type_name])
+        self._lib.listed_gpu_update_interaction_list(self.h, C.c_int(LISTED_TYPES[type_name]), C.c_int(n), _p(ia), C.c_int(num_atoms))
+
+    def have_interactions(self):
+        return bool(self._lib.listed_gpu_have_interactions(self.h))
+
+    def launch_kernel(self, d_xq, d_f, d_fshift, box, pbc_type, lambda_bonded, compute_energy=True, compute_virial=True):
+        b = _a(box, np.float32)
+        assert b.size == 9
+        self._lib.listed_gpu_launch_kernel(self.h, C.c_void_p(d_xq), C.c_void_p(d_f), C.c_void_p(d_fshift), _p(b), C.c_int(pbc_type),
+                                           C.c_float(lambda_bonded), C.c_int(1 if compute_energy else 0),
+                                           C.c_int(1 if compute_virial else 0))
+
+    def energies(self):
+        """launch_energy_transfer + wait_accumulate_energy_terms: (per-type energies, dV/dlambda)"""
+        epot = np.zeros(len(LISTED_TYPES), np.float64)
+        dvdl = C.c_double(0)
+        self._lib.listed_gpu_launch_energy_transfer(self.h)
+        self._lib.listed_gpu_wait_accumulate_energy_terms(self.h, _p(epot), C.byref(dvdl))
+        return epot, dvdl.value
+
+    def clear_energies(self):
+        self._lib.listed_gpu_clear_energies(self.h)
+
+    def free(self):
+        if getattr(self, "_h", None):
+            self._lib.listed_gpu_free(self.h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass

@@ -1,0 +1,466 @@
+/*
+ * Perturbed listed (bonded) interactions on gfx950 — C ABI include/listed_hip.h.
+ *
+ * One launch covers every function type: the interactions of all types form one flat index space (prefix table by
+ * value in the kernel arguments), one thread per interaction, 256-thread workgroups.  These are gather / few-flop /
+ * scatter kernels: per interaction 2-4 float4 coordinate gathers (64 B), one parameter record, 2-4 x 12 B of force
+ * atomics — latency / atomic bound, never VALU bound; the layout choices that matter are the coalesced index loads
+ * (iatoms as int2..int5 rows read by consecutive lanes) and LDS staging of the per-workgroup energy and shift-force
+ * sums so that a workgroup issues at most 7 + 135 global atomics for them.
+ *
+ * Semantics: listed_forces_gpu_internal.cu:781-1363 (harmonic_fep_gpu, bonds_fep_gpu, angles_fep_gpu,
+ * urey_bradley_fep_gpu, dopdihs_fep_gpu, pdihs_fep_gpu, rbdihs_fep_gpu, idihs_fep_gpu, do_dih_fup_gpu :415-473,
+ * dih_angle_gpu :374-402, bond_angle_gpu :166-185) = the CPU kernels of listed_forces/bonded.cpp with lambda.
+ */
+#include <hip/hip_runtime.h>
+
+#include <cstring>
+
+#include "device_utils.h"
+#include "listed_hip.h"
+
+using namespace nbnxm_hip;
+
+namespace
+{
+
+constexpr int   c_listedBlock  = 256;
+constexpr int   c_centralShift = 22;
+constexpr int   c_numShifts    = 45;
+constexpr float c_deg2rad      = 0.017453292519943295F;
+constexpr float c_pi           = 3.14159265358979323846F;
+
+struct PbcAiuc /* pbcutil/pbc_aiuc.h:67-96 */
+{
+    float invBoxDiagZ, boxZX, boxZY, boxZZ, invBoxDiagY, boxYX, boxYY, invBoxDiagX, boxXX;
+};
+
+struct ListedKernelArgs
+{
+    int                         start[LISTED_GPU_NUM_TYPES + 1]; /* prefix over the interactions of all types */
+    const int*                  iatoms[LISTED_GPU_NUM_TYPES];
+    const listed_gpu_iparams_t* params;
+    const float4*               xq;
+    float*                      f;
+    float*                      fshift;
+    float*                      epot; /* LISTED_GPU_NUM_TYPES + 1: per-type energies, then dV/dlambda */
+    PbcAiuc                     pbc;
+    float                       lambda;
+};
+
+__device__ __forceinline__ float3 operator-(float3 a, float3 b) { return make_float3(a.x - b.x, a.y - b.y, a.z - b.z); }
+__device__ __forceinline__ float3 operator*(float s, float3 a) { return make_float3(s * a.x, s * a.y, s * a.z); }
+__device__ __forceinline__ float  dot3(float3 a, float3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+__device__ __forceinline__ float3 cross3(float3 a, float3 b)
+{
+    return make_float3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
+}
+
+/* minimum image (pbcDxAiuc, pbc_aiuc_cuda.cuh:70-128); returns the shift index of the image */
+template<bool returnShift>
+__device__ __forceinline__ int pbcDx(const PbcAiuc& pbc, float4 a, float4 b, float3& dx)
+{
+    dx              = make_float3(a.x - b.x, a.y - b.y, a.z - b.z);
+    const float shz = rintf(dx.z * pbc.invBoxDiagZ);
+    dx.x -= shz * pbc.boxZX;
+    dx.y -= shz * pbc.boxZY;
+    dx.z -= shz * pbc.boxZZ;
+    const float shy = rintf(dx.y * pbc.invBoxDiagY);
+    dx.x -= shy * pbc.boxYX;
+    dx.y -= shy * pbc.boxYY;
+    const float shx = rintf(dx.x * pbc.invBoxDiagX);
+    dx.x -= shx * pbc.boxXX;
+    if (returnShift) { return (1 - static_cast<int>(shz)) * 15 + (1 - static_cast<int>(shy)) * 5 + (2 - static_cast<int>(shx)); }
+    return 0;
+}
+
+__device__ __forceinline__ void addForce(float* f, int atom, float3 v)
+{
+    atomicAdd(&f[3 * atom + 0], v.x);
+    atomicAdd(&f[3 * atom + 1], v.y);
+    atomicAdd(&f[3 * atom + 2], v.z);
+}
+__device__ __forceinline__ void addShift(float* sm, int idx, float3 v)
+{
+    atomicAdd(&sm[3 * idx + 0], v.x);
+    atomicAdd(&sm[3 * idx + 1], v.y);
+    atomicAdd(&sm[3 * idx + 2], v.z);
+}
+
+/* V = 1/2 k (x - x0)^2, k and x0 interpolated between the states; returns dV/dlambda */
+__device__ __forceinline__ float harmonicFep(float kA, float kB, float xA, float xB, float x, float lambda, float& V, float& F)
+{
+    const float L1 = 1.0F - lambda;
+    const float kk = L1 * kA + lambda * kB;
+    const float x0 = L1 * xA + lambda * xB;
+    const float dx = x - x0;
+    F              = -kk * dx;
+    V              = 0.5F * kk * dx * dx;
+    return 0.5F * (kB - kA) * dx * dx + (xA - xB) * kk * dx;
+}
+
+template<bool calcVir>
+__device__ __forceinline__ void bondPair(const ListedKernelArgs& a, float* smShift, int ai, int aj, float kA, float kB, float rA, float rB,
+                                         float& epot, float& dvdl)
+{
+    float3      dx;
+    const int   ki  = pbcDx<calcVir>(a.pbc, a.xq[ai], a.xq[aj], dx);
+    const float dr2 = dot3(dx, dx);
+    const float dr  = sqrtf(dr2);
+    float       vb, fb;
+    dvdl += harmonicFep(kA, kB, rA, rB, dr, a.lambda, vb, fb);
+    epot += vb;
+    if (dr2 != 0.0F)
+    {
+        const float3 fij = (fb * rsqrtf(dr2)) * dx;
+        addForce(a.f, ai, fij);
+        addForce(a.f, aj, -1.0F * fij);
+        if (calcVir && ki != c_centralShift)
+        {
+            addShift(smShift, ki, fij);
+            addShift(smShift, c_centralShift, -1.0F * fij);
+        }
+    }
+}
+
+template<bool calcVir>
+__device__ __forceinline__ void angleTriple(const ListedKernelArgs& a, float* smShift, int ai, int aj, int ak, float kA, float kB, float thA,
+                                            float thB, float& epot, float& dvdl)
+{
+    float3      r_ij, r_kj;
+    const int   t1    = pbcDx<calcVir>(a.pbc, a.xq[ai], a.xq[aj], r_ij);
+    const int   t2    = pbcDx<calcVir>(a.pbc, a.xq[ak], a.xq[aj], r_kj);
+    const float nrij2 = dot3(r_ij, r_ij), nrkj2 = dot3(r_kj, r_kj);
+    float       costh = dot3(r_ij, r_kj) * rsqrtf(nrij2 * nrkj2);
+    costh             = fminf(1.0F, fmaxf(-1.0F, costh));
+    const float theta = acosf(costh);
+    float       va, dVdt;
+    dvdl += harmonicFep(kA, kB, thA * c_deg2rad, thB * c_deg2rad, theta, a.lambda, va, dVdt);
+    epot += va;
+    const float c2 = costh * costh;
+    if (c2 < 1.0F)
+    {
+        const float  st  = dVdt * rsqrtf(1.0F - c2);
+        const float  sth = st * costh;
+        const float  cik = st * rsqrtf(nrij2 * nrkj2), cii = sth / nrij2, ckk = sth / nrkj2;
+        const float3 f_i = cii * r_ij - cik * r_kj;
+        const float3 f_k = ckk * r_kj - cik * r_ij;
+        const float3 f_j = -1.0F * f_i - f_k;
+        addForce(a.f, ai, f_i);
+        addForce(a.f, aj, f_j);
+        addForce(a.f, ak, f_k);
+        if (calcVir)
+        {
+            addShift(smShift, t1, f_i);
+            addShift(smShift, c_centralShift, f_j);
+            addShift(smShift, t2, f_k);
+        }
+    }
+}
+
+/* IUPAC dihedral angle and the vectors its force needs */
+template<bool calcVir>
+__device__ __forceinline__ float dihedralAngle(const ListedKernelArgs& a, int ai, int aj, int ak, int al, float3& r_ij, float3& r_kj,
+                                               float3& r_kl, float3& m, float3& n, int& t1, int& t2)
+{
+    t1             = pbcDx<calcVir>(a.pbc, a.xq[ai], a.xq[aj], r_ij);
+    t2             = pbcDx<calcVir>(a.pbc, a.xq[ak], a.xq[aj], r_kj);
+    (void)pbcDx<false>(a.pbc, a.xq[ak], a.xq[al], r_kl);
+    m              = cross3(r_ij, r_kj);
+    n              = cross3(r_kj, r_kl);
+    const float3 w = cross3(m, n);
+    const float  phi = atan2f(sqrtf(dot3(w, w)), dot3(m, n));
+    return (dot3(r_ij, n) < 0.0F) ? -phi : phi;
+}
+
+template<bool calcVir>
+__device__ __forceinline__ void dihedralForces(const ListedKernelArgs& a, float* smShift, int ai, int aj, int ak, int al, float ddphi,
+                                               float3 r_ij, float3 r_kj, float3 r_kl, float3 m, float3 n, int t1, int t2)
+{
+    const float iprm = dot3(m, m), iprn = dot3(n, n), nrkj2 = dot3(r_kj, r_kj);
+    const float toler = nrkj2 * 1.1920929e-07F;
+    if (iprm > toler && iprn > toler)
+    {
+        const float  nrkj_1 = rsqrtf(nrkj2);
+        const float  nrkj   = nrkj2 * nrkj_1;
+        const float3 f_i    = (-ddphi * nrkj / iprm) * m;
+        const float3 f_l    = (ddphi * nrkj / iprn) * n;
+        const float  p      = dot3(r_ij, r_kj) * nrkj_1 * nrkj_1;
+        const float  q      = dot3(r_kl, r_kj) * nrkj_1 * nrkj_1;
+        const float3 svec   = p * f_i - q * f_l;
+        const float3 f_j    = f_i - svec;
+        const float3 f_k    = make_float3(f_l.x + svec.x, f_l.y + svec.y, f_l.z + svec.z);
+        addForce(a.f, ai, f_i);
+        addForce(a.f, aj, -1.0F * f_j);
+        addForce(a.f, ak, -1.0F * f_k);
+        addForce(a.f, al, f_l);
+        if (calcVir)
+        {
+            float3    dx_jl;
+            const int t3 = pbcDx<true>(a.pbc, a.xq[al], a.xq[aj], dx_jl);
+            addShift(smShift, t1, f_i);
+            addShift(smShift, c_centralShift, -1.0F * f_j);
+            addShift(smShift, t2, -1.0F * f_k);
+            addShift(smShift, t3, f_l);
+        }
+    }
+}
+
+template<bool calcVir, bool calcEner>
+__launch_bounds__(c_listedBlock) __global__ void listedForcesKernel(const ListedKernelArgs a)
+{
+    __shared__ float smEner[LISTED_GPU_NUM_TYPES + 1];
+    __shared__ float smShift[3 * c_numShifts];
+    if (calcEner && threadIdx.x <= LISTED_GPU_NUM_TYPES) { smEner[threadIdx.x] = 0.0F; }
+    if (calcVir)
+    {
+        for (int i = threadIdx.x; i < 3 * c_numShifts; i += c_listedBlock) { smShift[i] = 0.0F; }
+    }
+    if (calcVir || calcEner) { __syncthreads(); }
+
+    const int tid = static_cast<int>(blockIdx.x) * c_listedBlock + static_cast<int>(threadIdx.x);
+    if (tid < a.start[LISTED_GPU_NUM_TYPES])
+    {
+        int ftype = 0;
+#pragma unroll
+        for (int t = 1; t < LISTED_GPU_NUM_TYPES; t++) { ftype += (tid >= a.start[t]) ? 1 : 0; }
+        const int  i    = tid - a.start[ftype];
+        const int* ia   = a.iatoms[ftype];
+        float      epot = 0.0F, dvdl = 0.0F;
+        if (ftype == LISTED_GPU_BONDS)
+        {
+            const float* p = a.params[ia[3 * i]].p;
+            bondPair<calcVir>(a, smShift, ia[3 * i + 1], ia[3 * i + 2], p[1], p[3], p[0], p[2], epot, dvdl);
+        }
+        else if (ftype == LISTED_GPU_ANGLES)
+        {
+            const float* p = a.params[ia[4 * i]].p;
+            angleTriple<calcVir>(a, smShift, ia[4 * i + 1], ia[4 * i + 2], ia[4 * i + 3], p[1], p[3], p[0], p[2], epot, dvdl);
+        }
+        else if (ftype == LISTED_GPU_UREY_BRADLEY)
+        {
+            const float* p = a.params[ia[4 * i]].p;
+            angleTriple<calcVir>(a, smShift, ia[4 * i + 1], ia[4 * i + 2], ia[4 * i + 3], p[1], p[5], p[0], p[4], epot, dvdl);
+            bondPair<calcVir>(a, smShift, ia[4 * i + 1], ia[4 * i + 3], p[3], p[7], p[2], p[6], epot, dvdl);
+        }
+        else
+        {
+            const listed_gpu_iparams_t& ip = a.params[ia[5 * i]];
+            const float*                p  = ip.p;
+            const int   ai = ia[5 * i + 1], aj = ia[5 * i + 2], ak = ia[5 * i + 3], al = ia[5 * i + 4];
+            float3      r_ij, r_kj, r_kl, m, n;
+            int         t1, t2;
+            float       phi = dihedralAngle<calcVir>(a, ai, aj, ak, al, r_ij, r_kj, r_kl, m, n, t1, t2);
+            const float L1  = 1.0F - a.lambda;
+            float       ddphi;
+            if (ftype == LISTED_GPU_PDIHS)
+            {
+                const float phi0  = (L1 * p[0] + a.lambda * p[2]) * c_deg2rad;
+                const float dph0  = (p[2] - p[0]) * c_deg2rad;
+                const float cp    = L1 * p[1] + a.lambda * p[3];
+                const float mdphi = ip.mult * phi - phi0;
+                float       s, c;
+                sincosf(mdphi, &s, &c);
+                ddphi = -cp * ip.mult * s;
+                dvdl += (p[3] - p[1]) * (1.0F + c) + cp * dph0 * s;
+                epot += cp * (1.0F + c);
+            }
+            else if (ftype == LISTED_GPU_IDIHS)
+            {
+                const float kk   = L1 * p[1] + a.lambda * p[3];
+                const float phi0 = (L1 * p[0] + a.lambda * p[2]) * c_deg2rad;
+                const float dph0 = (p[2] - p[0]) * c_deg2rad;
+                float       dp   = phi - phi0;
+                if (dp >= c_pi) { dp -= 2.0F * c_pi; }
+                else if (dp < -c_pi) { dp += 2.0F * c_pi; }
+                dvdl += 0.5F * (p[3] - p[1]) * dp * dp - kk * dph0 * dp;
+                epot += 0.5F * kk * dp * dp;
+                ddphi = kk * dp;
+            }
+            else
+            {
+                /* Ryckaert-Bellemans, polymer convention psi = phi - pi */
+                phi += (phi >= c_pi) ? -c_pi : c_pi;
+                float s, c;
+                sincosf(phi, &s, &c);
+                float v = 0.0F, dd = 0.0F, cosfac = 1.0F;
+#pragma unroll
+                for (int j = 0; j < 6; j++)
+                {
+                    const float rbp = L1 * p[j] + a.lambda * p[6 + j];
+                    if (j > 0)
+                    {
+                        dd += j * rbp * cosfac;
+                        cosfac *= c;
+                    }
+                    v += cosfac * rbp;
+                    dvdl += cosfac * (p[6 + j] - p[j]);
+                }
+                ddphi = -dd * s;
+                epot += v;
+            }
+            dihedralForces<calcVir>(a, smShift, ai, aj, ak, al, ddphi, r_ij, r_kj, r_kl, m, n, t1, t2);
+        }
+        if (calcEner)
+        {
+            atomicAdd(&smEner[ftype], epot);
+            atomicAdd(&smEner[LISTED_GPU_NUM_TYPES], dvdl);
+        }
+    }
+    if (calcVir || calcEner) { __syncthreads(); }
+    if (calcEner && threadIdx.x <= LISTED_GPU_NUM_TYPES && smEner[threadIdx.x] != 0.0F) { atomicAdd(&a.epot[threadIdx.x], smEner[threadIdx.x]); }
+    if (calcVir)
+    {
+        for (int i = threadIdx.x; i < 3 * c_numShifts; i += c_listedBlock)
+        {
+            if (smShift[i] != 0.0F) { atomicAdd(&a.fshift[i], smShift[i]); }
+        }
+    }
+}
+
+} // namespace
+
+struct ListedGpu
+{
+    DeviceStream          stream;
+    int                   numInteractions[LISTED_GPU_NUM_TYPES] = {};
+    int*                  d_iatoms[LISTED_GPU_NUM_TYPES]        = {};
+    int                   iatomsAlloc[LISTED_GPU_NUM_TYPES]     = {};
+    listed_gpu_iparams_t* d_params                              = nullptr;
+    int                   numParams = 0, paramsAlloc = 0;
+    float*                d_epot = nullptr; /* LISTED_GPU_NUM_TYPES + 1 */
+    PinnedBuffer<float>   h_epot;
+    PinnedBuffer<int>     h_iatoms[LISTED_GPU_NUM_TYPES];
+    PinnedBuffer<listed_gpu_iparams_t> h_params;
+};
+
+static int listedNral(int ftype)
+{
+    return ftype == LISTED_GPU_BONDS ? 2 : ((ftype == LISTED_GPU_ANGLES || ftype == LISTED_GPU_UREY_BRADLEY) ? 3 : 4);
+}
+
+extern "C"
+{
+
+ListedGpu* listed_gpu_create(void* stream)
+{
+    ListedGpu* lg = new ListedGpu;
+    lg->stream.init(stream);
+    allocateDeviceBuffer(&lg->d_epot, LISTED_GPU_NUM_TYPES + 1);
+    clearDeviceBufferAsync(&lg->d_epot, 0, LISTED_GPU_NUM_TYPES + 1, lg->stream.stream);
+    lg->h_epot.resize(LISTED_GPU_NUM_TYPES + 1);
+    NBNXM_HIP_CHECK(hipStreamSynchronize(lg->stream.stream));
+    return lg;
+}
+
+void listed_gpu_free(ListedGpu* lg)
+{
+    if (lg == nullptr) { return; }
+    (void)hipStreamSynchronize(lg->stream.stream);
+    for (auto& p : lg->d_iatoms) { freeDeviceBuffer(&p); }
+    freeDeviceBuffer(&lg->d_params);
+    freeDeviceBuffer(&lg->d_epot);
+    lg->stream.destroy();
+    delete lg;
+}
+
+void listed_gpu_set_force_params(ListedGpu* lg, int numParams, const listed_gpu_iparams_t* params)
+{
+    if (numParams > lg->paramsAlloc)
+    {
+        freeDeviceBuffer(&lg->d_params);
+        lg->paramsAlloc = numParams + 64;
+        allocateDeviceBuffer(&lg->d_params, lg->paramsAlloc);
+    }
+    lg->h_params.resize(numParams);
+    if (numParams) { std::memcpy(lg->h_params.data, params, sizeof(listed_gpu_iparams_t) * numParams); }
+    copyToDeviceBuffer(&lg->d_params, lg->h_params.data, 0, numParams, lg->stream.stream, true);
+    lg->numParams = numParams;
+}
+
+void listed_gpu_update_interaction_list(ListedGpu* lg, int ftype, int numInteractions, const int* iatoms, int numAtoms)
+{
+    NBNXM_ASSERT(ftype >= 0 && ftype < LISTED_GPU_NUM_TYPES, "unknown listed function type");
+    const int stride = 1 + listedNral(ftype);
+    /* shape checks on the host: an out-of-range index would fault on the device */
+    for (int i = 0; i < numInteractions; i++)
+    {
+        NBNXM_ASSERT(iatoms[stride * i] >= 0 && iatoms[stride * i] < lg->numParams, "parameter index out of range (set the force parameters first)");
+        for (int k = 1; k < stride; k++) { NBNXM_ASSERT(iatoms[stride * i + k] >= 0 && iatoms[stride * i + k] < numAtoms, "atom index out of range"); }
+    }
+    const int n = stride * numInteractions;
+    if (n > lg->iatomsAlloc[ftype])
+    {
+        freeDeviceBuffer(&lg->d_iatoms[ftype]);
+        lg->iatomsAlloc[ftype] = static_cast<int>(n * 1.2) + 64;
+        allocateDeviceBuffer(&lg->d_iatoms[ftype], lg->iatomsAlloc[ftype]);
+    }
+    lg->h_iatoms[ftype].resize(n);
+    if (n) { std::memcpy(lg->h_iatoms[ftype].data, iatoms, sizeof(int) * n); }
+    copyToDeviceBuffer(&lg->d_iatoms[ftype], lg->h_iatoms[ftype].data, 0, n, lg->stream.stream, true);
+    lg->numInteractions[ftype] = numInteractions;
+}
+
+int listed_gpu_have_interactions(const ListedGpu* lg)
+{
+    for (int n : lg->numInteractions)
+    {
+        if (n > 0) { return 1; }
+    }
+    return 0;
+}
+
+void listed_gpu_launch_kernel(ListedGpu* lg, const void* d_xq, void* d_f, void* d_fshift, const float* box, int pbcType,
+                              float lambdaBonded, int computeEnergy, int computeVirial)
+{
+    if (!listed_gpu_have_interactions(lg)) { return; }
+    NBNXM_ASSERT(d_xq != nullptr && d_f != nullptr, "coordinate / force buffer missing");
+    NBNXM_ASSERT(!computeVirial || d_fshift != nullptr, "virial step without a shift-force buffer");
+    ListedKernelArgs a;
+    a.start[0] = 0;
+    for (int t = 0; t < LISTED_GPU_NUM_TYPES; t++)
+    {
+        a.start[t + 1] = a.start[t] + lg->numInteractions[t];
+        a.iatoms[t]    = lg->d_iatoms[t];
+    }
+    a.params = lg->d_params;
+    a.xq     = static_cast<const float4*>(d_xq);
+    a.f      = static_cast<float*>(d_f);
+    a.fshift = static_cast<float*>(d_fshift);
+    a.epot   = lg->d_epot;
+    a.lambda = lambdaBonded;
+    /* setPbcAiuc (pbcutil/pbc_aiuc.h:98-140): dimensions without PBC get a zero inverse, which makes their shift 0 */
+    const int npbcdim = (pbcType == 3) ? 3 : ((pbcType == 2) ? 2 : 0);
+    a.pbc.invBoxDiagZ = (npbcdim > 2) ? 1.0F / box[8] : 0.0F;
+    a.pbc.invBoxDiagY = (npbcdim > 1) ? 1.0F / box[4] : 0.0F;
+    a.pbc.invBoxDiagX = (npbcdim > 0) ? 1.0F / box[0] : 0.0F;
+    a.pbc.boxZX = box[6]; a.pbc.boxZY = box[7]; a.pbc.boxZZ = box[8];
+    a.pbc.boxYX = box[3]; a.pbc.boxYY = box[4];
+    a.pbc.boxXX = box[0];
+    const int  total = a.start[LISTED_GPU_NUM_TYPES];
+    const dim3 grid((total + c_listedBlock - 1) / c_listedBlock);
+    auto       k = computeVirial ? (computeEnergy ? listedForcesKernel<true, true> : listedForcesKernel<true, false>)
+                                 : (computeEnergy ? listedForcesKernel<false, true> : listedForcesKernel<false, false>);
+    hipLaunchKernelGGL(k, grid, dim3(c_listedBlock), 0, lg->stream.stream, a);
+    NBNXM_HIP_CHECK(hipGetLastError());
+}
+
+void listed_gpu_launch_energy_transfer(ListedGpu* lg)
+{
+    NBNXM_HIP_CHECK(hipMemcpyAsync(lg->h_epot.data, lg->d_epot, sizeof(float) * (LISTED_GPU_NUM_TYPES + 1), hipMemcpyDeviceToHost,
+                                   lg->stream.stream));
+}
+
+void listed_gpu_wait_accumulate_energy_terms(ListedGpu* lg, double* epot, double* dvdlBonded)
+{
+    NBNXM_HIP_CHECK(hipStreamSynchronize(lg->stream.stream));
+    for (int t = 0; t < LISTED_GPU_NUM_TYPES; t++) { epot[t] += lg->h_epot.data[t]; }
+    *dvdlBonded += lg->h_epot.data[LISTED_GPU_NUM_TYPES];
+}
+
+void listed_gpu_clear_energies(ListedGpu* lg)
+{
+    clearDeviceBufferAsync(&lg->d_epot, 0, LISTED_GPU_NUM_TYPES + 1, lg->stream.stream);
+}
+
+} // extern "C"

@@ -1,0 +1,70 @@
+/*
+ * C ABI of the MI355X listed-forces (bonded) path with free-energy perturbation — SURVEY §8 row f3.
+ *
+ * Replaces the perturbed part of gmx::ListedForcesGpu (listed_forces/listed_forces_gpu.h:120-190; implementation
+ * listed_forces_gpu_impl.cu, kernels listed_forces_gpu_internal.cu:781-1363: bonds_fep_gpu, angles_fep_gpu,
+ * urey_bradley_fep_gpu, pdihs_fep_gpu, rbdihs_fep_gpu, idihs_fep_gpu) for the function types below; every type takes
+ * A- and B-state parameters and lambda_bonded, so the unperturbed interactions are the A == B case of the same code.
+ * Not built yet: the perturbed LJ-14 pairs (pairs_fep_gpu :1365-1600) and the restraint types.
+ *
+ * Conventions as in the reference: coordinates are the non-bonded module's xq (float4, nbnxm grid order), atom indices
+ * in the interaction lists are already translated to that order (nbnxnAtomOrder, listed_forces_gpu_impl.cu
+ * convertIlistToNbnxnOrder), forces are accumulated into the non-bonded force buffer with atomics, energies stay on
+ * the device until launch_energy_transfer / wait_accumulate_energy_terms.
+ */
+#ifndef LISTED_HIP_H
+#define LISTED_HIP_H
+
+#ifdef __cplusplus
+extern "C"
+{
+#endif
+
+typedef struct ListedGpu ListedGpu;
+
+enum
+{
+    LISTED_GPU_BONDS = 0,    /* F_BONDS           [type, ai, aj]          p: rA krA rB krB */
+    LISTED_GPU_ANGLES,       /* F_ANGLES          [type, ai, aj, ak]      p: thA kA thB kB (degrees) */
+    LISTED_GPU_UREY_BRADLEY, /* F_UREY_BRADLEY    [type, ai, aj, ak]      p: thetaA kthetaA r13A kUBA thetaB kthetaB r13B kUBB */
+    LISTED_GPU_PDIHS,        /* F_PDIHS, F_PIDIHS [type, ai, aj, ak, al]  p: phiA cpA phiB cpB; mult */
+    LISTED_GPU_RBDIHS,       /* F_RBDIHS          [type, ai, aj, ak, al]  p: rbcA[6] rbcB[6] */
+    LISTED_GPU_IDIHS,        /* F_IDIHS           [type, ai, aj, ak, al]  p: xA kA xB kB (degrees) */
+    LISTED_GPU_NUM_TYPES
+};
+
+/* t_iparams of the types above (topology/idef.h:71-330), float, A and B state side by side */
+typedef struct
+{
+    float p[12];
+    int   mult;
+} listed_gpu_iparams_t;
+
+/* ListedForcesGpu::ListedForcesGpu — listed_forces_gpu.h:125-131.  stream: hipStream_t to launch on (the non-bonded
+ * local stream in the reference), NULL: an own stream. */
+ListedGpu* listed_gpu_create(void* stream);
+void       listed_gpu_free(ListedGpu* lg);
+
+/* ListedForcesGpu::updateInteractionListsAndDeviceBuffers — listed_forces_gpu.h:146-151: the force parameters
+ * (idef.iparams) and, per function type, the interaction list in nbnxm atom order, 1 + nral ints per interaction. */
+void listed_gpu_set_force_params(ListedGpu* lg, int numParams, const listed_gpu_iparams_t* params);
+void listed_gpu_update_interaction_list(ListedGpu* lg, int ftype, int numInteractions, const int* iatoms, int numAtoms);
+
+/* ListedForcesGpu::haveInteractions — listed_forces_gpu.h:153-158 */
+int listed_gpu_have_interactions(const ListedGpu* lg);
+
+/* ListedForcesGpu::launchKernel(stepWork, box) — listed_forces_gpu.h:160-170.  d_xq: float4[], d_f: float3[] (+=),
+ * d_fshift: float3[45] (+= when computeVirial); box: 3x3 row-major; pbcType: 0 none, 2 xy, 3 xyz. */
+void listed_gpu_launch_kernel(ListedGpu* lg, const void* d_xq, void* d_f, void* d_fshift, const float* box, int pbcType,
+                              float lambdaBonded, int computeEnergy, int computeVirial);
+
+/* launchEnergyTransfer / waitAccumulateEnergyTerms / clearEnergies — listed_forces_gpu.h:172-190:
+ * epot[LISTED_GPU_NUM_TYPES] += per-type energies, *dvdlBonded += dV/dlambda of all types. */
+void listed_gpu_launch_energy_transfer(ListedGpu* lg);
+void listed_gpu_wait_accumulate_energy_terms(ListedGpu* lg, double* epot, double* dvdlBonded);
+void listed_gpu_clear_energies(ListedGpu* lg);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

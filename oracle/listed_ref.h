@@ -1,0 +1,47 @@
+/*
+ * CPU oracle of the perturbed listed (bonded) interactions: TEST INFRASTRUCTURE ONLY (see fep_oracle.h).
+ * Restates, in double precision, the semantics of the reference's CPU kernels
+ *   listed_forces/bonded.cpp:  harmonic :188-214, bonds :216-276, angles :941-1031, urey_bradley :1172-1278,
+ *                              dih_angle :1414-1434, do_dih_fup :1437-1500, dopdihs :1564-1590, pdihs :1648-1710,
+ *                              idihs :1968-2035, rbdihs :2560-2680
+ * which its GPU path (listed_forces_gpu_internal.cu:781-1363, *_fep_gpu) follows for the perturbed types.
+ * Pinned by the reference's own known answers (tests/golden/listed_refdata.json, test_oracle_golden.py).
+ */
+#ifndef LISTED_REF_H
+#define LISTED_REF_H
+
+#ifdef __cplusplus
+extern "C"
+{
+#endif
+
+enum
+{
+    LISTED_BONDS = 0,    /* F_BONDS          2 atoms  p: rA krA rB krB */
+    LISTED_ANGLES,       /* F_ANGLES         3 atoms  p: thA kA thB kB (degrees) */
+    LISTED_UREY_BRADLEY, /* F_UREY_BRADLEY   3 atoms  p: thetaA kthetaA r13A kUBA thetaB kthetaB r13B kUBB */
+    LISTED_PDIHS,        /* F_PDIHS/F_PIDIHS 4 atoms  p: phiA cpA phiB cpB, mult */
+    LISTED_RBDIHS,       /* F_RBDIHS         4 atoms  p: rbcA[6] rbcB[6] */
+    LISTED_IDIHS,        /* F_IDIHS          4 atoms  p: xA kA xB kB (degrees) */
+    LISTED_NUM_TYPES
+};
+
+/* double here (the reference's t_iparams are `real`, and its known answers hold to 1e-8 in double); the GPU path's
+ * listed_iparams_t (include/listed_hip.h) has the same layout in float */
+typedef struct
+{
+    double p[12];
+    int    mult;
+    int    pad;
+} listed_iparams_t;
+
+/* x: 3 doubles per atom; box: 3 diagonal lengths (rectangular), npbcdim: 0 none, 2 xy, 3 xyz;
+ * iatoms: (1 + nral) ints per interaction: parameter index, atoms; f: 3 doubles per atom (+=);
+ * fshift: 45 x 3 (+=, may be NULL). */
+void oracle_listed(int ftype, int numInteractions, const int* iatoms, const listed_iparams_t* params, const double* x,
+                   const double* box, int npbcdim, double lambda, double* f, double* fshift, double* epot, double* dvdl);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

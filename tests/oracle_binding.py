@@ -183,3 +183,43 @@ def nbnxm_prune(sci, cjPacked, xq, shiftvec, rlist):
     nsci = sci.size if sci.dtype.names else sci.reshape(-1, 4).shape[0]
     return lib().oracle_nbnxm_prune(C.c_int(nsci), _ptr(sci), _ptr(cjPacked), _ptr(xq_), _ptr(sv),
                                     C.c_double(rlist))
+
+
+# ---- listed (bonded) interactions with A/B parameters: oracle/listed_ref.h --------------------------------
+LISTED_TYPES = {"bonds": 0, "angles": 1, "urey_bradley": 2, "pdihs": 3, "rbdihs": 4, "idihs": 5}
+LISTED_NRAL = {"bonds": 2, "angles": 3, "urey_bradley": 3, "pdihs": 4, "rbdihs": 4, "idihs": 4}
+LISTED_IPARAMS = np.dtype([("p", np.float64, 12), ("mult", np.int32), ("pad", np.int32)])
+
+
+def listed_iparams(type_name, prm):
+    """One listed_iparams_t from the reference test's parameter names (tests/golden/make_listed_golden.py)."""
+    ip = np.zeros(1, LISTED_IPARAMS)
+    if type_name in ("bonds", "angles", "idihs"):
+        ip["p"][0, :4] = [prm["rA"], prm["krA"], prm["rB"], prm["krB"]]
+    elif type_name == "urey_bradley":
+        ip["p"][0, :8] = [prm[k] for k in ("thetaA", "kthetaA", "r13A", "kUBA", "thetaB", "kthetaB", "r13B", "kUBB")]
+    elif type_name == "pdihs":
+        ip["p"][0, :4] = [prm["phiA"], prm["cpA"], prm["phiB"], prm["cpB"]]
+        ip["mult"][0] = prm["mult"]
+    elif type_name == "rbdihs":
+        ip["p"][0, :6] = prm["rbcA"]
+        ip["p"][0, 6:] = prm["rbcB"]
+    else:
+        raise ValueError(type_name)
+    return ip
+
+
+def listed(type_name, iatoms, params, x, box, npbcdim, lam, want_fshift=True):
+    """iatoms: (n, 1 + nral) int32 rows [parameter index, atoms...]; returns dict(f, fshift, epot, dvdl)."""
+    ia = _arr(iatoms, np.int32)
+    prm = np.ascontiguousarray(params)
+    x_ = _arr(x, np.float64)
+    n = x_.reshape(-1, 3).shape[0]
+    f = np.zeros((n, 3), np.float64)
+    fshift = np.zeros((45, 3), np.float64)
+    box_ = _arr(box, np.float64)
+    epot, dvdl = C.c_double(0), C.c_double(0)
+    lib().oracle_listed(C.c_int(LISTED_TYPES[type_name]), C.c_int(ia.reshape(-1, 1 + LISTED_NRAL[type_name]).shape[0]), _ptr(ia),
+                        _ptr(prm), _ptr(x_), _ptr(box_), C.c_int(npbcdim), C.c_double(lam), _ptr(f),
+                        _ptr(fshift) if want_fshift else None, C.byref(epot), C.byref(dvdl))
+    return dict(f=f, fshift=fshift, epot=epot.value, dvdl=dvdl.value)

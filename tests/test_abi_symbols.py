@@ -26,6 +26,16 @@ def test_hip_library_exports_every_declared_symbol():
     assert lib.nbnxm_hip_abi_version() == 1
 
 
+def test_hip_library_exports_every_listed_forces_symbol():
+    lib = pkg.hip_lib()
+    names = declared_functions("listed_hip.h", "listed_gpu_")
+    assert len(names) == 9
+    for n in names:
+        assert hasattr(lib, n), "libnbnxm_hip.so does not export %s" % n
+    assert sorted(names) == sorted(pkg.LISTED_SYMBOLS)
+    assert pkg.LISTED_IPARAMS.itemsize == 52
+
+
 def test_host_library_exports_every_declared_symbol():
     lib = pkg.host_lib()
     names = declared_functions("nbnxm_host.h", "nbnxm_host_")

@@ -1,0 +1,163 @@
+"""GPU parity of the perturbed listed (bonded) interactions: the HIP kernels behind
+include/listed_hip.h against the reference's own known answers and against the CPU oracle (oracle/listed_ref.c, itself
+pinned by those known answers) on random molecules with periodic wrapping.  Tolerance 1e-4 relative of the largest force /
+energy term (fp32 on the GPU, double in the oracle), the bar of the non-bonded path."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import fep_testlib as tl
+import oracle_binding as ob
+
+pytestmark = pytest.mark.gpu
+pkg = tl.pkg
+HERE = os.path.dirname(os.path.abspath(__file__))
+GOLD = json.load(open(os.path.join(HERE, "golden", "listed_refdata.json")))
+PBC = {"none": 0, "xy": 2, "xyz": 3}
+
+
+def _gpu_params(prm64):
+    out = np.zeros(prm64.size, pkg.LISTED_IPARAMS)
+    out["p"] = prm64["p"].astype(np.float32)
+    out["mult"] = prm64["mult"]
+    return out
+
+
+def _run_gpu(lists, params64, x, box3, pbc_type, lam, energy=True, virial=True):
+    """lists: {type name: (n, 1 + nral) int32}; returns f, fshift, per-type energies, dvdl"""
+    import torch
+    n = x.shape[0]
+    xq = np.zeros((n, 4), np.float32)
+    xq[:, :3] = x
+    d_xq = torch.from_numpy(xq).cuda()
+    d_f = torch.zeros((n, 3), dtype=torch.float32, device="cuda")
+    d_fs = torch.zeros((45, 3), dtype=torch.float32, device="cuda")
+    lg = pkg.ListedGpu()
+    lg.set_force_params(_gpu_params(params64))
+    for name, ia in lists.items():
+        lg.update_interaction_list(name, ia, n)
+    assert lg.have_interactions() == any(len(ia) for ia in lists.values())
+    torch.cuda.synchronize()
+    box = np.diag(np.asarray(box3, np.float32))
+    lg.launch_kernel(d_xq.data_ptr(), d_f.data_ptr(), d_fs.data_ptr(), box, pbc_type, lam, energy, virial)
+    epot, dvdl = lg.energies()
+    torch.cuda.synchronize()
+    out = dict(f=d_f.cpu().numpy(), fshift=d_fs.cpu().numpy(), epot=epot, dvdl=dvdl)
+    lg.free()
+    return out
+
+
+@pytest.mark.parametrize("case", [pytest.param(c, id="%s-%d-%s" % (c["suite"], c["index"], c["pbc"])) for c in GOLD["cases"]])
+def test_listed_gpu_matches_reference_known_answers(case):
+    x = np.array(GOLD["coordinates"], np.float64)
+    ia = np.array([[0] + t for t in case["iatoms"]], np.int32)
+    prm = ob.listed_iparams(case["type"], case["params"])
+    for lam_name, want in case["results"].items():
+        got = _run_gpu({case["type"]: ia}, prm, x, [GOLD["box"]] * 3, PBC[case["pbc"]], float(lam_name))
+        fw = np.array(want["forces"])
+        scale = max(1.0, np.abs(fw).max())
+        assert np.abs(got["f"] - fw).max() <= 1e-4 * scale
+        t = pkg.LISTED_TYPES[case["type"]]
+        assert abs(got["epot"][t] - want["epot"]) <= 1e-4 * max(1.0, abs(want["epot"]))
+        assert abs(got["dvdl"] - want["dvdlambda"]) <= 1e-4 * max(1.0, abs(want["dvdlambda"]), scale)
+        assert np.abs(got["epot"]).sum() == pytest.approx(abs(got["epot"][t]))   # nothing leaks into other types
+
+
+def _random_system(seed, nmol=400, box=3.0):
+    """nmol 6-atom chains with random A/B parameters of every type, coordinates wrapped into the box so that bonds
+    cross the periodic boundaries"""
+    rng = np.random.default_rng(seed)
+    x = np.zeros((6 * nmol, 3))
+    for m in range(nmol):
+        p = rng.uniform(0, box, 3)
+        for a in range(6):
+            x[6 * m + a] = p
+            p = p + rng.normal(0, 1, 3) * 0.09
+    x = x % box
+    nprm = 40
+    prm = np.zeros(nprm, ob.LISTED_IPARAMS)
+    kinds = ["bonds", "angles", "urey_bradley", "pdihs", "rbdihs", "idihs"]
+    kind_of = [kinds[i % 6] for i in range(nprm)]
+    for i, k in enumerate(kind_of):
+        same = rng.random() < 0.3      # some interactions are not perturbed
+        if k == "bonds":
+            a = [rng.uniform(0.1, 0.2), rng.uniform(100, 500)]
+            b = a if same else [rng.uniform(0.1, 0.2), rng.uniform(100, 500)]
+            prm["p"][i, :4] = a + list(b)
+        elif k in ("angles", "idihs"):
+            a = [rng.uniform(60, 140) if k == "angles" else rng.uniform(-170, 170), rng.uniform(20, 80)]
+            b = a if same else [a[0] + rng.uniform(-10, 10), rng.uniform(20, 80)]
+            prm["p"][i, :4] = a + list(b)
+        elif k == "urey_bradley":
+            a = [rng.uniform(60, 140), rng.uniform(20, 80), rng.uniform(0.15, 0.3), rng.uniform(1, 10)]
+            b = a if same else [a[0] + rng.uniform(-8, 8), rng.uniform(20, 80), rng.uniform(0.15, 0.3), rng.uniform(1, 10)]
+            prm["p"][i, :8] = a + list(b)
+        elif k == "pdihs":
+            a = [rng.uniform(-180, 180), rng.uniform(1, 20)]
+            b = a if same else [rng.uniform(-180, 180), rng.uniform(1, 20)]
+            prm["p"][i, :4] = a + list(b)
+            prm["mult"][i] = rng.integers(1, 5)
+        else:
+            a = list(rng.uniform(-10, 10, 6))
+            b = a if same else list(rng.uniform(-10, 10, 6))
+            prm["p"][i, :12] = a + b
+    by_kind = {k: [i for i in range(nprm) if kind_of[i] == k] for k in kinds}
+    lists = {k: [] for k in kinds}
+    for m in range(nmol):
+        o = 6 * m
+        for a in range(5):
+            lists["bonds"].append([rng.choice(by_kind["bonds"]), o + a, o + a + 1])
+        for a in range(4):
+            k = "angles" if rng.random() < 0.5 else "urey_bradley"
+            lists[k].append([rng.choice(by_kind[k]), o + a, o + a + 1, o + a + 2])
+        for a in range(3):
+            k = ["pdihs", "rbdihs", "idihs"][rng.integers(0, 3)]
+            lists[k].append([rng.choice(by_kind[k]), o + a, o + a + 1, o + a + 2, o + a + 3])
+    return x, prm, {k: np.array(v, np.int32).reshape(-1, 1 + pkg.LISTED_NRAL[k]) for k, v in lists.items()}
+
+
+@pytest.mark.parametrize("pbc", ["xyz", "xy", "none"])
+@pytest.mark.parametrize("lam", [0.0, 0.35, 1.0])
+def test_listed_gpu_random_molecules_against_oracle(pbc, lam):
+    box = 3.0
+    x, prm, lists = _random_system(seed=3)
+    if pbc != "xyz":
+        # without full PBC the molecules must be whole: undo the wrapping through the minimum image along the chain
+        for m in range(x.shape[0] // 6):
+            for a in range(1, 6):
+                d = x[6 * m + a] - x[6 * m + a - 1]
+                x[6 * m + a] -= box * np.round(d / box)
+    got = _run_gpu(lists, prm, x, [box] * 3, PBC[pbc], lam)
+    f = np.zeros_like(x)
+    fs = np.zeros((45, 3))
+    epot = np.zeros(6)
+    dvdl = 0.0
+    xf = x.astype(np.float32).astype(np.float64)     # the coordinates the GPU sees
+    for k, ia in lists.items():
+        r = ob.listed(k, ia, prm, xf, np.full(3, box), PBC[pbc], lam)
+        f += r["f"]
+        fs += r["fshift"]
+        epot[pkg.LISTED_TYPES[k]] += r["epot"]
+        dvdl += r["dvdl"]
+    rms = np.sqrt((f ** 2).sum(axis=1).mean())
+    err = np.abs(got["f"] - f)
+    assert (err <= 1e-4 * np.maximum(np.linalg.norm(f, axis=1, keepdims=True), rms)).all()
+    assert np.abs(got["epot"] - epot).max() <= 1e-4 * np.abs(epot).max()
+    assert abs(got["dvdl"] - dvdl) <= 1e-4 * max(abs(dvdl), np.abs(epot).max())
+    # shift forces are sums of +f / -f terms that largely cancel: the fp32 noise scales with the sum of magnitudes
+    assert np.abs(got["fshift"] - fs).max() <= max(1e-4 * np.abs(fs).max(), 1e-6 * np.abs(f).sum())
+    if pbc == "xyz":
+        assert np.abs(fs).max() > 0          # bonds do cross the boundaries in this system
+
+
+def test_listed_gpu_force_only_and_empty_lists():
+    x, prm, lists = _random_system(seed=4, nmol=50)
+    got = _run_gpu(lists, prm, x, [3.0] * 3, 3, 0.5, energy=False, virial=False)
+    ref = _run_gpu(lists, prm, x, [3.0] * 3, 3, 0.5, energy=True, virial=True)
+    assert np.abs(got["f"] - ref["f"]).max() <= 1e-5 * np.abs(ref["f"]).max()   # atomic ordering only
+    assert not got["epot"].any() and got["dvdl"] == 0.0 and not got["fshift"].any()
+    empty = {k: np.zeros((0, 1 + pkg.LISTED_NRAL[k]), np.int32) for k in lists}
+    got = _run_gpu(empty, prm, x, [3.0] * 3, 3, 0.5)
+    assert not got["f"].any()

@@ -103,3 +103,34 @@ def test_oracle_f32_matches_reference_known_answers(case):
     fscale = max(1.0, float(np.max(np.abs(exp["Forces"]))))
     check(out["f"], exp["Forces"], rel, 1e-5 * fscale)
     check(out["fshift"][0], exp["ShiftForceCentral"], rel, 1e-5 * fscale)
+
+
+# ---- listed (bonded) interactions: oracle/listed_ref.c against the reference's known answers ----------------
+def _listed_cases():
+    import json
+    d = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "listed_refdata.json")))
+    return d, [pytest.param(c, id="%s-%d-%s" % (c["suite"], c["index"], c["pbc"])) for c in d["cases"]]
+
+
+_LISTED, _LISTED_PARAMS = _listed_cases()
+
+
+@pytest.mark.parametrize("case", _LISTED_PARAMS)
+def test_listed_oracle_reproduces_reference_known_answers(case):
+    """Epot, dV/dlambda and forces of bonds, angles, Urey-Bradley, proper / improper / Ryckaert-Bellemans dihedrals at
+    lambda 0, 0.5, 1 (listed_forces/tests/refdata).  Tolerances: the reference test's own relative tolerance per type
+    is 2e-6 ... 2e-2 in mixed precision; the double oracle is held to 1e-6 relative of the largest force."""
+    import oracle_binding as ob
+    x = np.array(_LISTED["coordinates"], np.float64)
+    box = np.full(3, _LISTED["box"])
+    npbc = {"none": 0, "xy": 2, "xyz": 3}[case["pbc"]]
+    ia = np.array([[0] + t for t in case["iatoms"]], np.int32)
+    prm = ob.listed_iparams(case["type"], case["params"])
+    for lam_name, want in case["results"].items():
+        got = ob.listed(case["type"], ia, prm, x, box, npbc, float(lam_name))
+        fw = np.array(want["forces"])
+        scale = max(1.0, np.abs(fw).max())
+        assert np.abs(got["f"] - fw).max() <= 1e-6 * scale, (case["type"], lam_name)
+        assert abs(got["epot"] - want["epot"]) <= 1e-6 * max(1.0, abs(want["epot"]))
+        assert abs(got["dvdl"] - want["dvdlambda"]) <= 1e-6 * max(1.0, abs(want["dvdlambda"]))
+        assert np.abs(got["fshift"].sum(axis=0)).max() <= 1e-9 * scale   # shift forces sum to zero
