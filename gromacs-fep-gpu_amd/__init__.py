@@ -494,9 +494,18 @@ def halo_unpack_f(stream, d_f, d_map, map_size, d_recv_buf, accumulate=True):
 
 
 # ---- listed (bonded) interactions with FEP: include/listed_hip.h ---------------------------------------------
-LISTED_TYPES = {"bonds": 0, "angles": 1, "urey_bradley": 2, "pdihs": 3, "rbdihs": 4, "idihs": 5}
-LISTED_NRAL = {"bonds": 2, "angles": 3, "urey_bradley": 3, "pdihs": 4, "rbdihs": 4, "idihs": 4}
+LISTED_TYPES = {"bonds": 0, "angles": 1, "urey_bradley": 2, "pdihs": 3, "rbdihs": 4, "idihs": 5, "lj14": 6}
+LISTED_NRAL = {"bonds": 2, "angles": 3, "urey_bradley": 3, "pdihs": 4, "rbdihs": 4, "idihs": 4, "lj14": 2}
 LISTED_IPARAMS = np.dtype([("p", np.float32, 12), ("mult", np.int32)])
+LISTED_NUM_ENERGY_TERMS = 8   # one per function type + Coulomb-14
+LISTED_ENERGY_COULOMB14 = 7
+LISTED_DVDL = {"bonded": 0, "coul": 1, "vdw": 2}
+
+
+class ListedFepParams(C.Structure):
+    """listed_gpu_fep_params_t (gmx::BondedFepParameters)"""
+    _fields_ = [("alphaCoul", C.c_float), ("alphaVdw", C.c_float), ("lambdaPower", C.c_int), ("sc_sigma6", C.c_float),
+                ("sc_sigma6_min", C.c_float), ("lambdaBonded", C.c_float), ("lambdaCoul", C.c_float), ("lambdaVdw", C.c_float)]
 
 
 class ListedGpu:
@@ -525,20 +534,22 @@ class ListedGpu:
     def have_interactions(self):
         return bool(self._lib.listed_gpu_have_interactions(self.h))
 
-    def launch_kernel(self, d_xq, d_f, d_fshift, box, pbc_type, lambda_bonded, compute_energy=True, compute_virial=True):
+    def launch_kernel(self, d_xq, d_f, d_fshift, box, pbc_type, fep, d_q4=None, elec_scale=0.0, compute_energy=True,
+                      compute_virial=True):
+        """fep: ListedFepParams; d_q4: device float4[] with (qA, qB) per atom, needed with 1-4 pairs"""
         b = _a(box, np.float32)
         assert b.size == 9
-        self._lib.listed_gpu_launch_kernel(self.h, C.c_void_p(d_xq), C.c_void_p(d_f), C.c_void_p(d_fshift), _p(b), C.c_int(pbc_type),
-                                           C.c_float(lambda_bonded), C.c_int(1 if compute_energy else 0),
-                                           C.c_int(1 if compute_virial else 0))
+        self._lib.listed_gpu_launch_kernel(self.h, C.c_void_p(d_xq), C.c_void_p(d_q4), C.c_void_p(d_f), C.c_void_p(d_fshift), _p(b),
+                                           C.c_int(pbc_type), C.byref(fep), C.c_float(elec_scale),
+                                           C.c_int(1 if compute_energy else 0), C.c_int(1 if compute_virial else 0))
 
     def energies(self):
-        """launch_energy_transfer + wait_accumulate_energy_terms: (per-type energies, dV/dlambda)"""
-        epot = np.zeros(len(LISTED_TYPES), np.float64)
-        dvdl = C.c_double(0)
+        """launch_energy_transfer + wait_accumulate_energy_terms: (energy terms[8], dV/dlambda[bonded, coul, vdw])"""
+        epot = np.zeros(LISTED_NUM_ENERGY_TERMS, np.float64)
+        dvdl = np.zeros(3, np.float64)
         self._lib.listed_gpu_launch_energy_transfer(self.h)
-        self._lib.listed_gpu_wait_accumulate_energy_terms(self.h, _p(epot), C.byref(dvdl))
-        return epot, dvdl.value
+        self._lib.listed_gpu_wait_accumulate_energy_terms(self.h, _p(epot), _p(dvdl))
+        return epot, dvdl
 
     def clear_energies(self):
         self._lib.listed_gpu_clear_energies(self.h)

@@ -41,12 +41,16 @@ struct ListedKernelArgs
     const int*                  iatoms[LISTED_GPU_NUM_TYPES];
     const listed_gpu_iparams_t* params;
     const float4*               xq;
+    const float4*               q4;
     float*                      f;
     float*                      fshift;
-    float*                      epot; /* LISTED_GPU_NUM_TYPES + 1: per-type energies, then dV/dlambda */
+    float*                      epot; /* c_numOut: the energy terms, then the dV/dlambda components */
     PbcAiuc                     pbc;
-    float                       lambda;
+    float                       lambda; /* lambda_bonded */
+    listed_gpu_fep_params_t     fep;
+    float                       elecScale;
 };
+constexpr int c_numOut = LISTED_GPU_NUM_ENERGY_TERMS + LISTED_GPU_NUM_DVDL;
 
 __device__ __forceinline__ float3 operator-(float3 a, float3 b) { return make_float3(a.x - b.x, a.y - b.y, a.z - b.z); }
 __device__ __forceinline__ float3 operator*(float s, float3 a) { return make_float3(s * a.x, s * a.y, s * a.z); }
@@ -206,12 +210,83 @@ __device__ __forceinline__ void dihedralForces(const ListedKernelArgs& a, float*
     }
 }
 
+/* Perturbed 1-4 pair: Beutler soft-core LJ + Coulomb between the A and B states, no cut-off, no tables
+ * (pairs_fep_gpu, listed_forces_gpu_internal.cu:1365-1600 = free_energy_evaluate_single, listed_forces/pairs.cpp:130-330,
+ * with the table look-ups replaced by the functions they tabulate). */
+template<bool calcVir>
+__device__ __forceinline__ void pair14(const ListedKernelArgs& a, float* smShift, int ai, int aj, const float* p, float& eLJ, float& eCoul,
+                                       float& dvdlVdw, float& dvdlCoul)
+{
+    const float4 qi = a.q4[ai], qj = a.q4[aj];
+    const float  qq[2]  = { qi.x * qj.x, qi.y * qj.y };
+    const float  c6[2]  = { p[0], p[2] };
+    const float  c12[2] = { p[1], p[3] };
+    float3       dr;
+    const int    ki   = pbcDx<calcVir>(a.pbc, a.xq[ai], a.xq[aj], dr);
+    const float  r2   = dot3(dr, dr);
+    const float  rInv = rsqrtf(r2), rInv2 = rInv * rInv, rInv6 = rInv2 * rInv2 * rInv2;
+    float        finvr;
+    if (qq[0] == qq[1] && c6[0] == c6[1] && c12[0] == c12[1])
+    {
+        const float velec = a.elecScale * qq[0] * rInv;
+        eCoul += velec;
+        eLJ += (c12[0] * rInv6 - c6[0]) * rInv6;
+        finvr = ((12.0F * c12[0] * rInv6 - 6.0F * c6[0]) * rInv6 + velec) * rInv2;
+    }
+    else
+    {
+        const listed_gpu_fep_params_t& fp = a.fep;
+        const float rpm2 = r2 * r2, rp = rpm2 * r2;
+        const bool  hard = (c12[0] > 0.0F && c12[1] > 0.0F);
+        const float alphaV = hard ? 0.0F : fp.alphaVdw, alphaC = hard ? 0.0F : fp.alphaCoul;
+        finvr              = 0.0F;
+#pragma unroll
+        for (int k = 0; k < 2; k++)
+        {
+            const float LFC = (k == 0) ? 1.0F - fp.lambdaCoul : fp.lambdaCoul;
+            const float LFV = (k == 0) ? 1.0F - fp.lambdaVdw : fp.lambdaVdw;
+            const float DLF = (k == 0) ? -1.0F : 1.0F;
+            /* soft-core lambda factors and their derivative factors (sc-r-power 6) */
+            const float scC  = (fp.lambdaPower == 2) ? (1.0F - LFC) * (1.0F - LFC) : (1.0F - LFC);
+            const float scV  = (fp.lambdaPower == 2) ? (1.0F - LFV) * (1.0F - LFV) : (1.0F - LFV);
+            const float dscC = DLF * fp.lambdaPower * (1.0F / 6.0F) * ((fp.lambdaPower == 2) ? (1.0F - LFC) : 1.0F);
+            const float dscV = DLF * fp.lambdaPower * (1.0F / 6.0F) * ((fp.lambdaPower == 2) ? (1.0F - LFV) : 1.0F);
+            float sigma6 = (c6[k] > 0.0F && c12[k] > 0.0F) ? fmaxf(c12[k] / c6[k], fp.sc_sigma6_min) : fp.sc_sigma6;
+            float FC = 0.0F, FV = 0.0F, VC = 0.0F, VV = 0.0F;
+            if (qq[k] != 0.0F || c6[k] != 0.0F || c12[k] != 0.0F)
+            {
+                const float rPInvC = 1.0F / (alphaC * scC * sigma6 + rp);
+                const float rPInvV = 1.0F / (alphaV * scV * sigma6 + rp);
+                const float rInvC  = sqrtf(cbrtf(rPInvC)); /* (r_C^-6)^(1/6) */
+                const float V6 = c6[k] * rPInvV, V12 = c12[k] * rPInvV * rPInvV;
+                VV = V12 - V6;
+                FV = (12.0F * V12 - 6.0F * V6) * rPInvV;
+                VC = a.elecScale * qq[k] * rInvC;
+                FC = VC * rPInvC;
+            }
+            eCoul += LFC * VC;
+            eLJ += LFV * VV;
+            dvdlCoul += VC * DLF + LFC * alphaC * dscC * FC * sigma6;
+            dvdlVdw += VV * DLF + LFV * alphaV * dscV * FV * sigma6;
+            finvr += (LFC * FC + LFV * FV) * rpm2;
+        }
+    }
+    const float3 f = finvr * dr;
+    addForce(a.f, ai, f);
+    addForce(a.f, aj, -1.0F * f);
+    if (calcVir && ki != c_centralShift)
+    {
+        addShift(smShift, ki, f);
+        addShift(smShift, c_centralShift, -1.0F * f);
+    }
+}
+
 template<bool calcVir, bool calcEner>
 __launch_bounds__(c_listedBlock) __global__ void listedForcesKernel(const ListedKernelArgs a)
 {
-    __shared__ float smEner[LISTED_GPU_NUM_TYPES + 1];
+    __shared__ float smEner[c_numOut];
     __shared__ float smShift[3 * c_numShifts];
-    if (calcEner && threadIdx.x <= LISTED_GPU_NUM_TYPES) { smEner[threadIdx.x] = 0.0F; }
+    if (calcEner && threadIdx.x < c_numOut) { smEner[threadIdx.x] = 0.0F; }
     if (calcVir)
     {
         for (int i = threadIdx.x; i < 3 * c_numShifts; i += c_listedBlock) { smShift[i] = 0.0F; }
@@ -227,7 +302,12 @@ __launch_bounds__(c_listedBlock) __global__ void listedForcesKernel(const Listed
         const int  i    = tid - a.start[ftype];
         const int* ia   = a.iatoms[ftype];
         float      epot = 0.0F, dvdl = 0.0F;
-        if (ftype == LISTED_GPU_BONDS)
+        float      eCoul = 0.0F, dvdlCoul = 0.0F, dvdlVdw = 0.0F;
+        if (ftype == LISTED_GPU_LJ14)
+        {
+            pair14<calcVir>(a, smShift, ia[3 * i + 1], ia[3 * i + 2], a.params[ia[3 * i]].p, epot, eCoul, dvdlVdw, dvdlCoul);
+        }
+        else if (ftype == LISTED_GPU_BONDS)
         {
             const float* p = a.params[ia[3 * i]].p;
             bondPair<calcVir>(a, smShift, ia[3 * i + 1], ia[3 * i + 2], p[1], p[3], p[0], p[2], epot, dvdl);
@@ -304,11 +384,17 @@ __launch_bounds__(c_listedBlock) __global__ void listedForcesKernel(const Listed
         if (calcEner)
         {
             atomicAdd(&smEner[ftype], epot);
-            atomicAdd(&smEner[LISTED_GPU_NUM_TYPES], dvdl);
+            if (ftype == LISTED_GPU_LJ14)
+            {
+                atomicAdd(&smEner[LISTED_GPU_ENERGY_COULOMB14], eCoul);
+                atomicAdd(&smEner[LISTED_GPU_NUM_ENERGY_TERMS + LISTED_GPU_DVDL_COUL], dvdlCoul);
+                atomicAdd(&smEner[LISTED_GPU_NUM_ENERGY_TERMS + LISTED_GPU_DVDL_VDW], dvdlVdw);
+            }
+            else { atomicAdd(&smEner[LISTED_GPU_NUM_ENERGY_TERMS + LISTED_GPU_DVDL_BONDED], dvdl); }
         }
     }
     if (calcVir || calcEner) { __syncthreads(); }
-    if (calcEner && threadIdx.x <= LISTED_GPU_NUM_TYPES && smEner[threadIdx.x] != 0.0F) { atomicAdd(&a.epot[threadIdx.x], smEner[threadIdx.x]); }
+    if (calcEner && threadIdx.x < c_numOut && smEner[threadIdx.x] != 0.0F) { atomicAdd(&a.epot[threadIdx.x], smEner[threadIdx.x]); }
     if (calcVir)
     {
         for (int i = threadIdx.x; i < 3 * c_numShifts; i += c_listedBlock)
@@ -328,7 +414,7 @@ struct ListedGpu
     int                   iatomsAlloc[LISTED_GPU_NUM_TYPES]     = {};
     listed_gpu_iparams_t* d_params                              = nullptr;
     int                   numParams = 0, paramsAlloc = 0;
-    float*                d_epot = nullptr; /* LISTED_GPU_NUM_TYPES + 1 */
+    float*                d_epot = nullptr; /* c_numOut */
     PinnedBuffer<float>   h_epot;
     PinnedBuffer<int>     h_iatoms[LISTED_GPU_NUM_TYPES];
     PinnedBuffer<listed_gpu_iparams_t> h_params;
@@ -336,7 +422,7 @@ struct ListedGpu
 
 static int listedNral(int ftype)
 {
-    return ftype == LISTED_GPU_BONDS ? 2 : ((ftype == LISTED_GPU_ANGLES || ftype == LISTED_GPU_UREY_BRADLEY) ? 3 : 4);
+    return (ftype == LISTED_GPU_BONDS || ftype == LISTED_GPU_LJ14) ? 2 : ((ftype == LISTED_GPU_ANGLES || ftype == LISTED_GPU_UREY_BRADLEY) ? 3 : 4);
 }
 
 extern "C"
@@ -346,9 +432,9 @@ ListedGpu* listed_gpu_create(void* stream)
 {
     ListedGpu* lg = new ListedGpu;
     lg->stream.init(stream);
-    allocateDeviceBuffer(&lg->d_epot, LISTED_GPU_NUM_TYPES + 1);
-    clearDeviceBufferAsync(&lg->d_epot, 0, LISTED_GPU_NUM_TYPES + 1, lg->stream.stream);
-    lg->h_epot.resize(LISTED_GPU_NUM_TYPES + 1);
+    allocateDeviceBuffer(&lg->d_epot, c_numOut);
+    clearDeviceBufferAsync(&lg->d_epot, 0, c_numOut, lg->stream.stream);
+    lg->h_epot.resize(c_numOut);
     NBNXM_HIP_CHECK(hipStreamSynchronize(lg->stream.stream));
     return lg;
 }
@@ -410,11 +496,14 @@ int listed_gpu_have_interactions(const ListedGpu* lg)
     return 0;
 }
 
-void listed_gpu_launch_kernel(ListedGpu* lg, const void* d_xq, void* d_f, void* d_fshift, const float* box, int pbcType,
-                              float lambdaBonded, int computeEnergy, int computeVirial)
+void listed_gpu_launch_kernel(ListedGpu* lg, const void* d_xq, const void* d_q4, void* d_f, void* d_fshift, const float* box,
+                              int pbcType, const listed_gpu_fep_params_t* fep, float electrostaticsScaleFactor, int computeEnergy,
+                              int computeVirial)
 {
     if (!listed_gpu_have_interactions(lg)) { return; }
     NBNXM_ASSERT(d_xq != nullptr && d_f != nullptr, "coordinate / force buffer missing");
+    NBNXM_ASSERT(fep != nullptr, "free-energy parameters missing");
+    NBNXM_ASSERT(lg->numInteractions[LISTED_GPU_LJ14] == 0 || d_q4 != nullptr, "1-4 pairs need the A/B charge buffer (q4)");
     NBNXM_ASSERT(!computeVirial || d_fshift != nullptr, "virial step without a shift-force buffer");
     ListedKernelArgs a;
     a.start[0] = 0;
@@ -425,10 +514,13 @@ void listed_gpu_launch_kernel(ListedGpu* lg, const void* d_xq, void* d_f, void* 
     }
     a.params = lg->d_params;
     a.xq     = static_cast<const float4*>(d_xq);
+    a.q4     = static_cast<const float4*>(d_q4);
+    a.fep    = *fep;
+    a.elecScale = electrostaticsScaleFactor;
     a.f      = static_cast<float*>(d_f);
     a.fshift = static_cast<float*>(d_fshift);
     a.epot   = lg->d_epot;
-    a.lambda = lambdaBonded;
+    a.lambda = fep->lambdaBonded;
     /* setPbcAiuc (pbcutil/pbc_aiuc.h:98-140): dimensions without PBC get a zero inverse, which makes their shift 0 */
     const int npbcdim = (pbcType == 3) ? 3 : ((pbcType == 2) ? 2 : 0);
     a.pbc.invBoxDiagZ = (npbcdim > 2) ? 1.0F / box[8] : 0.0F;
@@ -447,20 +539,19 @@ void listed_gpu_launch_kernel(ListedGpu* lg, const void* d_xq, void* d_f, void* 
 
 void listed_gpu_launch_energy_transfer(ListedGpu* lg)
 {
-    NBNXM_HIP_CHECK(hipMemcpyAsync(lg->h_epot.data, lg->d_epot, sizeof(float) * (LISTED_GPU_NUM_TYPES + 1), hipMemcpyDeviceToHost,
-                                   lg->stream.stream));
+    NBNXM_HIP_CHECK(hipMemcpyAsync(lg->h_epot.data, lg->d_epot, sizeof(float) * c_numOut, hipMemcpyDeviceToHost, lg->stream.stream));
 }
 
-void listed_gpu_wait_accumulate_energy_terms(ListedGpu* lg, double* epot, double* dvdlBonded)
+void listed_gpu_wait_accumulate_energy_terms(ListedGpu* lg, double* epot, double* dvdl)
 {
     NBNXM_HIP_CHECK(hipStreamSynchronize(lg->stream.stream));
-    for (int t = 0; t < LISTED_GPU_NUM_TYPES; t++) { epot[t] += lg->h_epot.data[t]; }
-    *dvdlBonded += lg->h_epot.data[LISTED_GPU_NUM_TYPES];
+    for (int t = 0; t < LISTED_GPU_NUM_ENERGY_TERMS; t++) { epot[t] += lg->h_epot.data[t]; }
+    for (int t = 0; t < LISTED_GPU_NUM_DVDL; t++) { dvdl[t] += lg->h_epot.data[LISTED_GPU_NUM_ENERGY_TERMS + t]; }
 }
 
 void listed_gpu_clear_energies(ListedGpu* lg)
 {
-    clearDeviceBufferAsync(&lg->d_epot, 0, LISTED_GPU_NUM_TYPES + 1, lg->stream.stream);
+    clearDeviceBufferAsync(&lg->d_epot, 0, c_numOut, lg->stream.stream);
 }
 
 } // extern "C"

@@ -5,7 +5,8 @@
  * listed_forces_gpu_impl.cu, kernels listed_forces_gpu_internal.cu:781-1363: bonds_fep_gpu, angles_fep_gpu,
  * urey_bradley_fep_gpu, pdihs_fep_gpu, rbdihs_fep_gpu, idihs_fep_gpu) for the function types below; every type takes
  * A- and B-state parameters and lambda_bonded, so the unperturbed interactions are the A == B case of the same code.
- * Not built yet: the perturbed LJ-14 pairs (pairs_fep_gpu :1365-1600) and the restraint types.
+ * The perturbed 1-4 pairs (pairs_fep_gpu :1365-1600: soft-core LJ + plain Coulomb between the A/B charges of the
+ * non-bonded module's q4 buffer) are the seventh type.  Not built: the restraint types.
  *
  * Conventions as in the reference: coordinates are the non-bonded module's xq (float4, nbnxm grid order), atom indices
  * in the interaction lists are already translated to that order (nbnxnAtomOrder, listed_forces_gpu_impl.cu
@@ -30,8 +31,34 @@ enum
     LISTED_GPU_PDIHS,        /* F_PDIHS, F_PIDIHS [type, ai, aj, ak, al]  p: phiA cpA phiB cpB; mult */
     LISTED_GPU_RBDIHS,       /* F_RBDIHS          [type, ai, aj, ak, al]  p: rbcA[6] rbcB[6] */
     LISTED_GPU_IDIHS,        /* F_IDIHS           [type, ai, aj, ak, al]  p: xA kA xB kB (degrees) */
+    LISTED_GPU_LJ14,         /* F_LJ14            [type, ai, aj]          p: c6A c12A c6B c12B (plain C6, C12) */
     LISTED_GPU_NUM_TYPES
 };
+
+/* energy terms returned by listed_gpu_wait_accumulate_energy_terms: one per function type (the LJ14 slot holds the
+ * Lennard-Jones part of the pairs) plus the pairs' Coulomb part */
+enum
+{
+    LISTED_GPU_ENERGY_COULOMB14 = LISTED_GPU_NUM_TYPES,
+    LISTED_GPU_NUM_ENERGY_TERMS
+};
+/* dV/dlambda components (FreeEnergyPerturbationCouplingType Bonded, Coul, Vdw) */
+enum
+{
+    LISTED_GPU_DVDL_BONDED = 0,
+    LISTED_GPU_DVDL_COUL,
+    LISTED_GPU_DVDL_VDW,
+    LISTED_GPU_NUM_DVDL
+};
+
+/* gmx::BondedFepParameters (listed_forces_gpu.h, set from interaction_const_t::SoftCoreParameters and the lambdas) */
+typedef struct
+{
+    float alphaCoul, alphaVdw;
+    int   lambdaPower;
+    float sc_sigma6, sc_sigma6_min;
+    float lambdaBonded, lambdaCoul, lambdaVdw;
+} listed_gpu_fep_params_t;
 
 /* t_iparams of the types above (topology/idef.h:71-330), float, A and B state side by side */
 typedef struct
@@ -53,15 +80,17 @@ void listed_gpu_update_interaction_list(ListedGpu* lg, int ftype, int numInterac
 /* ListedForcesGpu::haveInteractions — listed_forces_gpu.h:153-158 */
 int listed_gpu_have_interactions(const ListedGpu* lg);
 
-/* ListedForcesGpu::launchKernel(stepWork, box) — listed_forces_gpu.h:160-170.  d_xq: float4[], d_f: float3[] (+=),
- * d_fshift: float3[45] (+= when computeVirial); box: 3x3 row-major; pbcType: 0 none, 2 xy, 3 xyz. */
-void listed_gpu_launch_kernel(ListedGpu* lg, const void* d_xq, void* d_f, void* d_fshift, const float* box, int pbcType,
-                              float lambdaBonded, int computeEnergy, int computeVirial);
+/* ListedForcesGpu::launchKernel(stepWork, box) — listed_forces_gpu.h:160-170.  d_xq: float4[], d_q4: float4[] with
+ * .x = qA, .y = qB (NBAtomDataGpu::q4; may be NULL without LJ14 pairs), d_f: float3[] (+=), d_fshift: float3[45] (+= when
+ * computeVirial); box: 3x3 row-major; pbcType: 0 none, 2 xy, 3 xyz; electrostaticsScaleFactor = epsfac * fudgeQQ. */
+void listed_gpu_launch_kernel(ListedGpu* lg, const void* d_xq, const void* d_q4, void* d_f, void* d_fshift, const float* box,
+                              int pbcType, const listed_gpu_fep_params_t* fep, float electrostaticsScaleFactor,
+                              int computeEnergy, int computeVirial);
 
 /* launchEnergyTransfer / waitAccumulateEnergyTerms / clearEnergies — listed_forces_gpu.h:172-190:
- * epot[LISTED_GPU_NUM_TYPES] += per-type energies, *dvdlBonded += dV/dlambda of all types. */
+ * epot[LISTED_GPU_NUM_ENERGY_TERMS] += energies, dvdl[LISTED_GPU_NUM_DVDL] += dV/dlambda components. */
 void listed_gpu_launch_energy_transfer(ListedGpu* lg);
-void listed_gpu_wait_accumulate_energy_terms(ListedGpu* lg, double* epot, double* dvdlBonded);
+void listed_gpu_wait_accumulate_energy_terms(ListedGpu* lg, double* epot, double* dvdl);
 void listed_gpu_clear_energies(ListedGpu* lg);
 
 #ifdef __cplusplus

@@ -274,3 +274,72 @@ void oracle_listed(int ftype, int n, const int* iatoms, const listed_iparams_t* 
         }
     }
 }
+
+void oracle_listed_pairs(int n, const int* iatoms, const listed_iparams_t* params, const double* x, const double* qA, const double* qB,
+                         const double* box, int npbcdim, const listed_pairs_fep_t* fep, double elecScale, double* f, double* fshift,
+                         double* eLJ, double* eCoul, double* dvdlVdw, double* dvdlCoul)
+{
+    for (int i = 0; i < n; i++)
+    {
+        const int     ai = iatoms[3 * i + 1], aj = iatoms[3 * i + 2];
+        const double* p  = params[iatoms[3 * i]].p;
+        const double  qq[2]  = { qA[ai] * qA[aj], qB[ai] * qB[aj] };
+        const double  c6[2]  = { p[0], p[2] };
+        const double  c12[2] = { p[1], p[3] };
+        vec3          dr;
+        const int     ki = pbc_dx(box, npbcdim, getx(x, ai), getx(x, aj), &dr);
+        const double  r2 = vdot(dr, dr), rinv2 = 1.0 / r2, rinv6 = rinv2 * rinv2 * rinv2;
+        double        finvr = 0;
+        if (qq[0] == qq[1] && c6[0] == c6[1] && c12[0] == c12[1])
+        {
+            const double velec = elecScale * qq[0] * sqrt(rinv2);
+            *eCoul += velec;
+            *eLJ += (c12[0] * rinv6 - c6[0]) * rinv6;
+            finvr = ((12.0 * c12[0] * rinv6 - 6.0 * c6[0]) * rinv6 + velec) * rinv2;
+        }
+        else
+        {
+            const double rpm2 = r2 * r2, rp = rpm2 * r2;
+            const int    hard = (c12[0] > 0 && c12[1] > 0);
+            const double alphaV = hard ? 0.0 : fep->alphaVdw, alphaC = hard ? 0.0 : fep->alphaCoul;
+            for (int k = 0; k < 2; k++)
+            {
+                const double LFC = (k == 0) ? 1.0 - fep->lambdaCoul : fep->lambdaCoul;
+                const double LFV = (k == 0) ? 1.0 - fep->lambdaVdw : fep->lambdaVdw;
+                const double DLF = (k == 0) ? -1.0 : 1.0;
+                const int    pw  = fep->lambdaPower;
+                const double scC = (pw == 2) ? (1 - LFC) * (1 - LFC) : (1 - LFC), scV = (pw == 2) ? (1 - LFV) * (1 - LFV) : (1 - LFV);
+                const double dscC = DLF * pw / 6.0 * ((pw == 2) ? (1 - LFC) : 1.0), dscV = DLF * pw / 6.0 * ((pw == 2) ? (1 - LFV) : 1.0);
+                double       sigma6;
+                if (c6[k] > 0 && c12[k] > 0)
+                {
+                    sigma6 = c12[k] / c6[k];
+                    if (sigma6 < fep->sc_sigma6_min) { sigma6 = fep->sc_sigma6_min; }
+                }
+                else { sigma6 = fep->sc_sigma6; }
+                double FC = 0, FV = 0, VC = 0, VV = 0;
+                if (qq[k] != 0 || c6[k] != 0 || c12[k] != 0)
+                {
+                    const double rpinvC = 1.0 / (alphaC * scC * sigma6 + rp);
+                    const double rpinvV = 1.0 / (alphaV * scV * sigma6 + rp);
+                    const double rinvC  = pow(rpinvC, 1.0 / 6.0);
+                    const double V6 = c6[k] * rpinvV, V12 = c12[k] * rpinvV * rpinvV;
+                    VV = V12 - V6;
+                    FV = (12.0 * V12 - 6.0 * V6) * rpinvV;
+                    VC = elecScale * qq[k] * rinvC;
+                    FC = VC * rpinvC;
+                }
+                *eCoul += LFC * VC;
+                *eLJ += LFV * VV;
+                *dvdlCoul += VC * DLF + LFC * alphaC * dscC * FC * sigma6;
+                *dvdlVdw += VV * DLF + LFV * alphaV * dscV * FV * sigma6;
+                finvr += (LFC * FC + LFV * FV) * rpm2;
+            }
+        }
+        const vec3 fv = vscale(finvr, dr);
+        addf(f, ai, fv, 1);
+        addf(f, aj, fv, -1);
+        add_fshift(fshift, ki, fv, 1);
+        add_fshift(fshift, CENTRAL, fv, -1);
+    }
+}

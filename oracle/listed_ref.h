@@ -41,6 +41,21 @@ typedef struct
 void oracle_listed(int ftype, int numInteractions, const int* iatoms, const listed_iparams_t* params, const double* x,
                    const double* box, int npbcdim, double lambda, double* f, double* fshift, double* epot, double* dvdl);
 
+/* Perturbed 1-4 pairs (F_LJ14): Beutler soft-core LJ + plain Coulomb between the A and B states, no cut-off.
+ * Semantics: free_energy_evaluate_single (listed_forces/pairs.cpp:130-330, soft-core "beutler") with its table look-ups
+ * replaced by the functions they tabulate, which is also what pairs_fep_gpu does.  params[type].p = c6A c12A c6B c12B. */
+typedef struct
+{
+    double alphaCoul, alphaVdw;
+    int    lambdaPower, pad;
+    double sc_sigma6, sc_sigma6_min;
+    double lambdaCoul, lambdaVdw;
+} listed_pairs_fep_t;
+
+void oracle_listed_pairs(int numPairs, const int* iatoms, const listed_iparams_t* params, const double* x, const double* qA,
+                         const double* qB, const double* box, int npbcdim, const listed_pairs_fep_t* fep, double elecScale,
+                         double* f, double* fshift, double* eLJ, double* eCoul, double* dvdlVdw, double* dvdlCoul);
+
 #ifdef __cplusplus
 }
 #endif

@@ -65,6 +65,34 @@ def main():
                 results["0"] = parse_lambda_block(fep)
             out["cases"].append(dict(suite=suite, index=inp * 3 + ip, type=name, pbc=pbc, params=params,
                                      iatoms=IATOMS[NRAL[name]], fep=fep.get("Name") == "Yes", results=results))
+    # 1-4 pairs (listed_forces/tests/pairs.cpp): 3 atoms, box 1.0, interactions (1,2) and (0,2), charges A = {1, -0.5, -0.5},
+    # B = 0, fudgeQQ 0.5, epsfac 1 (default interaction_const_t), sc-alpha 0.3, sc-power 1, sc-sigma = sc-sigma-min = 0.3,
+    # sc-coul on; inputs :446-451: LJ14 (c6A, c12A, c6B, c12B).  Only the "beutler" soft-core entries are taken.
+    pairs = dict(coordinates=[[0.0, 0.0, 0.0], [1.0, 1.0, 1.0], [1.1, 1.2, 1.3]], box=1.0, iatoms=[[1, 2], [0, 2]],
+                 chargeA=[1.0, -0.5, -0.5], chargeB=[0.0, 0.0, 0.0], fudgeQQ=0.5, epsfac=1.0, sc_alpha=0.3, sc_power=1,
+                 sc_sigma=0.3, sc_sigma_min=0.3, cases=[])
+    for inp, prm in enumerate([dict(c6A=0.001458, c12A=1.0062882e-6, c6B=0.0, c12B=0.0),
+                               dict(c6A=0.001458, c12A=1.0062882e-6, c6B=0.001458, c12B=1.0062882e-6)]):
+        for ip, pbc in enumerate(PBC):
+            fn = os.path.join(REF, "14Interaction_ListedForcesPairsTest_Ifunc_%d.xml" % (inp * 3 + ip))
+            ft = ET.parse(fn).getroot().find("FunctionType")
+            assert ft.get("Name") == "LJ14", fn
+            fep = ft.find("FEP")
+            results = {}
+
+            def block(node):
+                reals = {r.get("Name").strip(): float(r.text) for r in node.findall("Real")}
+                forces = [[float(v.find("Real[@Name='%s']" % c).text) for c in "XYZ"]
+                          for v in node.find("Sequence[@Name='Forces']").findall("Vector")]
+                return dict(eCoul=reals["Epot Coulomb14"], eLJ=reals["Epot LJ14"], dvdlCoul=reals["dVdlCoul"],
+                            dvdlVdw=reals["dVdlVdw"], forces=forces)
+            if fep.get("Name") == "Yes":
+                for lam in fep.findall("Lambda"):
+                    results[lam.get("Name")] = block(lam.find("Sofcore[@Name='beutler']"))
+            else:
+                results["0"] = block(fep)
+            pairs["cases"].append(dict(index=inp * 3 + ip, pbc=pbc, params=prm, fep=fep.get("Name") == "Yes", results=results))
+    out["pairs"] = pairs
     json.dump(out, open(OUT, "w"), indent=1)
     print("wrote %s: %d cases" % (OUT, len(out["cases"])))
 

@@ -223,3 +223,23 @@ def listed(type_name, iatoms, params, x, box, npbcdim, lam, want_fshift=True):
                         _ptr(prm), _ptr(x_), _ptr(box_), C.c_int(npbcdim), C.c_double(lam), _ptr(f),
                         _ptr(fshift) if want_fshift else None, C.byref(epot), C.byref(dvdl))
     return dict(f=f, fshift=fshift, epot=epot.value, dvdl=dvdl.value)
+
+
+class ListedPairsFep(C.Structure):
+    _fields_ = [("alphaCoul", C.c_double), ("alphaVdw", C.c_double), ("lambdaPower", C.c_int), ("pad", C.c_int),
+                ("sc_sigma6", C.c_double), ("sc_sigma6_min", C.c_double), ("lambdaCoul", C.c_double), ("lambdaVdw", C.c_double)]
+
+
+def listed_pairs(iatoms, params, x, qA, qB, box, npbcdim, fep, elec_scale):
+    """iatoms: (n, 3) rows [parameter index, ai, aj]; params: LISTED_IPARAMS with p[:4] = c6A c12A c6B c12B"""
+    ia = _arr(iatoms, np.int32)
+    prm = np.ascontiguousarray(params)
+    x_ = _arr(x, np.float64)
+    n = x_.reshape(-1, 3).shape[0]
+    f = np.zeros((n, 3), np.float64)
+    fshift = np.zeros((45, 3), np.float64)
+    out = [C.c_double(0) for _ in range(4)]
+    lib().oracle_listed_pairs(C.c_int(ia.reshape(-1, 3).shape[0]), _ptr(ia), _ptr(prm), _ptr(x_), _ptr(_arr(qA, np.float64)),
+                              _ptr(_arr(qB, np.float64)), _ptr(_arr(box, np.float64)), C.c_int(npbcdim), C.byref(fep),
+                              C.c_double(elec_scale), _ptr(f), _ptr(fshift), *[C.byref(o) for o in out])
+    return dict(f=f, fshift=fshift, eLJ=out[0].value, eCoul=out[1].value, dvdlVdw=out[2].value, dvdlCoul=out[3].value)

@@ -34,6 +34,7 @@ def test_hip_library_exports_every_listed_forces_symbol():
         assert hasattr(lib, n), "libnbnxm_hip.so does not export %s" % n
     assert sorted(names) == sorted(pkg.LISTED_SYMBOLS)
     assert pkg.LISTED_IPARAMS.itemsize == 52
+    assert ctypes.sizeof(pkg.ListedFepParams) == 32
 
 
 def test_host_library_exports_every_declared_symbol():

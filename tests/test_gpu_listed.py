@@ -25,13 +25,23 @@ def _gpu_params(prm64):
     return out
 
 
-def _run_gpu(lists, params64, x, box3, pbc_type, lam, energy=True, virial=True):
-    """lists: {type name: (n, 1 + nral) int32}; returns f, fshift, per-type energies, dvdl"""
+def _fep(lam, alpha=0.3, power=1, sigma=0.3, sigma_min=0.3, lam_coul=None, lam_vdw=None):
+    return pkg.ListedFepParams(alpha, alpha, power, sigma ** 6, sigma_min ** 6, lam, lam if lam_coul is None else lam_coul,
+                               lam if lam_vdw is None else lam_vdw)
+
+
+def _run_gpu(lists, params64, x, box3, pbc_type, lam, energy=True, virial=True, qA=None, qB=None, elec_scale=0.0, fep=None):
+    """lists: {type name: (n, 1 + nral) int32}; returns f, fshift, energy terms, dvdl (bonded part unless pairs are given)"""
     import torch
     n = x.shape[0]
     xq = np.zeros((n, 4), np.float32)
     xq[:, :3] = x
     d_xq = torch.from_numpy(xq).cuda()
+    d_q4 = None
+    if qA is not None:
+        q4 = np.zeros((n, 4), np.float32)
+        q4[:, 0], q4[:, 1] = qA, qB
+        d_q4 = torch.from_numpy(q4).cuda()
     d_f = torch.zeros((n, 3), dtype=torch.float32, device="cuda")
     d_fs = torch.zeros((45, 3), dtype=torch.float32, device="cuda")
     lg = pkg.ListedGpu()
@@ -41,10 +51,12 @@ def _run_gpu(lists, params64, x, box3, pbc_type, lam, energy=True, virial=True):
     assert lg.have_interactions() == any(len(ia) for ia in lists.values())
     torch.cuda.synchronize()
     box = np.diag(np.asarray(box3, np.float32))
-    lg.launch_kernel(d_xq.data_ptr(), d_f.data_ptr(), d_fs.data_ptr(), box, pbc_type, lam, energy, virial)
-    epot, dvdl = lg.energies()
+    lg.launch_kernel(d_xq.data_ptr(), d_f.data_ptr(), d_fs.data_ptr(), box, pbc_type, fep or _fep(lam),
+                     d_q4=d_q4.data_ptr() if d_q4 is not None else None, elec_scale=elec_scale, compute_energy=energy,
+                     compute_virial=virial)
+    epot, dvdl3 = lg.energies()
     torch.cuda.synchronize()
-    out = dict(f=d_f.cpu().numpy(), fshift=d_fs.cpu().numpy(), epot=epot, dvdl=dvdl)
+    out = dict(f=d_f.cpu().numpy(), fshift=d_fs.cpu().numpy(), epot=epot, dvdl=dvdl3[0], dvdl3=dvdl3)
     lg.free()
     return out
 
@@ -132,7 +144,7 @@ def test_listed_gpu_random_molecules_against_oracle(pbc, lam):
     got = _run_gpu(lists, prm, x, [box] * 3, PBC[pbc], lam)
     f = np.zeros_like(x)
     fs = np.zeros((45, 3))
-    epot = np.zeros(6)
+    epot = np.zeros(pkg.LISTED_NUM_ENERGY_TERMS)
     dvdl = 0.0
     xf = x.astype(np.float32).astype(np.float64)     # the coordinates the GPU sees
     for k, ia in lists.items():
@@ -161,3 +173,64 @@ def test_listed_gpu_force_only_and_empty_lists():
     empty = {k: np.zeros((0, 1 + pkg.LISTED_NRAL[k]), np.int32) for k in lists}
     got = _run_gpu(empty, prm, x, [3.0] * 3, 3, 0.5)
     assert not got["f"].any()
+
+
+@pytest.mark.parametrize("case", [pytest.param(c, id="pairs-%d-%s" % (c["index"], c["pbc"])) for c in GOLD["pairs"]["cases"]])
+def test_listed_gpu_pairs_match_reference_known_answers(case):
+    """perturbed 1-4 pairs (Beutler soft-core) at lambda 0, 0.5, 1 against the reference's 14Interaction known answers"""
+    P = GOLD["pairs"]
+    x = np.array(P["coordinates"], np.float64)
+    ia = np.array([[0] + t for t in P["iatoms"]], np.int32)
+    prm = np.zeros(1, ob.LISTED_IPARAMS)
+    prm["p"][0, :4] = [case["params"][k] for k in ("c6A", "c12A", "c6B", "c12B")]
+    qB = P["chargeB"] if case["fep"] else P["chargeA"]
+    for lam_name, want in case["results"].items():
+        lam = float(lam_name)
+        got = _run_gpu({"lj14": ia}, prm, x, [P["box"]] * 3, PBC[case["pbc"]], lam, qA=P["chargeA"], qB=qB,
+                       elec_scale=P["epsfac"] * P["fudgeQQ"], fep=_fep(lam, P["sc_alpha"], P["sc_power"], P["sc_sigma"], P["sc_sigma_min"]))
+        fw = np.array(want["forces"])
+        scale = max(1e-3, np.abs(fw).max())
+        assert np.abs(got["f"] - fw).max() <= 1e-4 * scale
+        assert abs(got["epot"][pkg.LISTED_TYPES["lj14"]] - want["eLJ"]) <= 1e-4 * max(1e-3, abs(want["eLJ"]))
+        assert abs(got["epot"][pkg.LISTED_ENERGY_COULOMB14] - want["eCoul"]) <= 1e-4 * max(1e-3, abs(want["eCoul"]))
+        assert abs(got["dvdl3"][pkg.LISTED_DVDL["coul"]] - want["dvdlCoul"]) <= 1e-4 * max(1e-3, abs(want["dvdlCoul"]))
+        assert abs(got["dvdl3"][pkg.LISTED_DVDL["vdw"]] - want["dvdlVdw"]) <= 1e-4 * max(1e-3, abs(want["dvdlVdw"]))
+        assert got["dvdl3"][pkg.LISTED_DVDL["bonded"]] == 0.0
+
+
+@pytest.mark.parametrize("power", [1, 2])
+def test_listed_gpu_random_pairs_against_oracle(power):
+    """many 1-4 pairs with random A/B LJ parameters and charges (some hard-core, some vanishing, some unperturbed),
+    different lambda_coul / lambda_vdw, periodic wrapping"""
+    rng = np.random.default_rng(12)
+    box, n = 3.0, 3000
+    x = rng.uniform(0, box, (n, 3))
+    nprm = 12
+    prm = np.zeros(nprm, ob.LISTED_IPARAMS)
+    for i in range(nprm):
+        a = [rng.uniform(1e-3, 3e-3), rng.uniform(1e-6, 3e-6)]
+        kind = i % 4
+        b = a if kind == 0 else ([0.0, 0.0] if kind == 1 else [rng.uniform(1e-3, 3e-3), rng.uniform(1e-6, 3e-6)])
+        if kind == 3:
+            a = [0.0, 0.0]
+        prm["p"][i, :4] = a + list(b)
+    qA = rng.uniform(-1, 1, n)
+    qB = np.where(rng.random(n) < 0.5, qA, rng.uniform(-1, 1, n) * (rng.random(n) < 0.7))
+    ai = rng.integers(0, n, 8000)
+    aj = (ai + rng.integers(1, n - 1, 8000)) % n
+    # keep realistic 1-4 distances: move j next to i
+    x[aj] = (x[ai] + rng.normal(0, 1, (8000, 3)) * 0.12 + 0.15) % box
+    ia = np.stack([rng.integers(0, nprm, 8000), ai, aj], axis=1).astype(np.int32)
+    fep64 = ob.ListedPairsFep(0.5, 0.3, power, 0, 0.3 ** 6, 0.28 ** 6, 0.35, 0.6)
+    fep32 = pkg.ListedFepParams(0.5, 0.3, power, 0.3 ** 6, 0.28 ** 6, 0.5, 0.35, 0.6)
+    xf = x.astype(np.float32).astype(np.float64)
+    qAf, qBf = qA.astype(np.float32).astype(np.float64), qB.astype(np.float32).astype(np.float64)
+    want = ob.listed_pairs(ia, prm, xf, qAf, qBf, np.full(3, box), 3, fep64, 138.935 * 0.5)
+    got = _run_gpu({"lj14": ia}, prm, x, [box] * 3, 3, 0.5, qA=qA, qB=qB, elec_scale=138.935 * 0.5, fep=fep32)
+    f = want["f"]
+    rms = np.sqrt((f ** 2).sum(axis=1).mean())
+    assert (np.abs(got["f"] - f) <= 1e-4 * np.maximum(np.linalg.norm(f, axis=1, keepdims=True), rms)).all()
+    assert abs(got["epot"][6] - want["eLJ"]) <= 1e-4 * max(abs(want["eLJ"]), 1.0)
+    assert abs(got["epot"][7] - want["eCoul"]) <= 1e-4 * max(abs(want["eCoul"]), 1.0)
+    assert abs(got["dvdl3"][1] - want["dvdlCoul"]) <= 2e-4 * max(abs(want["dvdlCoul"]), abs(want["eCoul"]))
+    assert abs(got["dvdl3"][2] - want["dvdlVdw"]) <= 2e-4 * max(abs(want["dvdlVdw"]), abs(want["eLJ"]))
