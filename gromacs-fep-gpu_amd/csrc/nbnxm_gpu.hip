@@ -1121,6 +1121,14 @@ void nbnxm_gpu_debug_timeline(NbnxmGpu* nb, unsigned long long* out, int numWave
 }
 #endif
 
+void* nbnxm_gpu_debug_get_work_ranges(NbnxmGpu* nb, int iloc, int p, int* numRanges)
+{
+    NBNXM_ASSERT(p == 0 || p == 1, "partition index is 0 or 1");
+    if (nb->plist[iloc]->workRangesDirty) { updateWorkPartition(nb, iloc); }
+    *numRanges = nb->plist[iloc]->numWorkRanges[p];
+    return nb->plist[iloc]->workRangeStart[p];
+}
+
 void nbnxm_gpu_debug_download(NbnxmGpu* nb, const void* devicePtr, void* hostPtr, size_t numBytes)
 {
     NBNXM_HIP_CHECK(hipStreamSynchronize(nb->deviceStreams[0].stream));

@@ -244,14 +244,15 @@ __launch_bounds__(c_nbBlockSize) __attribute__((amdgpu_waves_per_eu(c_nbWavesPer
      * every scalar load in flight turns the next LDS wait into a full lgkmcnt(0)).  So nothing in the group
      * loop is loaded through registers.  With LDS-direct loads (global -> LDS, no VGPRs, counted by vmcnt),
      * while group g is computed:
-     *   W(g+2): the list words of group g+2 (32 bytes; FUSED: + the fepBits bytes of its j-clusters) go to a ring
-     *           of 4 records, and
+     *   W(g+3): the list words of group g+3 (32 bytes; FUSED: + the fepBits bytes of its j-clusters) go to a ring
+     *           of 4 records (three groups ahead: W(g+1) was issued before J(g-1), whose wait in the previous
+     *           iteration therefore covers it, and the words of g+1 can be read without a wait of their own), and
      *   J(g+1): the j-side of group g+1 (32 x float4 xq, 32 types or LJ parameters, 64 exclusion words), addressed
      *           with the words of g+1 read back from the ring, goes to the other one of two staging buffers.
      * Loads and atomics retire through ONE in-order vmcnt counter, so every group issues exactly c_vmOpsPerGroup
-     * VMEM operations (W + 3 J loads + 4 j-force atomics, dummies for skipped slots): both waits of an iteration,
-     * for W(g+1) and for J(g), are counted vmcnt(c_vmOpsPerGroup) and never wait for an atomic.  The pipeline
-     * runs across piece borders (the groups of a range are contiguous). */
+     * VMEM operations (W + 3 J loads + 4 j-force atomics, dummies for skipped slots): the one wait of an iteration,
+     * for J(g), is a counted vmcnt(c_vmOpsPerGroup) and never waits for an atomic.  The pipeline runs across
+     * piece borders (the groups of a range are contiguous). */
     constexpr int  c_vmOpsPerGroup = (FUSED ? 2 : 1) + 3 + 4;
     const unsigned jStageLds = __builtin_amdgcn_readfirstlane(static_cast<unsigned>(reinterpret_cast<size_t>(jStage)));
     const unsigned ringLds   = jStageLds + 2U * c_jStageBytes;
@@ -333,6 +334,7 @@ __launch_bounds__(c_nbBlockSize) __attribute__((amdgpu_waves_per_eu(c_nbWavesPer
         /* (re)start the pipeline: at the first piece, or behind groups that belong to no i-entry */
         NBNXM_STAGE_WORDS(cjPackedBegin)
         NBNXM_STAGE_WORDS(cjPackedBegin + 1)
+        NBNXM_STAGE_WORDS(cjPackedBegin + 2)
         NBNXM_WAIT_VMEM(0);
         NBNXM_STAGE_GROUP(cjPackedBegin, curBuf)
         NBNXM_DUMMY_ATOMIC();
@@ -423,9 +425,8 @@ __launch_bounds__(c_nbBlockSize) __attribute__((amdgpu_waves_per_eu(c_nbWavesPer
         else if (jPacked == prioStep2) { __builtin_amdgcn_s_setprio(1); }
         else if (jPacked == prioStep3) { __builtin_amdgcn_s_setprio(0); }
 
-        /* pipeline step (see above): W(g+2); wait for W(g+1); J(g+1); wait for J(g) */
-        NBNXM_STAGE_WORDS(jPacked + 2)
-        NBNXM_WAIT_VMEM(c_vmOpsPerGroup);
+        /* pipeline step (see above): W(g+3); J(g+1); wait for J(g) */
+        NBNXM_STAGE_WORDS(jPacked + 3)
         NBNXM_STAGE_GROUP(jPacked + 1, curBuf ^ 1)
         NBNXM_WAIT_VMEM(c_vmOpsPerGroup);
 

@@ -19,9 +19,9 @@
 
 constexpr int c_workBlockSize = 256;
 constexpr int c_weightPair    = 8;
-constexpr int c_weightSlot    = 6;
-constexpr int c_weightGroup   = 8;
-constexpr int c_weightEntry   = 80;
+constexpr int c_weightSlot    = 2;
+constexpr int c_weightGroup   = 30;
+constexpr int c_weightEntry   = 76;
 
 /* largest k with sciSorted[k].cjPackedBegin <= group (entries ordered by (cjPackedBegin, cjPackedEnd)); -1 if none */
 __device__ __forceinline__ int findSciOfGroup(const nbnxn_sci_t* __restrict__ sciSorted, int nsci, int group)

@@ -315,6 +315,9 @@ void nbnxm_gpu_set_fep_mode(NbnxmGpu* nb, int fused);
 /* Diagnostics for tests: device pointer of the packed j-list of a locality, and a synchronous
  * device-to-host copy on that object's local stream. */
 void* nbnxm_gpu_debug_get_cjpacked(NbnxmGpu* nb, int iloc);
+/* device pointer of the work partition's range borders (numRanges + 1 ints) for the 4- (p = 0) or 5-waves-per-SIMD
+ * (p = 1) kernels; *numRanges receives their count (tools/calibrate_weights.py) */
+void* nbnxm_gpu_debug_get_work_ranges(NbnxmGpu* nb, int iloc, int p, int* numRanges);
 void  nbnxm_gpu_debug_download(NbnxmGpu* nb, const void* devicePtr, void* hostPtr, size_t numBytes);
 
 /* Library/ABI version and a last-error string for diagnostics (never needed on the success path). */

@@ -1,0 +1,61 @@
+#!/usr/bin/env python3
+"""Fits the cost model of the work partition (csrc/nbnxm_work_partition.h: c_weightPair/Slot/Group/Entry) to measured
+per-SIMD busy times.  Needs the diagnostics build (make HIPFLAGS+=-DNBNXM_WAVE_TIMELINE).
+
+For every wave: features of its range (cluster pairs, non-empty j-slots, non-empty groups, i-entry starts); the waves
+are grouped by the SIMD they ran on (HW_ID); least squares of the SIMD's last finish time against the summed features."""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import torch
+import fep_testlib as tl
+pkg = tl.pkg
+
+case = tl.make_case(nm=(40, 40, 20), num_perturbed_molecules=16, elec="ewald", seed=2026, n_lambda=11, max_cjpacked_per_sci=16)
+nb = tl.setup_gpu(case, fused=False, use_dynamic_pruning=True)
+sw = pkg.step_workload(energy=False, virial=False, dhdl=False)
+for _ in range(8):
+    nb.clear_outputs(False); nb.launch_kernel(sw)
+torch.cuda.synchronize()
+lib = pkg.hip_lib()
+lib.nbnxm_gpu_debug_get_work_ranges.restype = C.c_void_p
+nr = C.c_int(0)
+ptr = lib.nbnxm_gpu_debug_get_work_ranges(C.c_void_p(nb._h), 0, 1, C.byref(nr))
+n = nr.value
+ranges = np.zeros(n + 1, np.int32)
+lib.nbnxm_gpu_debug_download(C.c_void_p(nb._h), C.c_void_p(ptr), ranges.ctypes.data_as(C.c_void_p), C.c_size_t(ranges.nbytes))
+cj = pkg.download_cjpacked(nb, len(case.plist.cjPacked))
+imask = cj["imei"][:, 0]["imask"].astype(np.uint32)
+popc = np.array([bin(int(m)).count("1") for m in imask])
+slots = sum(((imask >> (8 * k)) & 0xFF) != 0 for k in range(4)).astype(np.int64)
+groups = (imask != 0).astype(np.int64)
+starts = np.zeros(len(imask), np.int64)
+starts[case.plist.sci["cjPackedBegin"][case.plist.sci["cjPackedEnd"] > case.plist.sci["cjPackedBegin"]]] = 1
+cs = lambda a: np.concatenate([[0], np.cumsum(a)])
+feat = np.stack([cs(popc)[ranges[1:]] - cs(popc)[ranges[:-1]], cs(slots)[ranges[1:]] - cs(slots)[ranges[:-1]],
+                 cs(groups)[ranges[1:]] - cs(groups)[ranges[:-1]], cs(starts)[ranges[1:]] - cs(starts)[ranges[:-1]] + 1], axis=1).astype(np.float64)
+buf = (C.c_ulonglong * (4 * n))()
+lib.nbnxm_gpu_debug_timeline(C.c_void_p(nb._h), buf, n)
+a = np.frombuffer(buf, dtype=np.uint64).reshape(n, 4)
+t0 = a[:, 0].min()
+end = (a[:, 2] - t0).astype(np.float64) / 100.0
+hw = a[:, 3] & np.uint64(0xFFFFFFFF); xcc = (a[:, 3] >> np.uint64(32)) & np.uint64(0xF)
+simd = (hw >> np.uint64(4)) & np.uint64(3); cu = (hw >> np.uint64(8)) & np.uint64(0xF); sh = (hw >> np.uint64(12)) & np.uint64(1); se = (hw >> np.uint64(13)) & np.uint64(7)
+key = (((xcc * 8 + se) * 2 + sh) * 16 + cu) * 4 + simd
+uk = np.unique(key)
+X = np.array([feat[key == k].sum(axis=0) for k in uk])
+y = np.array([end[key == k].max() for k in uk])
+A = np.concatenate([X, np.ones((len(uk), 1))], axis=1)
+coef, res, *_ = np.linalg.lstsq(A, y, rcond=None)
+pred = A @ coef
+print("SIMDs %d; per-SIMD finish: mean %.1f std %.2f us; features per SIMD mean %s" % (len(uk), y.mean(), y.std(), X.mean(axis=0).round(1)))
+print("fit: us per cluster pair %.5f, per slot %.5f, per group %.5f, per piece %.5f, const %.2f; residual std %.2f us" % (*coef, (y - pred).std()))
+w = coef[:4] / coef[0] * 8
+print("weights relative to 8 per cluster pair: slot %.1f group %.1f piece %.1f (current 6 / 8 / 80)" % (w[1], w[2], w[3]))
+cur = feat @ np.array([8, 6, 8, 80.0])
+print("current weight per wave: mean %.0f std %.1f (%.2f %%)" % (cur.mean(), cur.std(), 100 * cur.std() / cur.mean()))
