@@ -99,6 +99,7 @@ HIP_SYMBOLS = [
     "nbnxm_gpu_setup_short_range_work", "nbnxm_gpu_force_reduction_reinit", "nbnxm_gpu_force_reduction_execute",
     "nbnxm_gpu_halo_pack_x", "nbnxm_gpu_halo_unpack_f",
 ]
+UPDATE_SYMBOLS = ["langevin_gpu_create", "langevin_gpu_free", "langevin_gpu_set", "langevin_gpu_integrate"]
 LISTED_SYMBOLS = [
     "listed_gpu_create", "listed_gpu_free", "listed_gpu_set_force_params", "listed_gpu_update_interaction_list",
     "listed_gpu_have_interactions", "listed_gpu_launch_kernel", "listed_gpu_launch_energy_transfer",
@@ -557,6 +558,45 @@ class ListedGpu:
     def free(self):
         if getattr(self, "_h", None):
             self._lib.listed_gpu_free(self.h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+# ---- stochastic-dynamics update: include/update_hip.h ---------------------------------------------------------
+LANGEVIN_FORCES_ONLY, LANGEVIN_FRICTION_AND_NOISE = 0, 1
+
+
+class LangevinGpu:
+    """ctypes mirror of gmx::LangevinGpu (mdlib/langevin_gpu.h:90-160)"""
+
+    def __init__(self, ref_t, tau_t, delta_t, stream=None):
+        self._lib = hip_lib()
+        self._lib.langevin_gpu_create.restype = C.c_void_p
+        rt, tt = _a(ref_t, np.float32), _a(tau_t, np.float32)
+        assert rt.size == tt.size
+        self._h = self._lib.langevin_gpu_create(C.c_void_p(stream), C.c_int(rt.size), C.c_float(delta_t), _p(rt), _p(tt))
+
+    @property
+    def h(self):
+        return C.c_void_p(self._h)
+
+    def set(self, inverse_masses, temp_coupl_groups):
+        im, tc = _a(inverse_masses, np.float32), _a(temp_coupl_groups, np.uint16)
+        assert im.size == tc.size
+        self._lib.langevin_gpu_set(self.h, C.c_int(im.size), _p(im), _p(tc))
+
+    def integrate(self, d_x, d_xp, d_v, d_f, dt, seed, step, update_type):
+        self._lib.langevin_gpu_integrate(self.h, C.c_void_p(d_x), C.c_void_p(d_xp), C.c_void_p(d_v), C.c_void_p(d_f), C.c_float(dt),
+                                         C.c_int(seed), C.c_int(step), C.c_int(update_type))
+
+    def free(self):
+        if getattr(self, "_h", None):
+            self._lib.langevin_gpu_free(self.h)
             self._h = None
 
     def __del__(self):

@@ -243,3 +243,35 @@ def listed_pairs(iatoms, params, x, qA, qB, box, npbcdim, fep, elec_scale):
                               _ptr(_arr(qB, np.float64)), _ptr(_arr(box, np.float64)), C.c_int(npbcdim), C.byref(fep),
                               C.c_double(elec_scale), _ptr(f), _ptr(fshift), *[C.byref(o) for o in out])
     return dict(f=f, fshift=fshift, eLJ=out[0].value, eCoul=out[1].value, dvdlVdw=out[2].value, dvdlCoul=out[3].value)
+
+
+# ---- Langevin update: oracle/langevin_ref.h -----------------------------------------------------------------
+def threefry2x64(key0, key1, ctr0, ctr1):
+    out = (C.c_uint64 * 2)()
+    lib().oracle_threefry2x64(C.c_uint64(key0), C.c_uint64(key1), C.c_uint64(ctr0), C.c_uint64(ctr1), out)
+    return int(out[0]), int(out[1])
+
+
+def normal_table(bits=14):
+    t = np.zeros(1 << bits, np.float32)
+    lib().oracle_normal_table(C.c_int(bits), _ptr(t))
+    return t
+
+
+def tabulated_normal(key0, domain, internal_counter_bits, ctr0, ctr1, mean, stddev, n):
+    out = np.zeros(n, np.float32)
+    lib().oracle_tabulated_normal(C.c_uint64(key0), C.c_uint64(domain), C.c_int(internal_counter_bits), C.c_uint64(ctr0),
+                                  C.c_uint64(ctr1), C.c_float(mean), C.c_float(stddev), C.c_int(n), _ptr(out))
+    return out
+
+
+def langevin_update(update_type, x, v, f, inverse_masses, tc_groups, ref_t, tau_t, dt, seed, step):
+    """returns (x, xp, v) after the update; update_type 0 = forces only, 1 = friction and noise only"""
+    x_ = np.array(x, np.float32).copy()
+    v_ = np.array(v, np.float32).copy()
+    xp = np.zeros_like(x_)
+    n = x_.shape[0]
+    lib().oracle_langevin_update(C.c_int(update_type), C.c_int(n), _ptr(x_), _ptr(xp), _ptr(v_), _ptr(_arr(f, np.float32)),
+                                 _ptr(_arr(inverse_masses, np.float32)), _ptr(_arr(tc_groups, np.uint16)), C.c_int(len(ref_t)),
+                                 _ptr(_arr(ref_t, np.float32)), _ptr(_arr(tau_t, np.float32)), C.c_float(dt), C.c_int(seed), C.c_int(step))
+    return x_, xp, v_

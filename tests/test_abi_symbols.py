@@ -37,6 +37,14 @@ def test_hip_library_exports_every_listed_forces_symbol():
     assert ctypes.sizeof(pkg.ListedFepParams) == 32
 
 
+def test_hip_library_exports_every_update_symbol():
+    lib = pkg.hip_lib()
+    names = declared_functions("update_hip.h", "langevin_gpu_")
+    for n in names:
+        assert hasattr(lib, n), "libnbnxm_hip.so does not export %s" % n
+    assert sorted(names) == sorted(pkg.UPDATE_SYMBOLS)
+
+
 def test_host_library_exports_every_declared_symbol():
     lib = pkg.host_lib()
     names = declared_functions("nbnxm_host.h", "nbnxm_host_")

@@ -164,3 +164,18 @@ def test_listed_pairs_oracle_reproduces_reference_known_answers(case):
         assert np.abs(got["f"] - fw).max() <= 2e-6 * scale, lam_name
         for k in ("eLJ", "eCoul", "dvdlVdw", "dvdlCoul"):
             assert abs(got[k] - want[k]) <= 2e-6 * max(1e-3, abs(want[k])), (k, lam_name)
+
+
+# ---- random engine + tabulated normal distribution of the Langevin update ---------------------------------------
+def test_threefry_and_tabulated_normal_reproduce_reference_known_answers():
+    import json
+    import oracle_binding as ob
+    d = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "langevin_refdata.json")))
+    for kat in d["threefry"]:
+        got = ob.threefry2x64(int(kat["key"][0]), int(kat["key"][1]), int(kat["ctr"][0]), int(kat["ctr"][1]))
+        assert [str(g) for g in got] == kat["out"]                       # bit-exact
+    t = d["tabulated"]
+    got = ob.tabulated_normal(t["key0"], t["domain"], t["internalCounterBits"], 0, 0, t["mean"], t["stddev"], len(t["values"]))
+    assert np.allclose(got, np.array(t["values"], np.float32), rtol=1e-6, atol=0)   # 1-2 float ulp: erfinv implementation, mean + v * stddev rounding
+    tab = ob.normal_table(14)
+    assert abs(float((tab.astype(np.float64) ** 2).mean()) - 1.0) < 1e-6 and tab[0] == -tab[-1] and (np.diff(tab) > 0).all()
