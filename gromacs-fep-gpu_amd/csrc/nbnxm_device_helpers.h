@@ -128,7 +128,7 @@ NB_DEVINL float interpolateCoulombForceR(const NBParamGpu& nbp, float r)
 
 /* ---- non-perturbed atom pair (nbnxm_cuda_kernel.cuh:518-645) ---------------------------------- */
 
-template<int ELEC, bool TWIN, int VDW, bool ENERGY, bool EXCL_FORCES, bool HAS_EXCL = true>
+template<int ELEC, bool TWIN, int VDW, bool ENERGY, bool EXCL_FORCES, bool HAS_EXCL = true, bool CORR_TABLE = true>
 NB_DEVINL void nbPair(const NBParamGpu& nbp,
                       const float2*     ewaldCorrLds, /* analytical Ewald: NBParamGpu::ewaldCorrTab in LDS */
                       float             r2,
@@ -209,12 +209,21 @@ NB_DEVINL void nbPair(const NBParamGpu& nbp,
         const float beta = nbp.ewald_beta;
         if constexpr (ELEC == ELK_EWALD_ANA)
         {
-            /* beta^3 F((beta r)^2) by linear interpolation in the LDS table; only pairs within rcoulomb get here,
-             * which is what bounds the index */
-            const float    xs   = r2 * nbp.ewaldCorrTabScale;
-            const unsigned idx  = static_cast<unsigned>(xs);
-            const float2   t    = ewaldCorrLds[idx];
-            F_invr += qq * (inv_r3m + fmaf(__builtin_amdgcn_fractf(xs), t.y, t.x));
+            if constexpr (CORR_TABLE)
+            {
+                /* beta^3 F((beta r)^2) by linear interpolation in the LDS table; only pairs within rcoulomb get here,
+                 * which is what bounds the index */
+                const float    xs  = r2 * nbp.ewaldCorrTabScale;
+                const unsigned idx = static_cast<unsigned>(xs);
+                const float2   t   = ewaldCorrLds[idx];
+                F_invr += qq * (inv_r3m + fmaf(__builtin_amdgcn_fractf(xs), t.y, t.x));
+            }
+            else
+            {
+                /* the rational form (callers without the table in LDS: the perturbed-cluster-pair kernel) */
+                const float beta2 = beta * beta;
+                F_invr += qq * (inv_r3m + pmeCorrF(beta2 * r2) * beta2 * beta);
+            }
         }
         else
         {

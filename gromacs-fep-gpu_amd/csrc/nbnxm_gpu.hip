@@ -208,7 +208,11 @@ NbnxmGpu* nbnxm_gpu_init(const nbnxm_interaction_params_t* ic, int numTypes, con
         if (const char* env = std::getenv("NBNXM_HIP_NUM_WORK_RANGES")) { nb->numWorkRangesOverride = std::atoi(env); }
         if (const char* env = std::getenv("NBNXM_HIP_MIN_GROUPS_PER_WAVE")) { nb->minGroupsPerWave = std::max(1, std::atoi(env)); }
     }
-    if (const char* env = std::getenv("NBNXM_HIP_FEP_CONCURRENT")) { nb->fepConcurrent = (std::atoi(env) != 0); }
+    if (const char* env = std::getenv("NBNXM_HIP_FEP_CONCURRENT"))
+    {
+        nb->fepConcurrent      = (std::atoi(env) != 0);
+        nb->fepConcurrentFused = (std::atoi(env) == 2);
+    }
     if (bFEP && nb->fepConcurrent)
     {
         for (int i = 0; i < (nb->bUseTwoStreams ? 2 : 1); i++)
@@ -359,7 +363,10 @@ void nbnxm_gpu_free(NbnxmGpu* nb)
             freeDeviceBuffer(&nb->plist[i]->excl);
             freeDeviceBuffer(&nb->plist[i]->sciSorted);
             freeDeviceBuffer(&nb->plist[i]->groupWeight);
-            freeDeviceBuffer(&nb->plist[i]->groupFepJ);
+            freeDeviceBuffer(&nb->plist[i]->groupSlowMask);
+            freeDeviceBuffer(&nb->plist[i]->slowGroups);
+            freeDeviceBuffer(&nb->plist[i]->slowGroupSci);
+            freeDeviceBuffer(&nb->plist[i]->slowCount);
             freeDeviceBuffer(&nb->plist[i]->weightBlockSum);
             for (int p = 0; p < 2; p++)
             {
@@ -580,6 +587,7 @@ void nbnxm_gpu_init_pairlist(NbnxmGpu* nb, int iloc, int na_c, int nsci, const n
     }
     NBNXM_HIP_CHECK(hipStreamSynchronize(s));
     d->workRangesDirty        = true;
+    d->slowListDirty          = true;
     d->haveFreshList          = true;
     d->rollingPruningNumParts = 0;
     d->rollingPruningPart     = 0;
@@ -673,7 +681,11 @@ void nbnxm_gpu_init_fep_cluster_bits(NbnxmGpu* nb, int numClusters, const unsign
     copyToDeviceBuffer(&ad->fepBits, nb->h_fepBits.data, 0, numClusters, nb->deviceStreams[0].stream, true);
     for (gpu_plist* pl : nb->plist)
     {
-        if (pl) { pl->workRangesDirty = true; }
+        if (pl)
+        {
+            pl->workRangesDirty = true;
+            pl->slowListDirty   = true;
+        }
     }
 }
 
@@ -683,7 +695,11 @@ void nbnxm_gpu_set_fep_mode(NbnxmGpu* nb, int fused)
     nb->fusedFep = fused != 0;
     for (gpu_plist* pl : nb->plist)
     {
-        if (pl) { pl->workRangesDirty = true; }
+        if (pl)
+        {
+            pl->workRangesDirty = true;
+            pl->slowListDirty   = true;
+        }
     }
 }
 
@@ -752,14 +768,40 @@ static void updateWorkPartition(NbnxmGpu* nb, int iloc)
     reallocateDeviceBuffer(&d->groupWeight, d->ncjPacked, &dummy, &d->groupWeight_nalloc);
     if (d->groupWeight_nalloc != oldAlloc)
     {
-        freeDeviceBuffer(&d->groupFepJ);
-        allocateDeviceBuffer(&d->groupFepJ, d->groupWeight_nalloc);
+        freeDeviceBuffer(&d->groupSlowMask);
+        freeDeviceBuffer(&d->slowGroups);
+        freeDeviceBuffer(&d->slowGroupSci);
+        allocateDeviceBuffer(&d->groupSlowMask, d->groupWeight_nalloc);
+        allocateDeviceBuffer(&d->slowGroups, d->groupWeight_nalloc);
+        allocateDeviceBuffer(&d->slowGroupSci, d->groupWeight_nalloc);
+        d->slowListDirty = true;
     }
+    if (d->slowCount == nullptr) { allocateDeviceBuffer(&d->slowCount, 1); }
     reallocateDeviceBuffer(&d->weightBlockSum, numBlocks + 1, &dummy, &d->weightBlockSum_nalloc);
+    const bool fused     = nb->fusedFep && nb->nbparam->bFEP && nb->atdat->fepBits != nullptr;
+    const bool buildSlow = fused && d->slowListDirty;
+    if (buildSlow) { clearDeviceBufferAsync(&d->slowCount, 0, 1, s); }
+    hipLaunchKernelGGL(nbnxmWorkWeightKernel, dim3(numBlocks), dim3(c_workBlockSize), 0, s, d->cjPacked, d->ncjPacked, d->sciSorted,
+                       d->nsci, fused ? nb->atdat->fepBits : nullptr, buildSlow ? 1 : 0, d->groupSlowMask, d->slowGroups, d->slowGroupSci,
+                       d->slowCount, d->groupWeight, d->weightBlockSum);
+    hipLaunchKernelGGL(nbnxmWorkScanKernel, dim3(1), dim3(c_workBlockSize), 0, s, d->weightBlockSum, numBlocks);
+    NBNXM_HIP_CHECK(hipGetLastError());
+    if (buildSlow)
+    {
+        /* the launch of the perturbed-cluster-pair kernel (and the room left for it, below) needs the count on the
+         * host: one small synchronous copy per new list (not per prune) */
+        nb->h_slowCount.resize(1);
+        NBNXM_HIP_CHECK(hipMemcpyAsync(nb->h_slowCount.data, d->slowCount, sizeof(int), hipMemcpyDeviceToHost, s));
+        NBNXM_HIP_CHECK(hipStreamSynchronize(s));
+        d->numSlowGroups = nb->h_slowCount.data[0];
+        d->slowListDirty = false;
+    }
+    if (!fused) { d->numSlowGroups = 0; }
+
     WorkPartitionOut out[2];
     for (int p = 0; p < 2; p++)
     {
-        const int slots     = nb->numSimds * (4 + p);
+        const int slots = nb->numSimds * (4 + p);
         d->numWorkRanges[p] = std::max(1, std::min(slots, d->ncjPacked / nb->minGroupsPerWave));
         if (nb->numWorkRangesOverride > 0) { d->numWorkRanges[p] = std::min(nb->numWorkRangesOverride, d->ncjPacked); }
         reallocateDeviceBuffer(&d->workRangeStart[p], d->numWorkRanges[p] + 1, &dummy, &d->work_nalloc[p]);
@@ -777,10 +819,6 @@ static void updateWorkPartition(NbnxmGpu* nb, int iloc)
         out[p].rangeStart = d->workRangeStart[p];
         out[p].firstSci   = d->workFirstSci[p];
     }
-    const bool fused = nb->fusedFep && nb->nbparam->bFEP && nb->atdat->fepBits != nullptr;
-    hipLaunchKernelGGL(nbnxmWorkWeightKernel, dim3(numBlocks), dim3(c_workBlockSize), 0, s, d->cjPacked, d->ncjPacked, d->sciSorted,
-                       d->nsci, fused ? nb->atdat->fepBits : nullptr, nb->fepPairWeight, d->groupFepJ, d->groupWeight, d->weightBlockSum);
-    hipLaunchKernelGGL(nbnxmWorkScanKernel, dim3(1), dim3(c_workBlockSize), 0, s, d->weightBlockSum, numBlocks);
     hipLaunchKernelGGL(nbnxmWorkRangesKernel, dim3(numBlocks), dim3(c_workBlockSize), 0, s, d->groupWeight, d->weightBlockSum,
                        d->ncjPacked, numBlocks, d->sciSorted, d->nsci, out[0], out[1]);
     NBNXM_HIP_CHECK(hipGetLastError());
@@ -854,7 +892,7 @@ void nbnxm_gpu_launch_kernel(NbnxmGpu* nb, const nbnxm_step_workload_t* stepWork
      * overlap with the cluster-pair kernel (the reference queues them behind it, nbnxm_cuda.cu:762-857). */
     const bool fused = nb->fusedFep && nbp->bFEP;
     /* foreign-lambda energies are wanted on dH/dl steps of soft-core runs (nbnxm_cuda.cu:817-856).  In fused mode
-     * the cluster kernel's second pass accumulates them itself: no atom-pair list is needed at all. */
+     * nbnxmFepClusterKernel accumulates them itself: no atom-pair list is needed at all. */
     const bool wantForeign = nbp->bFEP && nb->n_lambda > 0 && stepWork->computeDhdl && (nbp->alpha_coul != 0.0F || nbp->alpha_vdw != 0.0F);
     bool       fepForked = false;
     if (nbp->bFEP && !fused)
@@ -900,14 +938,48 @@ void nbnxm_gpu_launch_kernel(NbnxmGpu* nb, const nbnxm_step_workload_t* stepWork
 
     if (plist->nsci > 0)
     {
-        /* fused dH/dl steps run the energy flavour (the foreign terms are energies of its second pass) */
-        const bool        energyFlavour = stepWork->computeEnergy != 0 || (fused && wantForeign);
-        const NbKernelPtr kernel        = selectNbKernel(nbp->elecType, nbp->vdwType, energyFlavour, fused, fused && wantForeign);
+        const bool        energyFlavour = stepWork->computeEnergy != 0;
+        const NbKernelPtr kernel        = selectNbKernel(nbp->elecType, nbp->vdwType, energyFlavour, fused);
         if (kernel == nullptr)
         {
             fatal(__FILE__, __LINE__, "nbnxm_gpu_launch_kernel", "no kernel for this electrostatics / VdW combination (LJ-PME grid flavours are not built)");
         }
         if (plist->workRangesDirty) { updateWorkPartition(nb, iloc); }
+
+        if (fused && plist->numSlowGroups > 0)
+        {
+            /* the cluster pairs that touch a perturbed atom: a few thousand short latency-bound waves, ~13 us on the 96k
+             * box.  On the same stream, ahead of the cluster kernel: measured on MI355X a second stream does not help here
+             * (the cluster kernel fills every wave slot, so the other kernel's waves only start when those retire, and
+             * the fork / join events cost more than the overlap gains: 0.101 vs 0.099 ms per step); the option stays
+             * for experiments (NBNXM_HIP_FEP_CONCURRENT=2). */
+            const FepClusterKernelPtr fk = selectFepClusterKernel(nbp->elecType, nbp->vdwType, stepWork->computeEnergy != 0 || wantForeign, wantForeign);
+            NBNXM_ASSERT(fk != nullptr, "no perturbed-cluster-pair kernel for this electrostatics / VdW combination");
+            hipStream_t fs = s;
+            if (nb->fepConcurrentFused && nb->fepStreams[iloc].stream != nullptr)
+            {
+                fs = nb->fepStreams[iloc].stream;
+                NBNXM_HIP_CHECK(hipEventRecord(nb->fepFork[iloc], s));
+                NBNXM_HIP_CHECK(hipStreamWaitEvent(fs, nb->fepFork[iloc], 0));
+                fepForked = true;
+            }
+            const bool fepUseTable = (nbp->vdwType == NBNXM_VDW_CUT || nbp->vdwType == NBNXM_VDW_FSWITCH || nbp->vdwType == NBNXM_VDW_PSWITCH);
+            const int  fepLds      = (fepUseTable ? ((adat->numTypes * adat->numTypes * 8 + 15) & ~15) : 0) + c_fepClusterWavesPerBlockDef * c_iStageBytes;
+            NBNXM_ASSERT(fepLds <= 160 * 1024, "too many atom types: the LJ parameter table does not fit the 160 KB LDS");
+            if (fepLds > 64 * 1024)
+            {
+                NBNXM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(fk), hipFuncAttributeMaxDynamicSharedMemorySize, fepLds));
+            }
+            if (nb->bDoTime) { t.fep_k.openTimingRegion(fs); }
+            const int numFepWaves = plist->numSlowGroups * c_jGroupSize; /* one wave per (group, j-cluster slot) */
+            hipLaunchKernelGGL(fk, dim3((numFepWaves + c_fepClusterWavesPerBlockDef - 1) / c_fepClusterWavesPerBlockDef),
+                               dim3(c_fepClusterWavesPerBlockDef * c_waveSize), fepLds, fs, *adat, *nbp, *plist, stepWork->computeVirial,
+                               plist->sciSorted, plist->cjPacked, plist->excl, adat->xq, adat->atomTypes, adat->ljComb,
+                               reinterpret_cast<const unsigned*>(adat->fepBits), wantForeign ? nb->n_lambda : -1);
+            NBNXM_HIP_CHECK(hipGetLastError());
+            if (nb->bDoTime) { t.fep_k.closeTimingRegion(fs); }
+            if (fepForked) { NBNXM_HIP_CHECK(hipEventRecord(nb->fepJoin[iloc], fs)); }
+        }
         if (nb->bDoTime) { t.nb_k.openTimingRegion(s); }
         /* The LJ table lives in LDS (up to ~140 types in the 160 KB; large tables cost occupancy) */
         const bool useTable = (nbp->vdwType == NBNXM_VDW_CUT || nbp->vdwType == NBNXM_VDW_FSWITCH || nbp->vdwType == NBNXM_VDW_PSWITCH);
@@ -928,8 +1000,7 @@ void nbnxm_gpu_launch_kernel(NbnxmGpu* nb, const nbnxm_step_workload_t* stepWork
         hipLaunchKernelGGL(kernel, dim3((numRanges + wavesPerBlock - 1) / wavesPerBlock), dim3(wavesPerBlock * c_waveSize), ldsBytes, s,
                            *adat, *nbp, *plist, stepWork->computeVirial, plist->sciSorted, plist->cjPacked, plist->excl, adat->xq,
                            adat->atomTypes, adat->ljComb, reinterpret_cast<const unsigned*>(adat->fepBits),
-                           plist->workRangeStart[p], plist->workFirstSci[p], numRanges, plist->groupFepJ,
-                           (fused && wantForeign) ? nb->n_lambda : -1);
+                           plist->workRangeStart[p], plist->workFirstSci[p], numRanges, plist->groupSlowMask);
         NBNXM_HIP_CHECK(hipGetLastError());
         if (nb->bDoTime) { t.nb_k.closeTimingRegion(s); }
     }

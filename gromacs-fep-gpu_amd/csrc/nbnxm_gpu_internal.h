@@ -53,7 +53,8 @@ struct NbnxmGpu
     DeviceStream   fepStreams[2];
     hipEvent_t     fepFork[2]                  = { nullptr, nullptr };
     hipEvent_t     fepJoin[2]                  = { nullptr, nullptr };
-    bool           fepConcurrent               = true;
+    bool           fepConcurrent               = true;  /* split mode: atom-pair kernels on the FEP stream */
+    bool           fepConcurrentFused          = false; /* fused mode: perturbed-cluster-pair kernel on the FEP stream */
     hipEvent_t     nonlocal_done               = nullptr;
     hipEvent_t     misc_ops_and_local_H2D_done = nullptr;
     bool           haveWork[2]                 = { false, false };
@@ -74,6 +75,7 @@ struct NbnxmGpu
     int minGroupsPerWave  = 2;
     int numWorkRangesOverride = 0; /* experiments: NBNXM_HIP_NUM_WORK_RANGES */
     PinnedBuffer<nbnxn_sci_t> h_sciSorted;
+    PinnedBuffer<int>         h_slowCount;
 
     /* coordinate / force buffer operations (nbnxm_buffer_ops.hip; nbnxm_cuda_types.h:131-142) */
     int* atomIndices        = nullptr; /* grid slot -> atom index, -1 for fillers */

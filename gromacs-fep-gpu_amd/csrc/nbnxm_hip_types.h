@@ -129,6 +129,8 @@ struct NBParamGpu
 };
 
 constexpr int c_ewaldCorrTabSize = 2048;
+/* waves per workgroup of nbnxmFepClusterKernel */
+constexpr int c_fepClusterWavesPerBlockDef = 4;
 
 /* nbnxm/gpu_types_common.h:297-341 */
 struct gpu_plist
@@ -161,7 +163,12 @@ struct gpu_plist
      * Recomputed on the device after every (re)prune of the list. */
     nbnxn_sci_t* sciSorted;
     int          sciSorted_nalloc;
-    unsigned*    groupFepJ;       /* ncjPacked: Grid::fepBits of each group's 4 j-clusters, one byte each (fused kernel) */
+    unsigned*    groupSlowMask;   /* ncjPacked: fused mode, the cluster pairs of each group that touch a perturbed atom */
+    int*         slowGroups;      /* numSlowGroups (<= ncjPacked): the groups with a non-zero slow mask */
+    int*         slowGroupSci;    /* ... and the index of their i-entry in sciSorted */
+    int*         slowCount;       /* device counter behind numSlowGroups */
+    int          numSlowGroups;
+    bool         slowListDirty;   /* the list, fepBits or the mode changed since groupSlowMask / slowGroups were built */
     int*         groupWeight;     /* ncjPacked, scratch */
     int          groupWeight_nalloc;
     int*         weightBlockSum;  /* per 256 groups, then its exclusive scan; last entry = total */
@@ -214,7 +221,8 @@ inline int nbLdsBytes(int numTypes, bool useTable, bool ewaldCorrTable, bool fus
 {
     const int tableBytes = (useTable ? ((numTypes * numTypes * static_cast<int>(sizeof(float2)) + 15) & ~15) : 0)
                            + (ewaldCorrTable ? c_ewaldCorrTabSize * static_cast<int>(sizeof(float2)) : 0);
-    return tableBytes + wavesPerBlock * (2 * c_jStageBytes + c_jRingBytes + (fused ? c_iStageBytes : 0));
+    (void)fused;
+    return tableBytes + wavesPerBlock * (2 * c_jStageBytes + c_jRingBytes);
 }
 
 #endif

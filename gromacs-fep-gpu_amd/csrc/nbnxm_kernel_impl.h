@@ -14,7 +14,7 @@
  *   - the 8 i-atoms a lane meets (x, q*epsfac, +shift, type row / LJ parameters) stay in 40 VGPRs for the
  *     whole entry (the 512-entry register file makes the CUDA kernel's per-pair LDS round trip unnecessary);
  *     LDS holds what is indexed at run time: the whole nbfp table (shared by the workgroup's waves, one
- *     ds_read_b64 per pair instead of a 512-byte global gather) and, for FUSED, the i-atoms' A/B data;
+ *     ds_read_b64 per pair instead of a 512-byte global gather);
  *   - j-atom data: one 16-byte load per lane of 128 contiguous bytes per j-cluster;
  *   - j-forces: 3 DPP adds per component over the 8 lanes that share a j atom, then one no-return buffer
  *     atomic from 24 lanes (96 contiguous bytes), deferred behind the next j-cluster's loads: gfx950 retires
@@ -22,11 +22,9 @@
  *     counted vmcnt(1-2) instead of a full drain behind a ~1-3 us memory-side atomic;
  *   - i-forces: 24 accumulators in registers, reduced over tidxj once per entry and written with
  *     64-lane coalesced atomics (768 contiguous bytes);
- *   - FUSED: (i-cluster, j-cluster) pairs that touch a perturbed atom (Grid::fepBits) are left out of the
- *     main pass and evaluated in a second pass of the same wavefront, run only by the ~1 % of entries that
- *     have any: perturbed lanes take the soft-core A/B pair (fepPair), the other lanes the plain pair.  The
- *     second pass starts after the main pass's registers are dead, so the common case keeps the register
- *     budget (and the 5 waves per SIMD) of the plain kernel.
+ *   - FUSED: (i-cluster, j-cluster) pairs that touch a perturbed atom (Grid::fepBits) are masked out of the list
+ *     words with a per-group mask computed once per list (gpu_plist::groupSlowMask, one more staged dword and one
+ *     scalar AND per group) and evaluated by nbnxmFepClusterKernel on the FEP stream; the main pass is the plain kernel.
  *   - built with -fno-slp-vectorize: on gfx950 v_pk_*_f32 issues at half rate and costs v_mov shuffles.
  */
 #ifndef NBNXM_KERNEL_IMPL_H
@@ -144,13 +142,13 @@ NB_DEVINL void ljFromComb(int vdwKind, const float2& a, const float2& b, float& 
 
 /* 5 waves per SIMD (<= 96 VGPRs) for the flavours that fit without scratch; the energy, combination-rule and
  * switch flavours carry more live values and run at 4 waves (<= 128 VGPRs) instead of spilling. */
-template<int VDW, bool ENERGY, bool FUSED>
-constexpr int c_nbWavesPerEu = (VDW == VDK_CUT && !ENERGY && !FUSED) ? 5 : 4;
+template<int VDW, bool ENERGY>
+constexpr int c_nbWavesPerEu = (VDW == VDK_CUT && !ENERGY) ? 5 : 4;
 
-/* FOREIGN (only with ENERGY && FUSED): the flavour of dH/dl steps, whose second pass also accumulates the perturbed
- * pairs' energies at the foreign lambdas; a flavour of its own so that the plain energy kernel keeps its registers */
-template<int ELEC, bool TWIN, int VDW, bool ENERGY, bool FUSED, bool FOREIGN = false>
-__launch_bounds__(c_nbBlockSize) __attribute__((amdgpu_waves_per_eu(c_nbWavesPerEu<VDW, ENERGY, FUSED>))) __global__
+/* FUSED: the cluster pairs that touch a perturbed atom are masked out of the list words (gpu_plist::groupSlowMask) and
+ * left to nbnxmFepClusterKernel; otherwise the kernel is the plain one */
+template<int ELEC, bool TWIN, int VDW, bool ENERGY, bool FUSED>
+__launch_bounds__(c_nbBlockSize) __attribute__((amdgpu_waves_per_eu(c_nbWavesPerEu<VDW, ENERGY>))) __global__
         void nbnxmKernel(const NBAtomDataGpu atdat,
                          const NBParamGpu    nbp,
                          const gpu_plist     plist,
@@ -170,11 +168,7 @@ __launch_bounds__(c_nbBlockSize) __attribute__((amdgpu_waves_per_eu(c_nbWavesPer
                          const int* __restrict__ workRangeStart,
                          const int* __restrict__ workFirstSci,
                          const int numWorkRanges,
-                         const unsigned* __restrict__ groupFepJ, /* FUSED: fepBits bytes of each group's 4 j-clusters */
-                         /* FUSED energy flavours: >= 0: also accumulate the perturbed pairs' energies and dV/dl at
-                          * lambda index 0 (current) .. numForeignLambda (allLambdaCoul/Vdw[k-1]) into the foreign
-                          * arrays, what nbnxn_foreign_fep_kernel_* does on the atom-pair list; -1: not this step */
-                         const int numForeignLambda)
+                         const unsigned* __restrict__ groupSlowMask /* FUSED: perturbed cluster pairs of each group */)
 {
     constexpr bool EXCL_FORCES = (ELEC != ELK_CUT) || ENERGY; /* nbnxm_cuda_kernel.cuh:69-78 */
     constexpr bool USE_TABLE   = VdwTraits<VDW>::useTable;
@@ -191,8 +185,7 @@ __launch_bounds__(c_nbBlockSize) __attribute__((amdgpu_waves_per_eu(c_nbWavesPer
 
     /* LDS (all dynamic, sized by nbLdsBytes()): the LJ parameter table shared by the waves of the workgroup,
      * then per wave: two staging buffers for the j-side of a packed group (filled by LDS-direct loads, see the
-     * group loop) and (FUSED) its 64 i-atoms:
-     * { float4 x,q*epsfac (shifted) ; float2 epsfac*(qA,qB) ; int2 (typeA,typeB) } */
+     * group loop) */
     extern __shared__ __align__(16) unsigned char nbLds[];
     const int numTypes   = atdat.numTypes;
     float2*   nbfpLds    = reinterpret_cast<float2*>(nbLds);
@@ -200,10 +193,7 @@ __launch_bounds__(c_nbBlockSize) __attribute__((amdgpu_waves_per_eu(c_nbWavesPer
     const int      nbfpBytes  = USE_TABLE ? ((numTypes * numTypes * static_cast<int>(sizeof(float2)) + 15) & ~15) : 0;
     const int      tableBytes = nbfpBytes + (EWALD_CORR_TABLE ? c_ewaldCorrTabSize * static_cast<int>(sizeof(float2)) : 0);
     [[maybe_unused]] const float2* ewaldCorrLds = reinterpret_cast<const float2*>(nbLds + nbfpBytes);
-    unsigned char* jStage = nbLds + tableBytes + wave * (2 * c_jStageBytes + c_jRingBytes + (FUSED ? c_iStageBytes : 0));
-    float4*   xqib       = reinterpret_cast<float4*>(jStage + 2 * c_jStageBytes + c_jRingBytes);
-    float2*   qABib      = reinterpret_cast<float2*>(xqib + c_superClSize);
-    int2*     tABib      = reinterpret_cast<int2*>(qABib + c_superClSize);
+    unsigned char* jStage = nbLds + tableBytes + wave * (2 * c_jStageBytes + c_jRingBytes);
     if constexpr (USE_TABLE)
     {
         for (int t = threadIdx.x; t < numTypes * numTypes; t += blockSize) { nbfpLds[t] = nbp.nbfp[t]; }
@@ -244,7 +234,7 @@ __launch_bounds__(c_nbBlockSize) __attribute__((amdgpu_waves_per_eu(c_nbWavesPer
      * every scalar load in flight turns the next LDS wait into a full lgkmcnt(0)).  So nothing in the group
      * loop is loaded through registers.  With LDS-direct loads (global -> LDS, no VGPRs, counted by vmcnt),
      * while group g is computed:
-     *   W(g+3): the list words of group g+3 (32 bytes; FUSED: + the fepBits bytes of its j-clusters) go to a ring
+     *   W(g+3): the list words of group g+3 (32 bytes; FUSED: + its mask of perturbed cluster pairs) go to a ring
      *           of 4 records (three groups ahead: W(g+1) was issued before J(g-1), whose wait in the previous
      *           iteration therefore covers it, and the words of g+1 can be read without a wait of their own), and
      *   J(g+1): the j-side of group g+1 (32 x float4 xq, 32 types or LJ parameters, 64 exclusion words), addressed
@@ -271,7 +261,7 @@ __launch_bounds__(c_nbBlockSize) __attribute__((amdgpu_waves_per_eu(c_nbWavesPer
         if (lane < 8U) { ldsDirectLoad4(rec, gw * 32U + lane * 4U, cjPackedList); }                            \
         if constexpr (FUSED)                                                                                   \
         {                                                                                                      \
-            if (lane == 8U) { ldsDirectLoad4(rec, gw * 4U, groupFepJ); }                                       \
+            if (lane == 8U) { ldsDirectLoad4(rec, gw * 4U, groupSlowMask); }                                   \
         }                                                                                                      \
     }
 /* J(g): the three staging loads of group g into buffer buf; each lane reads the list words it needs from the ring */
@@ -311,7 +301,7 @@ __launch_bounds__(c_nbBlockSize) __attribute__((amdgpu_waves_per_eu(c_nbWavesPer
     int curBuf      = 0;  /* staging buffer that holds (or receives) the j-side of group stagedGroup */
     int stagedGroup = -1;
 
-    float E_lj = 0.0F, E_el = 0.0F, DVDL_lj = 0.0F, DVDL_el = 0.0F;
+    float E_lj = 0.0F, E_el = 0.0F;
 
     /* ---- the pieces of this wave's range: one per i-entry it touches ---------------------------------- */
 #pragma unroll 1
@@ -364,44 +354,16 @@ __launch_bounds__(c_nbBlockSize) __attribute__((amdgpu_waves_per_eu(c_nbWavesPer
         }
     }
 
-    /* perturbed-atom bits of the 8 i-clusters (FUSED) */
-    unsigned long long iFepBits        = 0;
-    unsigned           iFepClusterMask = 0U; /* bit i: i-cluster i holds a perturbed atom */
-    if constexpr (FUSED)
-    {
-        iFepBits = static_cast<unsigned long long>(fepWords[2 * sci]) | (static_cast<unsigned long long>(fepWords[2 * sci + 1]) << 32);
-#pragma unroll
-        for (int i = 0; i < c_numClPerSupercl; i++)
-        {
-            if ((iFepBits >> (i * c_clSize)) & 0xFFULL) { iFepClusterMask |= (1U << i); }
-        }
-    }
-
-    [[maybe_unused]] bool diagPiece = false; /* this piece holds the i-entry's own clusters as j-clusters */
     if constexpr (ENERGY && EXCL_FORCES)
     {
         /* self terms on the diagonal entry (nbnxm_cuda_kernel.cuh:365-400); lane l owns atom l.  The
-         * cluster's own j-cluster is the first one of the entry, so exactly one piece sees it. */
-        diagPiece = central && cjPackedList[cjPackedBegin].cj[0] == sci * c_numClPerSupercl;
-        if (diagPiece)
+         * cluster's own j-cluster is the first one of the entry, so exactly one piece sees it.  (Perturbed atoms
+         * carry q = 0 here; their lambda-dependent self term is nbnxmFepClusterKernel's.) */
+        if (central && cjPackedList[cjPackedBegin].cj[0] == sci * c_numClPerSupercl)
         {
             const float coef = (ELEC == ELK_CUT || ELEC == ELK_RF) ? -0.5F * nbp.c_rf : -nbp.ewald_beta * c_oneOverSqrtPi;
             const float qi   = xq[sci * c_superClSize + static_cast<int>(lane)].w * nbp.epsfac;
             E_el += qi * qi / nbp.epsfac * coef;
-            if constexpr (FUSED)
-            {
-                /* perturbed atoms carry q = 0 in xq; their lambda-dependent self term is what the i == j
-                 * entry of the atom-pair list contributes (nb_free_energy.cpp:1035-1052,1079-1100) */
-                if ((iFepBits >> lane) & 1ULL)
-                {
-                    const float4 q4l = atdat.q4[sci * c_superClSize + static_cast<int>(lane)];
-                    const float2 qAB = make_float2(q4l.x * nbp.epsfac, q4l.y * nbp.epsfac);
-                    const float  sA  = qAB.x * qAB.x / nbp.epsfac * coef;
-                    const float  sB  = qAB.y * qAB.y / nbp.epsfac * coef;
-                    E_el += (1.0F - nbp.lambda_q) * sA + nbp.lambda_q * sB;
-                    DVDL_el += sB - sA;
-                }
-            }
         }
     }
 
@@ -410,10 +372,6 @@ __launch_bounds__(c_nbBlockSize) __attribute__((amdgpu_waves_per_eu(c_nbWavesPer
 #pragma unroll
     for (int i = 0; i < c_numClPerSupercl; i++) { fci_buf[i] = make_float3(0.0F, 0.0F, 0.0F); }
 
-    /* FUSED: which j-cluster slots of this piece hold pairs left for pass 2: one bit per slot for the first 64
-     * slots (16 packed groups), one flag for everything beyond */
-    unsigned long long slowSlots    = 0ULL;
-    bool               slowOverflow = false;
 #pragma unroll 1
     for (int jPacked = cjPackedBegin; jPacked < cjPackedEnd; jPacked++)
     {
@@ -438,12 +396,10 @@ __launch_bounds__(c_nbBlockSize) __attribute__((amdgpu_waves_per_eu(c_nbWavesPer
         const nb_int4        recA = *reinterpret_cast<const nb_int4*>(rec);
         const nb_int4 curA = { __builtin_amdgcn_readfirstlane(recA.x), __builtin_amdgcn_readfirstlane(recA.y),
                                __builtin_amdgcn_readfirstlane(recA.z), __builtin_amdgcn_readfirstlane(recA.w) };
-        const unsigned imask = __builtin_amdgcn_readfirstlane(*reinterpret_cast<const unsigned*>(rec + 16U));
-        [[maybe_unused]] unsigned fepJCur = 0U; /* FUSED: fepBits of the 4 j-clusters, one byte each */
-        if constexpr (FUSED) { fepJCur = __builtin_amdgcn_readfirstlane(*reinterpret_cast<const unsigned*>(rec + 32U)); }
+        unsigned imask = __builtin_amdgcn_readfirstlane(*reinterpret_cast<const unsigned*>(rec + 16U));
+        /* FUSED: the cluster pairs that touch a perturbed atom are nbnxmFepClusterKernel's */
+        if constexpr (FUSED) { imask &= ~__builtin_amdgcn_readfirstlane(*reinterpret_cast<const unsigned*>(rec + 32U)); }
         const unsigned char* jData = jStage + curBuf * c_jStageBytes;
-        /* FUSED: can any pair of this group touch a perturbed atom?  (one scalar test for the common "no") */
-        [[maybe_unused]] const bool groupMaySkipPairs = FUSED && ((fepJCur | iFepClusterMask) != 0U);
         {
             const unsigned laneG = laneIdNow(); /* see NBNXM_STAGE_GROUP */
             const unsigned wexcl = *reinterpret_cast<const unsigned*>(jData + c_jStageExclOffset + laneG * 4U);
@@ -470,21 +426,7 @@ __launch_bounds__(c_nbBlockSize) __attribute__((amdgpu_waves_per_eu(c_nbWavesPer
                     ljcp_j.y = *reinterpret_cast<const float*>(jData + c_jStageLjOffset + 128U + jAtom * 4U);
                 }
 
-                unsigned fastMask = imaskJ;
-                if (FUSED && groupMaySkipPairs)
-                {
-                    /* pairs for pass 2: every i-cluster when the j-cluster holds a perturbed atom, otherwise the
-                     * i-clusters that hold one */
-                    const unsigned jFepBits = (fepJCur >> (jm * 8)) & 0xFFU;
-                    const unsigned slowMask = (jFepBits != 0U) ? imaskJ : (imaskJ & iFepClusterMask);
-                    if (slowMask != 0U)
-                    {
-                        const int slot = (jPacked - cjPackedBegin) * c_jGroupSize + jm;
-                        if (slot < 64) { slowSlots |= (1ULL << slot); }
-                        else { slowOverflow = true; }
-                    }
-                    fastMask = imaskJ & ~slowMask;
-                }
+                const unsigned fastMask = imaskJ;
                 /* which i-cluster (if any) is this j-cluster itself on the central image */
                 [[maybe_unused]] const int diagI = (central && (cj >> 3) == sci) ? (cj & 7) : -1;
 
@@ -530,261 +472,6 @@ __launch_bounds__(c_nbBlockSize) __attribute__((amdgpu_waves_per_eu(c_nbWavesPer
     }
     float3 fshiftAcc = mine; /* per-lane share of this entry's total i-force */
 
-    /* ---- pass 2 (FUSED, rare): pairs that touch a perturbed atom ------------------------------------ */
-    if constexpr (FUSED)
-    {
-        /* (a piece can hold the diagonal of an i-entry with perturbed atoms without holding any of its perturbed
-         * cluster pairs: it still owes the atoms' self terms at the foreign lambdas) */
-        if (slowSlots != 0ULL || slowOverflow || (FOREIGN && numForeignLambda >= 0 && diagPiece && iFepBits != 0ULL))
-        {
-            const FepLambda L = makeFepLambda(nbp.lambda_q, nbp.lambda_v, nbp.lam_power, nbp.alpha_coul, nbp.alpha_vdw);
-            const float2* __restrict__ nbfp = nbp.nbfp;
-            {
-                /* only now, for the ~1 % of the pieces that get here: the 64 i-atoms' A/B data, staged in LDS
-                 * because pass 2 indexes the i-clusters at run time */
-                const float3 sh = atdat.shiftVec[shiftIdx];
-                const int    ai = sci * c_superClSize + static_cast<int>(lane);
-                float4       xl = xq[ai];
-                xl.x += sh.x;
-                xl.y += sh.y;
-                xl.z += sh.z;
-                xl.w *= nbp.epsfac;
-                xqib[lane]      = xl;
-                const float4 q4 = atdat.q4[ai];
-                qABib[lane]     = make_float2(q4.x * nbp.epsfac, q4.y * nbp.epsfac);
-                const int4 t4   = atdat.atomTypes4[ai];
-                tABib[lane]     = make_int2(t4.x, t4.y);
-                /* the staged copy is private to this wave: LDS operations of one wave complete in order */
-                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-            }
-            for (int jPacked = cjPackedBegin; jPacked < cjPackedEnd; jPacked++)
-            {
-                /* only the slots flagged by the main pass are visited (no list or fepBits reads for the rest) */
-                const int      group     = jPacked - cjPackedBegin;
-                const unsigned groupSlow = (group < 16) ? static_cast<unsigned>(slowSlots >> (group * c_jGroupSize)) & 0xFU
-                                                        : (slowOverflow ? 0xFU : 0U);
-                if (groupSlow == 0U) { continue; }
-                const nbnxn_cj_packed_t* __restrict__ grp = &cjPackedList[jPacked];
-                const unsigned imask = grp->imei[0].imask;
-                if (imask == 0U) { continue; }
-                const int      exclInd0 = grp->imei[0].excl_ind;
-                const int      exclInd1 = grp->imei[1].excl_ind;
-                const unsigned wexcl    = exclList[half ? exclInd1 : exclInd0].pair[lane & 31U];
-#pragma unroll 1
-                for (int jm = 0; jm < c_jGroupSize; jm++)
-                {
-                    const unsigned imaskJ = (imask >> (jm * c_numClPerSupercl)) & 0xFFU;
-                    if (imaskJ == 0U || !((groupSlow >> jm) & 1U)) { continue; }
-                    const int      cj       = grp->cj[jm];
-                    const unsigned jFepBits = (fepWords[cj >> 2] >> ((cj & 3) * 8)) & 0xFFU;
-                    const unsigned slowMask = (jFepBits != 0U) ? imaskJ : (imaskJ & iFepClusterMask);
-                    if (slowMask == 0U) { continue; }
-                    const unsigned wexclJ = wexcl >> (jm * c_numClPerSupercl);
-                    const int      aj     = cj * c_clSize + static_cast<int>(tidxj);
-                    const float4   xqj    = xq[aj];
-                    const float4   q4j    = atdat.q4[aj];
-                    const int4     t4j    = atdat.atomTypes4[aj];
-                    int            typej  = 0;
-                    float2         ljcp_j = make_float2(0.0F, 0.0F);
-                    if constexpr (USE_TABLE) { typej = atomTypes[aj]; }
-                    else { ljcp_j = ljComb[aj]; }
-                    float3 fcj_buf = make_float3(0.0F, 0.0F, 0.0F);
-                    /* i is a run-time index here: the i-atom data comes from the wave's LDS copy.  Nothing in
-                     * this loop reads global memory, so its force atomics never stall a later load. */
-#pragma unroll 1
-                    for (int i = 0; i < c_numClPerSupercl; i++)
-                    {
-                        if (!(slowMask & (1U << i))) { continue; }
-                        const unsigned iBits    = static_cast<unsigned>(iFepBits >> (i * c_clSize)) & 0xFFU;
-                        const int      ci       = sci * c_numClPerSupercl + i;
-                        const int      ai       = ci * c_clSize + static_cast<int>(tidxi);
-                        const float4   xi       = xqib[i * c_clSize + tidxi];
-                        const int2     tABi     = tABib[i * c_clSize + tidxi];
-                        const float3   rv       = make_float3(xi.x - xqj.x, xi.y - xqj.y, xi.z - xqj.z);
-                        const float    r2       = rv.x * rv.x + rv.y * rv.y + rv.z * rv.z;
-                        const bool     included = ((wexclJ >> i) & 1U) != 0U;
-                        const bool     subDiag  = central && (ci == cj) && (tidxj <= tidxi);
-                        const bool     pert     = (((iBits >> tidxi) | (jFepBits >> tidxj)) & 1U) != 0U;
-                        float          F_invr   = 0.0F;
-                        if (pert)
-                        {
-                            if (!subDiag)
-                            {
-                                const float2 qABi   = qABib[i * c_clSize + tidxi];
-                                const float  qq[2]  = { qABi.x * q4j.x, qABi.y * q4j.y };
-                                const float2 pA     = USE_TABLE ? nbfpLds[numTypes * tABi.x + t4j.x] : nbfp[numTypes * tABi.x + t4j.x];
-                                const float2 pB     = USE_TABLE ? nbfpLds[numTypes * tABi.y + t4j.y] : nbfp[numTypes * tABi.y + t4j.y];
-                                const float  c6[2]  = { pA.x, pB.x };
-                                const float  c12[2] = { pA.y, pB.y };
-                                float        fscal  = 0.0F;
-                                const bool   done   = fepPair<FEP_ELEC, VDW == VDK_PSWITCH, true, ENERGY>(
-                                        nbp, L, r2, included, false, qq, c6, c12, fscal, E_lj, E_el, DVDL_lj, DVDL_el);
-                                F_invr = done ? fscal : 0.0F;
-                            }
-                        }
-                        else
-                        {
-                            const int intMask = included ? -1 : 0;
-                            bool        active;
-                            if constexpr (EXCL_FORCES) { active = (r2 < rcoulomb_sq) && !subDiag; }
-                            else { active = (r2 < rcoulomb_sq) && included; }
-                            if (active)
-                            {
-                                float c6, c12;
-                                if constexpr (USE_TABLE)
-                                {
-                                    /* a non-perturbed atom's type is its A-state type */
-                                    const float2 c6c12 = nbfpLds[numTypes * tABi.x + typej];
-                                    c6                 = c6c12.x;
-                                    c12                = c6c12.y;
-                                }
-                                else { ljFromComb(VDW, ljComb[ai], ljcp_j, c6, c12); }
-                                float E_lj_p = 0.0F, E_el_p = 0.0F;
-                                nbPair<ELEC, TWIN, VDW, ENERGY, EXCL_FORCES>(nbp, ewaldCorrLds, r2, intMask, xi.w * xqj.w, c6, c12, F_invr,
-                                                                             E_lj_p, E_el_p);
-                                if constexpr (ENERGY)
-                                {
-                                    E_lj += E_lj_p;
-                                    E_el += E_el_p;
-                                }
-                            }
-                        }
-                        const float3 f_ij = make_float3(rv.x * F_invr, rv.y * F_invr, rv.z * F_invr);
-                        fcj_buf.x -= f_ij.x;
-                        fcj_buf.y -= f_ij.y;
-                        fcj_buf.z -= f_ij.z;
-                        const float fix = reduceOverTidxj(f_ij.x);
-                        const float fiy = reduceOverTidxj(f_ij.y);
-                        const float fiz = reduceOverTidxj(f_ij.z);
-                        {
-                            const float v   = (tidxj == 0U) ? fix : ((tidxj == 1U) ? fiy : fiz);
-                            const int   off = (tidxj < 3U) ? (3 * ai + static_cast<int>(tidxj)) * static_cast<int>(sizeof(float)) : c_dropLane;
-                            __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(v, fRsrc, off, 0, 0);
-                        }
-                        fshiftAcc.x += f_ij.x;
-                        fshiftAcc.y += f_ij.y;
-                        fshiftAcc.z += f_ij.z;
-                    }
-                    const float fjx = reduceOver8Lanes(fcj_buf.x);
-                    const float fjy = reduceOver8Lanes(fcj_buf.y);
-                    const float fjz = reduceOver8Lanes(fcj_buf.z);
-                    {
-                        const float v   = (tidxi == 0U) ? fjx : ((tidxi == 1U) ? fjy : fjz);
-                        const int   off = (tidxi < 3U) ? (3 * aj + static_cast<int>(tidxi)) * static_cast<int>(sizeof(float)) : c_dropLane;
-                        __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(v, fRsrc, off, 0, 0);
-                    }
-                }
-            }
-
-            /* ---- foreign lambdas (dH/dl steps): energies of this piece's perturbed pairs at every lambda index,
-             * one more walk over the flagged slots per index; the role of nbnxn_foreign_fep_kernel_*
-             * (nbnxm/cuda/nbnxm_foreign_fep_cuda_kernel.cuh:88-583), without an atom-pair list */
-            if constexpr (FOREIGN)
-            {
-                static_assert(!FOREIGN || (ENERGY && FUSED), "the foreign-lambda flavour is an energy flavour of the fused kernel");
-                /* c_foreignChunk lambda indices per walk: the pair's geometry and parameters are loaded once for them */
-                constexpr int c_foreignChunk = 4;
-                for (int fbase = 0; fbase <= numForeignLambda; fbase += c_foreignChunk)
-                {
-                    FepLambda Lf[c_foreignChunk];
-                    float     fE_lj[c_foreignChunk], fE_el[c_foreignChunk], fDVDL_lj[c_foreignChunk], fDVDL_el[c_foreignChunk];
-#pragma unroll
-                    for (int q = 0; q < c_foreignChunk; q++)
-                    {
-                        const int   fidx = min(fbase + q, numForeignLambda);
-                        const float lc   = (fidx == 0) ? nbp.lambda_q : nbp.allLambdaCoul[fidx - 1];
-                        const float lv   = (fidx == 0) ? nbp.lambda_v : nbp.allLambdaVdw[fidx - 1];
-                        Lf[q]            = makeFepLambda(lc, lv, nbp.lam_power, nbp.alpha_coul, nbp.alpha_vdw);
-                        fE_lj[q] = fE_el[q] = fDVDL_lj[q] = fDVDL_el[q] = 0.0F;
-                        if constexpr (EXCL_FORCES)
-                        {
-                            if (diagPiece && ((iFepBits >> lane) & 1ULL))
-                            {
-                                const float  coef = (ELEC == ELK_CUT || ELEC == ELK_RF) ? -0.5F * nbp.c_rf : -nbp.ewald_beta * c_oneOverSqrtPi;
-                                const float2 qAB  = qABib[lane];
-                                const float  sA   = qAB.x * qAB.x / nbp.epsfac * coef;
-                                const float  sB   = qAB.y * qAB.y / nbp.epsfac * coef;
-                                fE_el[q] += (1.0F - lc) * sA + lc * sB;
-                                fDVDL_el[q] += sB - sA;
-                            }
-                        }
-                    }
-                    for (int jPacked = cjPackedBegin; jPacked < cjPackedEnd; jPacked++)
-                    {
-                        const int      group     = jPacked - cjPackedBegin;
-                        const unsigned groupSlow = (group < 16) ? static_cast<unsigned>(slowSlots >> (group * c_jGroupSize)) & 0xFU
-                                                                : (slowOverflow ? 0xFU : 0U);
-                        if (groupSlow == 0U) { continue; }
-                        const nbnxn_cj_packed_t* __restrict__ grp = &cjPackedList[jPacked];
-                        const unsigned imask = grp->imei[0].imask;
-                        if (imask == 0U) { continue; }
-                        const unsigned wexcl = exclList[half ? grp->imei[1].excl_ind : grp->imei[0].excl_ind].pair[lane & 31U];
-#pragma unroll 1
-                        for (int jm = 0; jm < c_jGroupSize; jm++)
-                        {
-                            const unsigned imaskJ = (imask >> (jm * c_numClPerSupercl)) & 0xFFU;
-                            if (imaskJ == 0U || !((groupSlow >> jm) & 1U)) { continue; }
-                            const int      cj       = grp->cj[jm];
-                            const unsigned jFepBits = (fepWords[cj >> 2] >> ((cj & 3) * 8)) & 0xFFU;
-                            const unsigned slowMask = (jFepBits != 0U) ? imaskJ : (imaskJ & iFepClusterMask);
-                            if (slowMask == 0U) { continue; }
-                            const unsigned wexclJ = wexcl >> (jm * c_numClPerSupercl);
-                            const int      aj     = cj * c_clSize + static_cast<int>(tidxj);
-                            const float4   xqj    = xq[aj];
-                            const float4   q4j    = atdat.q4[aj];
-                            const int4     t4j    = atdat.atomTypes4[aj];
-#pragma unroll 1
-                            for (int i = 0; i < c_numClPerSupercl; i++)
-                            {
-                                if (!(slowMask & (1U << i))) { continue; }
-                                const unsigned iBits   = static_cast<unsigned>(iFepBits >> (i * c_clSize)) & 0xFFU;
-                                const int      ci      = sci * c_numClPerSupercl + i;
-                                const bool     subDiag = central && (ci == cj) && (tidxj <= tidxi);
-                                const bool     pert    = (((iBits >> tidxi) | (jFepBits >> tidxj)) & 1U) != 0U;
-                                if (pert && !subDiag)
-                                {
-                                    const float4 xi     = xqib[i * c_clSize + tidxi];
-                                    const int2   tABi   = tABib[i * c_clSize + tidxi];
-                                    const float3 rv     = make_float3(xi.x - xqj.x, xi.y - xqj.y, xi.z - xqj.z);
-                                    const float  r2     = rv.x * rv.x + rv.y * rv.y + rv.z * rv.z;
-                                    const float2 qABi   = qABib[i * c_clSize + tidxi];
-                                    const float  qq[2]  = { qABi.x * q4j.x, qABi.y * q4j.y };
-                                    const float2 pA     = USE_TABLE ? nbfpLds[numTypes * tABi.x + t4j.x] : nbfp[numTypes * tABi.x + t4j.x];
-                                    const float2 pB     = USE_TABLE ? nbfpLds[numTypes * tABi.y + t4j.y] : nbfp[numTypes * tABi.y + t4j.y];
-                                    const float  c6[2]  = { pA.x, pB.x };
-                                    const float  c12[2] = { pA.y, pB.y };
-                                    float        fscal  = 0.0F;
-#pragma unroll
-                                    for (int q = 0; q < c_foreignChunk; q++)
-                                    {
-                                        fepPair<FEP_ELEC, VDW == VDK_PSWITCH, false, true>(nbp, Lf[q], r2, ((wexclJ >> i) & 1U) != 0U, false, qq, c6,
-                                                                                           c12, fscal, fE_lj[q], fE_el[q], fDVDL_lj[q], fDVDL_el[q]);
-                                    }
-                                }
-                            }
-                        }
-                    }
-#pragma unroll
-                    for (int q = 0; q < c_foreignChunk; q++)
-                    {
-                        const float s0 = waveSum(fE_lj[q]);
-                        const float s1 = waveSum(fE_el[q]);
-                        const float s2 = waveSum(fDVDL_lj[q]);
-                        const float s3 = waveSum(fDVDL_el[q]);
-                        if (lane < 4U && fbase + q <= numForeignLambda)
-                        {
-                            const float v   = (lane == 0U) ? s0 : ((lane == 1U) ? s1 : ((lane == 2U) ? s2 : s3));
-                            float*      out = (lane == 0U) ? atdat.eLJForeign
-                                                           : ((lane == 1U) ? atdat.eElecForeign
-                                                                           : ((lane == 2U) ? atdat.dvdlLJForeign : atdat.dvdlElecForeign));
-                            if (v != 0.0F) { atomicAdd(out + fbase + q, v); }
-                        }
-                    }
-                }
-            }
-        }
-    }
-
     if (bCalcFshiftIn && !central)
     {
         const float sx = waveSum(fshiftAcc.x);
@@ -821,16 +508,9 @@ __launch_bounds__(c_nbBlockSize) __attribute__((amdgpu_waves_per_eu(c_nbWavesPer
     {
         E_lj = waveSum(E_lj);
         E_el = waveSum(E_el);
-        if constexpr (FUSED)
-        {
-            DVDL_lj = waveSum(DVDL_lj);
-            DVDL_el = waveSum(DVDL_el);
-        }
-        /* lanes 0..3 add the four sums to this wave's accumulator slot (see NBAtomDataGpu::energySlots) */
-        const int slot = workItem & (c_numEnergySlots - 1);
-        float          v    = (lane == 0U) ? E_lj : E_el;
-        if constexpr (FUSED) { v = (lane == 2U) ? DVDL_lj : ((lane == 3U) ? DVDL_el : v); }
-        if (lane < (FUSED ? 4U : 2U)) { atomicAdd(atdat.energySlots + slot * c_energySlotStride + static_cast<int>(lane), v); }
+        const int   slot = workItem & (c_numEnergySlots - 1);
+        const float v    = (lane == 0U) ? E_lj : E_el;
+        if (lane < 2U) { atomicAdd(atdat.energySlots + slot * c_energySlotStride + static_cast<int>(lane), v); }
     }
 }
 

@@ -10,20 +10,29 @@
 
 using NbKernelPtr = void (*)(NBAtomDataGpu, NBParamGpu, gpu_plist, int, const nbnxn_sci_t*, const nbnxn_cj_packed_t*,
                              const nbnxn_excl_t*, const float4*, const int*, const float2*, const unsigned*, const int*,
-                             const int*, int, const unsigned*, int);
+                             const int*, int, const unsigned*);
+using FepClusterKernelPtr = void (*)(NBAtomDataGpu, NBParamGpu, gpu_plist, int, const nbnxn_sci_t*, const nbnxn_cj_packed_t*,
+                                     const nbnxn_excl_t*, const float4*, const int*, const float2*, const unsigned*, int);
 using FepKernelPtr   = void (*)(NBAtomDataGpu, NBParamGpu, gpu_feplist, int);
 using PruneKernelPtr = void (*)(NBAtomDataGpu, NBParamGpu, gpu_plist, int, int);
 
 /* vdwKind: VDK_* of nbnxm_device_helpers.h; returns nullptr for an unsupported flavour */
-NbKernelPtr nbKernelElecCut(int vdwKind, bool energy, bool fused, bool foreign);
-NbKernelPtr nbKernelElecRF(int vdwKind, bool energy, bool fused, bool foreign);
-NbKernelPtr nbKernelElecEwaldAna(int vdwKind, bool energy, bool fused, bool foreign);
-NbKernelPtr nbKernelElecEwaldTab(int vdwKind, bool energy, bool fused, bool foreign);
-NbKernelPtr nbKernelElecEwaldAnaTwin(int vdwKind, bool energy, bool fused, bool foreign);
-NbKernelPtr nbKernelElecEwaldTabTwin(int vdwKind, bool energy, bool fused, bool foreign);
+NbKernelPtr nbKernelElecCut(int vdwKind, bool energy, bool fused);
+FepClusterKernelPtr nbKernelElecCutFepCluster(int vdwKind, bool energy, bool foreign);
+NbKernelPtr nbKernelElecRF(int vdwKind, bool energy, bool fused);
+FepClusterKernelPtr nbKernelElecRFFepCluster(int vdwKind, bool energy, bool foreign);
+NbKernelPtr nbKernelElecEwaldAna(int vdwKind, bool energy, bool fused);
+FepClusterKernelPtr nbKernelElecEwaldAnaFepCluster(int vdwKind, bool energy, bool foreign);
+NbKernelPtr nbKernelElecEwaldTab(int vdwKind, bool energy, bool fused);
+FepClusterKernelPtr nbKernelElecEwaldTabFepCluster(int vdwKind, bool energy, bool foreign);
+NbKernelPtr nbKernelElecEwaldAnaTwin(int vdwKind, bool energy, bool fused);
+FepClusterKernelPtr nbKernelElecEwaldAnaTwinFepCluster(int vdwKind, bool energy, bool foreign);
+NbKernelPtr nbKernelElecEwaldTabTwin(int vdwKind, bool energy, bool fused);
+FepClusterKernelPtr nbKernelElecEwaldTabTwinFepCluster(int vdwKind, bool energy, bool foreign);
 
-/* foreign: the dH/dl-step flavour of the fused energy kernel (implies energy and fused) */
-NbKernelPtr    selectNbKernel(int elecType, int vdwType, bool energy, bool fused, bool foreign = false);
+NbKernelPtr    selectNbKernel(int elecType, int vdwType, bool energy, bool fused);
+/* fused mode: the kernel of the perturbed cluster pairs; foreign: its dH/dl-step flavour (implies energy) */
+FepClusterKernelPtr selectFepClusterKernel(int elecType, int vdwType, bool energy, bool foreign);
 FepKernelPtr   selectFepKernel(int elecType, int vdwType, bool energy);
 FepKernelPtr   selectFepForeignKernel(int elecType, int vdwType);
 PruneKernelPtr selectPruneKernel(bool haveFreshList);

@@ -1,24 +1,44 @@
 /* Cluster-pair kernel instantiations, electrostatics flavour: elec_rf (see nbnxm_kernel_impl.h). */
+#include "nbnxm_fep_cluster_kernel_impl.h"
 #include "nbnxm_kernel_impl.h"
 #include "nbnxm_kernels.h"
 
 template<int VDW>
-static NbKernelPtr pick(bool energy, bool fused, bool foreign)
+static NbKernelPtr pick(bool energy, bool fused)
 {
-    if (foreign) { return nbnxmKernel<ELK_RF, false, VDW, true, true, true>; }
-    if (energy) { return fused ? nbnxmKernel<ELK_RF, false, VDW, true, true> : nbnxmKernel<ELK_RF, false, VDW, true, false>; }
+        if (energy) { return fused ? nbnxmKernel<ELK_RF, false, VDW, true, true> : nbnxmKernel<ELK_RF, false, VDW, true, false>; }
     return fused ? nbnxmKernel<ELK_RF, false, VDW, false, true> : nbnxmKernel<ELK_RF, false, VDW, false, false>;
 }
 
-NbKernelPtr nbKernelElecRF(int vdwKind, bool energy, bool fused, bool foreign)
+NbKernelPtr nbKernelElecRF(int vdwKind, bool energy, bool fused)
 {
     switch (vdwKind)
     {
-        case VDK_CUT: return pick<VDK_CUT>(energy, fused, foreign);
-        case VDK_COMB_GEOM: return pick<VDK_COMB_GEOM>(energy, fused, foreign);
-        case VDK_COMB_LB: return pick<VDK_COMB_LB>(energy, fused, foreign);
-        case VDK_FSWITCH: return pick<VDK_FSWITCH>(energy, fused, foreign);
-        case VDK_PSWITCH: return pick<VDK_PSWITCH>(energy, fused, foreign);
+        case VDK_CUT: return pick<VDK_CUT>(energy, fused);
+        case VDK_COMB_GEOM: return pick<VDK_COMB_GEOM>(energy, fused);
+        case VDK_COMB_LB: return pick<VDK_COMB_LB>(energy, fused);
+        case VDK_FSWITCH: return pick<VDK_FSWITCH>(energy, fused);
+        case VDK_PSWITCH: return pick<VDK_PSWITCH>(energy, fused);
+        default: return nullptr;
+    }
+}
+
+template<int VDW>
+static FepClusterKernelPtr pickFepCluster(bool energy, bool foreign)
+{
+    if (foreign) { return nbnxmFepClusterKernel<ELK_RF, false, VDW, true, true>; }
+    return energy ? nbnxmFepClusterKernel<ELK_RF, false, VDW, true, false> : nbnxmFepClusterKernel<ELK_RF, false, VDW, false, false>;
+}
+
+FepClusterKernelPtr nbKernelElecRFFepCluster(int vdwKind, bool energy, bool foreign)
+{
+    switch (vdwKind)
+    {
+        case VDK_CUT: return pickFepCluster<VDK_CUT>(energy, foreign);
+        case VDK_COMB_GEOM: return pickFepCluster<VDK_COMB_GEOM>(energy, foreign);
+        case VDK_COMB_LB: return pickFepCluster<VDK_COMB_LB>(energy, foreign);
+        case VDK_FSWITCH: return pickFepCluster<VDK_FSWITCH>(energy, foreign);
+        case VDK_PSWITCH: return pickFepCluster<VDK_PSWITCH>(energy, foreign);
         default: return nullptr;
     }
 }

@@ -16,18 +16,34 @@ static int vdwKindOf(int vdwType)
     }
 }
 
-NbKernelPtr selectNbKernel(int elecType, int vdwType, bool energy, bool fused, bool foreign)
+NbKernelPtr selectNbKernel(int elecType, int vdwType, bool energy, bool fused)
 {
     const int vdwKind = vdwKindOf(vdwType);
     if (vdwKind < 0) { return nullptr; }
     switch (elecType)
     {
-        case NBNXM_ELEC_CUT: return nbKernelElecCut(vdwKind, energy, fused, foreign);
-        case NBNXM_ELEC_RF: return nbKernelElecRF(vdwKind, energy, fused, foreign);
-        case NBNXM_ELEC_EWALD_ANA: return nbKernelElecEwaldAna(vdwKind, energy, fused, foreign);
-        case NBNXM_ELEC_EWALD_TAB: return nbKernelElecEwaldTab(vdwKind, energy, fused, foreign);
-        case NBNXM_ELEC_EWALD_ANA_TWIN: return nbKernelElecEwaldAnaTwin(vdwKind, energy, fused, foreign);
-        case NBNXM_ELEC_EWALD_TAB_TWIN: return nbKernelElecEwaldTabTwin(vdwKind, energy, fused, foreign);
+        case NBNXM_ELEC_CUT: return nbKernelElecCut(vdwKind, energy, fused);
+        case NBNXM_ELEC_RF: return nbKernelElecRF(vdwKind, energy, fused);
+        case NBNXM_ELEC_EWALD_ANA: return nbKernelElecEwaldAna(vdwKind, energy, fused);
+        case NBNXM_ELEC_EWALD_TAB: return nbKernelElecEwaldTab(vdwKind, energy, fused);
+        case NBNXM_ELEC_EWALD_ANA_TWIN: return nbKernelElecEwaldAnaTwin(vdwKind, energy, fused);
+        case NBNXM_ELEC_EWALD_TAB_TWIN: return nbKernelElecEwaldTabTwin(vdwKind, energy, fused);
+        default: return nullptr;
+    }
+}
+
+FepClusterKernelPtr selectFepClusterKernel(int elecType, int vdwType, bool energy, bool foreign)
+{
+    const int vdwKind = vdwKindOf(vdwType);
+    if (vdwKind < 0) { return nullptr; }
+    switch (elecType)
+    {
+        case NBNXM_ELEC_CUT: return nbKernelElecCutFepCluster(vdwKind, energy, foreign);
+        case NBNXM_ELEC_RF: return nbKernelElecRFFepCluster(vdwKind, energy, foreign);
+        case NBNXM_ELEC_EWALD_ANA: return nbKernelElecEwaldAnaFepCluster(vdwKind, energy, foreign);
+        case NBNXM_ELEC_EWALD_TAB: return nbKernelElecEwaldTabFepCluster(vdwKind, energy, foreign);
+        case NBNXM_ELEC_EWALD_ANA_TWIN: return nbKernelElecEwaldAnaTwinFepCluster(vdwKind, energy, foreign);
+        case NBNXM_ELEC_EWALD_TAB_TWIN: return nbKernelElecEwaldTabTwinFepCluster(vdwKind, energy, foreign);
         default: return nullptr;
     }
 }
@@ -76,7 +92,8 @@ FepKernelPtr selectFepForeignKernel(int elecType, int vdwType)
 
 int nbKernelWavesPerEu(int vdwType, bool energy, bool fused)
 {
-    return (vdwKindOf(vdwType) == VDK_CUT && !energy && !fused) ? c_nbWavesPerEu<VDK_CUT, false, false> : c_nbWavesPerEu<VDK_PSWITCH, true, true>;
+    (void)fused;
+    return (vdwKindOf(vdwType) == VDK_CUT && !energy) ? c_nbWavesPerEu<VDK_CUT, false> : c_nbWavesPerEu<VDK_PSWITCH, true>;
 }
 
 PruneKernelPtr selectPruneKernel(bool haveFreshList)

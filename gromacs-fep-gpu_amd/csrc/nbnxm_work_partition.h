@@ -3,11 +3,13 @@
  * balancing is the host-side sci splitting of nbnxm/pairlist.cpp:2283-2400 against gpu_min_ci_balanced).
  *
  * The list is cut into as many contiguous ranges of packed j-groups as the device has resident wave slots,
- * all of the same weight: weight(group) = set imask bits (+ fepPairWeight x cluster pairs that hold a perturbed
- * atom when the fused kernel evaluates them in its second pass).  Three small kernels, run on the list's own
+ * all of the same weight (an instruction-count model of the kernel's loop levels, see nbnxmWorkWeightKernel).  In
+ * fused mode the same pass marks the cluster pairs that touch a perturbed atom (they are left to
+ * nbnxmFepClusterKernel) and lists the groups that have any.  Three small kernels, run on the list's own
  * stream after every (re)prune, because pruning changes the masks on the device:
- *   nbnxmWorkWeightKernel  one thread per group: weight + per-256-group sums (+ the fepBits bytes of the group's
- *                          j-clusters, which the fused kernel stages together with the list words)
+ *   nbnxmWorkWeightKernel  one thread per group: weight + per-256-group sums (+ fused mode: the group's mask of
+ *                          perturbed cluster pairs, staged by the cluster kernel together with the list words, and
+ *                          the list of groups that have any)
  *   nbnxmWorkScanKernel    one workgroup: exclusive scan of the sums
  *   nbnxmWorkRangesKernel  one thread per group: global prefix -> the range borders that fall on this group,
  *                          for both partitions (4 and 5 waves per SIMD), plus the i-entry each range starts in
@@ -60,9 +62,12 @@ __launch_bounds__(c_workBlockSize) __global__
                                    const int                             ncjPacked,
                                    const nbnxn_sci_t* __restrict__       sciSorted,
                                    const int                             nsci,
-                                   const unsigned char* __restrict__     fepBits, /* nullptr: no perturbed-pair weighting */
-                                   const int                             fepPairWeight, /* 0: count plain pairs only */
-                                   unsigned* __restrict__                groupFepJ,
+                                   const unsigned char* __restrict__     fepBits, /* nullptr: not the fused mode */
+                                   const int                             buildSlowList, /* 0: groupSlowMask is up to date */
+                                   unsigned* __restrict__                groupSlowMask,
+                                   int* __restrict__                     slowGroups,   /* groups with a non-zero slow mask ... */
+                                   int* __restrict__                     slowGroupSci, /* ... and the index of their i-entry */
+                                   int* __restrict__                     slowCount,
                                    int* __restrict__                     groupWeight,
                                    int* __restrict__                     blockSum)
 {
@@ -71,40 +76,43 @@ __launch_bounds__(c_workBlockSize) __global__
     int            w = 0;
     if (g < ncjPacked)
     {
-        /* cost model in units of 1/8 cluster pair (instruction counts of the kernel's loop levels): a cluster pair,
-         * a non-empty j-cluster slot (staged reads, j-force reduction, atomic), a group (staging loads), and the
-         * start of an i-entry (i-atom loads, i-force reduction and atomics) */
         const unsigned imask = cjPacked[g].imei[0].imask;
-        int            slots = 0;
-        for (int jm = 0; jm < c_jGroupSize; jm++) { slots += ((imask >> (jm * c_numClPerSupercl)) & 0xFFU) != 0U ? 1 : 0; }
-        w                    = c_weightPair * __popc(imask) + c_weightSlot * slots + (imask != 0U ? c_weightGroup : 0);
-        const int k          = findSciOfGroup(sciSorted, nsci, g);
-        if (k >= 0 && sciSorted[k].cjPackedBegin == g) { w += c_weightEntry; }
-        unsigned fepJ        = 0U;
-        if (fepBits != nullptr)
+        const int      k     = findSciOfGroup(sciSorted, nsci, g);
+        const bool     owned = (k >= 0 && g < sciSorted[k].cjPackedEnd);
+        /* fused mode: the cluster pairs of this group that touch a perturbed atom (Grid::fepBits): every i-cluster when
+         * the j-cluster holds one, otherwise the i-clusters that hold one.  Independent of the distance pruning, so it is
+         * computed once per list; the cluster kernel masks them out, nbnxmFepClusterKernel evaluates them. */
+        unsigned slow = 0U;
+        if (fepBits != nullptr && !buildSlowList) { slow = groupSlowMask[g]; }
+        if (fepBits != nullptr && buildSlowList && owned)
         {
-            for (int jm = 0; jm < c_jGroupSize; jm++) { fepJ |= static_cast<unsigned>(fepBits[cjPacked[g].cj[jm]]) << (8 * jm); }
-        }
-        groupFepJ[g] = fepJ;
-        if (fepBits != nullptr && fepPairWeight > 0 && imask != 0U)
-        {
-            if (k >= 0 && g < sciSorted[k].cjPackedEnd)
+            const int sci          = sciSorted[k].sci;
+            unsigned  iClusterMask = 0U;
+            for (int i = 0; i < c_numClPerSupercl; i++)
             {
-                const int sci          = sciSorted[k].sci;
-                unsigned  iClusterMask = 0U;
-                for (int i = 0; i < c_numClPerSupercl; i++)
-                {
-                    if (fepBits[sci * c_numClPerSupercl + i] != 0) { iClusterMask |= (1U << i); }
-                }
-                for (int jm = 0; jm < c_jGroupSize; jm++)
-                {
-                    const unsigned imaskJ = (imask >> (jm * c_numClPerSupercl)) & 0xFFU;
-                    if (imaskJ == 0U) { continue; }
-                    const unsigned slow = (fepBits[cjPacked[g].cj[jm]] != 0) ? imaskJ : (imaskJ & iClusterMask);
-                    w += c_weightPair * fepPairWeight * __popc(slow);
-                }
+                if (fepBits[sci * c_numClPerSupercl + i] != 0) { iClusterMask |= (1U << i); }
+            }
+            for (int jm = 0; jm < c_jGroupSize; jm++)
+            {
+                const unsigned m = (fepBits[cjPacked[g].cj[jm]] != 0) ? 0xFFU : iClusterMask;
+                slow |= m << (jm * c_numClPerSupercl);
+            }
+            if (slow != 0U)
+            {
+                const int idx     = atomicAdd(slowCount, 1);
+                slowGroups[idx]   = g;
+                slowGroupSci[idx] = k;
             }
         }
+        if (buildSlowList) { groupSlowMask[g] = slow; }
+        /* cost model in units of 1/8 cluster pair (fitted to per-SIMD finish times, tools/calibrate_weights.py): a
+         * cluster pair, a non-empty j-cluster slot (staged reads, j-force reduction, atomic), a group (staging loads,
+         * waits), and the start of an i-entry (i-atom loads, i-force reduction and atomics) */
+        const unsigned fast  = imask & ~slow;
+        int            slots = 0;
+        for (int jm = 0; jm < c_jGroupSize; jm++) { slots += ((fast >> (jm * c_numClPerSupercl)) & 0xFFU) != 0U ? 1 : 0; }
+        w = c_weightPair * __popc(fast) + c_weightSlot * slots + (fast != 0U ? c_weightGroup : 0);
+        if (owned && sciSorted[k].cjPackedBegin == g) { w += c_weightEntry; }
         groupWeight[g] = w;
     }
     int total;
