@@ -1192,6 +1192,30 @@ void nbnxm_gpu_debug_timeline(NbnxmGpu* nb, unsigned long long* out, int numWave
 }
 #endif
 
+/* Experiment: clear + kernels of one force step captured into a hipGraph and replayed numSteps times */
+void nbnxm_gpu_debug_graph_steps(NbnxmGpu* nb, const nbnxm_step_workload_t* stepWork, int numSteps)
+{
+    hipStream_t s = nb->deviceStreams[0].stream;
+    /* steady state only: no fresh list, no dirty partition */
+    nbnxm_gpu_clear_outputs(nb, stepWork->computeVirial);
+    nbnxm_gpu_launch_kernel(nb, stepWork, NBNXM_LOCAL);
+    NBNXM_HIP_CHECK(hipStreamSynchronize(s));
+    const bool timing = nb->bDoTime;
+    nb->bDoTime       = false;
+    hipGraph_t     graph;
+    hipGraphExec_t exec;
+    NBNXM_HIP_CHECK(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+    nbnxm_gpu_clear_outputs(nb, stepWork->computeVirial);
+    nbnxm_gpu_launch_kernel(nb, stepWork, NBNXM_LOCAL);
+    NBNXM_HIP_CHECK(hipStreamEndCapture(s, &graph));
+    NBNXM_HIP_CHECK(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
+    for (int i = 0; i < numSteps; i++) { NBNXM_HIP_CHECK(hipGraphLaunch(exec, s)); }
+    NBNXM_HIP_CHECK(hipStreamSynchronize(s));
+    NBNXM_HIP_CHECK(hipGraphExecDestroy(exec));
+    NBNXM_HIP_CHECK(hipGraphDestroy(graph));
+    nb->bDoTime = timing;
+}
+
 void* nbnxm_gpu_debug_get_work_ranges(NbnxmGpu* nb, int iloc, int p, int* numRanges)
 {
     NBNXM_ASSERT(p == 0 || p == 1, "partition index is 0 or 1");
