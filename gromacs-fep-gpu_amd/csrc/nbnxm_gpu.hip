@@ -260,7 +260,9 @@ NbnxmGpu* nbnxm_gpu_init(const nbnxm_interaction_params_t* ic, int numTypes, con
      *  pad to a 128-byte line, energySlots[c_numEnergySlots][c_energySlotStride]] */
     nb->numHeadScalars   = 4 + 4 * (n_lambda + 1);
     nb->slotOffset       = (nb->numHeadScalars + c_energySlotStride - 1) / c_energySlotStride * c_energySlotStride;
-    nb->numScalarOutputs = nb->slotOffset + c_numEnergySlots * c_energySlotStride;
+    nb->foreignSlotOffset = nb->slotOffset + c_numEnergySlots * c_energySlotStride;
+    nb->foreignSlotStride = (4 * (n_lambda + 1) + c_energySlotStride - 1) / c_energySlotStride * c_energySlotStride;
+    nb->numScalarOutputs  = nb->foreignSlotOffset + c_numForeignSlots * nb->foreignSlotStride;
     pinned(&nb->nbst.scalars, nb->numScalarOutputs);
     pinned(&nb->nbst.fShift, 3 * c_numShiftVectors);
     nb->nbst.eLJ             = nb->nbst.scalars + 0;
@@ -272,6 +274,7 @@ NbnxmGpu* nbnxm_gpu_init(const nbnxm_interaction_params_t* ic, int numTypes, con
     nb->nbst.dvdlLJForeign   = nb->nbst.eElecForeign + (n_lambda + 1);
     nb->nbst.dvdlElecForeign = nb->nbst.dvdlLJForeign + (n_lambda + 1);
     nb->nbst.energySlots     = nb->nbst.scalars + nb->slotOffset;
+    nb->nbst.foreignSlots    = nb->nbst.scalars + nb->foreignSlotOffset;
 
     /* initNbparam :421-489 */
     NBParamGpu* nbp = nb->nbparam;
@@ -317,6 +320,8 @@ NbnxmGpu* nbnxm_gpu_init(const nbnxm_interaction_params_t* ic, int numTypes, con
     ad->dvdlLJForeign   = ad->eElecForeign + (n_lambda + 1);
     ad->dvdlElecForeign = ad->dvdlLJForeign + (n_lambda + 1);
     ad->energySlots     = nb->scalarOutputs + nb->slotOffset;
+    ad->foreignSlots      = nb->scalarOutputs + nb->foreignSlotOffset;
+    ad->foreignSlotStride = nb->foreignSlotStride;
     allocateDeviceBuffer(&ad->fShift, c_numShiftVectors);
     clearDeviceBufferAsync(&ad->fShift, 0, c_numShiftVectors, s);
     clearDeviceBufferAsync(&nb->scalarOutputs, 0, nb->numScalarOutputs, s);
@@ -364,8 +369,8 @@ void nbnxm_gpu_free(NbnxmGpu* nb)
             freeDeviceBuffer(&nb->plist[i]->sciSorted);
             freeDeviceBuffer(&nb->plist[i]->groupWeight);
             freeDeviceBuffer(&nb->plist[i]->groupSlowMask);
-            freeDeviceBuffer(&nb->plist[i]->slowGroups);
-            freeDeviceBuffer(&nb->plist[i]->slowGroupSci);
+            freeDeviceBuffer(&nb->plist[i]->slowPairs);
+            freeDeviceBuffer(&nb->plist[i]->slowPairSci);
             freeDeviceBuffer(&nb->plist[i]->slowCount);
             freeDeviceBuffer(&nb->plist[i]->weightBlockSum);
             for (int p = 0; p < 2; p++)
@@ -769,11 +774,12 @@ static void updateWorkPartition(NbnxmGpu* nb, int iloc)
     if (d->groupWeight_nalloc != oldAlloc)
     {
         freeDeviceBuffer(&d->groupSlowMask);
-        freeDeviceBuffer(&d->slowGroups);
-        freeDeviceBuffer(&d->slowGroupSci);
+        freeDeviceBuffer(&d->slowPairs);
+        freeDeviceBuffer(&d->slowPairSci);
+        d->slowPairs_nalloc = std::max(8192, 2 * d->groupWeight_nalloc); /* a ligand-sized region has a few thousand */
         allocateDeviceBuffer(&d->groupSlowMask, d->groupWeight_nalloc);
-        allocateDeviceBuffer(&d->slowGroups, d->groupWeight_nalloc);
-        allocateDeviceBuffer(&d->slowGroupSci, d->groupWeight_nalloc);
+        allocateDeviceBuffer(&d->slowPairs, d->slowPairs_nalloc);
+        allocateDeviceBuffer(&d->slowPairSci, d->slowPairs_nalloc);
         d->slowListDirty = true;
     }
     if (d->slowCount == nullptr) { allocateDeviceBuffer(&d->slowCount, 1); }
@@ -782,8 +788,8 @@ static void updateWorkPartition(NbnxmGpu* nb, int iloc)
     const bool buildSlow = fused && d->slowListDirty;
     if (buildSlow) { clearDeviceBufferAsync(&d->slowCount, 0, 1, s); }
     hipLaunchKernelGGL(nbnxmWorkWeightKernel, dim3(numBlocks), dim3(c_workBlockSize), 0, s, d->cjPacked, d->ncjPacked, d->sciSorted,
-                       d->nsci, fused ? nb->atdat->fepBits : nullptr, buildSlow ? 1 : 0, d->groupSlowMask, d->slowGroups, d->slowGroupSci,
-                       d->slowCount, d->groupWeight, d->weightBlockSum);
+                       d->nsci, fused ? nb->atdat->fepBits : nullptr, buildSlow ? 1 : 0, d->groupSlowMask, d->slowPairs, d->slowPairSci,
+                       d->slowPairs_nalloc, d->slowCount, d->groupWeight, d->weightBlockSum);
     hipLaunchKernelGGL(nbnxmWorkScanKernel, dim3(1), dim3(c_workBlockSize), 0, s, d->weightBlockSum, numBlocks);
     NBNXM_HIP_CHECK(hipGetLastError());
     if (buildSlow)
@@ -793,10 +799,12 @@ static void updateWorkPartition(NbnxmGpu* nb, int iloc)
         nb->h_slowCount.resize(1);
         NBNXM_HIP_CHECK(hipMemcpyAsync(nb->h_slowCount.data, d->slowCount, sizeof(int), hipMemcpyDeviceToHost, s));
         NBNXM_HIP_CHECK(hipStreamSynchronize(s));
-        d->numSlowGroups = nb->h_slowCount.data[0];
+        d->numSlowPairs  = nb->h_slowCount.data[0];
         d->slowListDirty = false;
+        NBNXM_ASSERT(d->numSlowPairs <= d->slowPairs_nalloc,
+                     "more perturbed cluster pairs than the fused mode provides for (use the atom-pair list mode for large perturbed regions)");
     }
-    if (!fused) { d->numSlowGroups = 0; }
+    if (!fused) { d->numSlowPairs = 0; }
 
     WorkPartitionOut out[2];
     for (int p = 0; p < 2; p++)
@@ -931,6 +939,8 @@ void nbnxm_gpu_launch_kernel(NbnxmGpu* nb, const nbnxm_step_workload_t* stepWork
         }
     }
 
+    /* fused mode: the list of perturbed cluster pairs is built from the masks of the unpruned list */
+    if (fused && plist->slowListDirty && plist->nsci > 0) { updateWorkPartition(nb, iloc); }
     if (nbp->useDynamicPruning && plist->haveFreshList)
     {
         nbnxm_gpu_launch_kernel_pruneonly(nb, iloc, 1);
@@ -946,7 +956,7 @@ void nbnxm_gpu_launch_kernel(NbnxmGpu* nb, const nbnxm_step_workload_t* stepWork
         }
         if (plist->workRangesDirty) { updateWorkPartition(nb, iloc); }
 
-        if (fused && plist->numSlowGroups > 0)
+        if (fused && plist->numSlowPairs > 0)
         {
             /* the cluster pairs that touch a perturbed atom: a few thousand short latency-bound waves, ~13 us on the 96k
              * box.  On the same stream, ahead of the cluster kernel: measured on MI355X a second stream does not help here
@@ -964,14 +974,14 @@ void nbnxm_gpu_launch_kernel(NbnxmGpu* nb, const nbnxm_step_workload_t* stepWork
                 fepForked = true;
             }
             const bool fepUseTable = (nbp->vdwType == NBNXM_VDW_CUT || nbp->vdwType == NBNXM_VDW_FSWITCH || nbp->vdwType == NBNXM_VDW_PSWITCH);
-            const int  fepLds      = (fepUseTable ? ((adat->numTypes * adat->numTypes * 8 + 15) & ~15) : 0) + c_fepClusterWavesPerBlockDef * c_iStageBytes;
+            const int  fepLds      = fepUseTable ? ((adat->numTypes * adat->numTypes * 8 + 15) & ~15) : 0;
             NBNXM_ASSERT(fepLds <= 160 * 1024, "too many atom types: the LJ parameter table does not fit the 160 KB LDS");
             if (fepLds > 64 * 1024)
             {
                 NBNXM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(fk), hipFuncAttributeMaxDynamicSharedMemorySize, fepLds));
             }
             if (nb->bDoTime) { t.fep_k.openTimingRegion(fs); }
-            const int numFepWaves = plist->numSlowGroups * c_jGroupSize; /* one wave per (group, j-cluster slot) */
+            const int numFepWaves = plist->numSlowPairs; /* one wave per perturbed cluster pair */
             hipLaunchKernelGGL(fk, dim3((numFepWaves + c_fepClusterWavesPerBlockDef - 1) / c_fepClusterWavesPerBlockDef),
                                dim3(c_fepClusterWavesPerBlockDef * c_waveSize), fepLds, fs, *adat, *nbp, *plist, stepWork->computeVirial,
                                plist->sciSorted, plist->cjPacked, plist->excl, adat->xq, adat->atomTypes, adat->ljComb,
@@ -1046,7 +1056,8 @@ void nbnxm_gpu_launch_cpyback(NbnxmGpu* nb, float* f_out, const nbnxm_step_workl
         const bool wantForeign = nb->n_lambda > 0 && stepWork->computeDhdl;
         if (stepWork->computeEnergy || wantForeign)
         {
-            const int n = stepWork->computeEnergy ? nb->numScalarOutputs : nb->numHeadScalars;
+            /* (dH/dl steps bring the foreign-lambda slots, which lie behind the energy slots) */
+            const int n = wantForeign ? nb->numScalarOutputs : (stepWork->computeEnergy ? nb->foreignSlotOffset : nb->numHeadScalars);
             NBNXM_HIP_CHECK(hipMemcpyAsync(nb->nbst.scalars, nb->scalarOutputs, sizeof(float) * n, hipMemcpyDeviceToHost, s));
         }
     }
@@ -1091,12 +1102,19 @@ static int finishTask(NbnxmGpu* nb, const nbnxm_step_workload_t* stepWork, int a
             if (nb->n_lambda > 0 && stepWork->computeDhdl && enerd != nullptr && enerd->foreign_energies != nullptr)
             {
                 NBNXM_ASSERT(enerd->n_lambda == nb->n_lambda, "foreign-lambda accumulator has a different n_lambda");
+                const int n1 = nb->n_lambda + 1;
                 for (int idx = 0; idx <= nb->n_lambda; idx++)
                 {
-                    enerd->foreign_energies[idx] += nb->nbst.eLJForeign[idx];
-                    enerd->foreign_dhdl_vdw[idx] += nb->nbst.dvdlLJForeign[idx];
-                    enerd->foreign_energies[idx] += nb->nbst.eElecForeign[idx];
-                    enerd->foreign_dhdl_coul[idx] += nb->nbst.dvdlElecForeign[idx];
+                    /* staged arrays (atom-pair foreign kernel) + the accumulator slots of the fused mode's kernel */
+                    double t[4] = { nb->nbst.eLJForeign[idx], nb->nbst.eElecForeign[idx], nb->nbst.dvdlLJForeign[idx], nb->nbst.dvdlElecForeign[idx] };
+                    for (int k = 0; k < c_numForeignSlots; k++)
+                    {
+                        const float* slot = nb->nbst.foreignSlots + k * nb->foreignSlotStride;
+                        for (int c = 0; c < 4; c++) { t[c] += slot[c * n1 + idx]; }
+                    }
+                    enerd->foreign_energies[idx] += t[0] + t[1];
+                    enerd->foreign_dhdl_vdw[idx] += t[2];
+                    enerd->foreign_dhdl_coul[idx] += t[3];
                 }
             }
         }

@@ -29,7 +29,8 @@ struct NBStagingData
     /* MI355X: one pinned mirror of the device's scalar-output block (the pointers above, except fShift, point
      * into it) so that one D2H copy brings everything back; energySlots: see NBAtomDataGpu::energySlots */
     float* scalars     = nullptr;
-    float* energySlots = nullptr;
+    float* energySlots  = nullptr;
+    float* foreignSlots = nullptr;
 };
 
 struct InteractionTimers
@@ -91,6 +92,8 @@ struct NbnxmGpu
     float* scalarOutputs    = nullptr; /* device block behind atdat->eLJ ... dvdlElecForeign, energySlots */
     int    numHeadScalars   = 0;       /* scalars + foreign arrays */
     int    slotOffset       = 0;       /* first float of the energy slots */
+    int    foreignSlotOffset = 0;      /* first float of the foreign-lambda slots */
+    int    foreignSlotStride = 0;
     int    numScalarOutputs = 0;
 
     /* allocation bookkeeping */

@@ -29,6 +29,7 @@ constexpr float c_nbnxnMinDistanceSquared = 3.82e-07F;
 /* nb_free_energy.cpp:107: cap on r^-6 in the perturbed-pair math */
 constexpr float c_maxRInvSix = 1.0e15F;
 constexpr int c_numEnergySlots   = 128;
+constexpr int c_numForeignSlots  = 64;
 constexpr int c_energySlotStride = 32;
 
 /* nbnxm/gpu_types_common.h:103-155 */
@@ -70,6 +71,10 @@ struct NBAtomDataGpu
      * thousands of waves adding to ONE address serialise in L2 at ~10 ns per atomic (measured: +0.25 ms per
      * energy step at 96k atoms).  The slots are summed on the host with the staged scalars (gpu_try_finish_task). */
     float* energySlots;
+    /* ... and the same for the foreign-lambda terms of nbnxmFepClusterKernel: c_numForeignSlots accumulators of
+     * foreignSlotStride floats, [eLJ[n+1], eElec[n+1], dvdlLJ[n+1], dvdlElec[n+1], pad] each */
+    float* foreignSlots;
+    int    foreignSlotStride;
 };
 
 /* nbnxm/gpu_types_common.h:160-237 */
@@ -164,10 +169,11 @@ struct gpu_plist
     nbnxn_sci_t* sciSorted;
     int          sciSorted_nalloc;
     unsigned*    groupSlowMask;   /* ncjPacked: fused mode, the cluster pairs of each group that touch a perturbed atom */
-    int*         slowGroups;      /* numSlowGroups (<= ncjPacked): the groups with a non-zero slow mask */
-    int*         slowGroupSci;    /* ... and the index of their i-entry in sciSorted */
-    int*         slowCount;       /* device counter behind numSlowGroups */
-    int          numSlowGroups;
+    int*         slowPairs;       /* numSlowPairs: group * 32 + jm * 8 + i of every listed cluster pair with a perturbed atom */
+    int*         slowPairSci;     /* ... and its i-entry as sci * 64 + shift index */
+    int*         slowCount;       /* device counter behind numSlowPairs */
+    int          numSlowPairs;
+    int          slowPairs_nalloc;
     bool         slowListDirty;   /* the list, fepBits or the mode changed since groupSlowMask / slowGroups were built */
     int*         groupWeight;     /* ncjPacked, scratch */
     int          groupWeight_nalloc;

@@ -5,11 +5,11 @@
  * The list is cut into as many contiguous ranges of packed j-groups as the device has resident wave slots,
  * all of the same weight (an instruction-count model of the kernel's loop levels, see nbnxmWorkWeightKernel).  In
  * fused mode the same pass marks the cluster pairs that touch a perturbed atom (they are left to
- * nbnxmFepClusterKernel) and lists the groups that have any.  Three small kernels, run on the list's own
+ * nbnxmFepClusterKernel) and lists them.  Three small kernels, run on the list's own
  * stream after every (re)prune, because pruning changes the masks on the device:
  *   nbnxmWorkWeightKernel  one thread per group: weight + per-256-group sums (+ fused mode: the group's mask of
  *                          perturbed cluster pairs, staged by the cluster kernel together with the list words, and
- *                          the list of groups that have any)
+ *                          the list of those pairs)
  *   nbnxmWorkScanKernel    one workgroup: exclusive scan of the sums
  *   nbnxmWorkRangesKernel  one thread per group: global prefix -> the range borders that fall on this group,
  *                          for both partitions (4 and 5 waves per SIMD), plus the i-entry each range starts in
@@ -65,8 +65,9 @@ __launch_bounds__(c_workBlockSize) __global__
                                    const unsigned char* __restrict__     fepBits, /* nullptr: not the fused mode */
                                    const int                             buildSlowList, /* 0: groupSlowMask is up to date */
                                    unsigned* __restrict__                groupSlowMask,
-                                   int* __restrict__                     slowGroups,   /* groups with a non-zero slow mask ... */
-                                   int* __restrict__                     slowGroupSci, /* ... and the index of their i-entry */
+                                   int* __restrict__                     slowPairs,   /* group * 32 + jm * 8 + i of every listed slow pair ... */
+                                   int* __restrict__                     slowPairSci, /* ... and its i-entry: sci * 64 + shift index */
+                                   const int                             slowCapacity,
                                    int* __restrict__                     slowCount,
                                    int* __restrict__                     groupWeight,
                                    int* __restrict__                     blockSum)
@@ -97,11 +98,21 @@ __launch_bounds__(c_workBlockSize) __global__
                 const unsigned m = (fepBits[cjPacked[g].cj[jm]] != 0) ? 0xFFU : iClusterMask;
                 slow |= m << (jm * c_numClPerSupercl);
             }
-            if (slow != 0U)
+            /* the list masks are those of the fresh, unpruned list here (the launcher builds this before the first prune),
+             * so the pairs are a superset of what any later pruning leaves */
+            unsigned  todo = slow & imask;
+            const int n    = __popc(todo);
+            if (n > 0)
             {
-                const int idx     = atomicAdd(slowCount, 1);
-                slowGroups[idx]   = g;
-                slowGroupSci[idx] = k;
+                int idx = atomicAdd(slowCount, n);
+                while (todo != 0U && idx < slowCapacity)
+                {
+                    const int bit    = __ffs(todo) - 1;
+                    slowPairs[idx]   = g * 32 + bit;
+                    slowPairSci[idx] = sciSorted[k].sci * 64 + (sciSorted[k].shift & NBNXM_CI_SHIFT_MASK);
+                    todo &= todo - 1U;
+                    idx++;
+                }
             }
         }
         if (buildSlowList) { groupSlowMask[g] = slow; }
