@@ -204,7 +204,6 @@ NbnxmGpu* nbnxm_gpu_init(const nbnxm_interaction_params_t* ic, int numTypes, con
         NBNXM_HIP_CHECK(hipGetDevice(&device));
         NBNXM_HIP_CHECK(hipGetDeviceProperties(&prop, device));
         nb->numSimds = prop.multiProcessorCount * 4; /* CDNA: 4 SIMDs per CU */
-        if (const char* env = std::getenv("NBNXM_HIP_FEP_PAIR_WEIGHT")) { nb->fepPairWeight = std::max(0, std::atoi(env)); }
         if (const char* env = std::getenv("NBNXM_HIP_NUM_WORK_RANGES")) { nb->numWorkRangesOverride = std::atoi(env); }
         if (const char* env = std::getenv("NBNXM_HIP_MIN_GROUPS_PER_WAVE")) { nb->minGroupsPerWave = std::max(1, std::atoi(env)); }
     }

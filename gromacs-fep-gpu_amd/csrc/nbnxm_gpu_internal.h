@@ -69,10 +69,8 @@ struct NbnxmGpu
     int  numCUs    = 256;
 
     int nbWavesPerBlock = c_nbWavesPerBlock; /* tunable: NBNXM_HIP_WAVES_PER_BLOCK = 1..4 */
-    /* work partition (gpu_plist::work*): SIMDs of the device, weight of a perturbed cluster pair relative to a
-     * plain one (NBNXM_HIP_FEP_PAIR_WEIGHT), smallest range worth a wave (NBNXM_HIP_MIN_GROUPS_PER_WAVE) */
+    /* work partition (gpu_plist::work*): SIMDs of the device, smallest range worth a wave (NBNXM_HIP_MIN_GROUPS_PER_WAVE) */
     int numSimds          = 1024;
-    int fepPairWeight     = 16;
     int minGroupsPerWave  = 2;
     int numWorkRangesOverride = 0; /* experiments: NBNXM_HIP_NUM_WORK_RANGES */
     PinnedBuffer<nbnxn_sci_t> h_sciSorted;

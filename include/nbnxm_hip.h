@@ -309,7 +309,8 @@ void nbnxm_gpu_halo_unpack_f(void* stream, void* d_f, const int* d_map, int mapS
 
 /* Selects how perturbed pairs are evaluated (MI355X extension):
  *   0 = reference shape: cluster kernel + separate atom-pair FEP-list kernels (gpu_feplist);
- *   1 = fused: perturbed pairs inside the cluster-pair kernel (needs nbnxm_gpu_init_fep_cluster_bits). */
+ *   1 = fused: no FEP list; perturbed cluster pairs are found from Grid::fepBits on the device and evaluated by the
+ *       cluster-pair FEP kernel from the same packed list (needs nbnxm_gpu_init_fep_cluster_bits). */
 void nbnxm_gpu_set_fep_mode(NbnxmGpu* nb, int fused);
 
 /* Diagnostics for tests: device pointer of the packed j-list of a locality, and a synchronous
@@ -319,6 +320,9 @@ void* nbnxm_gpu_debug_get_cjpacked(NbnxmGpu* nb, int iloc);
  * (p = 1) kernels; *numRanges receives their count (tools/calibrate_weights.py) */
 void* nbnxm_gpu_debug_get_work_ranges(NbnxmGpu* nb, int iloc, int p, int* numRanges);
 void  nbnxm_gpu_debug_download(NbnxmGpu* nb, const void* devicePtr, void* hostPtr, size_t numBytes);
+/* measurement only (tools/graph_test.py): the clear + kernel launches of one steady-state local force step captured into
+ * a hipGraph and replayed numSteps times; on MI355X this was slower than the plain launches */
+void  nbnxm_gpu_debug_graph_steps(NbnxmGpu* nb, const nbnxm_step_workload_t* stepWork, int numSteps);
 
 /* Library/ABI version and a last-error string for diagnostics (never needed on the success path). */
 int         nbnxm_hip_abi_version(void);

@@ -323,15 +323,13 @@ def test_halo_pack_unpack_kernels():
     pkg.halo_pack_x(s, d_x.data_ptr(), d_map.data_ptr(), 0, d_send.data_ptr(), None)
 
 
-@pytest.mark.parametrize("num_ranks", [2, 3])
-def test_domain_decomposition_virtual_ranks(num_ranks):
+def _check_virtual_rank_decomposition(c, num_ranks, oracle_threads=1):
     """All ranks of a slab decomposition in one process on one GPU (LoopbackComm): HIP pack / unpack, x -> xq, the fused
     cluster kernel on each rank's share of the list, force reduction, force halo.  Owners must end up with the forces of
     the single-domain evaluation (and of the CPU oracle)."""
     import importlib
     import torch
     domdec = importlib.import_module("gromacs_fep_gpu_amd.domdec")
-    c = tl.make_case(nm=(12, 8, 8), num_perturbed_molecules=3, elec="ewald", seed=78)
     g = c.grid
     full = c.plist_fused
     dd = domdec.SlabDecomposition(g, full, num_ranks)
@@ -371,7 +369,7 @@ def test_domain_decomposition_virtual_ranks(num_ranks):
     f_dd = np.zeros((c.natoms, 3), np.float32)
     for s, p in zip(steps, plans):
         f_dd[p.home_atoms] = s.d_f.cpu().numpy()[p.home_atoms]
-    want = tl.run_oracle(c, energy=False)
+    want = tl.run_oracle(c, energy=False, num_threads=oracle_threads)
     f_ref = np.zeros((c.natoms, 3))
     f_ref[ai[real]] = want["f"][real]
     rms = np.sqrt((f_ref ** 2).sum(axis=1).mean())
@@ -379,3 +377,23 @@ def test_domain_decomposition_virtual_ranks(num_ranks):
     assert (err <= 1e-4 * np.maximum(np.linalg.norm(f_ref, axis=1, keepdims=True), rms)).all()
     for s in steps:
         s.nb.free()
+
+
+@pytest.mark.parametrize("num_ranks", [2, 3])
+def test_domain_decomposition_virtual_ranks(num_ranks):
+    _check_virtual_rank_decomposition(tl.make_case(nm=(12, 8, 8), num_perturbed_molecules=3, elec="ewald", seed=78), num_ranks)
+
+
+def test_full_size_properties_1m():
+    """BASELINE configs[4] size (1.05 M atoms): Newton's third law, fused == split, parity with the (threaded) oracle on the
+    whole box, and the 8-domain decomposition with all ranks on this one GPU."""
+    c = tl.make_case(elec="ewald", seed=404, nm=(88, 88, 44), num_perturbed_molecules=16, max_cjpacked_per_sci=16)
+    split = tl.run_gpu(c, energy=True, fused=False)
+    fused = tl.run_gpu(c, energy=True, fused=True)
+    frms = np.sqrt(np.mean(split["f"] ** 2))
+    assert np.max(np.abs(split["f"].sum(axis=0))) <= 1e-3 * frms * np.sqrt(c.grid.num_atoms)
+    assert np.max(np.abs(split["f"] - fused["f"])) <= 1e-4 * frms
+    want = tl.run_oracle(c, energy=True, num_threads=8)
+    tl.assert_parity(fused, want, rel=1e-4, label="1M fused")
+    tl.assert_parity(split, want, rel=1e-4, label="1M split")
+    _check_virtual_rank_decomposition(c, 8, oracle_threads=8)
