@@ -100,7 +100,15 @@ HIP_SYMBOLS = [
     "nbnxm_gpu_setup_short_range_work", "nbnxm_gpu_force_reduction_reinit", "nbnxm_gpu_force_reduction_execute",
     "nbnxm_gpu_halo_pack_x", "nbnxm_gpu_halo_unpack_f",
 ]
-UPDATE_SYMBOLS = ["langevin_gpu_create", "langevin_gpu_free", "langevin_gpu_set", "langevin_gpu_integrate"]
+UPDATE_SYMBOLS = [
+    "langevin_gpu_create", "langevin_gpu_free", "langevin_gpu_set", "langevin_gpu_integrate",
+    "leapfrog_gpu_create", "leapfrog_gpu_free", "leapfrog_gpu_set", "leapfrog_gpu_integrate",
+    "settle_gpu_create", "settle_gpu_free", "settle_gpu_set", "settle_gpu_apply",
+    "lincs_gpu_create", "lincs_gpu_free", "lincs_gpu_set", "lincs_gpu_apply",
+    "update_constrain_gpu_create", "update_constrain_gpu_free", "update_constrain_gpu_set", "update_constrain_gpu_set_pbc",
+    "update_constrain_gpu_integrate", "update_constrain_gpu_scale_coordinates", "update_constrain_gpu_scale_velocities",
+    "update_constrain_gpu_x_updated_event",
+]
 LISTED_SYMBOLS = [
     "listed_gpu_create", "listed_gpu_free", "listed_gpu_set_force_params", "listed_gpu_update_interaction_list",
     "listed_gpu_have_interactions", "listed_gpu_launch_kernel", "listed_gpu_launch_energy_transfer",
@@ -605,3 +613,155 @@ class LangevinGpu:
             self.free()
         except Exception:
             pass
+
+
+class _Handle:
+    _free_name = None
+
+    @property
+    def h(self):
+        return C.c_void_p(self._h)
+
+    def free(self):
+        if getattr(self, "_h", None):
+            getattr(self._lib, self._free_name)(self.h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+def _box9(box):
+    return _a(np.zeros((3, 3)) if box is None else box, np.float32).reshape(-1)
+
+
+class LeapFrogGpu(_Handle):
+    """ctypes mirror of gmx::LeapFrogGpu (mdlib/leapfrog_gpu.h:95-170)"""
+    _free_name = "leapfrog_gpu_free"
+
+    def __init__(self, num_temp_scale_values=0, stream=None):
+        self._lib = hip_lib()
+        self._lib.leapfrog_gpu_create.restype = C.c_void_p
+        self._h = self._lib.leapfrog_gpu_create(C.c_void_p(stream), C.c_int(num_temp_scale_values))
+
+    def set(self, inverse_masses, temp_scale_groups=None):
+        im = _a(inverse_masses, np.float32)
+        tc = _a(temp_scale_groups, np.uint16) if temp_scale_groups is not None else None
+        self._lib.leapfrog_gpu_set(self.h, C.c_int(im.size), _p(im), _p(tc) if tc is not None else None)
+
+    def integrate(self, d_x, d_xp, d_v, d_f, dt, tc_lambdas=None, pr_matrix=None, dt_pressure_couple=0.0):
+        lam = _a(tc_lambdas, np.float32) if tc_lambdas is not None else None
+        prm = _a(pr_matrix, np.float32).reshape(-1) if pr_matrix is not None else None
+        self._lib.leapfrog_gpu_integrate(self.h, C.c_void_p(d_x), C.c_void_p(d_xp), C.c_void_p(d_v), C.c_void_p(d_f), C.c_float(dt),
+                                         C.c_int(lam is not None), _p(lam) if lam is not None else None, C.c_int(prm is not None),
+                                         C.c_float(dt_pressure_couple), _p(prm) if prm is not None else None)
+
+
+class SettleGpu(_Handle):
+    """ctypes mirror of gmx::SettleGpu (mdlib/settle_gpu.h:70-150)"""
+    _free_name = "settle_gpu_free"
+
+    def __init__(self, mO, mH, dOH, dHH, stream=None):
+        self._lib = hip_lib()
+        self._lib.settle_gpu_create.restype = C.c_void_p
+        self._h = self._lib.settle_gpu_create(C.c_void_p(stream), C.c_float(mO), C.c_float(mH), C.c_float(dOH), C.c_float(dHH))
+
+    def set(self, atoms):
+        at = _a(atoms, np.int32).reshape(-1)
+        self._lib.settle_gpu_set(self.h, C.c_int(at.size // 3), _p(at))
+
+    def apply(self, d_x, d_xp, d_v=None, invdt=0.0, compute_virial=False, pbc_type=3, box=None):
+        """returns the scaled virial contribution (3x3) when compute_virial"""
+        vir = np.zeros(9, np.float32)
+        self._lib.settle_gpu_apply(self.h, C.c_void_p(d_x), C.c_void_p(d_xp), C.c_int(d_v is not None), C.c_void_p(d_v), C.c_float(invdt),
+                                   C.c_int(bool(compute_virial)), _p(vir), C.c_int(pbc_type), _p(_box9(box)))
+        return vir.reshape(3, 3)
+
+
+class LincsGpu(_Handle):
+    """ctypes mirror of gmx::LincsGpu (mdlib/lincs_gpu.h:75-160)"""
+    _free_name = "lincs_gpu_free"
+
+    def __init__(self, num_iterations, expansion_order, stream=None):
+        self._lib = hip_lib()
+        self._lib.lincs_gpu_create.restype = C.c_void_p
+        self._h = self._lib.lincs_gpu_create(C.c_void_p(stream), C.c_int(num_iterations), C.c_int(expansion_order))
+
+    def set(self, iatoms, lengths, inverse_masses):
+        """iatoms: (type, i, j) triples; returns False when a group of coupled constraints is too large for the GPU"""
+        ia, ln, im = _a(iatoms, np.int32).reshape(-1), _a(lengths, np.float32), _a(inverse_masses, np.float32)
+        return self._lib.lincs_gpu_set(self.h, C.c_int(ia.size // 3), _p(ia), _p(ln), C.c_int(im.size), _p(im)) == 0
+
+    def apply(self, d_x, d_xp, d_v=None, invdt=0.0, compute_virial=False, pbc_type=3, box=None):
+        vir = np.zeros(9, np.float32)
+        self._lib.lincs_gpu_apply(self.h, C.c_void_p(d_x), C.c_void_p(d_xp), C.c_int(d_v is not None), C.c_void_p(d_v), C.c_float(invdt),
+                                  C.c_int(bool(compute_virial)), _p(vir), C.c_int(pbc_type), _p(_box9(box)))
+        return vir.reshape(3, 3)
+
+
+class _UpdateConstrainParams(C.Structure):
+    _fields_ = [("useStochasticDynamics", C.c_int), ("numTempCouplGroups", C.c_int), ("delta_t", C.c_float),
+                ("ref_t", C.POINTER(C.c_float)), ("tau_t", C.POINTER(C.c_float)), ("nLincsIter", C.c_int), ("nProjOrder", C.c_int),
+                ("haveSettle", C.c_int), ("mO", C.c_float), ("mH", C.c_float), ("dOH", C.c_float), ("dHH", C.c_float)]
+
+
+class _UpdateConstrainTopology(C.Structure):
+    _fields_ = [("numAtoms", C.c_int), ("inverseMasses", C.POINTER(C.c_float)), ("tempCouplGroups", C.POINTER(C.c_ushort)),
+                ("numConstraints", C.c_int), ("constraints", C.POINTER(C.c_int)), ("constraintLengths", C.POINTER(C.c_float)),
+                ("numSettles", C.c_int), ("settles", C.POINTER(C.c_int))]
+
+
+class UpdateConstrainGpu(_Handle):
+    """ctypes mirror of gmx::UpdateConstrainGpu (mdlib/update_constrain_gpu.h:70-185)"""
+    _free_name = "update_constrain_gpu_free"
+
+    def __init__(self, delta_t, num_temp_coupl_groups=0, stochastic_dynamics=False, ref_t=None, tau_t=None, n_lincs_iter=1, n_proj_order=4,
+                 settle=None, stream=None):
+        """settle: None or (mO, mH, dOH, dHH)"""
+        self._lib = hip_lib()
+        self._lib.update_constrain_gpu_create.restype = C.c_void_p
+        self._lib.update_constrain_gpu_x_updated_event.restype = C.c_void_p
+        rt = _a(ref_t if ref_t is not None else [0.0], np.float32)
+        tt = _a(tau_t if tau_t is not None else [0.0], np.float32)
+        p = _UpdateConstrainParams(int(stochastic_dynamics), num_temp_coupl_groups, delta_t, rt.ctypes.data_as(C.POINTER(C.c_float)),
+                                   tt.ctypes.data_as(C.POINTER(C.c_float)), n_lincs_iter, n_proj_order, int(settle is not None),
+                                   *(settle if settle is not None else (0.0, 0.0, 0.0, 0.0)))
+        self._h = self._lib.update_constrain_gpu_create(C.c_void_p(stream), C.byref(p))
+
+    def set(self, d_x, d_v, d_f, inverse_masses, temp_coupl_groups=None, constraints=None, constraint_lengths=None, settles=None):
+        im = _a(inverse_masses, np.float32)
+        tc = _a(temp_coupl_groups if temp_coupl_groups is not None else np.zeros(im.size), np.uint16)
+        cs = _a(constraints if constraints is not None else [], np.int32).reshape(-1)
+        cl = _a(constraint_lengths if constraint_lengths is not None else [0.0], np.float32)
+        st = _a(settles if settles is not None else [], np.int32).reshape(-1)
+        t = _UpdateConstrainTopology(im.size, im.ctypes.data_as(C.POINTER(C.c_float)), tc.ctypes.data_as(C.POINTER(C.c_ushort)),
+                                     cs.size // 3, cs.ctypes.data_as(C.POINTER(C.c_int)), cl.ctypes.data_as(C.POINTER(C.c_float)),
+                                     st.size // 3, st.ctypes.data_as(C.POINTER(C.c_int)))
+        return self._lib.update_constrain_gpu_set(self.h, C.c_void_p(d_x), C.c_void_p(d_v), C.c_void_p(d_f), C.byref(t)) == 0
+
+    def set_pbc(self, pbc_type, box):
+        self._lib.update_constrain_gpu_set_pbc(self.h, C.c_int(pbc_type), _p(_box9(box)))
+
+    def integrate(self, dt, update_velocities=True, compute_virial=False, tc_lambdas=None, pr_matrix=None, dt_pressure_couple=0.0, seed=0,
+                  step=0, f_ready_event=None):
+        """returns the constraint virial (3x3; zeros unless compute_virial)"""
+        vir = np.zeros(9, np.float32)
+        lam = _a(tc_lambdas, np.float32) if tc_lambdas is not None else None
+        prm = _a(pr_matrix, np.float32).reshape(-1) if pr_matrix is not None else None
+        self._lib.update_constrain_gpu_integrate(self.h, C.c_void_p(f_ready_event), C.c_float(dt), C.c_int(bool(update_velocities)),
+                                                 C.c_int(bool(compute_virial)), _p(vir), C.c_int(lam is not None),
+                                                 _p(lam) if lam is not None else None, C.c_int(prm is not None), C.c_float(dt_pressure_couple),
+                                                 _p(prm) if prm is not None else None, C.c_int(seed), C.c_int(step))
+        return vir.reshape(3, 3)
+
+    def scale_coordinates(self, matrix):
+        self._lib.update_constrain_gpu_scale_coordinates(self.h, _p(_box9(matrix)))
+
+    def scale_velocities(self, matrix):
+        self._lib.update_constrain_gpu_scale_velocities(self.h, _p(_box9(matrix)))
+
+    def x_updated_event(self):
+        return self._lib.update_constrain_gpu_x_updated_event(self.h)

@@ -275,3 +275,52 @@ def langevin_update(update_type, x, v, f, inverse_masses, tc_groups, ref_t, tau_
                                  _ptr(_arr(inverse_masses, np.float32)), _ptr(_arr(tc_groups, np.uint16)), C.c_int(len(ref_t)),
                                  _ptr(_arr(ref_t, np.float32)), _ptr(_arr(tau_t, np.float32)), C.c_float(dt), C.c_int(seed), C.c_int(step))
     return x_, xp, v_
+
+
+def _dptr(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def leapfrog(x, v, f, inverse_masses, dt, lambdas=None, groups=None, pr_diag=None):
+    """one leap-frog step (double); lambdas: None, [l] or per-group factors with groups; pr_diag = dtPressureCouple * diag(M).
+    Returns (x, xp, v)."""
+    x_ = np.array(x, np.float64).copy()
+    v_ = np.array(v, np.float64).copy()
+    xp = np.zeros_like(x_)
+    n = x_.shape[0]
+    lam = _arr(lambdas if lambdas is not None else [1.0], np.float64)
+    grp = _arr(groups if groups is not None else np.zeros(n), np.uint16)
+    prd = _arr(pr_diag, np.float64) if pr_diag is not None else None
+    lib().oracle_leapfrog(C.c_int(n), _dptr(x_), _dptr(xp), _dptr(v_), _dptr(_arr(f, np.float64)), _dptr(_arr(inverse_masses, np.float64)),
+                          C.c_double(dt), C.c_int(0 if lambdas is None else len(lam)), _dptr(lam), _dptr(grp),
+                          _dptr(prd) if prd is not None else None)
+    return x_, xp, v_
+
+
+def settle(atoms, mO, mH, dOH, dHH, x, xp, v=None, invdt=0.0, compute_virial=False, pbc_type=3, box=None):
+    """returns (xp, v, virial[3,3])"""
+    at = _arr(atoms, np.int32).reshape(-1)
+    xp_ = np.array(xp, np.float64).copy()
+    v_ = np.array(v, np.float64).copy() if v is not None else None
+    vir = np.zeros((3, 3))
+    bx = _arr(box if box is not None else np.zeros((3, 3)), np.float64)
+    lib().oracle_settle(C.c_int(len(at) // 3), _dptr(at), C.c_double(mO), C.c_double(mH), C.c_double(dOH), C.c_double(dHH),
+                        _dptr(_arr(x, np.float64)), _dptr(xp_), _dptr(v_) if v_ is not None else None, C.c_double(invdt),
+                        _dptr(vir) if compute_virial else None, C.c_int(pbc_type), _dptr(bx))
+    return xp_, v_, vir
+
+
+def lincs(iatoms, lengths, inverse_masses, num_iterations, expansion_order, x, xp, v=None, invdt=0.0, compute_virial=False, pbc_type=3,
+          box=None):
+    """returns (xp, v, virial[3,3])"""
+    ia = _arr(iatoms, np.int32).reshape(-1)
+    xp_ = np.array(xp, np.float64).copy()
+    v_ = np.array(v, np.float64).copy() if v is not None else None
+    vir = np.zeros((3, 3))
+    im = _arr(inverse_masses, np.float64)
+    bx = _arr(box if box is not None else np.zeros((3, 3)), np.float64)
+    lib().oracle_lincs(C.c_int(len(ia) // 3), _dptr(ia), _dptr(_arr(lengths, np.float64)), C.c_int(len(im)), _dptr(im),
+                       C.c_int(num_iterations), C.c_int(expansion_order), _dptr(_arr(x, np.float64)), _dptr(xp_),
+                       _dptr(v_) if v_ is not None else None, C.c_double(invdt), _dptr(vir) if compute_virial else None,
+                       C.c_int(pbc_type), _dptr(bx))
+    return xp_, v_, vir

@@ -71,3 +71,298 @@ def test_langevin_noise_has_the_right_temperature():
     want = 0.0083144626 * T * (1 - em * em) / 12.011
     assert abs(v.var() / want - 1.0) < 0.01 and abs(v.mean()) < 3 * np.sqrt(want / (3 * n)) * 3
     lg.free()
+
+
+# ---- leap-frog, SETTLE, LINCS and their composition -----------------------------------------------------------------------
+import update_cases as uc
+
+
+def _dev(a):
+    import torch
+    return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).cuda()
+
+
+@pytest.mark.parametrize("idx", range(16))
+def test_leapfrog_reproduces_reference_known_answers(idx):
+    """the reference's own LeapFrogTest cases (mdlib/tests/leapfrog.cpp) through the C ABI, and the double oracle beside them"""
+    import torch
+    c = uc.leapfrog_cases()[idx]
+    lf = pkg.LeapFrogGpu(c.num_tc)
+    lf.set(c.invmass, c.groups)
+    d_x, d_v, d_f = _dev(c.x0), _dev(c.v0), _dev(c.f)
+    d_xp = torch.zeros_like(d_x)
+    xo, vo = c.x0, c.v0
+    pr_matrix = np.diag(c.pr_diag)
+    for step in range(c.num_steps):
+        pc = c.do_pressure_couple(step)
+        x_before = d_x.clone()
+        lf.integrate(d_x.data_ptr(), d_xp.data_ptr(), d_v.data_ptr(), d_f.data_ptr(), c.dt, tc_lambdas=c.lambdas if c.num_tc > 0 else None,
+                     pr_matrix=pr_matrix if pc else None, dt_pressure_couple=c.dt_pc)
+        xo, _, vo = ob.leapfrog(xo, vo, c.f, c.invmass, c.dt, lambdas=c.lambdas if c.num_tc > 0 else None, groups=c.groups,
+                                pr_diag=c.dt_pc * c.pr_diag if pc else None)
+        torch.cuda.synchronize()
+        assert torch.equal(d_xp, x_before)
+    gx, gv = d_x.cpu().numpy(), d_v.cpu().numpy()
+    assert np.max(np.abs(gx - c.final_x)) <= c.tolerance and np.max(np.abs(gv - c.final_v)) <= c.tolerance
+    assert np.allclose(gx, xo, rtol=1e-6, atol=1e-6 * c.num_steps) and np.allclose(gv, vo, rtol=1e-6, atol=1e-6 * c.num_steps)
+    lf.free()
+
+
+def test_leapfrog_many_groups_and_large_system():
+    """40 temperature-coupling groups (factors through a device buffer instead of kernel arguments), 100003 atoms"""
+    import torch
+    n = 100003
+    x, v, f, im, _ = _system(n, 3)
+    groups = (np.arange(n) % 40).astype(np.uint16)
+    lambdas = 1.0 - 0.01 * np.arange(40)
+    for ntc, lam, grp in ((40, lambdas, groups), (3, lambdas[:3], (groups % 3).astype(np.uint16)), (1, lambdas[5:6], None), (0, None, None)):
+        lf = pkg.LeapFrogGpu(ntc)
+        lf.set(im, grp)
+        d_x, d_v, d_f = _dev(x), _dev(v), _dev(f)
+        d_xp = torch.zeros_like(d_x)
+        lf.integrate(d_x.data_ptr(), d_xp.data_ptr(), d_v.data_ptr(), d_f.data_ptr(), 0.002, tc_lambdas=lam, pr_matrix=np.diag([0.3, -0.2, 0.1]),
+                     dt_pressure_couple=0.02)
+        xo, xpo, vo = ob.leapfrog(x, v, f, im, 0.002, lambdas=lam, groups=grp, pr_diag=0.02 * np.array([0.3, -0.2, 0.1]))
+        torch.cuda.synchronize()
+        assert np.array_equal(d_xp.cpu().numpy(), x)
+        assert np.allclose(d_v.cpu().numpy(), vo, rtol=2e-6, atol=1e-6) and np.allclose(d_x.cpu().numpy(), xo, rtol=1e-6, atol=1e-6)
+        lf.free()
+
+
+@pytest.mark.parametrize("idx", range(13))
+def test_settle_reproduces_reference_known_answers(idx):
+    """the reference's own SettleTest cases (mdlib/tests/settle.cpp)"""
+    import torch
+    c = uc.settle_cases()[idx]
+    sg = pkg.SettleGpu(c.mO, c.mH, c.dOH, c.dHH)
+    sg.set(c.atoms)
+    d_x, d_xp, d_v = _dev(c.x), _dev(c.xp), _dev(c.v)
+    vir = sg.apply(d_x.data_ptr(), d_xp.data_ptr(), d_v.data_ptr() if c.update_velocities else None, c.invdt, c.calc_virial, c.pbc_type, c.box)
+    torch.cuda.synchronize()
+    n = 3 * c.num_settles
+    gxp, gv = d_xp.cpu().numpy().astype(np.float64), d_v.cpu().numpy()
+    assert np.max(np.abs(gxp[:n] - c.final_x)) <= 1e-6                    # settle.cpp:363-371
+    assert np.array_equal(gxp[n:].astype(np.float32), c.xp[n:].astype(np.float32))
+    w = gxp[:n].reshape(-1, 3, 3)
+    for a, b, d in ((0, 1, c.dOH), (0, 2, c.dOH), (1, 2, c.dHH)):
+        assert np.max(np.abs(np.sum((w[:, a] - w[:, b]) ** 2, axis=1) - d * d)) <= 380 * 1.2e-7 * c.dOH * c.dOH
+    if c.update_velocities:
+        assert np.max(np.abs(gv[:n] - c.final_v)) <= 1e-4
+    else:
+        assert not gv.any()
+    assert (vir != 0).all() == c.calc_virial and (vir != 0).any() == c.calc_virial
+    if c.calc_virial:
+        assert np.max(np.abs(vir - c.virial)) <= 1e-6 and np.max(np.abs(vir - vir.T)) <= 1e-6
+    sg.free()
+
+
+def _water_box(num_waters, seed, box=4.0, dOH=0.09572, dHH=0.15139):
+    """rigid waters at random places and orientations in a periodic box (some straddle the faces), then a random displacement"""
+    rng = np.random.default_rng(seed)
+    h = np.sqrt(dOH * dOH - 0.25 * dHH * dHH)
+    local = np.array([[0, 0, 0], [0.5 * dHH, h, 0], [-0.5 * dHH, h, 0]])
+    q = rng.normal(size=(num_waters, 4))
+    q /= np.linalg.norm(q, axis=1, keepdims=True)
+    a, b, c_, d = q.T
+    rot = np.stack([np.stack([a*a+b*b-c_*c_-d*d, 2*(b*c_-a*d), 2*(b*d+a*c_)], 1), np.stack([2*(b*c_+a*d), a*a-b*b+c_*c_-d*d, 2*(c_*d-a*b)], 1),
+                    np.stack([2*(b*d-a*c_), 2*(c_*d+a*b), a*a-b*b-c_*c_+d*d], 1)], 1)
+    x = (rng.uniform(0, box, (num_waters, 1, 3)) + np.einsum("wij,aj->wai", rot, local)).reshape(-1, 3)
+    x = x.astype(np.float32).astype(np.float64)
+    xp = (x + rng.normal(0, 0.004, x.shape)).astype(np.float32).astype(np.float64)
+    # atoms in the unit cell, molecules broken over the faces: the minimum image has to put them together again
+    sh = np.floor(x / box) * box
+    return x - sh, xp - sh, rng.normal(0, 0.5, x.shape).astype(np.float32).astype(np.float64)
+
+
+def test_settle_large_periodic_box_matches_oracle():
+    import torch
+    nw, box = 33333, 4.0
+    x, xp, v = _water_box(nw, 11, box)
+    atoms = np.arange(3 * nw, dtype=np.int32).reshape(-1, 3)
+    atoms[::2] = atoms[::2][:, [0, 2, 1]]       # the order of the hydrogens must not matter
+    mO, mH, dOH, dHH, invdt = 15.9994, 1.008, 0.09572, 0.15139, 500.0
+    bx = np.eye(3) * box
+    sg = pkg.SettleGpu(mO, mH, dOH, dHH)
+    sg.set(atoms)
+    d_x, d_xp, d_v = _dev(x), _dev(xp), _dev(v)
+    vir = sg.apply(d_x.data_ptr(), d_xp.data_ptr(), d_v.data_ptr(), invdt, True, 3, bx)
+    oxp, ov, ovir = ob.settle(atoms, mO, mH, dOH, dHH, x, xp, v=v, invdt=invdt, compute_virial=True, pbc_type=3, box=bx)
+    gxp, gv = d_xp.cpu().numpy(), d_v.cpu().numpy()
+    assert np.max(np.abs(gxp - oxp)) <= 2e-6          # fp32 coordinates of size ~4
+    assert np.max(np.abs(gv - ov)) <= 5e-4            # position error times 1/dt
+    assert np.max(np.abs(vir - ovir)) <= 2e-4 * np.max(np.abs(ovir))
+    sg.free()
+
+
+@pytest.mark.parametrize("idx", range(14))
+def test_lincs_reproduces_reference_known_answers(idx):
+    """the reference's own ConstraintsTest cases (mdlib/tests/constr.cpp) with its tolerances, and the double oracle of the same
+    algorithm beside them"""
+    import torch
+    c = uc.constraints_cases()[idx]
+    lg = pkg.LincsGpu(c.n_iter, c.order)
+    assert lg.set(c.iatoms, c.lengths, c.invmass)
+    d_x, d_xp, d_v = _dev(c.x), _dev(c.xp), _dev(c.v)
+    vir = lg.apply(d_x.data_ptr(), d_xp.data_ptr(), d_v.data_ptr(), c.invdt, True, c.pbc_type, c.box)
+    torch.cuda.synchronize()
+    gxp, gv = d_xp.cpu().numpy().astype(np.float64), d_v.cpu().numpy().astype(np.float64)
+    assert np.max(np.abs(gxp - c.final_x)) <= c.tol_x, c.title
+    assert np.max(np.abs(gv - c.final_v)) <= c.tol_v, c.title
+    assert np.max(np.abs(vir - c.virial)) <= c.tol_virial, c.title
+    oxp, ov, ovir = ob.lincs(c.iatoms, c.lengths, c.invmass, c.n_iter, c.order, c.x, c.xp, v=c.v, invdt=c.invdt, compute_virial=True,
+                             pbc_type=c.pbc_type, box=c.box)
+    scale = max(1.0, np.max(np.abs(c.xp)))
+    assert np.max(np.abs(gxp - oxp)) <= 2e-6 * scale, c.title
+    assert np.max(np.abs(gv - ov)) <= 2e-6 * scale * c.invdt, c.title
+    assert np.max(np.abs(vir - ovir)) <= 1e-4 * max(np.max(np.abs(ovir)), 1e-6), c.title
+    for t, i, j in c.iatoms:
+        d1 = gxp[i] - gxp[j]
+        if c.pbc_type == 3:
+            d1 -= np.rint(d1 / np.diag(c.box)) * np.diag(c.box)
+        assert abs(np.linalg.norm(d1) - c.lengths[t]) <= 0.002 * c.lengths[t] + 1e-12     # constr.cpp:655
+    lg.free()
+
+
+def _molecule_soup(seed, num_molecules=4000, box=6.0, chain=0):
+    """a mix of OH (1 constraint), CH2 (2), CH3 (3), triangles (3) and, if chain, one all-bonds chain of that many atoms"""
+    rng = np.random.default_rng(seed)
+    templ = [
+        (np.array([[0, 0, 0], [0.1, 0, 0]]), [12.0, 1.0], [(0, 0, 1)]),
+        (np.array([[0, 0, 0], [0.109, 0, 0], [-0.036, 0.103, 0]]), [12.0, 1.0, 1.0], [(1, 0, 1), (1, 0, 2)]),
+        (np.array([[0, 0, 0], [0.109, 0, 0], [-0.036, 0.103, 0], [-0.036, -0.051, 0.089]]), [12.0, 1.0, 1.0, 1.0], [(1, 0, 1), (1, 0, 2), (1, 0, 3)]),
+        (np.array([[0, 0, 0], [0.1, 0, 0], [0.05, 0.0866025, 0]]), [16.0, 1.0, 1.0], [(0, 0, 1), (0, 0, 2), (0, 1, 2)]),
+    ]
+    lengths = np.array([0.1, 0.109, 0.153])
+    xs, ms, cons = [], [], []
+    for m in range(num_molecules):
+        pos, mass, cs = templ[rng.integers(0, 4)]
+        q = rng.normal(size=4)
+        q /= np.linalg.norm(q)
+        a, b, c_, d = q
+        rot = np.array([[a*a+b*b-c_*c_-d*d, 2*(b*c_-a*d), 2*(b*d+a*c_)], [2*(b*c_+a*d), a*a-b*b+c_*c_-d*d, 2*(c_*d-a*b)],
+                        [2*(b*d-a*c_), 2*(c_*d+a*b), a*a-b*b-c_*c_+d*d]])
+        off = sum(len(p) for p in xs)
+        xs.append(rng.uniform(0, box, 3) + pos @ rot.T)
+        ms += mass
+        for t, i, j in cs:
+            cons.append((t, off + j, off + i) if rng.random() < 0.5 else (t, off + i, off + j))   # both orientations
+    if chain:
+        off = sum(len(p) for p in xs)
+        ang = np.deg2rad(111.0)
+        pos = np.zeros((chain, 3))
+        for k in range(1, chain):
+            pos[k] = pos[k - 1] + 0.153 * np.array([np.cos((k % 2) * (np.pi - ang)), np.sin((k % 2) * (np.pi - ang)), 0.0])
+        xs.append(np.array([1.0, 1.0, 1.0]) + pos)
+        ms += [12.0] * chain
+        cons += [(2, off + k, off + k + 1) for k in range(chain - 1)]
+    x = np.concatenate(xs).astype(np.float32).astype(np.float64)
+    # lengths as they are in x (the templates are only approximately at the target lengths)
+    xp = (x + rng.normal(0, 0.003, x.shape)).astype(np.float32).astype(np.float64)
+    sh = np.floor(x / box) * box
+    perm = rng.permutation(len(cons))
+    return x - sh, xp - sh, rng.normal(0, 0.5, x.shape), 1.0 / np.array(ms), np.array(cons, np.int32)[perm], lengths
+
+
+@pytest.mark.parametrize("chain,block", [(0, 64), (100, 128), (600, 1024)])
+def test_lincs_mixed_system_matches_oracle(chain, block):
+    """thousands of small coupled groups packed into one-wave work-groups, and one long all-bonds chain that needs a larger one"""
+    import torch
+    box = 6.0
+    x, xp, v, im, iatoms, lengths = _molecule_soup(5 + chain, 4000, box, chain)
+    bx = np.eye(3) * box
+    n_iter, order, invdt = (2, 6, 500.0) if chain else (1, 4, 500.0)
+    lg = pkg.LincsGpu(n_iter, order)
+    assert lg.set(iatoms, lengths, im)
+    d_x, d_xp, d_v = _dev(x), _dev(xp), _dev(v)
+    vir = lg.apply(d_x.data_ptr(), d_xp.data_ptr(), d_v.data_ptr(), invdt, True, 3, bx)
+    oxp, ov, ovir = ob.lincs(iatoms, lengths, im, n_iter, order, x, xp, v=v, invdt=invdt, compute_virial=True, pbc_type=3, box=bx)
+    gxp, gv = d_xp.cpu().numpy(), d_v.cpu().numpy()
+    assert np.max(np.abs(gxp - oxp)) <= 3e-6
+    assert np.max(np.abs(gv - ov)) <= 3e-6 * invdt
+    assert np.max(np.abs(vir - ovir)) <= 1e-3 * np.max(np.abs(ovir))
+    # atoms without a constraint are not touched; a second application with the same object gives the same answer
+    free = np.setdiff1d(np.arange(len(im)), iatoms[:, 1:].ravel())
+    assert np.array_equal(gxp[free], xp[free].astype(np.float32))
+    d_xp2, d_v2 = _dev(xp), _dev(v)
+    lg.apply(d_x.data_ptr(), d_xp2.data_ptr(), d_v2.data_ptr(), invdt, False, 3, bx)
+    torch.cuda.synchronize()      # the object's own stream: nothing waits for it without the virial
+    assert np.max(np.abs(d_xp2.cpu().numpy() - gxp)) <= 1e-6
+    lg.free()
+
+
+def test_lincs_refuses_too_many_coupled_constraints():
+    n = 1100                                           # 1099 coupled constraints > the largest work-group
+    iatoms = np.array([(0, k, k + 1) for k in range(n - 1)], np.int32)
+    lg = pkg.LincsGpu(1, 4)
+    assert not lg.set(iatoms, [0.15], np.ones(n))
+    assert lg.set(iatoms[:1000], [0.15], np.ones(n))
+    lg.free()
+
+
+@pytest.mark.parametrize("sd", [False, True])
+def test_update_constrain_composition(sd):
+    """UpdateConstrainGpu::integrate against the same sequence of oracle calls: integrator, LINCS, SETTLE and, for stochastic
+    dynamics, friction + noise and the second constraint pass; the virial comes out scaled by 0.5 / dt^2"""
+    import torch
+    box, dt, seed = 5.0, 0.002, 77
+    nw = 3000
+    xw, _, vw = _water_box(nw, 21, box)
+    xm, _, vm, imm, iatoms, lengths = _molecule_soup(9, 800, box, 0)
+    x = np.concatenate([xw, xm]).astype(np.float32)
+    v = np.concatenate([vw, vm]).astype(np.float32)
+    mO, mH, dOH, dHH = 15.9994, 1.008, 0.09572, 0.15139
+    im = np.concatenate([np.tile([1 / mO, 1 / mH, 1 / mH], nw), imm]).astype(np.float32)
+    iatoms = iatoms.copy()
+    iatoms[:, 1:] += 3 * nw
+    # start from satisfied constraints: one projection of x onto itself-ish lengths
+    x64 = x.astype(np.float64)
+    x64, _, _ = ob.lincs(iatoms, lengths, im, 4, 8, x64, x64, pbc_type=3, box=np.eye(3) * box)
+    x = x64.astype(np.float32)
+    n = len(im)
+    rng = np.random.default_rng(2)
+    f = rng.normal(0, 300, (n, 3)).astype(np.float32)
+    tc = (np.arange(n) % 2).astype(np.uint16)
+    settles = np.arange(3 * nw, dtype=np.int32).reshape(-1, 3)
+    ref_t, tau_t = [300.0, 250.0], [0.5, 2.0]
+    up = pkg.UpdateConstrainGpu(dt, num_temp_coupl_groups=2, stochastic_dynamics=sd, ref_t=ref_t, tau_t=tau_t, n_lincs_iter=1, n_proj_order=4,
+                                settle=(mO, mH, dOH, dHH))
+    d_x, d_v, d_f = _dev(x), _dev(v), _dev(f)
+    assert up.set(d_x.data_ptr(), d_v.data_ptr(), d_f.data_ptr(), im, tc, iatoms, lengths, settles)
+    bx = np.eye(3) * box
+    up.set_pbc(3, bx)
+    lambdas = [0.98, 1.03]
+    xo, vo = x.astype(np.float64), v.astype(np.float64)
+    for step in (0, 1):
+        vir = up.integrate(dt, update_velocities=True, compute_virial=True, tc_lambdas=None if sd else lambdas, seed=seed, step=step)
+        if sd:
+            x1, xb, v1 = ob.langevin_update(0, xo, vo, f, im, tc, ref_t, tau_t, dt, seed, step)
+            x1, xb, v1 = (a.astype(np.float64) for a in (x1, xb, v1))
+        else:
+            x1, xb, v1 = ob.leapfrog(xo, vo, f, im, dt, lambdas=lambdas, groups=tc)
+        x2, v2, vl = ob.lincs(iatoms, lengths, im, 1, 4, xb, x1, v=v1, invdt=1 / dt, compute_virial=True, pbc_type=3, box=bx)
+        x3, v3, vs = ob.settle(settles, mO, mH, dOH, dHH, xb, x2, v=v2, invdt=1 / dt, compute_virial=True, pbc_type=3, box=bx)
+        if sd:
+            x4, _, v4 = ob.langevin_update(1, x3, v3, f, im, tc, ref_t, tau_t, dt, seed, step)
+            x4, v4 = x4.astype(np.float64), v4.astype(np.float64)
+            x5, _, _ = ob.lincs(iatoms, lengths, im, 1, 4, xb, x4, pbc_type=3, box=bx)
+            x3, _, _ = ob.settle(settles, mO, mH, dOH, dHH, xb, x5, pbc_type=3, box=bx)
+            v3 = v4
+        torch.cuda.synchronize()
+        gx, gv = d_x.cpu().numpy(), d_v.cpu().numpy()
+        assert np.max(np.abs(gx - x3)) <= 4e-6
+        assert np.max(np.abs(gv - v3)) <= 2e-3
+        want_vir = 0.5 / (dt * dt) * (vl + vs)
+        assert np.max(np.abs(vir - want_vir)) <= 2e-3 * np.max(np.abs(want_vir))
+        xo, vo = gx.astype(np.float64), gv.astype(np.float64)     # continue from the GPU state: errors do not accumulate in the check
+    # scaling of coordinates and velocities (pressure coupling)
+    mu = np.array([[1.01, 0, 0], [0.002, 0.99, 0], [-0.001, 0.003, 1.02]])
+    before = d_x.cpu().numpy().astype(np.float64)
+    up.scale_coordinates(mu)
+    want = np.stack([mu[0, 0] * before[:, 0] + mu[1, 0] * before[:, 1] + mu[2, 0] * before[:, 2], mu[1, 1] * before[:, 1] + mu[2, 1] * before[:, 2],
+                     mu[2, 2] * before[:, 2]], axis=1)
+    assert np.allclose(d_x.cpu().numpy(), want, rtol=1e-6, atol=1e-6)
+    vb = d_v.cpu().numpy().astype(np.float64)
+    up.scale_velocities(np.diag([0.5, 2.0, 1.0]))
+    assert np.allclose(d_v.cpu().numpy(), vb * [0.5, 2.0, 1.0], rtol=1e-6, atol=1e-6)
+    assert up.x_updated_event()
+    up.free()

@@ -179,3 +179,59 @@ def test_threefry_and_tabulated_normal_reproduce_reference_known_answers():
     assert np.allclose(got, np.array(t["values"], np.float32), rtol=1e-6, atol=0)   # 1-2 float ulp: erfinv implementation, mean + v * stddev rounding
     tab = ob.normal_table(14)
     assert abs(float((tab.astype(np.float64) ** 2).mean()) - 1.0) < 1e-6 and tab[0] == -tab[-1] and (np.diff(tab) > 0).all()
+
+
+# ---- coordinate update: leap-frog, SETTLE, LINCS (oracle/update_ref.c) against mdlib/tests/refdata ---------------------------
+import update_cases as uc
+
+
+@pytest.mark.parametrize("idx", range(16))
+def test_leapfrog_oracle_reproduces_reference_known_answers(idx):
+    c = uc.leapfrog_cases()[idx]
+    x, v = c.x0, c.v0
+    for step in range(c.num_steps):
+        pr = c.dt_pc * c.pr_diag if c.do_pressure_couple(step) else None
+        x, xp, v = ob.leapfrog(x, v, c.f, c.invmass, c.dt, lambdas=c.lambdas if c.num_tc > 0 else None, groups=c.groups, pr_diag=pr)
+    assert np.max(np.abs(x - c.final_x)) <= c.tolerance
+    assert np.max(np.abs(v - c.final_v)) <= c.tolerance
+    if c.num_tc == 0 and c.nstpcouple == 0:
+        t = c.num_steps * c.dt  # the analytical solution for a constant force (leapfrog.cpp:150-176)
+        assert np.max(np.abs(x - (c.x0 + c.v0 * t + 0.5 * c.f * t * t * c.invmass[:, None]))) <= c.tolerance
+
+
+@pytest.mark.parametrize("idx", range(13))
+def test_settle_oracle_reproduces_reference_known_answers(idx):
+    c = uc.settle_cases()[idx]
+    xp, v, vir = ob.settle(c.atoms, c.mO, c.mH, c.dOH, c.dHH, c.x, c.xp, v=c.v if c.update_velocities else None, invdt=c.invdt,
+                           compute_virial=c.calc_virial, pbc_type=c.pbc_type, box=c.box)
+    n = 3 * c.num_settles
+    assert np.max(np.abs(xp[:n] - c.final_x)) <= 1e-6  # settle.cpp:363
+    assert np.array_equal(xp[n:], c.xp[n:])
+    w = xp[:n].reshape(-1, 3, 3)
+    for a, b, d in ((0, 1, c.dOH), (0, 2, c.dOH), (1, 2, c.dHH)):
+        assert np.max(np.abs(np.sum((w[:, a] - w[:, b]) ** 2, axis=1) - d * d)) <= 1e-12
+    if c.update_velocities:
+        assert np.max(np.abs(v[:n] - c.final_v)) <= 1e-4
+    if c.calc_virial:
+        assert np.max(np.abs(vir - c.virial)) <= 1e-6
+        assert np.max(np.abs(vir - vir.T)) <= 1e-6
+
+
+@pytest.mark.parametrize("idx", range(14))
+def test_lincs_oracle_reproduces_reference_known_answers(idx):
+    c = uc.constraints_cases()[idx]
+    xp, v, vir = ob.lincs(c.iatoms, c.lengths, c.invmass, c.n_iter, c.order, c.x, c.xp, v=c.v, invdt=c.invdt, compute_virial=True,
+                          pbc_type=c.pbc_type, box=c.box)
+    assert np.max(np.abs(xp - c.final_x)) <= c.tol_x, c.title
+    assert np.max(np.abs(v - c.final_v)) <= c.tol_v, c.title
+    assert np.max(np.abs(vir - c.virial)) <= c.tol_virial, c.title
+    # constr.cpp:668-676: lengths, direction, centre of mass and its velocity
+    for t, i, j in c.iatoms:
+        d0, d1 = c.x[i] - c.x[j], xp[i] - xp[j]
+        if c.pbc_type == 3:
+            d0 -= np.rint(d0 / np.diag(c.box)) * np.diag(c.box)
+            d1 -= np.rint(d1 / np.diag(c.box)) * np.diag(c.box)
+        assert abs(np.linalg.norm(d1) - c.lengths[t]) <= 0.002 * c.lengths[t] + 1e-12
+        assert d0 @ d1 >= 0
+    assert np.max(np.abs((c.masses[:, None] * (xp - c.xp)).sum(axis=0) / len(c.masses))) <= c.tol_x
+    assert np.max(np.abs((c.masses[:, None] * (v - c.v)).sum(axis=0) / len(c.masses))) <= c.tol_v
