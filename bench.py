@@ -242,6 +242,39 @@ def main():
     ms_virial_only = timed(pkg.step_workload(energy=False, virial=True, dhdl=False))
     ms_energy_only = timed(pkg.step_workload(energy=True, virial=False, dhdl=False))
 
+    # GPU-resident MD steps between two searches (secondary figure): x -> xq, clear, kernels, force reduction, leap-frog and
+    # SETTLE with coordinates, velocities and forces staying in HBM; 0.5 fs steps so that the list stays valid over the run
+    ms_md_step = ms_md_step_sequence = None
+    if fused and world == 1:
+        mdloop = importlib.import_module("gromacs_fep_gpu_amd.mdloop")
+        nat = case.natoms
+        im = np.tile([1 / 15.9994, 1 / 1.008, 1 / 1.008], nat // 3)
+        loop = mdloop.ShortRangeMdLoop(nb, case.grid, case.grid.x_wrapped, np.zeros((nat, 3)), im, 0.0005, np.diag(case.grid.box),
+                                       settles=np.arange(nat, dtype=np.int32).reshape(-1, 3), settle_params=(15.9994, 1.008, 0.1, 0.16330))
+
+        def time_md(lp, first):
+            for i in range(10):
+                lp.step(first + i)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for i in range(50):
+                lp.step(first + 10 + i)
+            torch.cuda.synchronize()
+            return 1e3 * (time.perf_counter() - t1) / 50
+
+        ms_md_step_sequence = time_md(loop, 0)       # the reference's kernel sequence
+        x_now, v_now = loop.d_x.cpu().numpy(), loop.d_v.cpu().numpy()
+        loop.free()
+        loop = mdloop.ShortRangeMdLoop(nb, case.grid, x_now, v_now, im, 0.0005, np.diag(case.grid.box), fused_update=True,
+                                       settles=np.arange(nat, dtype=np.int32).reshape(-1, 3), settle_params=(15.9994, 1.008, 0.1, 0.16330))
+        ms_md_step = time_md(loop, 60)               # one fused update kernel
+        md_finite = bool(torch.isfinite(loop.d_x).all().item())
+        loop.free()
+        if not md_finite:
+            ms_md_step = ms_md_step_sequence = None
+        # put the object back into the state of the timed loop (coordinates of the search)
+        nb.copy_xq_to_gpu(case.grid.xq)
+
     ms_per_step = 1e3 * elapsed / args.steps
     pair_evals = 64 * stats["cluster_pairs"]          # atom pairs in the (pruned) list, SURVEY §8d
     fep_pairs = len(case.plist.fep["jjnr"])
@@ -276,6 +309,7 @@ def main():
         "kernel_us": {"k_calc_nb": nb_k_us, "k_calc_nb_fep": fep_k_us},
         "ms_per_energy_step": ms_energy_step, "ms_per_dhdl_step_11_foreign_lambdas": ms_dhdl_step,
         "ms_per_virial_only_step": ms_virial_only, "ms_per_energy_only_step": ms_energy_only,
+        "ms_per_gpu_resident_md_step": ms_md_step, "ms_per_gpu_resident_md_step_unfused_update": ms_md_step_sequence,
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                      "kernel": "nbnxmKernel<EwaldAna,LJcut,F,%s>" % ("fused" if fused else "plain"),

@@ -107,7 +107,8 @@ UPDATE_SYMBOLS = [
     "lincs_gpu_create", "lincs_gpu_free", "lincs_gpu_set", "lincs_gpu_apply",
     "update_constrain_gpu_create", "update_constrain_gpu_free", "update_constrain_gpu_set", "update_constrain_gpu_set_pbc",
     "update_constrain_gpu_integrate", "update_constrain_gpu_scale_coordinates", "update_constrain_gpu_scale_velocities",
-    "update_constrain_gpu_x_updated_event",
+    "update_constrain_gpu_x_updated_event", "update_constrain_gpu_set_nbat_coupling", "update_constrain_gpu_can_fuse",
+    "update_constrain_gpu_integrate_fused",
 ]
 LISTED_SYMBOLS = [
     "listed_gpu_create", "listed_gpu_free", "listed_gpu_set_force_params", "listed_gpu_update_interaction_list",
@@ -755,6 +756,25 @@ class UpdateConstrainGpu(_Handle):
                                                  C.c_int(bool(compute_virial)), _p(vir), C.c_int(lam is not None),
                                                  _p(lam) if lam is not None else None, C.c_int(prm is not None), C.c_float(dt_pressure_couple),
                                                  _p(prm) if prm is not None else None, C.c_int(seed), C.c_int(step))
+        return vir.reshape(3, 3)
+
+    def set_nbat_coupling(self, cell, d_xq, d_f_nbat):
+        """MI355X extension: atom -> grid-slot map and the non-bonded xq / f device buffers, for integrate_fused"""
+        self._lib.update_constrain_gpu_set_nbat_coupling(self.h, _p(_a(cell, np.int32)), C.c_void_p(d_xq), C.c_void_p(d_f_nbat))
+
+    def can_fuse(self):
+        return bool(self._lib.update_constrain_gpu_can_fuse(self.h))
+
+    def integrate_fused(self, dt, compute_virial=False, tc_lambdas=None, pr_matrix=None, dt_pressure_couple=0.0, seed=0, step=0,
+                        add_atom_order_forces=False, f_ready_event=None):
+        vir = np.zeros(9, np.float32)
+        lam = _a(tc_lambdas, np.float32) if tc_lambdas is not None else None
+        prm = _a(pr_matrix, np.float32).reshape(-1) if pr_matrix is not None else None
+        self._lib.update_constrain_gpu_integrate_fused(self.h, C.c_void_p(f_ready_event), C.c_float(dt), C.c_int(bool(compute_virial)), _p(vir),
+                                                       C.c_int(lam is not None), _p(lam) if lam is not None else None,
+                                                       C.c_int(prm is not None), C.c_float(dt_pressure_couple),
+                                                       _p(prm) if prm is not None else None, C.c_int(seed), C.c_int(step),
+                                                       C.c_int(bool(add_atom_order_forces)))
         return vir.reshape(3, 3)
 
     def scale_coordinates(self, matrix):

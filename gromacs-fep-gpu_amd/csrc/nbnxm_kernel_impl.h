@@ -172,7 +172,6 @@ __launch_bounds__(c_nbBlockSize) __attribute__((amdgpu_waves_per_eu(c_nbWavesPer
 {
     constexpr bool EXCL_FORCES = (ELEC != ELK_CUT) || ENERGY; /* nbnxm_cuda_kernel.cuh:69-78 */
     constexpr bool USE_TABLE   = VdwTraits<VDW>::useTable;
-    constexpr int  FEP_ELEC    = (ELEC == ELK_CUT) ? ELK_RF : ELEC;
 
     /* wave-uniform values are pinned to SGPRs with readfirstlane so that everything derived from them
      * (list walk, branches, list loads) stays on the scalar unit */
@@ -181,7 +180,6 @@ __launch_bounds__(c_nbBlockSize) __attribute__((amdgpu_waves_per_eu(c_nbWavesPer
     const unsigned wave      = __builtin_amdgcn_readfirstlane(threadIdx.x / c_waveSize);
     const unsigned tidxi     = lane & 7U;
     const unsigned tidxj     = lane >> 3;
-    const unsigned half      = lane >> 5;
 
     /* LDS (all dynamic, sized by nbLdsBytes()): the LJ parameter table shared by the waves of the workgroup,
      * then per wave: two staging buffers for the j-side of a packed group (filled by LDS-direct loads, see the

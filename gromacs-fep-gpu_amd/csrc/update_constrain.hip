@@ -25,6 +25,7 @@
 
 #include "device_utils.h"
 #include "pbc_aiuc.h"
+#include "update_device.h"
 #include "update_hip.h"
 
 using namespace nbnxm_hip;
@@ -32,47 +33,8 @@ using namespace nbnxm_hip;
 namespace
 {
 
-constexpr int c_updateBlock = 256;
-
-__device__ __forceinline__ float3 operator+(float3 a, float3 b) { return make_float3(a.x + b.x, a.y + b.y, a.z + b.z); }
-__device__ __forceinline__ float3 operator-(float3 a, float3 b) { return make_float3(a.x - b.x, a.y - b.y, a.z - b.z); }
-__device__ __forceinline__ float3 operator*(float s, float3 a) { return make_float3(s * a.x, s * a.y, s * a.z); }
-__device__ __forceinline__ float  dot3(float3 a, float3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
-__device__ __forceinline__ float3 cross3(float3 a, float3 b)
-{
-    return make_float3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
-}
-
-/* sum over the 64 lanes of a wave, result in every lane */
-__device__ __forceinline__ float waveSum(float v)
-{
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) { v += __shfl_xor(v, m); }
-    return v;
-}
-
-/* the six independent components of sum_lanes w (x) u, added to virial[XX XY XZ YY YZ ZZ] once per wave */
-__device__ __forceinline__ void addWaveVirial(float* virial, const float (&c)[6])
-{
-    const int lane = static_cast<int>(threadIdx.x) & 63;
-#pragma unroll
-    for (int d = 0; d < 6; d++)
-    {
-        const float s = waveSum(c[d]);
-        if (lane == 0 && s != 0.0F) { atomicAdd(&virial[d], s); }
-    }
-}
-
 /* ---------------------------------------------------------------------------------------------------------------------- */
 /* leap-frog */
-
-/* the temperature-scaling factors of a step travel as kernel arguments (no staging copy, nothing to wait for) when
- * they fit; more groups than this go through a device buffer */
-constexpr int c_maxLambdasInArgs = 32;
-struct TcLambdas
-{
-    float v[c_maxLambdasInArgs];
-};
 
 template<int tempScaling /* 0 none, 1 one factor, 2 per group (kernel arguments), 3 per group (device buffer) */, bool parrinelloRahman>
 __launch_bounds__(c_updateBlock) __global__
@@ -125,11 +87,6 @@ __launch_bounds__(c_updateBlock) __global__ void scaleKernel(const int numAtoms,
 /* ---------------------------------------------------------------------------------------------------------------------- */
 /* SETTLE */
 
-struct SettlePars /* mdlib/settle.h:68-100, the part the coordinate constraint needs */
-{
-    float mO, mH, wh, ra, rb, rc, irc2;
-};
-
 template<bool updateVelocities, bool computeVirial>
 __launch_bounds__(c_updateBlock) __global__
         void settleKernel(const int numSettles, const int* __restrict__ atoms, const SettlePars pars, const float3* __restrict__ x,
@@ -148,56 +105,8 @@ __launch_bounds__(c_updateBlock) __global__
         const float3 doh2   = pbcDxAiuc(pbc, ph2, po);
         const float3 doh3   = pbcDxAiuc(pbc, ph3, po);
 
-        /* the updated triangle relative to its mass centre (O as reference point: no centre of mass is formed) */
-        const float3 a1 = (-pars.wh) * (doh2 + doh3);
-        const float3 b1 = doh2 + a1;
-        const float3 c1 = doh3 + a1;
-
-        /* frame: ez normal to the old triangle, ex = a1 x ez, ey = ez x ex */
-        float3 ez = cross3(dist21, dist31);
-        float3 ex = cross3(a1, ez);
-        float3 ey = cross3(ez, ex);
-        ex        = rsqrtf(dot3(ex, ex)) * ex;
-        ey        = rsqrtf(dot3(ey, ey)) * ey;
-        ez        = rsqrtf(dot3(ez, ez)) * ez;
-
-        const float b0dx = dot3(ex, dist21), b0dy = dot3(ey, dist21);
-        const float c0dx = dot3(ex, dist31), c0dy = dot3(ey, dist31);
-        const float a1dz = dot3(ez, a1);
-        const float b1dx = dot3(ex, b1), b1dy = dot3(ey, b1), b1dz = dot3(ez, b1);
-        const float c1dx = dot3(ex, c1), c1dy = dot3(ey, c1), c1dz = dot3(ez, c1);
-
-        const float sinphi = a1dz * rsqrtf(pars.ra * pars.ra);
-        float       tmp2   = fmaxf(1.0F - sinphi * sinphi, 1e-12F);
-        const float tmp    = rsqrtf(tmp2);
-        const float cosphi = tmp2 * tmp;
-        const float sinpsi = (b1dz - c1dz) * pars.irc2 * tmp;
-        tmp2               = 1.0F - sinpsi * sinpsi;
-        const float cospsi = tmp2 * rsqrtf(tmp2);
-
-        const float a2dy = pars.ra * cosphi;
-        const float b2dx = -pars.rc * cospsi;
-        const float t1   = -pars.rb * cosphi;
-        const float t2   = pars.rc * sinpsi * sinphi;
-        const float b2dy = t1 - t2;
-        const float c2dy = t1 + t2;
-
-        const float alpha  = b2dx * (b0dx - c0dx) + b0dy * b2dy + c0dy * c2dy;
-        const float beta   = b2dx * (c0dy - b0dy) + b0dx * b2dy + c0dx * c2dy;
-        const float gamma  = b0dx * b1dy - b1dx * b0dy + c0dx * c1dy - c1dx * c0dy;
-        const float al2be2 = alpha * alpha + beta * beta;
-        tmp2               = al2be2 - gamma * gamma;
-        const float sinthe = (alpha * gamma - beta * tmp2 * rsqrtf(tmp2)) * rsqrtf(al2be2 * al2be2);
-        tmp2               = 1.0F - sinthe * sinthe;
-        const float costhe = tmp2 * rsqrtf(tmp2);
-
-        const float3 a3d = make_float3(-a2dy * sinthe, a2dy * costhe, a1dz);
-        const float3 b3d = make_float3(b2dx * costhe - b2dy * sinthe, b2dx * sinthe + b2dy * costhe, b1dz);
-        const float3 c3d = make_float3(-b2dx * costhe - c2dy * sinthe, -b2dx * sinthe + c2dy * costhe, c1dz);
-
-        const float3 dxO  = (a3d.x * ex + a3d.y * ey + a3d.z * ez) - a1;
-        const float3 dxH2 = (b3d.x * ex + b3d.y * ey + b3d.z * ez) - b1;
-        const float3 dxH3 = (c3d.x * ex + c3d.y * ey + c3d.z * ez) - c1;
+        float3 dxO, dxH2, dxH3;
+        settleTriangle(pars, dist21, dist31, doh2, doh3, dxO, dxH2, dxH3);
 
         xp[io]  = po + dxO;
         xp[ih2] = ph2 + dxH2;
@@ -208,18 +117,7 @@ __launch_bounds__(c_updateBlock) __global__
             v[ih2] = v[ih2] + invdt * dxH2;
             v[ih3] = v[ih3] + invdt * dxH3;
         }
-        if (computeVirial)
-        {
-            const float3 mdb = pars.mH * dxH2;
-            const float3 mdc = pars.mH * dxH3;
-            const float3 mdo = pars.mO * dxO + mdb + mdc;
-            vir[0]           = -(xo.x * mdo.x + dist21.x * mdb.x + dist31.x * mdc.x);
-            vir[1]           = -(xo.x * mdo.y + dist21.x * mdb.y + dist31.x * mdc.y);
-            vir[2]           = -(xo.x * mdo.z + dist21.x * mdb.z + dist31.x * mdc.z);
-            vir[3]           = -(xo.y * mdo.y + dist21.y * mdb.y + dist31.y * mdc.y);
-            vir[4]           = -(xo.y * mdo.z + dist21.y * mdb.z + dist31.y * mdc.z);
-            vir[5]           = -(xo.z * mdo.z + dist21.z * mdb.z + dist31.z * mdc.z);
-        }
+        if (computeVirial) { settleVirial(pars, xo, dist21, dist31, dxO, dxH2, dxH3, vir); }
     }
     if (computeVirial) { addWaveVirial(virial, vir); }
 }
@@ -363,6 +261,147 @@ __global__ void lincsKernel(const LincsKernelArgs a, const float3* __restrict__ 
     }
 }
 
+/* ---------------------------------------------------------------------------------------------------------------------- */
+/* fused update (MI355X extension): force gather from the non-bonded buffer, integrator, SETTLE, and the coordinates of the next
+ * step written straight into the non-bonded xq buffer.  One thread per update unit = one SETTLE water or one other atom. */
+
+struct FusedUpdateArgs
+{
+    int                   numUnits;
+    const int*            units; /* per unit 3 atoms (second < 0: a single atom), then their 3 grid slots */
+    float3*               x;
+    float3*               v;
+    const float3*         fAtom; /* forces in atom order to add (listed, long-range), or null */
+    float3*               fNbat; /* non-bonded forces in grid order: read, then cleared for the next step */
+    float*                xq;    /* float4 per grid slot: xyz rewritten, charge kept */
+    const float*          inverseMasses;
+    const unsigned short* groups;
+    float                 dt;
+    int                   tempScaling; /* as leapfrogKernel */
+    TcLambdas             lambdaArgs;
+    const float*          lambdas;
+    int                   parrinelloRahman;
+    float3                prDiagonal;
+    SettlePars            pars;
+    PbcAiuc               pbc;
+    float*                virial;
+    const float*          sdSigmaV;
+    const float*          sdConstEm;
+    const float*          table;
+    int                   seed, step;
+};
+
+/* one wave per work-group: 32k waters are 500 waves, fewer than the chip has SIMDs, so they are spread over all CUs */
+constexpr int c_fusedBlock = 64;
+
+template<bool stochasticDynamics, bool computeVirial>
+__launch_bounds__(c_fusedBlock) __global__ void fusedUpdateKernel(const FusedUpdateArgs a)
+{
+    const int u      = static_cast<int>(blockIdx.x) * c_fusedBlock + static_cast<int>(threadIdx.x);
+    float     vir[6] = { 0, 0, 0, 0, 0, 0 };
+    if (u < a.numUnits)
+    {
+        const int2* unit  = reinterpret_cast<const int2*>(a.units) + 3 * u; /* one 24-byte record: no dependent second load */
+        const int2  u01   = unit[0], u2s0 = unit[1], s12 = unit[2];
+        int         at[3] = { u01.x, u01.y, u2s0.x };
+        int         slot[3] = { u2s0.y, s12.x, s12.y };
+        const bool  water = (at[1] >= 0);
+        if (!water)
+        {
+            at[1] = at[2] = at[0]; /* the extra two copies are computed and dropped */
+            slot[1] = slot[2] = slot[0];
+        }
+        float3 xOld[3], xNew[3], vel[3];
+        float  im[3];
+#pragma unroll
+        for (int k = 0; k < 3; k++)
+        {
+            float3 f = a.fNbat[slot[k]];
+            if (a.fAtom) { f = f + a.fAtom[at[k]]; }
+            xOld[k]        = a.x[at[k]];
+            const float3 v = a.v[at[k]];
+            im[k]          = a.inverseMasses[at[k]];
+            float3 vs      = v;
+            if (!stochasticDynamics)
+            {
+                if (a.tempScaling != 0)
+                {
+                    const float lambda = (a.tempScaling == 1)   ? a.lambdaArgs.v[0]
+                                         : (a.tempScaling == 2) ? a.lambdaArgs.v[a.groups[at[k]]]
+                                                                : a.lambdas[a.groups[at[k]]];
+                    vs                 = lambda * vs;
+                }
+                if (a.parrinelloRahman)
+                {
+                    vs.x -= a.prDiagonal.x * v.x;
+                    vs.y -= a.prDiagonal.y * v.y;
+                    vs.z -= a.prDiagonal.z * v.z;
+                }
+            }
+            vel[k]  = vs + (im[k] * a.dt) * f;
+            xNew[k] = xOld[k] + a.dt * vel[k];
+        }
+        /* every grid slot is cleared by the one unit that owns its atom */
+        a.fNbat[slot[0]] = make_float3(0.0F, 0.0F, 0.0F);
+        if (water)
+        {
+            a.fNbat[slot[1]] = make_float3(0.0F, 0.0F, 0.0F);
+            a.fNbat[slot[2]] = make_float3(0.0F, 0.0F, 0.0F);
+        }
+        float3 dist21, dist31;
+        if (water)
+        {
+            dist21 = pbcDxAiuc(a.pbc, xOld[1], xOld[0]);
+            dist31 = pbcDxAiuc(a.pbc, xOld[2], xOld[0]);
+            float3 dxO, dxH2, dxH3;
+            settleTriangle(a.pars, dist21, dist31, pbcDxAiuc(a.pbc, xNew[1], xNew[0]), pbcDxAiuc(a.pbc, xNew[2], xNew[0]), dxO, dxH2, dxH3);
+            const float invdt = 1.0F / a.dt;
+            xNew[0] = xNew[0] + dxO;
+            xNew[1] = xNew[1] + dxH2;
+            xNew[2] = xNew[2] + dxH3;
+            vel[0]  = vel[0] + invdt * dxO;
+            vel[1]  = vel[1] + invdt * dxH2;
+            vel[2]  = vel[2] + invdt * dxH3;
+            if (computeVirial) { settleVirial(a.pars, xOld[0], dist21, dist31, dxO, dxH2, dxH3, vir); }
+        }
+        if (stochasticDynamics)
+        {
+#pragma unroll
+            for (int k = 0; k < 3; k++)
+            {
+                const float3 xi  = langevinNoise(a.table, a.seed, a.step, at[k]);
+                const int    g   = a.groups[at[k]];
+                const float  em  = a.sdConstEm[g];
+                const float  amp = sqrtf(im[k]) * a.sdSigmaV[g];
+                const float3 vn  = vel[k];
+                vel[k]           = em * vn + amp * xi;
+                xNew[k]          = xNew[k] + (0.5F * a.dt) * (vel[k] - vn);
+            }
+            if (water)
+            {
+                float3 dxO, dxH2, dxH3;
+                settleTriangle(a.pars, dist21, dist31, pbcDxAiuc(a.pbc, xNew[1], xNew[0]), pbcDxAiuc(a.pbc, xNew[2], xNew[0]), dxO, dxH2, dxH3);
+                xNew[0] = xNew[0] + dxO;
+                xNew[1] = xNew[1] + dxH2;
+                xNew[2] = xNew[2] + dxH3;
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 3; k++)
+        {
+            if (k == 0 || water)
+            {
+                a.x[at[k]]             = xNew[k];
+                a.v[at[k]]             = vel[k];
+                a.xq[4 * slot[k] + 0] = xNew[k].x;
+                a.xq[4 * slot[k] + 1] = xNew[k].y;
+                a.xq[4 * slot[k] + 2] = xNew[k].z;
+            }
+        }
+    }
+    if (computeVirial) { addWaveVirial(a.virial, vir); }
+}
+
 /* [XX XY XZ YY YZ ZZ] -> += into a row-major symmetric 3x3 */
 void addSymmetricVirial(float* tensor, const float* six)
 {
@@ -453,7 +492,47 @@ struct UpdateConstrainGpu
     int          pbcType = 0;
     float        box[9] = { 0, 0, 0, 0, 0, 0, 0, 0, 0 };
     hipEvent_t   xUpdated = nullptr;
+    bool         recordXUpdated = false; /* set once a consumer has asked for the event */
+    /* fused update */
+    int          numUnits = 0, numConstraints = 0;
+    int*         d_units = nullptr; /* 6 ints per unit, complete after set_nbat_coupling */
+    size_t       unitsAlloc = 0;
+    std::vector<int> h_unitAtoms; /* 3 per unit */
+    float*       d_xq = nullptr;
+    float3*      d_fNbat = nullptr;
+    float*       d_virial = nullptr;
+    PinnedBuffer<float> h_virial;
 };
+
+/* temperature-scaling factors into kernel arguments (or the device buffer when there are too many groups) and the diagonal of
+ * the Parrinello-Rahman matrix times its period; returns the tempScaling mode of the kernels */
+static int prepareCoupling(LeapFrogGpu* lf, int doTemperatureScaling, const float* tcLambdas, int doParrinelloRahman, float dtPressureCouple,
+                           const float* prMatrix, TcLambdas* lambdaArgs, float3* prDiagonal)
+{
+    NBNXM_ASSERT(!doTemperatureScaling || lf->numTempScaleValues > 0, "temperature coupling was requested with no temperature-coupling groups");
+    hipStream_t s = lf->stream.stream;
+    std::memset(lambdaArgs, 0, sizeof(*lambdaArgs));
+    const bool lambdasInArgs = (lf->numTempScaleValues <= c_maxLambdasInArgs);
+    if (doTemperatureScaling)
+    {
+        if (lambdasInArgs) { std::memcpy(lambdaArgs->v, tcLambdas, sizeof(float) * lf->numTempScaleValues); }
+        else
+        {
+            /* the pinned staging copy may still be read by the previous step's transfer */
+            NBNXM_HIP_CHECK(hipStreamSynchronize(s));
+            std::memcpy(lf->h_lambdas.data, tcLambdas, sizeof(float) * lf->numTempScaleValues);
+            NBNXM_HIP_CHECK(hipMemcpyAsync(lf->d_lambdas, lf->h_lambdas.data, sizeof(float) * lf->numTempScaleValues, hipMemcpyHostToDevice, s));
+        }
+    }
+    *prDiagonal = make_float3(0.0F, 0.0F, 0.0F);
+    if (doParrinelloRahman)
+    {
+        NBNXM_ASSERT(prMatrix[1] == 0 && prMatrix[2] == 0 && prMatrix[3] == 0 && prMatrix[5] == 0 && prMatrix[6] == 0 && prMatrix[7] == 0,
+                     "fully anisotropic Parrinello-Rahman pressure coupling is not supported by the GPU leap-frog integrator");
+        *prDiagonal = make_float3(dtPressureCouple * prMatrix[0], dtPressureCouple * prMatrix[4], dtPressureCouple * prMatrix[8]);
+    }
+    return !doTemperatureScaling ? 0 : (lf->numTempScaleValues == 1 ? 1 : (lambdasInArgs ? 2 : 3));
+}
 
 extern "C"
 {
@@ -503,31 +582,11 @@ void leapfrog_gpu_integrate(LeapFrogGpu* lf, void* d_x, void* d_xp, void* d_v, c
                             const float* tcLambdas, int doParrinelloRahman, float dtPressureCouple, const float* prMatrix)
 {
     NBNXM_ASSERT(lf->numAtoms > 0, "the number of atoms needs to be > 0");
-    NBNXM_ASSERT(!doTemperatureScaling || lf->numTempScaleValues > 0, "temperature coupling was requested with no temperature-coupling groups");
     hipStream_t s = lf->stream.stream;
     TcLambdas   lambdaArgs;
-    std::memset(&lambdaArgs, 0, sizeof(lambdaArgs));
-    const bool lambdasInArgs = (lf->numTempScaleValues <= c_maxLambdasInArgs);
-    if (doTemperatureScaling)
-    {
-        if (lambdasInArgs) { std::memcpy(lambdaArgs.v, tcLambdas, sizeof(float) * lf->numTempScaleValues); }
-        else
-        {
-            /* the pinned staging copy may still be read by the previous step's transfer */
-            NBNXM_HIP_CHECK(hipStreamSynchronize(s));
-            std::memcpy(lf->h_lambdas.data, tcLambdas, sizeof(float) * lf->numTempScaleValues);
-            NBNXM_HIP_CHECK(hipMemcpyAsync(lf->d_lambdas, lf->h_lambdas.data, sizeof(float) * lf->numTempScaleValues, hipMemcpyHostToDevice, s));
-        }
-    }
-    float3 prDiagonal = make_float3(0.0F, 0.0F, 0.0F);
-    if (doParrinelloRahman)
-    {
-        NBNXM_ASSERT(prMatrix[1] == 0 && prMatrix[2] == 0 && prMatrix[3] == 0 && prMatrix[5] == 0 && prMatrix[6] == 0 && prMatrix[7] == 0,
-                     "fully anisotropic Parrinello-Rahman pressure coupling is not supported by the GPU leap-frog integrator");
-        prDiagonal = make_float3(dtPressureCouple * prMatrix[0], dtPressureCouple * prMatrix[4], dtPressureCouple * prMatrix[8]);
-    }
-    const int mode = !doTemperatureScaling ? 0 : (lf->numTempScaleValues == 1 ? 1 : (lambdasInArgs ? 2 : 3));
-    auto      k    = leapfrogKernel<0, false>;
+    float3      prDiagonal;
+    const int   mode = prepareCoupling(lf, doTemperatureScaling, tcLambdas, doParrinelloRahman, dtPressureCouple, prMatrix, &lambdaArgs, &prDiagonal);
+    auto        k    = leapfrogKernel<0, false>;
     if (doParrinelloRahman)
     {
         k = (mode == 0) ? leapfrogKernel<0, true> : (mode == 1) ? leapfrogKernel<1, true> : (mode == 2) ? leapfrogKernel<2, true> : leapfrogKernel<3, true>;
@@ -853,6 +912,8 @@ UpdateConstrainGpu* update_constrain_gpu_create(void* stream, const update_const
     uc->lincs = lincs_gpu_create(s, p->nLincsIter, p->nProjOrder);
     if (p->haveSettle) { uc->settle = settle_gpu_create(s, p->mO, p->mH, p->dOH, p->dHH); }
     NBNXM_HIP_CHECK(hipEventCreateWithFlags(&uc->xUpdated, hipEventDisableTiming));
+    allocateDeviceBuffer(&uc->d_virial, 6);
+    uc->h_virial.resize(6);
     return uc;
 }
 
@@ -865,6 +926,8 @@ void update_constrain_gpu_free(UpdateConstrainGpu* uc)
     lincs_gpu_free(uc->lincs);
     settle_gpu_free(uc->settle);
     freeDeviceBuffer(&uc->d_xp);
+    freeDeviceBuffer(&uc->d_units);
+    freeDeviceBuffer(&uc->d_virial);
     (void)hipEventDestroy(uc->xUpdated);
     uc->stream.destroy();
     delete uc;
@@ -882,6 +945,35 @@ int update_constrain_gpu_set(UpdateConstrainGpu* uc, void* d_x, void* d_v, const
     if (uc->leapFrog) { leapfrog_gpu_set(uc->leapFrog, t->numAtoms, t->inverseMasses, t->tempCouplGroups); }
     else { langevin_gpu_set(uc->langevin, t->numAtoms, t->inverseMasses, t->tempCouplGroups); }
     if (uc->settle) { settle_gpu_set(uc->settle, t->numSettles, t->settles); }
+    /* update units of the fused path: the waters, then every atom that is not part of one */
+    {
+        std::vector<char> inWater(t->numAtoms, 0);
+        std::vector<int>  units;
+        units.reserve(3 * static_cast<size_t>(t->numAtoms));
+        for (int w = 0; w < t->numSettles; w++)
+        {
+            for (int k = 0; k < 3; k++)
+            {
+                const int at = t->settles[3 * w + k];
+                NBNXM_ASSERT(at >= 0 && at < t->numAtoms && !inWater[at], "SETTLE atom outside the home atoms or in two waters");
+                inWater[at] = 1;
+                units.push_back(at);
+            }
+        }
+        for (int at = 0; at < t->numAtoms; at++)
+        {
+            if (!inWater[at])
+            {
+                units.push_back(at);
+                units.push_back(-1);
+                units.push_back(-1);
+            }
+        }
+        uc->numUnits = static_cast<int>(units.size() / 3);
+        uc->h_unitAtoms.swap(units);
+        uc->d_xq = nullptr; /* the coupling belongs to the previous search */
+    }
+    uc->numConstraints = t->numConstraints;
     return lincs_gpu_set(uc->lincs, t->numConstraints, t->constraints, t->constraintLengths, t->numAtoms, t->inverseMasses);
 }
 
@@ -927,7 +1019,94 @@ void update_constrain_gpu_integrate(UpdateConstrainGpu* uc, void* fReadyEvent, f
             for (int i = 0; i < 9; i++) { virial[i] *= scale; }
         }
     }
-    NBNXM_HIP_CHECK(hipEventRecord(uc->xUpdated, s));
+    if (uc->recordXUpdated) { NBNXM_HIP_CHECK(hipEventRecord(uc->xUpdated, s)); }
+}
+
+/* ---- fused update (MI355X extension) ---------------------------------------------------------------------------------- */
+
+void update_constrain_gpu_set_nbat_coupling(UpdateConstrainGpu* uc, const int* cell, void* d_xq, void* d_f_nbat)
+{
+    NBNXM_ASSERT(cell && d_xq && d_f_nbat, "the atom -> grid-slot map and the non-bonded xq and f buffers are needed");
+    for (int i = 0; i < uc->numAtoms; i++) { NBNXM_ASSERT(cell[i] >= 0, "every home atom needs a grid slot"); }
+    std::vector<int> units(6 * static_cast<size_t>(uc->numUnits));
+    for (int u = 0; u < uc->numUnits; u++)
+    {
+        for (int k = 0; k < 3; k++)
+        {
+            const int at     = uc->h_unitAtoms[3 * u + k];
+            units[6 * u + k] = at;
+            units[6 * u + 3 + k] = (at >= 0) ? cell[at] : -1;
+        }
+    }
+    uploadVector(&uc->d_units, &uc->unitsAlloc, units, uc->stream.stream);
+    uc->d_xq    = static_cast<float*>(d_xq);
+    uc->d_fNbat = static_cast<float3*>(d_f_nbat);
+}
+
+int update_constrain_gpu_can_fuse(const UpdateConstrainGpu* uc)
+{
+    return (uc->numConstraints == 0 && uc->d_xq != nullptr) ? 1 : 0;
+}
+
+void update_constrain_gpu_integrate_fused(UpdateConstrainGpu* uc, void* fReadyEvent, float dt, int computeVirial, float* virial,
+                                          int doTemperatureScaling, const float* tcLambdas, int doParrinelloRahman, float dtPressureCouple,
+                                          const float* prVelocityScalingMatrix, int seed, int step, int addAtomOrderForces)
+{
+    NBNXM_ASSERT(update_constrain_gpu_can_fuse(uc), "the fused update needs the non-bonded coupling and a topology without LINCS constraints");
+    NBNXM_ASSERT(!computeVirial || virial != nullptr, "a virial tensor is needed to compute the virial");
+    hipStream_t s = uc->stream.stream;
+    if (virial) { std::fill(virial, virial + 9, 0.0F); }
+    if (fReadyEvent) { NBNXM_HIP_CHECK(hipStreamWaitEvent(s, static_cast<hipEvent_t>(fReadyEvent), 0)); }
+    if (uc->numUnits != 0)
+    {
+        FusedUpdateArgs a;
+        std::memset(&a, 0, sizeof(a));
+        a.numUnits = uc->numUnits;
+        a.units    = uc->d_units;
+        a.x        = uc->d_x;
+        a.v        = uc->d_v;
+        a.fAtom    = addAtomOrderForces ? uc->d_f : nullptr;
+        a.fNbat    = uc->d_fNbat;
+        a.xq       = uc->d_xq;
+        a.dt       = dt;
+        a.pbc      = makePbcAiuc(uc->pbcType, uc->box);
+        a.virial   = uc->d_virial;
+        a.seed     = seed;
+        a.step     = step;
+        if (uc->settle) { a.pars = uc->settle->pars; }
+        if (uc->leapFrog)
+        {
+            a.inverseMasses    = uc->leapFrog->d_inverseMasses;
+            a.groups           = uc->leapFrog->d_groups;
+            a.lambdas          = uc->leapFrog->d_lambdas;
+            a.parrinelloRahman = doParrinelloRahman;
+            a.tempScaling      = prepareCoupling(uc->leapFrog, doTemperatureScaling, tcLambdas, doParrinelloRahman, dtPressureCouple,
+                                                 prVelocityScalingMatrix, &a.lambdaArgs, &a.prDiagonal);
+        }
+        else
+        {
+            a.inverseMasses = uc->langevin->d_inverseMasses;
+            a.groups        = uc->langevin->d_tcGroups;
+            a.sdSigmaV      = uc->langevin->d_sdSigmaV;
+            a.sdConstEm     = uc->langevin->d_sdConstEm;
+            a.table         = uc->langevin->d_table;
+        }
+        if (computeVirial) { NBNXM_HIP_CHECK(hipMemsetAsync(uc->d_virial, 0, 6 * sizeof(float), s)); }
+        auto k = uc->langevin ? (computeVirial ? fusedUpdateKernel<true, true> : fusedUpdateKernel<true, false>)
+                              : (computeVirial ? fusedUpdateKernel<false, true> : fusedUpdateKernel<false, false>);
+        const dim3 grid((uc->numUnits + c_fusedBlock - 1) / c_fusedBlock);
+        hipLaunchKernelGGL(k, grid, dim3(c_fusedBlock), 0, s, a);
+        NBNXM_HIP_CHECK(hipGetLastError());
+        if (computeVirial)
+        {
+            NBNXM_HIP_CHECK(hipMemcpyAsync(uc->h_virial.data, uc->d_virial, 6 * sizeof(float), hipMemcpyDeviceToHost, s));
+            NBNXM_HIP_CHECK(hipStreamSynchronize(s));
+            addSymmetricVirial(virial, uc->h_virial.data);
+            const float scale = 0.5F / (dt * dt);
+            for (int i = 0; i < 9; i++) { virial[i] *= scale; }
+        }
+    }
+    if (uc->recordXUpdated) { NBNXM_HIP_CHECK(hipEventRecord(uc->xUpdated, s)); }
 }
 
 static void scaleBuffer(UpdateConstrainGpu* uc, float3* d_buf, const float* m)
@@ -942,6 +1121,11 @@ static void scaleBuffer(UpdateConstrainGpu* uc, float3* d_buf, const float* m)
 void update_constrain_gpu_scale_coordinates(UpdateConstrainGpu* uc, const float* scalingMatrix) { scaleBuffer(uc, uc->d_x, scalingMatrix); }
 void update_constrain_gpu_scale_velocities(UpdateConstrainGpu* uc, const float* scalingMatrix) { scaleBuffer(uc, uc->d_v, scalingMatrix); }
 
-void* update_constrain_gpu_x_updated_event(UpdateConstrainGpu* uc) { return uc->xUpdated; }
+void* update_constrain_gpu_x_updated_event(UpdateConstrainGpu* uc)
+{
+    /* an event record costs a ~5 us bubble in front of the next kernel of the stream (measured): only pay it for a consumer */
+    uc->recordXUpdated = true;
+    return uc->xUpdated;
+}
 
 } // extern "C"

@@ -11,6 +11,7 @@
 #include <vector>
 
 #include "device_utils.h"
+#include "update_device.h"
 #include "update_hip.h"
 
 using namespace nbnxm_hip;
@@ -18,38 +19,7 @@ using namespace nbnxm_hip;
 namespace
 {
 
-constexpr int                c_updateBlock       = 256;
-constexpr int                c_tableBits         = 14; /* langevin_gpu.h:79 */
-constexpr unsigned long long c_domainUpdateCoord = 0x00003000ULL; /* random/seed.h:95 */
-constexpr double             c_boltz             = 1.380649e-23 * 6.02214076e23 / 1000.0; /* kJ/(mol K) */
-
-__device__ __forceinline__ unsigned long long rotl64(unsigned long long v, unsigned b)
-{
-    return (v << b) | (v >> (64U - b));
-}
-
-/* first word of the Threefry-2x64-20 block of (key, counter) */
-__device__ __forceinline__ unsigned long long threefry2x64First(unsigned long long k0, unsigned long long k1, unsigned long long c0,
-                                                                unsigned long long c1)
-{
-    const unsigned long long ks[3] = { k0, k1, 0x1bd11bdaa9fc1a22ULL ^ k0 ^ k1 };
-    constexpr unsigned       rot[8] = { 16, 42, 12, 31, 16, 32, 24, 21 };
-    unsigned long long       x0 = c0 + ks[0], x1 = c1 + ks[1];
-#pragma unroll
-    for (unsigned r = 0; r < 20; r++)
-    {
-        x0 += x1;
-        x1 = rotl64(x1, rot[r % 8]);
-        x1 ^= x0;
-        if (((r + 1) & 3) == 0)
-        {
-            const unsigned r4 = (r + 1) >> 2;
-            x0 += ks[r4 % 3];
-            x1 += ks[(r4 + 1) % 3] + r4;
-        }
-    }
-    return x0;
-}
+constexpr double c_boltz = 1.380649e-23 * 6.02214076e23 / 1000.0; /* kJ/(mol K) */
 
 template<int updateType>
 __launch_bounds__(c_updateBlock) __global__
@@ -73,11 +43,7 @@ __launch_bounds__(c_updateBlock) __global__
     }
     else
     {
-        const unsigned long long bits = threefry2x64First(static_cast<unsigned long long>(static_cast<long long>(seed)), c_domainUpdateCoord,
-                                                          static_cast<unsigned long long>(static_cast<long long>(step)),
-                                                          static_cast<unsigned long long>(a));
-        constexpr unsigned mask = (1U << c_tableBits) - 1U;
-        const float3 xi  = make_float3(table[bits & mask], table[(bits >> c_tableBits) & mask], table[(bits >> (2 * c_tableBits)) & mask]);
+        const float3 xi  = langevinNoise(table, seed, step, a);
         const int    g   = tcGroups[a];
         const float  em  = sdConstEm[g];
         const float  amp = sqrtf(im) * sdSigmaV[g];
@@ -129,18 +95,6 @@ std::vector<float> makeNormalTable()
 
 } // namespace
 
-struct LangevinGpu
-{
-    DeviceStream    stream;
-    int             numGroups = 0, numAtoms = 0, atomsAlloc = 0;
-    float*          d_sdSigmaV = nullptr;
-    float*          d_sdConstEm = nullptr;
-    float*          d_table = nullptr;
-    float*          d_inverseMasses = nullptr;
-    unsigned short* d_tcGroups = nullptr;
-    PinnedBuffer<float>          h_im;
-    PinnedBuffer<unsigned short> h_tc;
-};
 
 extern "C"
 {

@@ -128,8 +128,27 @@ void update_constrain_gpu_integrate(UpdateConstrainGpu* uc, void* fReadyEvent, f
  * row-major 3x3 matrix, kernel update_constrain_gpu_internal.cu:60-77) */
 void update_constrain_gpu_scale_coordinates(UpdateConstrainGpu* uc, const float* scalingMatrix);
 void update_constrain_gpu_scale_velocities(UpdateConstrainGpu* uc, const float* scalingMatrix);
-/* UpdateConstrainGpu::xUpdatedOnDeviceEvent — hipEvent_t recorded at the end of integrate */
+/* UpdateConstrainGpu::xUpdatedOnDeviceEvent — hipEvent_t recorded at the end of every integrate that FOLLOWS this call (a stream
+ * whose coordinates nobody else waits for is spared the event) */
 void* update_constrain_gpu_x_updated_event(UpdateConstrainGpu* uc);
+
+/* ---- MI355X extension: the update fused with the non-bonded buffers ---------------------------------------------------------
+ * Between two searches the reference runs five kernels per step around the non-bonded ones: x -> xq (nbnxn_gpu_x_to_nbat_x),
+ * clear, force reduction, integrator, SETTLE, each one pass over all atoms.  With the atom -> grid-slot map of the search the
+ * update can read the non-bonded force buffer itself, clear it behind itself and write the new coordinates straight into xq:
+ * ONE kernel, coordinates before the update live in registers only.  Available when the home atoms have no LINCS constraints
+ * (waters and unconstrained atoms); otherwise use update_constrain_gpu_integrate. */
+
+/* after update_constrain_gpu_set, every search: cell[numAtoms] = grid slot of each atom (inverse of gridSet.atomIndices()),
+ * d_xq / d_f_nbat = nbnxm_gpu_get_xq / nbnxm_gpu_get_f of the non-bonded object */
+void update_constrain_gpu_set_nbat_coupling(UpdateConstrainGpu* uc, const int* cell, void* d_xq, void* d_f_nbat);
+int  update_constrain_gpu_can_fuse(const UpdateConstrainGpu* uc);
+/* as update_constrain_gpu_integrate with updateVelocities = true.  Forces: the non-bonded buffer (grid order), plus the d_f of
+ * update_constrain_gpu_set (atom order) when addAtomOrderForces.  Leaves the non-bonded force buffer cleared and xq holding the
+ * new coordinates: the next step needs neither nbnxm_gpu_x_to_nbat_x nor the force part of nbnxm_gpu_clear_outputs. */
+void update_constrain_gpu_integrate_fused(UpdateConstrainGpu* uc, void* fReadyEvent, float dt, int computeVirial, float* virial,
+                                          int doTemperatureScaling, const float* tcLambdas, int doParrinelloRahman, float dtPressureCouple,
+                                          const float* prVelocityScalingMatrix, int seed, int step, int addAtomOrderForces);
 
 #ifdef __cplusplus
 }

@@ -40,7 +40,7 @@ def test_hip_library_exports_every_listed_forces_symbol():
 def test_hip_library_exports_every_update_symbol():
     lib = pkg.hip_lib()
     names = declared_functions("update_hip.h", "(?:langevin|leapfrog|settle|lincs|update_constrain)_gpu_")
-    assert len(names) == 24
+    assert len(names) == 27
     for n in names:
         assert hasattr(lib, n), "libnbnxm_hip.so does not export %s" % n
     assert sorted(names) == sorted(pkg.UPDATE_SYMBOLS)

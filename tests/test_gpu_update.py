@@ -2,6 +2,8 @@
 oracle (oracle/langevin_ref.c; its random engine and normal table are pinned by the reference's known answers).  The random
 numbers must be the same numbers (same Threefry block, same table entries): velocities and coordinates agree to fp32
 rounding of a handful of operations."""
+import ctypes as C
+
 import numpy as np
 import pytest
 
@@ -366,3 +368,100 @@ def test_update_constrain_composition(sd):
     assert np.allclose(d_v.cpu().numpy(), vb * [0.5, 2.0, 1.0], rtol=1e-6, atol=1e-6)
     assert up.x_updated_event()
     up.free()
+
+
+def test_gpu_resident_md_steps_match_the_oracle_schedule():
+    """x -> xq, cluster-pair + FEP kernels, force reduction, leap-frog, SETTLE over several steps with nothing leaving HBM, against
+    the same schedule made of oracle calls (forces from the CPU kernels on the same pair list)."""
+    import importlib
+    import torch
+    mdloop = importlib.import_module("gromacs_fep_gpu_amd.mdloop")
+    c = tl.make_case(nm=(8, 8, 8), num_perturbed_molecules=3, elec="rf", seed=12)
+    g = c.grid
+    nb = tl.setup_gpu(c, fused=True)
+    n = c.natoms
+    mO, mH, dOH, dHH = 15.9994, 1.008, 0.1, 0.16330
+    im = np.tile([1 / mO, 1 / mH, 1 / mH], n // 3)
+    settles = np.arange(n, dtype=np.int32).reshape(-1, 3)
+    rng = np.random.default_rng(4)
+    v0 = np.zeros((n, 3))
+    v0 += np.repeat(rng.normal(0, 0.3, (n // 3, 3)), 3, axis=0)          # rigid-body translation: satisfies the constraints
+    dt, bx = 0.001, np.diag(g.box.astype(np.float64))
+    loop = mdloop.ShortRangeMdLoop(nb, g, g.x_wrapped, v0, im, dt, bx, settles=settles, settle_params=(mO, mH, dOH, dHH))
+    ai = g.atomIndices
+    real = ai >= 0
+    xq0, xw0 = g.xq.copy(), g.x_wrapped.copy()
+    try:
+        for step in range(4):
+            x_start = loop.d_x.cpu().numpy()
+            v_start = loop.d_v.cpu().numpy()
+            loop.step(step)
+            loop.synchronize()
+            # the oracle on the coordinates the step started from
+            g.xq.reshape(-1, 4)[real, :3] = x_start[ai[real]]
+            g.x_wrapped[:] = x_start
+            want = tl.run_oracle(c, energy=False)
+            f = np.zeros((n, 3))
+            f[ai[real]] = want["f"][real]
+            frms = np.sqrt(np.mean(f ** 2))
+            assert np.max(np.abs(loop.d_f.cpu().numpy() - f)) <= 1e-4 * max(frms, np.max(np.abs(f)) * 0.05)
+            x1, xb, v1 = ob.leapfrog(x_start, v_start, f, im, dt)
+            x2, v2, _ = ob.settle(settles, mO, mH, dOH, dHH, xb, x1, v=v1, invdt=1 / dt, pbc_type=3, box=bx)
+            assert np.max(np.abs(loop.d_x.cpu().numpy() - x2)) <= 2e-6
+            assert np.max(np.abs(loop.d_v.cpu().numpy() - v2)) <= 2e-3
+            w = loop.d_x.cpu().numpy().astype(np.float64).reshape(-1, 3, 3)
+            d = w[:, 0] - w[:, 1]
+            d -= np.rint(d / np.diag(bx)) * np.diag(bx)
+            assert np.max(np.abs(np.linalg.norm(d, axis=1) - dOH)) <= 2e-6
+    finally:
+        g.xq[:] = xq0
+        g.x_wrapped[:] = xw0
+    loop.free()
+    nb.free()
+
+
+@pytest.mark.parametrize("sd", [False, True])
+def test_fused_update_equals_the_kernel_sequence(sd):
+    """MI355X extension: force gather + integrator + SETTLE + clear + xq write in one kernel must give the trajectory of the
+    reference's sequence x -> xq, clear, kernels, reduction, integrator, SETTLE (waters and, for some molecules left out of the
+    SETTLE list, unconstrained atoms; temperature coupling or stochastic dynamics)."""
+    import importlib
+    import torch
+    mdloop = importlib.import_module("gromacs_fep_gpu_amd.mdloop")
+    c = tl.make_case(nm=(8, 8, 8), num_perturbed_molecules=3, elec="ewald", seed=31)
+    g = c.grid
+    n = c.natoms
+    mO, mH = 15.9994, 1.008
+    im = np.tile([1 / mO, 1 / mH, 1 / mH], n // 3)
+    settles = np.arange(n, dtype=np.int32).reshape(-1, 3)
+    settles = np.delete(settles, np.arange(5, len(settles), 17), axis=0)      # these waters are integrated atom by atom
+    rng = np.random.default_rng(8)
+    v0 = np.repeat(rng.normal(0, 0.3, (n // 3, 3)), 3, axis=0)
+    tc = (np.arange(n) // 3 % 2).astype(np.uint16)
+    kw = dict(settles=settles, settle_params=(mO, mH, 0.1, 0.16330), temp_coupl_groups=tc, num_temp_coupl_groups=2, stochastic_dynamics=sd,
+              ref_t=[300.0, 280.0], tau_t=[0.1, 1.0])
+    dt, bx = 0.001, np.diag(g.box.astype(np.float64))
+    out = {}
+    for fused_update in (False, True):
+        nb = tl.setup_gpu(c, fused=True)
+        loop = mdloop.ShortRangeMdLoop(nb, g, g.x_wrapped, v0, im, dt, bx, fused_update=fused_update, **kw)
+        vir = None
+        for step in range(3):
+            sw = pkg.step_workload(energy=(step == 1), virial=(step == 1), dhdl=False)
+            vir = loop.step(step, step_work=sw, seed=5, compute_virial=(step == 2), tc_lambdas=None if sd else [0.97, 1.02])
+        loop.synchronize()
+        xq = np.zeros((g.num_atoms, 4), np.float32)
+        pkg.hip_lib().nbnxm_gpu_debug_download(nb.h, C.c_void_p(pkg.hip_lib().nbnxm_gpu_get_xq(nb.h)), xq.ctypes.data_as(C.c_void_p),
+                                               C.c_size_t(xq.nbytes))
+        out[fused_update] = (loop.d_x.cpu().numpy(), loop.d_v.cpu().numpy(), vir, xq)
+        loop.free()
+        nb.free()
+    (x0, vv0, vir0, _), (x1, vv1, vir1, xq1) = out[False], out[True]
+    assert np.max(np.abs(x1 - x0)) <= 2e-6
+    assert np.max(np.abs(vv1 - vv0)) <= 2e-3
+    assert np.max(np.abs(vir1 - vir0)) <= 1e-3 * np.max(np.abs(vir0)) and np.max(np.abs(vir0)) > 0
+    # the non-bonded coordinates of the next step are the updated coordinates, charges untouched
+    ai = g.atomIndices
+    real = ai >= 0
+    assert np.array_equal(xq1[real, :3], x1[ai[real]])
+    assert np.array_equal(xq1[:, 3], g.xq.reshape(-1, 4)[:, 3])
