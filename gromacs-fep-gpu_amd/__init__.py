@@ -95,7 +95,7 @@ HIP_SYMBOLS = [
     "nbnxm_gpu_get_f", "nbnxm_gpu_get_fshift", "nbnxm_gpu_get_stream",
     "nbnxm_gpu_have_short_range_work", "nbnxm_gpu_set_fep_mode", "nbnxm_hip_abi_version",
     "nbnxm_hip_last_error", "nbnxm_gpu_debug_get_cjpacked", "nbnxm_gpu_debug_download", "nbnxm_gpu_debug_get_work_ranges",
-    "nbnxm_gpu_debug_graph_steps",
+    "nbnxm_gpu_debug_graph_steps", "nbnxm_gpu_debug_set_work_shares",
     "nbnxm_gpu_init_x_to_nbat_x", "nbnxm_gpu_x_to_nbat_x", "nbnxm_gpu_insert_nonlocal_dependency",
     "nbnxm_gpu_setup_short_range_work", "nbnxm_gpu_force_reduction_reinit", "nbnxm_gpu_force_reduction_execute",
     "nbnxm_gpu_halo_pack_x", "nbnxm_gpu_halo_unpack_f",

@@ -206,6 +206,26 @@ NbnxmGpu* nbnxm_gpu_init(const nbnxm_interaction_params_t* ic, int numTypes, con
         nb->numSimds = prop.multiProcessorCount * 4; /* CDNA: 4 SIMDs per CU */
         if (const char* env = std::getenv("NBNXM_HIP_NUM_WORK_RANGES")) { nb->numWorkRangesOverride = std::atoi(env); }
         if (const char* env = std::getenv("NBNXM_HIP_MIN_GROUPS_PER_WAVE")) { nb->minGroupsPerWave = std::max(1, std::atoi(env)); }
+        /* NBNXM_HIP_CLASS_SHARES4 / 5 = "s0,s1,.." in 1/1024 of an average range, oldest wave of a SIMD first (renormalised) */
+        for (int p = 0; p < 2; p++)
+        {
+            const char* env = std::getenv(p == 0 ? "NBNXM_HIP_CLASS_SHARES4" : "NBNXM_HIP_CLASS_SHARES5");
+            if (env == nullptr) { continue; }
+            int       v[5] = { 0, 0, 0, 0, 0 };
+            const int got = std::sscanf(env, "%d,%d,%d,%d,%d", &v[0], &v[1], &v[2], &v[3], &v[4]);
+            long long sum = 0;
+            for (int k = 0; k < 4 + p; k++) { sum += v[k]; }
+            if (got >= 4 + p && sum > 0)
+            {
+                int acc = 0;
+                for (int k = 0; k < 4 + p; k++)
+                {
+                    nb->waveClassShare[p][k] = std::max(1, static_cast<int>(static_cast<long long>(v[k]) * 1024 * (4 + p) / sum));
+                    acc += nb->waveClassShare[p][k];
+                }
+                nb->waveClassShare[p][4 + p - 1] += 1024 * (4 + p) - acc;
+            }
+        }
     }
     if (const char* env = std::getenv("NBNXM_HIP_FEP_CONCURRENT"))
     {
@@ -376,6 +396,8 @@ void nbnxm_gpu_free(NbnxmGpu* nb)
             {
                 freeDeviceBuffer(&nb->plist[i]->workRangeStart[p]);
                 freeDeviceBuffer(&nb->plist[i]->workFirstSci[p]);
+                freeDeviceBuffer(&nb->plist[i]->workShare[p]);
+                freeDeviceBuffer(&nb->plist[i]->workShareCum[p]);
             }
             delete nb->plist[i];
         }
@@ -752,6 +774,34 @@ void nbnxm_gpu_clear_outputs(NbnxmGpu* nb, int computeVirial)
     NBNXM_HIP_CHECK(hipGetLastError());
 }
 
+/* uploads the shares of the ranges of partition p and their normalised running sum (synchronous: rare) */
+static void setWorkShares(gpu_plist* d, int p, const float* share, int n, hipStream_t s)
+{
+    if (d->workShareCount[p] != n)
+    {
+        freeDeviceBuffer(&d->workShare[p]);
+        freeDeviceBuffer(&d->workShareCum[p]);
+        allocateDeviceBuffer(&d->workShare[p], n);
+        allocateDeviceBuffer(&d->workShareCum[p], n + 1);
+        d->workShareCount[p] = n;
+    }
+    double sum = 0;
+    for (int r = 0; r < n; r++) { sum += share[r]; }
+    std::vector<float> norm(n), cum(n + 1);
+    double             run = 0;
+    for (int r = 0; r < n; r++)
+    {
+        norm[r] = static_cast<float>(share[r] * n / sum);
+        cum[r]  = static_cast<float>(run / sum);
+        run += share[r];
+    }
+    cum[n] = 1.0F;
+    NBNXM_HIP_CHECK(hipStreamSynchronize(s));
+    NBNXM_HIP_CHECK(hipMemcpy(d->workShare[p], norm.data(), sizeof(float) * n, hipMemcpyHostToDevice));
+    NBNXM_HIP_CHECK(hipMemcpy(d->workShareCum[p], cum.data(), sizeof(float) * (n + 1), hipMemcpyHostToDevice));
+    d->workRangesDirty = true;
+}
+
 /* (Re)computes the work partition of a list on its stream; cheap (three launches over ncjPacked ints). */
 static void updateWorkPartition(NbnxmGpu* nb, int iloc)
 {
@@ -777,6 +827,7 @@ static void updateWorkPartition(NbnxmGpu* nb, int iloc)
         freeDeviceBuffer(&d->slowPairSci);
         d->slowPairs_nalloc = std::max(8192, 2 * d->groupWeight_nalloc); /* a ligand-sized region has a few thousand */
         allocateDeviceBuffer(&d->groupSlowMask, d->groupWeight_nalloc);
+
         allocateDeviceBuffer(&d->slowPairs, d->slowPairs_nalloc);
         allocateDeviceBuffer(&d->slowPairSci, d->slowPairs_nalloc);
         d->slowListDirty = true;
@@ -813,6 +864,16 @@ static void updateWorkPartition(NbnxmGpu* nb, int iloc)
         if (nb->numWorkRangesOverride > 0) { d->numWorkRanges[p] = std::min(nb->numWorkRangesOverride, d->ncjPacked); }
         reallocateDeviceBuffer(&d->workRangeStart[p], d->numWorkRanges[p] + 1, &dummy, &d->work_nalloc[p]);
         out[p].numRanges = d->numWorkRanges[p];
+        /* shares: only for the launch they are meant for, one wave per slot of every SIMD; they start from the age classes
+         * (the waves of a SIMD are dispatched numRanges / classes apart) and survive new lists of the same size */
+        if (d->numWorkRanges[p] == slots && d->workShareCount[p] != slots)
+        {
+            const int          classes = 4 + p, perClass = slots / classes;
+            std::vector<float> share(slots);
+            for (int r = 0; r < slots; r++) { share[r] = nb->waveClassShare[p][std::min(classes - 1, r / perClass)] / 1024.0F; }
+            setWorkShares(d, p, share.data(), slots, s);
+        }
+        out[p].shareCum = (d->numWorkRanges[p] == slots) ? d->workShareCum[p] : nullptr;
     }
     /* workFirstSci shares work_nalloc with workRangeStart: reallocate when that one grew */
     for (int p = 0; p < 2; p++)
@@ -1239,6 +1300,15 @@ void* nbnxm_gpu_debug_get_work_ranges(NbnxmGpu* nb, int iloc, int p, int* numRan
     if (nb->plist[iloc]->workRangesDirty) { updateWorkPartition(nb, iloc); }
     *numRanges = nb->plist[iloc]->numWorkRanges[p];
     return nb->plist[iloc]->workRangeStart[p];
+}
+
+void nbnxm_gpu_debug_set_work_shares(NbnxmGpu* nb, int iloc, int p, const float* shares, int numRanges)
+{
+    NBNXM_ASSERT(p == 0 || p == 1, "partition index is 0 or 1");
+    gpu_plist* d = nb->plist[iloc];
+    if (d->workRangesDirty) { updateWorkPartition(nb, iloc); }
+    NBNXM_ASSERT(numRanges == d->numWorkRanges[p] && numRanges == nb->numSimds * (4 + p), "one share per wave slot of the device");
+    setWorkShares(d, p, shares, numRanges, nb->deviceStreams[iloc].stream);
 }
 
 void nbnxm_gpu_debug_download(NbnxmGpu* nb, const void* devicePtr, void* hostPtr, size_t numBytes)

@@ -72,6 +72,8 @@ struct NbnxmGpu
     /* work partition (gpu_plist::work*): SIMDs of the device, smallest range worth a wave (NBNXM_HIP_MIN_GROUPS_PER_WAVE) */
     int numSimds          = 1024;
     int minGroupsPerWave  = 2;
+    /* share of work per age class of the waves of a SIMD, [0]: 4 waves per SIMD, [1]: 5 (see WorkPartitionOut) */
+    int waveClassShare[2][5] = { { 1024, 1024, 1024, 1024, 0 }, { 1100, 1060, 1024, 990, 946 } };
     int numWorkRangesOverride = 0; /* experiments: NBNXM_HIP_NUM_WORK_RANGES */
     PinnedBuffer<nbnxn_sci_t> h_sciSorted;
     PinnedBuffer<int>         h_slowCount;

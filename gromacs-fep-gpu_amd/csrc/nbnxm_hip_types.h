@@ -184,6 +184,9 @@ struct gpu_plist
     int          numWorkRanges[2];
     int          work_nalloc[2];
     int          workFirstSciAlloc[2];
+    float*       workShare[2];      /* numWorkRanges: share of the total weight of each range, mean 1 (see WorkPartitionOut) */
+    float*       workShareCum[2];   /* numWorkRanges + 1: its running sum, normalised to 1 */
+    int          workShareCount[2]; /* the number of ranges the shares were set up for */
     bool         workRangesDirty;
     unsigned long long* debugTimeline; /* diagnostics builds (NBNXM_WAVE_TIMELINE) only, else nullptr */
 };

@@ -153,7 +153,29 @@ struct WorkPartitionOut
     int  numRanges;
     int* rangeStart; /* numRanges + 1 */
     int* firstSci;   /* numRanges */
+    /* Share of the total weight each range gets, as a running sum: range a owns the weight fractions
+     * [shareCum[a], shareCum[a + 1]), shareCum[0] = 0, shareCum[numRanges] = 1.  nullptr: equal shares.
+     * Unequal shares make up for what the weights cannot know: the arbiter of a SIMD favours its older waves (with equal
+     * work they finish one after the other and the youngest runs alone at the end), and some SIMDs are persistently
+     * slower than others (measured: the same ones on every launch). */
+    const float* shareCum;
 };
+
+/* the range that owns a group with weight e in front of it, out of total */
+__device__ __forceinline__ int rangeOfWeight(const WorkPartitionOut& out, long long e, long long total)
+{
+    const int nW = out.numRanges;
+    if (out.shareCum == nullptr) { return static_cast<int>(min(static_cast<long long>(nW - 1), e * nW / total)); }
+    const float phi = static_cast<float>(static_cast<double>(e) / static_cast<double>(total));
+    int         lo = 0, hi = nW; /* largest a with shareCum[a] <= phi */
+    while (hi - lo > 1)
+    {
+        const int mid = (lo + hi) >> 1;
+        if (out.shareCum[mid] <= phi) { lo = mid; }
+        else { hi = mid; }
+    }
+    return lo;
+}
 
 __launch_bounds__(c_workBlockSize) __global__
         void nbnxmWorkRangesKernel(const int* __restrict__         groupWeight,
@@ -181,9 +203,9 @@ __launch_bounds__(c_workBlockSize) __global__
         const WorkPartitionOut& out = (p == 0) ? out0 : out1;
         const int               nW  = out.numRanges;
         if (nW <= 0) { continue; }
-        /* range a owns the groups whose preceding weight lies in [a total / nW, (a + 1) total / nW) */
-        const int a  = static_cast<int>(min(static_cast<long long>(nW - 1), e * nW / total));
-        const int lo = (g == 0) ? 0 : static_cast<int>(min(static_cast<long long>(nW - 1), ePrev * nW / total)) + 1;
+        /* range a owns the groups whose preceding weight lies in its share of the total (equal shares: [a, a + 1) total / nW) */
+        const int a  = rangeOfWeight(out, e, total);
+        const int lo = (g == 0) ? 0 : rangeOfWeight(out, ePrev, total) + 1;
         if (lo <= a && sciOfGroup == -2) { sciOfGroup = max(0, findSciOfGroup(sciSorted, nsci, g)); }
         for (int r = lo; r <= a; r++)
         {

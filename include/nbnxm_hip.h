@@ -320,6 +320,9 @@ void* nbnxm_gpu_debug_get_cjpacked(NbnxmGpu* nb, int iloc);
  * (p = 1) kernels; *numRanges receives their count (tools/calibrate_weights.py) */
 void* nbnxm_gpu_debug_get_work_ranges(NbnxmGpu* nb, int iloc, int p, int* numRanges);
 void  nbnxm_gpu_debug_download(NbnxmGpu* nb, const void* devicePtr, void* hostPtr, size_t numBytes);
+/* share of the total weight each range of partition p gets (numRanges = wave slots of the device, any positive numbers,
+ * normalised inside; default: by age class of the wave on its SIMD).  For tests and tools/feedback_test.py. */
+void  nbnxm_gpu_debug_set_work_shares(NbnxmGpu* nb, int iloc, int p, const float* shares, int numRanges);
 /* measurement only (tools/graph_test.py): the clear + kernel launches of one steady-state local force step captured into
  * a hipGraph and replayed numSteps times; on MI355X this was slower than the plain launches */
 void  nbnxm_gpu_debug_graph_steps(NbnxmGpu* nb, const nbnxm_step_workload_t* stepWork, int numSteps);

@@ -397,3 +397,37 @@ def test_full_size_properties_1m():
     tl.assert_parity(fused, want, rel=1e-4, label="1M fused")
     tl.assert_parity(split, want, rel=1e-4, label="1M split")
     _check_virtual_rank_decomposition(c, 8, oracle_threads=8)
+
+
+def test_work_partition_with_unequal_shares_covers_the_list_once():
+    """The ranges of the work partition get unequal shares of the weight (by default: by the age of the wave on its SIMD).  Whatever
+    the shares, the ranges must tile the list: same forces as the oracle, borders monotone from 0 to the number of groups."""
+    import torch
+    c = tl.make_case(elec="ewald", seed=2026, nm=(40, 40, 20), num_perturbed_molecules=16, max_cjpacked_per_sci=16)
+    want = tl.run_oracle(c, energy=True, num_threads=8)
+    lib = pkg.hip_lib()
+    lib.nbnxm_gpu_debug_get_work_ranges.restype = C.c_void_p
+    rng = np.random.default_rng(3)
+    for fused in (True, False):
+        nb = tl.setup_gpu(c, fused=fused)
+        for p, energy in ((1, False), (0, True)):
+            nr = C.c_int(0)
+            lib.nbnxm_gpu_debug_get_work_ranges(nb.h, 0, p, C.byref(nr))
+            n = nr.value
+            assert n == 1024 * (4 + p)
+            shares = rng.uniform(0.3, 1.7, n).astype(np.float32)
+            shares[rng.integers(0, n, 50)] = 1e-4                      # nearly empty ranges
+            lib.nbnxm_gpu_debug_set_work_shares(nb.h, 0, p, shares.ctypes.data_as(C.c_void_p), n)
+            ptr = lib.nbnxm_gpu_debug_get_work_ranges(nb.h, 0, p, C.byref(nr))
+            ranges = np.zeros(n + 1, np.int32)
+            lib.nbnxm_gpu_debug_download(nb.h, C.c_void_p(ptr), ranges.ctypes.data_as(C.c_void_p), C.c_size_t(ranges.nbytes))
+            ncj = len((c.plist_fused if fused else c.plist).cjPacked)
+            assert ranges[0] == 0 and ranges[-1] == ncj and (np.diff(ranges) >= 0).all()
+            sizes = np.diff(ranges).astype(np.float64)
+            big, small = shares > 1.4, (shares < 0.6) & (shares > 1e-3)
+            assert sizes[big].mean() > 1.8 * sizes[small].mean()       # the shares steer the sizes
+        got = tl.run_gpu(c, energy=True, fused=fused, nb=nb)
+        tl.assert_parity(got, want, rel=1e-4, label="unequal shares, fused=%s" % fused)
+        got = tl.run_gpu(c, energy=False, fused=fused, nb=nb)
+        tl.assert_parity(got, want, rel=1e-4, energy=False, label="unequal shares, F only, fused=%s" % fused)
+        nb.free()

@@ -17,7 +17,8 @@ import fep_testlib as tl
 pkg = tl.pkg
 
 case = tl.make_case(nm=(40, 40, 20), num_perturbed_molecules=16, elec="ewald", seed=2026, n_lambda=11, max_cjpacked_per_sci=16)
-nb = tl.setup_gpu(case, fused=False, use_dynamic_pruning=True)
+FUSED = "--split" not in sys.argv   # split mode: the atom-pair FEP kernels run beside the cluster kernel and disturb the SIMD times
+nb = tl.setup_gpu(case, fused=FUSED, use_dynamic_pruning=True)
 sw = pkg.step_workload(energy=False, virial=False, dhdl=False)
 for _ in range(8):
     nb.clear_outputs(False); nb.launch_kernel(sw)
@@ -29,16 +30,20 @@ ptr = lib.nbnxm_gpu_debug_get_work_ranges(C.c_void_p(nb._h), 0, 1, C.byref(nr))
 n = nr.value
 ranges = np.zeros(n + 1, np.int32)
 lib.nbnxm_gpu_debug_download(C.c_void_p(nb._h), C.c_void_p(ptr), ranges.ctypes.data_as(C.c_void_p), C.c_size_t(ranges.nbytes))
-cj = pkg.download_cjpacked(nb, len(case.plist.cjPacked))
+pl = case.plist_fused if FUSED else case.plist
+cj = pkg.download_cjpacked(nb, len(pl.cjPacked))
 imask = cj["imei"][:, 0]["imask"].astype(np.uint32)
 popc = np.array([bin(int(m)).count("1") for m in imask])
 slots = sum(((imask >> (8 * k)) & 0xFF) != 0 for k in range(4)).astype(np.int64)
 groups = (imask != 0).astype(np.int64)
+excl_ind = cj["imei"][:, 0]["excl_ind"]
+xpairs = np.where(excl_ind != 0, popc, 0).astype(np.int64)      # cluster pairs of the groups that carry an exclusion mask
 starts = np.zeros(len(imask), np.int64)
-starts[case.plist.sci["cjPackedBegin"][case.plist.sci["cjPackedEnd"] > case.plist.sci["cjPackedBegin"]]] = 1
+starts[pl.sci["cjPackedBegin"][pl.sci["cjPackedEnd"] > pl.sci["cjPackedBegin"]]] = 1
 cs = lambda a: np.concatenate([[0], np.cumsum(a)])
 feat = np.stack([cs(popc)[ranges[1:]] - cs(popc)[ranges[:-1]], cs(slots)[ranges[1:]] - cs(slots)[ranges[:-1]],
-                 cs(groups)[ranges[1:]] - cs(groups)[ranges[:-1]], cs(starts)[ranges[1:]] - cs(starts)[ranges[:-1]] + 1], axis=1).astype(np.float64)
+                 cs(groups)[ranges[1:]] - cs(groups)[ranges[:-1]], cs(starts)[ranges[1:]] - cs(starts)[ranges[:-1]] + 1,
+                 cs(xpairs)[ranges[1:]] - cs(xpairs)[ranges[:-1]]], axis=1).astype(np.float64)
 buf = (C.c_ulonglong * (4 * n))()
 lib.nbnxm_gpu_debug_timeline(C.c_void_p(nb._h), buf, n)
 a = np.frombuffer(buf, dtype=np.uint64).reshape(n, 4)
@@ -54,8 +59,26 @@ A = np.concatenate([X, np.ones((len(uk), 1))], axis=1)
 coef, res, *_ = np.linalg.lstsq(A, y, rcond=None)
 pred = A @ coef
 print("SIMDs %d; per-SIMD finish: mean %.1f std %.2f us; features per SIMD mean %s" % (len(uk), y.mean(), y.std(), X.mean(axis=0).round(1)))
-print("fit: us per cluster pair %.5f, per slot %.5f, per group %.5f, per piece %.5f, const %.2f; residual std %.2f us" % (*coef, (y - pred).std()))
-w = coef[:4] / coef[0] * 8
-print("weights relative to 8 per cluster pair: slot %.1f group %.1f piece %.1f (current 6 / 8 / 80)" % (w[1], w[2], w[3]))
-cur = feat @ np.array([8, 6, 8, 80.0])
+print("fit: us per cluster pair %.5f, per slot %.5f, per group %.5f, per piece %.5f, per cluster pair with exclusion mask %.5f, const %.2f; "
+      "residual std %.2f us" % (*coef, (y - pred).std()))
+w = coef[:5] / coef[0] * 8
+print("weights relative to 8 per cluster pair: slot %.1f group %.1f piece %.1f excl-pair %.1f (current 2 / 30 / 76 / 0)" % (w[1], w[2], w[3], w[4]))
+A4 = np.concatenate([X[:, :4], np.ones((len(uk), 1))], axis=1)
+c4 = np.linalg.lstsq(A4, y, rcond=None)[0]
+print("without the exclusion feature: residual std %.2f us" % (y - A4 @ c4).std())
+print("per-SIMD features: std/mean %s" % (X.std(axis=0) / X.mean(axis=0)).round(3))
+cur = feat[:, :4] @ np.array([8, 2, 30, 76.0])
 print("current weight per wave: mean %.0f std %.1f (%.2f %%)" % (cur.mean(), cur.std(), 100 * cur.std() / cur.mean()))
+# a second launch of the same work: is a slow SIMD slow again?
+nb.clear_outputs(False); nb.launch_kernel(sw)
+torch.cuda.synchronize()
+lib.nbnxm_gpu_debug_timeline(C.c_void_p(nb._h), buf, n)
+b = np.frombuffer(buf, dtype=np.uint64).reshape(n, 4)
+end2 = (b[:, 2] - b[:, 0].min()).astype(np.float64) / 100.0
+same_place = np.array_equal(a[:, 3], b[:, 3])
+y2 = np.array([end2[key == k].max() for k in uk])
+print("second launch: waves on the same SIMDs: %s; correlation of the per-SIMD finish times %.3f; of the residuals %.3f"
+      % (same_place, np.corrcoef(y, y2)[0, 1], np.corrcoef(y - pred, y2 - A @ np.linalg.lstsq(A, y2, rcond=None)[0])[0, 1]))
+cuk = uk // 4
+print("residual: std of CU means %.2f us, of XCC means %.2f us" % (np.std([np.mean((y - pred)[cuk == c]) for c in np.unique(cuk)]),
+      np.std([np.mean((y - pred)[uk // 1024 == x]) for x in range(8)])))
