@@ -431,3 +431,33 @@ def test_work_partition_with_unequal_shares_covers_the_list_once():
         got = tl.run_gpu(c, energy=False, fused=fused, nb=nb)
         tl.assert_parity(got, want, rel=1e-4, energy=False, label="unequal shares, F only, fused=%s" % fused)
         nb.free()
+
+
+@pytest.mark.parametrize("elec,vdw", [("rf", "cut"), ("ewald", "cut"), ("ewald", "pswitch")])
+@pytest.mark.parametrize("fused", [False, True])
+def test_forces_are_the_gradient_of_the_energy(elec, vdw, fused):
+    """Central difference of the kernel's own energy along a random displacement of all atoms against its own forces: the
+    energy and force flavours (cluster-pair and perturbed-pair kernels, soft-core at lambda = 0.5, exclusion corrections) must
+    describe one Hamiltonian.  fp32 energies resolve the difference to ~1e-3 of its size."""
+    c = tl.make_case(nm=(8, 8, 8), num_perturbed_molecules=3, elec=elec, vdw=vdw, seed=77)
+    g = c.grid
+    nb = tl.setup_gpu(c, fused=fused)
+    base = tl.run_gpu(c, energy=True, fused=fused, nb=nb)
+    rng = np.random.default_rng(1)
+    real = g.atomIndices >= 0
+    d = np.zeros((g.num_atoms, 3))
+    d[real] = rng.normal(0, 1, (int(real.sum()), 3))
+    eps = 2e-4
+    xq0 = g.xq.reshape(-1, 4).copy()
+    energies = []
+    for sign in (+1, -1):
+        xq = xq0.copy()
+        xq[:, :3] += sign * eps * d
+        nb.copy_xq_to_gpu(xq)
+        r = tl.run_gpu(c, energy=True, fused=fused, nb=nb)
+        energies.append(r["e_lj"] + r["e_el"])
+    nb.free()
+    de = energies[0] - energies[1]
+    want = -2 * eps * float(np.sum(base["f"] * d))
+    scale = 2 * eps * float(np.sqrt(np.sum(base["f"] ** 2) * np.sum(d * d) / d.size))     # size of a typical projection
+    assert abs(de - want) <= 0.02 * max(abs(want), scale), (de, want, scale)

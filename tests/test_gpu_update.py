@@ -465,3 +465,51 @@ def test_fused_update_equals_the_kernel_sequence(sd):
     real = ai >= 0
     assert np.array_equal(xq1[real, :3], x1[ai[real]])
     assert np.array_equal(xq1[:, 3], g.xq.reshape(-1, 4)[:, 3])
+
+
+def test_nve_energy_conservation_of_the_gpu_resident_loop():
+    """Forces and energies of the kernels must belong to one Hamiltonian, and the update + SETTLE must integrate it: total energy
+    (non-bonded potential from energy steps + kinetic energy, average of the two half-step values) over 300 steps of 0.1 fs of a
+    water box with a half-decoupled solute (reaction field, soft-core at lambda = 0.5) stays constant while kinetic and potential
+    energy exchange many times the allowed drift."""
+    import importlib
+    import torch
+    mdloop = importlib.import_module("gromacs_fep_gpu_amd.mdloop")
+    c = tl.make_case(nm=(8, 8, 8), num_perturbed_molecules=3, elec="rf", seed=5)
+    g = c.grid
+    nb = tl.setup_gpu(c, fused=True)
+    n = c.natoms
+    mO, mH = 15.9994, 1.008
+    mass = np.tile([mO, mH, mH], n // 3)
+    settles = np.arange(n, dtype=np.int32).reshape(-1, 3)
+    dt = 0.0001     # the start from a lattice is violent: the half-step average of the kinetic energy is off by dt^2 m a^2 / 8
+    loop = mdloop.ShortRangeMdLoop(nb, g, g.x_wrapped, np.zeros((n, 3)), 1.0 / mass, dt, np.diag(g.box.astype(np.float64)), settles=settles,
+                                   settle_params=(mO, mH, 0.1, 0.16330), fused_update=True)
+    sw_e = pkg.step_workload(energy=True, virial=False, dhdl=False)
+
+    def kinetic():
+        v = loop.d_v.cpu().numpy().astype(np.float64)
+        return 0.5 * float(np.sum(mass[:, None] * v * v))
+
+    etot, ekin, epot = [], [], []
+    for step in range(300):
+        if step % 10 == 0:
+            k0 = kinetic()
+            loop.step(step, step_work=sw_e)
+            f = np.zeros((g.num_atoms, 3), np.float32)
+            nb.launch_cpyback(f, sw_e)                              # energies of x(t); the forces are consumed (and cleared) already
+            res = nb.wait_finish_task(sw_e, c.have_soft_core)
+            k1 = kinetic()
+            ekin.append(0.5 * (k0 + k1))
+            epot.append(res["e_lj"] + res["e_el"])
+            etot.append(ekin[-1] + epot[-1])
+        else:
+            loop.step(step)
+    loop.synchronize()
+    etot, ekin, epot = np.array(etot), np.array(ekin), np.array(epot)
+    exchange = ekin.max() - ekin.min()
+    drift = np.max(np.abs(etot - etot[0]))
+    assert exchange > 50.0                       # kJ/mol: the lattice start relaxes, plenty of energy moves
+    assert drift < 0.02 * exchange, (drift, exchange, etot.tolist())
+    loop.free()
+    nb.free()
