@@ -400,6 +400,14 @@ class NbnxmGpu:
         assert xq.size == 4 * self.num_atoms, "xq must hold 4 floats for each of the %d atoms" % self.num_atoms
         self._lib.nbnxm_gpu_copy_xq_to_gpu(self.h, _p(xq), C.c_int(aloc))
 
+    def xq_device_pointer(self):
+        """gpuGetNBAtomData()->xq: float4 per grid slot"""
+        return self._lib.nbnxm_gpu_get_xq(self.h)
+
+    def f_device_pointer(self):
+        """gpu_get_f: float3 per grid slot"""
+        return self._lib.nbnxm_gpu_get_f(self.h)
+
     def stream(self, iloc=LOCAL):
         """hipStream_t of a locality as an integer (e.g. for torch.cuda.ExternalStream)."""
         return int(self._lib.nbnxm_gpu_get_stream(self.h, C.c_int(iloc)) or 0)
@@ -505,18 +513,22 @@ def halo_unpack_f(stream, d_f, d_map, map_size, d_recv_buf, accumulate=True):
 
 
 # ---- listed (bonded) interactions with FEP: include/listed_hip.h ---------------------------------------------
-LISTED_TYPES = {"bonds": 0, "angles": 1, "urey_bradley": 2, "pdihs": 3, "rbdihs": 4, "idihs": 5, "lj14": 6}
-LISTED_NRAL = {"bonds": 2, "angles": 3, "urey_bradley": 3, "pdihs": 4, "rbdihs": 4, "idihs": 4, "lj14": 2}
+LISTED_TYPES = {"bonds": 0, "angles": 1, "urey_bradley": 2, "pdihs": 3, "rbdihs": 4, "idihs": 5, "lj14": 6, "ljc14_q": 7,
+                "ljc_pairs_nb": 8, "restrbonds": 9, "angres": 10, "dihres": 11}
+LISTED_NRAL = {"bonds": 2, "angles": 3, "urey_bradley": 3, "pdihs": 4, "rbdihs": 4, "idihs": 4, "lj14": 2, "ljc14_q": 2,
+               "ljc_pairs_nb": 2, "restrbonds": 2, "angres": 4, "dihres": 4}
 LISTED_IPARAMS = np.dtype([("p", np.float32, 12), ("mult", np.int32)])
-LISTED_NUM_ENERGY_TERMS = 8   # one per function type + Coulomb-14
-LISTED_ENERGY_COULOMB14 = 7
-LISTED_DVDL = {"bonded": 0, "coul": 1, "vdw": 2}
+LISTED_NUM_ENERGY_TERMS = 14   # one per function type + Coulomb-14 + Coulomb of F_LJC_PAIRS_NB
+LISTED_ENERGY_COULOMB14 = 12
+LISTED_ENERGY_COULOMB_PAIRS_NB = 13
+LISTED_DVDL = {"bonded": 0, "coul": 1, "vdw": 2, "restraint": 3}
 
 
 class ListedFepParams(C.Structure):
     """listed_gpu_fep_params_t (gmx::BondedFepParameters)"""
     _fields_ = [("alphaCoul", C.c_float), ("alphaVdw", C.c_float), ("lambdaPower", C.c_int), ("sc_sigma6", C.c_float),
-                ("sc_sigma6_min", C.c_float), ("lambdaBonded", C.c_float), ("lambdaCoul", C.c_float), ("lambdaVdw", C.c_float)]
+                ("sc_sigma6_min", C.c_float), ("lambdaBonded", C.c_float), ("lambdaCoul", C.c_float), ("lambdaVdw", C.c_float),
+                ("lambdaRestraint", C.c_float)]
 
 
 class ListedGpu:
@@ -546,18 +558,19 @@ class ListedGpu:
         return bool(self._lib.listed_gpu_have_interactions(self.h))
 
     def launch_kernel(self, d_xq, d_f, d_fshift, box, pbc_type, fep, d_q4=None, elec_scale=0.0, compute_energy=True,
-                      compute_virial=True):
-        """fep: ListedFepParams; d_q4: device float4[] with (qA, qB) per atom, needed with 1-4 pairs"""
+                      compute_virial=True, epsfac=0.0):
+        """fep: ListedFepParams; d_q4: device float4[] with (qA, qB) per atom, needed with 1-4 pairs; elec_scale = epsfac * fudgeQQ
+        for F_LJ14, epsfac for F_LJC14_Q and F_LJC_PAIRS_NB"""
         b = _a(box, np.float32)
         assert b.size == 9
         self._lib.listed_gpu_launch_kernel(self.h, C.c_void_p(d_xq), C.c_void_p(d_q4), C.c_void_p(d_f), C.c_void_p(d_fshift), _p(b),
-                                           C.c_int(pbc_type), C.byref(fep), C.c_float(elec_scale),
+                                           C.c_int(pbc_type), C.byref(fep), C.c_float(elec_scale), C.c_float(epsfac),
                                            C.c_int(1 if compute_energy else 0), C.c_int(1 if compute_virial else 0))
 
     def energies(self):
-        """launch_energy_transfer + wait_accumulate_energy_terms: (energy terms[8], dV/dlambda[bonded, coul, vdw])"""
+        """launch_energy_transfer + wait_accumulate_energy_terms: (energy terms[14], dV/dlambda[bonded, coul, vdw, restraint])"""
         epot = np.zeros(LISTED_NUM_ENERGY_TERMS, np.float64)
-        dvdl = np.zeros(3, np.float64)
+        dvdl = np.zeros(len(LISTED_DVDL), np.float64)
         self._lib.listed_gpu_launch_energy_transfer(self.h)
         self._lib.listed_gpu_wait_accumulate_energy_terms(self.h, _p(epot), _p(dvdl))
         return epot, dvdl

@@ -49,6 +49,7 @@ struct ListedKernelArgs
     float                       lambda; /* lambda_bonded */
     listed_gpu_fep_params_t     fep;
     float                       elecScale;
+    float                       epsfac;
 };
 constexpr int c_numOut = LISTED_GPU_NUM_ENERGY_TERMS + LISTED_GPU_NUM_DVDL;
 
@@ -281,6 +282,123 @@ __device__ __forceinline__ void pair14(const ListedKernelArgs& a, float* smShift
     }
 }
 
+/* Unperturbed pair with its own charges and LJ parameters (pairs_gpu pType 1 and 2, listed_forces_gpu_internal.cu:700-778) */
+template<bool calcVir>
+__device__ __forceinline__ void simplePair(const ListedKernelArgs& a, float* smShift, int ai, int aj, float qq, float c6, float c12, float& eLJ,
+                                           float& eCoul)
+{
+    float3      dr;
+    const int   ki    = pbcDx<calcVir>(a.pbc, a.xq[ai], a.xq[aj], dr);
+    const float r2    = dot3(dr, dr);
+    const float rinv  = rsqrtf(r2), rinv2 = rinv * rinv, rinv6 = rinv2 * rinv2 * rinv2;
+    const float velec = a.epsfac * qq * rinv;
+    eCoul += velec;
+    eLJ += (c12 * rinv6 - c6) * rinv6;
+    const float3 f = (((12.0F * c12 * rinv6 - 6.0F * c6) * rinv6 + velec) * rinv2) * dr;
+    addForce(a.f, ai, f);
+    addForce(a.f, aj, -1.0F * f);
+    if (calcVir && ki != c_centralShift)
+    {
+        addShift(smShift, ki, f);
+        addShift(smShift, c_centralShift, -1.0F * f);
+    }
+}
+
+/* Flat-bottomed distance restraint, linear beyond up2 (restraint_bonds_gpu, listed_forces_gpu_internal.cu:1605-1697;
+ * bonded.cpp:619-712).  p: lowA up1A up2A kA lowB up1B up2B kB */
+template<bool calcVir>
+__device__ __forceinline__ void restraintBond(const ListedKernelArgs& a, float* smShift, int ai, int aj, const float* p, float lambda,
+                                              float& epot, float& dvdl)
+{
+    float3      dx;
+    const int   ki  = pbcDx<calcVir>(a.pbc, a.xq[ai], a.xq[aj], dx);
+    const float dr2 = dot3(dx, dx), dr = sqrtf(dr2);
+    const float L1  = 1.0F - lambda;
+    const float low = L1 * p[0] + lambda * p[4], dlow = p[4] - p[0];
+    const float up1 = L1 * p[1] + lambda * p[5], dup1 = p[5] - p[1];
+    const float up2 = L1 * p[2] + lambda * p[6], dup2 = p[6] - p[2];
+    const float k   = L1 * p[3] + lambda * p[7], dk = p[7] - p[3];
+    float       vb = 0.0F, fb = 0.0F, dv = 0.0F;
+    if (dr < low)
+    {
+        const float drh = dr - low;
+        vb = 0.5F * k * drh * drh;
+        fb = -k * drh;
+        dv = 0.5F * dk * drh * drh - k * dlow * drh;
+    }
+    else if (dr <= up1) {}
+    else if (dr <= up2)
+    {
+        const float drh = dr - up1;
+        vb = 0.5F * k * drh * drh;
+        fb = -k * drh;
+        dv = 0.5F * dk * drh * drh - k * dup1 * drh;
+    }
+    else
+    {
+        const float drh = dr - up2;
+        vb = k * (up2 - up1) * (0.5F * (up2 - up1) + drh);
+        fb = -k * (up2 - up1);
+        dv = dk * (up2 - up1) * (0.5F * (up2 - up1) + drh) + k * (dup2 - dup1) * (up2 - up1 + drh) - k * (up2 - up1) * dup2;
+    }
+    dvdl += dv;
+    if (dr2 != 0.0F)
+    {
+        epot += vb;
+        const float3 fij = (fb * rsqrtf(dr2)) * dx;
+        addForce(a.f, ai, fij);
+        addForce(a.f, aj, -1.0F * fij);
+        if (calcVir && ki != c_centralShift)
+        {
+            addShift(smShift, ki, fij);
+            addShift(smShift, c_centralShift, -1.0F * fij);
+        }
+    }
+}
+
+/* Angle restraint between the vectors i->j and k->l, V = cp (1 - cos(mult (phi - phi0))) (angleres_gpu,
+ * listed_forces_gpu_internal.cu:1699-1777; bonded.cpp low_angres :2337-2420).  p: phiA cpA phiB cpB */
+template<bool calcVir>
+__device__ __forceinline__ void angleRestraint(const ListedKernelArgs& a, float* smShift, int ai, int aj, int ak, int al, const float* p, int mult,
+                                               float lambda, float& epot, float& dvdl)
+{
+    float3      r_ij, r_kl;
+    const int   t1   = pbcDx<calcVir>(a.pbc, a.xq[aj], a.xq[ai], r_ij);
+    const int   t2   = pbcDx<calcVir>(a.pbc, a.xq[al], a.xq[ak], r_kl);
+    const float nij2 = dot3(r_ij, r_ij), nkl2 = dot3(r_kl, r_kl);
+    const float cosPhi = fminf(1.0F, fmaxf(-1.0F, dot3(r_ij, r_kl) * rsqrtf(nij2 * nkl2)));
+    const float phi    = acosf(cosPhi);
+    const float L1     = 1.0F - lambda;
+    const float phi0   = (L1 * p[0] + lambda * p[2]) * c_deg2rad;
+    const float dph0   = (p[2] - p[0]) * c_deg2rad;
+    const float cp     = L1 * p[1] + lambda * p[3];
+    float       s, c;
+    sincosf(mult * (phi - phi0), &s, &c);
+    const float dVdphi = cp * mult * s;
+    dvdl += (p[3] - p[1]) * (1.0F - c) + cp * dph0 * s;
+    epot += cp * (1.0F - c);
+    const float cosPhi2 = cosPhi * cosPhi;
+    if (cosPhi2 < 1.0F)
+    {
+        const float  st  = -dVdphi * rsqrtf(1.0F - cosPhi2);
+        const float  sth = st * cosPhi;
+        const float  cc  = st * rsqrtf(nij2 * nkl2);
+        const float3 f_i = cc * r_kl - (sth / nij2) * r_ij;
+        const float3 f_k = cc * r_ij - (sth / nkl2) * r_kl;
+        addForce(a.f, ai, f_i);
+        addForce(a.f, aj, -1.0F * f_i);
+        addForce(a.f, ak, f_k);
+        addForce(a.f, al, -1.0F * f_k);
+        if (calcVir)
+        {
+            addShift(smShift, t1, f_i);
+            addShift(smShift, c_centralShift, -1.0F * f_i);
+            addShift(smShift, t2, f_k);
+            addShift(smShift, c_centralShift, -1.0F * f_k);
+        }
+    }
+}
+
 template<bool calcVir, bool calcEner>
 __launch_bounds__(c_listedBlock) __global__ void listedForcesKernel(const ListedKernelArgs a)
 {
@@ -306,6 +424,23 @@ __launch_bounds__(c_listedBlock) __global__ void listedForcesKernel(const Listed
         if (ftype == LISTED_GPU_LJ14)
         {
             pair14<calcVir>(a, smShift, ia[3 * i + 1], ia[3 * i + 2], a.params[ia[3 * i]].p, epot, eCoul, dvdlVdw, dvdlCoul);
+        }
+        else if (ftype == LISTED_GPU_LJC14_Q || ftype == LISTED_GPU_LJC_PAIRS_NB)
+        {
+            const float* p  = a.params[ia[3 * i]].p;
+            const bool   q14 = (ftype == LISTED_GPU_LJC14_Q);
+            simplePair<calcVir>(a, smShift, ia[3 * i + 1], ia[3 * i + 2], q14 ? p[0] * p[1] * p[2] : p[0] * p[1], q14 ? p[3] : p[2],
+                                q14 ? p[4] : p[3], epot, eCoul);
+        }
+        else if (ftype == LISTED_GPU_RESTRBONDS)
+        {
+            restraintBond<calcVir>(a, smShift, ia[3 * i + 1], ia[3 * i + 2], a.params[ia[3 * i]].p, a.fep.lambdaRestraint, epot, dvdl);
+        }
+        else if (ftype == LISTED_GPU_ANGRES)
+        {
+            const listed_gpu_iparams_t& ip = a.params[ia[5 * i]];
+            angleRestraint<calcVir>(a, smShift, ia[5 * i + 1], ia[5 * i + 2], ia[5 * i + 3], ia[5 * i + 4], ip.p, ip.mult, a.fep.lambdaRestraint,
+                                    epot, dvdl);
         }
         else if (ftype == LISTED_GPU_BONDS)
         {
@@ -333,7 +468,23 @@ __launch_bounds__(c_listedBlock) __global__ void listedForcesKernel(const Listed
             float       phi = dihedralAngle<calcVir>(a, ai, aj, ak, al, r_ij, r_kj, r_kl, m, n, t1, t2);
             const float L1  = 1.0F - a.lambda;
             float       ddphi;
-            if (ftype == LISTED_GPU_PDIHS)
+            if (ftype == LISTED_GPU_DIHRES)
+            {
+                /* flat-bottomed dihedral restraint (dihres_gpu, listed_forces_gpu_internal.cu:1779-1872; bonded.cpp:2472-2560) */
+                const float lr = a.fep.lambdaRestraint, l1 = 1.0F - lr;
+                const float phi0A = p[0] * c_deg2rad, dphiA = p[1] * c_deg2rad, phi0B = p[3] * c_deg2rad, dphiB = p[4] * c_deg2rad;
+                const float phi0 = l1 * phi0A + lr * phi0B, dphi = l1 * dphiA + lr * dphiB, kfac = l1 * p[2] + lr * p[5];
+                float       dp   = phi - phi0;
+                if (dp >= c_pi) { dp -= 2.0F * c_pi; }
+                else if (dp < -c_pi) { dp += 2.0F * c_pi; }
+                const float ddp = (dp > dphi) ? dp - dphi : ((dp < -dphi) ? dp + dphi : 0.0F);
+                epot += 0.5F * kfac * ddp * ddp;
+                dvdl += 0.5F * (p[5] - p[2]) * ddp * ddp;
+                if (ddp > 0.0F) { dvdl -= kfac * ddp * ((dphiB - dphiA) + (phi0B - phi0A)); }
+                else if (ddp < 0.0F) { dvdl += kfac * ddp * ((dphiB - dphiA) - (phi0B - phi0A)); }
+                ddphi = kfac * ddp;
+            }
+            else if (ftype == LISTED_GPU_PDIHS)
             {
                 const float phi0  = (L1 * p[0] + a.lambda * p[2]) * c_deg2rad;
                 const float dph0  = (p[2] - p[0]) * c_deg2rad;
@@ -390,6 +541,12 @@ __launch_bounds__(c_listedBlock) __global__ void listedForcesKernel(const Listed
                 atomicAdd(&smEner[LISTED_GPU_NUM_ENERGY_TERMS + LISTED_GPU_DVDL_COUL], dvdlCoul);
                 atomicAdd(&smEner[LISTED_GPU_NUM_ENERGY_TERMS + LISTED_GPU_DVDL_VDW], dvdlVdw);
             }
+            else if (ftype == LISTED_GPU_LJC14_Q) { atomicAdd(&smEner[LISTED_GPU_ENERGY_COULOMB14], eCoul); }
+            else if (ftype == LISTED_GPU_LJC_PAIRS_NB) { atomicAdd(&smEner[LISTED_GPU_ENERGY_COULOMB_PAIRS_NB], eCoul); }
+            else if (ftype == LISTED_GPU_RESTRBONDS || ftype == LISTED_GPU_ANGRES || ftype == LISTED_GPU_DIHRES)
+            {
+                atomicAdd(&smEner[LISTED_GPU_NUM_ENERGY_TERMS + LISTED_GPU_DVDL_RESTRAINT], dvdl);
+            }
             else { atomicAdd(&smEner[LISTED_GPU_NUM_ENERGY_TERMS + LISTED_GPU_DVDL_BONDED], dvdl); }
         }
     }
@@ -422,7 +579,17 @@ struct ListedGpu
 
 static int listedNral(int ftype)
 {
-    return (ftype == LISTED_GPU_BONDS || ftype == LISTED_GPU_LJ14) ? 2 : ((ftype == LISTED_GPU_ANGLES || ftype == LISTED_GPU_UREY_BRADLEY) ? 3 : 4);
+    switch (ftype)
+    {
+        case LISTED_GPU_BONDS:
+        case LISTED_GPU_LJ14:
+        case LISTED_GPU_LJC14_Q:
+        case LISTED_GPU_LJC_PAIRS_NB:
+        case LISTED_GPU_RESTRBONDS: return 2;
+        case LISTED_GPU_ANGLES:
+        case LISTED_GPU_UREY_BRADLEY: return 3;
+        default: return 4;
+    }
 }
 
 extern "C"
@@ -497,8 +664,8 @@ int listed_gpu_have_interactions(const ListedGpu* lg)
 }
 
 void listed_gpu_launch_kernel(ListedGpu* lg, const void* d_xq, const void* d_q4, void* d_f, void* d_fshift, const float* box,
-                              int pbcType, const listed_gpu_fep_params_t* fep, float electrostaticsScaleFactor, int computeEnergy,
-                              int computeVirial)
+                              int pbcType, const listed_gpu_fep_params_t* fep, float electrostaticsScaleFactor, float epsfac,
+                              int computeEnergy, int computeVirial)
 {
     if (!listed_gpu_have_interactions(lg)) { return; }
     NBNXM_ASSERT(d_xq != nullptr && d_f != nullptr, "coordinate / force buffer missing");
@@ -517,6 +684,7 @@ void listed_gpu_launch_kernel(ListedGpu* lg, const void* d_xq, const void* d_q4,
     a.q4     = static_cast<const float4*>(d_q4);
     a.fep    = *fep;
     a.elecScale = electrostaticsScaleFactor;
+    a.epsfac    = epsfac;
     a.f      = static_cast<float*>(d_f);
     a.fshift = static_cast<float*>(d_fshift);
     a.epot   = lg->d_epot;

@@ -46,9 +46,7 @@ class ShortRangeMdLoop:
         self.update.set_pbc(3, box)
         self.fused_update = False
         if fused_update:
-            lib = nb._lib
-            lib.nbnxm_gpu_get_xq.restype = lib.nbnxm_gpu_get_f.restype = __import__("ctypes").c_void_p
-            self.update.set_nbat_coupling(cell, lib.nbnxm_gpu_get_xq(nb.h), lib.nbnxm_gpu_get_f(nb.h))
+            self.update.set_nbat_coupling(cell, nb.xq_device_pointer(), nb.f_device_pointer())
             if not self.update.can_fuse():
                 raise ValueError("the fused update needs a topology without LINCS constraints")
             self.fused_update = True

@@ -25,29 +25,39 @@ typedef struct ListedGpu ListedGpu;
 
 enum
 {
-    LISTED_GPU_BONDS = 0,    /* F_BONDS           [type, ai, aj]          p: rA krA rB krB */
+    LISTED_GPU_BONDS = 0,    /* F_BONDS, F_HARMONIC [type, ai, aj]        p: rA krA rB krB */
     LISTED_GPU_ANGLES,       /* F_ANGLES          [type, ai, aj, ak]      p: thA kA thB kB (degrees) */
     LISTED_GPU_UREY_BRADLEY, /* F_UREY_BRADLEY    [type, ai, aj, ak]      p: thetaA kthetaA r13A kUBA thetaB kthetaB r13B kUBB */
     LISTED_GPU_PDIHS,        /* F_PDIHS, F_PIDIHS [type, ai, aj, ak, al]  p: phiA cpA phiB cpB; mult */
     LISTED_GPU_RBDIHS,       /* F_RBDIHS          [type, ai, aj, ak, al]  p: rbcA[6] rbcB[6] */
     LISTED_GPU_IDIHS,        /* F_IDIHS           [type, ai, aj, ak, al]  p: xA kA xB kB (degrees) */
     LISTED_GPU_LJ14,         /* F_LJ14            [type, ai, aj]          p: c6A c12A c6B c12B (plain C6, C12) */
+    /* the other types of the fork's GPU list (listed_forces_gpu.h:87-90) */
+    LISTED_GPU_LJC14_Q,      /* F_LJC14_Q         [type, ai, aj]          p: qi qj fqq c6 c12; Coulomb with epsfac, unperturbed */
+    LISTED_GPU_LJC_PAIRS_NB, /* F_LJC_PAIRS_NB    [type, ai, aj]          p: qi qj c6 c12; Coulomb with epsfac, unperturbed */
+    LISTED_GPU_RESTRBONDS,   /* F_RESTRBONDS      [type, ai, aj]          p: lowA up1A up2A kA lowB up1B up2B kB */
+    LISTED_GPU_ANGRES,       /* F_ANGRES          [type, ai, aj, ak, al]  p: phiA cpA phiB cpB; mult (angle between i->j and k->l) */
+    LISTED_GPU_DIHRES,       /* F_DIHRES          [type, ai, aj, ak, al]  p: phiA dphiA kfacA phiB dphiB kfacB (degrees) */
     LISTED_GPU_NUM_TYPES
 };
 
-/* energy terms returned by listed_gpu_wait_accumulate_energy_terms: one per function type (the LJ14 slot holds the
- * Lennard-Jones part of the pairs) plus the pairs' Coulomb part */
+/* energy terms returned by listed_gpu_wait_accumulate_energy_terms: one per function type (the slots of the pair types hold
+ * the Lennard-Jones part) plus the Coulomb part of the 1-4 pairs (F_LJ14, F_LJC14_Q -> F_COUL14) and of F_LJC_PAIRS_NB
+ * (-> F_COUL_SR) */
 enum
 {
     LISTED_GPU_ENERGY_COULOMB14 = LISTED_GPU_NUM_TYPES,
+    LISTED_GPU_ENERGY_COULOMB_PAIRS_NB,
     LISTED_GPU_NUM_ENERGY_TERMS
 };
-/* dV/dlambda components (FreeEnergyPerturbationCouplingType Bonded, Coul, Vdw) */
+/* dV/dlambda components (FreeEnergyPerturbationCouplingType Bonded, Coul, Vdw, Restraint: the reference's CPU path books
+ * the restraint types under Restraint, listed_forces.cpp calc_one_bond; its GPU path adds them to Bonded) */
 enum
 {
     LISTED_GPU_DVDL_BONDED = 0,
     LISTED_GPU_DVDL_COUL,
     LISTED_GPU_DVDL_VDW,
+    LISTED_GPU_DVDL_RESTRAINT,
     LISTED_GPU_NUM_DVDL
 };
 
@@ -58,6 +68,7 @@ typedef struct
     int   lambdaPower;
     float sc_sigma6, sc_sigma6_min;
     float lambdaBonded, lambdaCoul, lambdaVdw;
+    float lambdaRestraint;
 } listed_gpu_fep_params_t;
 
 /* t_iparams of the types above (topology/idef.h:71-330), float, A and B state side by side */
@@ -82,9 +93,10 @@ int listed_gpu_have_interactions(const ListedGpu* lg);
 
 /* ListedForcesGpu::launchKernel(stepWork, box) — listed_forces_gpu.h:160-170.  d_xq: float4[], d_q4: float4[] with
  * .x = qA, .y = qB (NBAtomDataGpu::q4; may be NULL without LJ14 pairs), d_f: float3[] (+=), d_fshift: float3[45] (+= when
- * computeVirial); box: 3x3 row-major; pbcType: 0 none, 2 xy, 3 xyz; electrostaticsScaleFactor = epsfac * fudgeQQ. */
+ * computeVirial); box: 3x3 row-major; pbcType: 0 none, 2 xy, 3 xyz; electrostaticsScaleFactor = epsfac * fudgeQQ (F_LJ14),
+ * epsfac alone scales the Coulomb part of F_LJC14_Q and F_LJC_PAIRS_NB (BondedGpuKernelParameters::epsFac). */
 void listed_gpu_launch_kernel(ListedGpu* lg, const void* d_xq, const void* d_q4, void* d_f, void* d_fshift, const float* box,
-                              int pbcType, const listed_gpu_fep_params_t* fep, float electrostaticsScaleFactor,
+                              int pbcType, const listed_gpu_fep_params_t* fep, float electrostaticsScaleFactor, float epsfac,
                               int computeEnergy, int computeVirial);
 
 /* launchEnergyTransfer / waitAccumulateEnergyTerms / clearEnergies — listed_forces_gpu.h:172-190:

@@ -167,7 +167,7 @@ void oracle_listed(int ftype, int n, const int* iatoms, const listed_iparams_t* 
                    int npbcdim, double lambda, double* f, double* fshift, double* epot, double* dvdl)
 {
     const double L1   = 1.0 - lambda;
-    const int    nral = (ftype == LISTED_BONDS) ? 2 : ((ftype == LISTED_ANGLES || ftype == LISTED_UREY_BRADLEY) ? 3 : 4);
+    const int    nral = (ftype == LISTED_BONDS || ftype == LISTED_RESTRBONDS) ? 2 : ((ftype == LISTED_ANGLES || ftype == LISTED_UREY_BRADLEY) ? 3 : 4);
     for (int i = 0; i < n; i++)
     {
         const int*              ia = iatoms + (size_t)i * (1 + nral);
@@ -188,6 +188,86 @@ void oracle_listed(int ftype, int n, const int* iatoms, const listed_iparams_t* 
                 addf(f, ia[2], fij, -1);
                 add_fshift(fshift, ki, fij, 1);
                 add_fshift(fshift, CENTRAL, fij, -1);
+            }
+        }
+        else if (ftype == LISTED_RESTRBONDS)
+        {
+            vec3         dx;
+            const int    ki  = pbc_dx(box, npbcdim, getx(x, ia[1]), getx(x, ia[2]), &dx);
+            const double dr2 = vdot(dx, dx), dr = sqrt(dr2);
+            const double low = L1 * p[0] + lambda * p[4], dlow = p[4] - p[0];
+            const double up1 = L1 * p[1] + lambda * p[5], dup1 = p[5] - p[1];
+            const double up2 = L1 * p[2] + lambda * p[6], dup2 = p[6] - p[2];
+            const double k   = L1 * p[3] + lambda * p[7], dk = p[7] - p[3];
+            double       vb = 0, fb = 0, dv = 0;
+            if (dr < low)
+            {
+                const double drh = dr - low;
+                vb = 0.5 * k * drh * drh;
+                fb = -k * drh;
+                dv = 0.5 * dk * drh * drh - k * dlow * drh;
+            }
+            else if (dr <= up1) {}
+            else if (dr <= up2)
+            {
+                const double drh = dr - up1;
+                vb = 0.5 * k * drh * drh;
+                fb = -k * drh;
+                dv = 0.5 * dk * drh * drh - k * dup1 * drh;
+            }
+            else
+            {
+                const double drh = dr - up2;
+                vb = k * (up2 - up1) * (0.5 * (up2 - up1) + drh);
+                fb = -k * (up2 - up1);
+                dv = dk * (up2 - up1) * (0.5 * (up2 - up1) + drh) + k * (dup2 - dup1) * (up2 - up1 + drh) - k * (up2 - up1) * dup2;
+            }
+            *dvdl += dv;
+            if (dr2 != 0.0)
+            {
+                *epot += vb;
+                const vec3 fij = vscale(fb / dr, dx);
+                addf(f, ia[1], fij, 1);
+                addf(f, ia[2], fij, -1);
+                add_fshift(fshift, ki, fij, 1);
+                add_fshift(fshift, CENTRAL, fij, -1);
+            }
+        }
+        else if (ftype == LISTED_ANGRES)
+        {
+            vec3         r_ij, r_kl;
+            const int    t1 = pbc_dx(box, npbcdim, getx(x, ia[2]), getx(x, ia[1]), &r_ij);
+            const int    t2 = pbc_dx(box, npbcdim, getx(x, ia[4]), getx(x, ia[3]), &r_kl);
+            const double nij2 = vdot(r_ij, r_ij), nkl2 = vdot(r_kl, r_kl);
+            double       cos_phi = vdot(r_ij, r_kl) / sqrt(nij2 * nkl2);
+            if (cos_phi > 1.0) { cos_phi = 1.0; }
+            if (cos_phi < -1.0) { cos_phi = -1.0; }
+            const double phi = acos(cos_phi);
+            /* dopdihs_min: V = cp (1 - cos(mult (phi - phi0))) */
+            const double phi0  = (L1 * p[0] + lambda * p[2]) * DEG2RAD;
+            const double dph0  = (p[2] - p[0]) * DEG2RAD;
+            const double cp    = L1 * p[1] + lambda * p[3];
+            const double mdphi = ip->mult * (phi - phi0);
+            const double v1    = 1.0 - cos(mdphi);
+            const double dVdphi = cp * ip->mult * sin(mdphi);
+            *dvdl += (p[3] - p[1]) * v1 + cp * dph0 * sin(mdphi);
+            *epot += cp * v1;
+            const double cos_phi2 = cos_phi * cos_phi;
+            if (cos_phi2 < 1.0)
+            {
+                const double st  = -dVdphi / sqrt(1.0 - cos_phi2);
+                const double sth = st * cos_phi;
+                const double c   = st / sqrt(nij2 * nkl2), cij = sth / nij2, ckl = sth / nkl2;
+                const vec3   f_i = vsub(vscale(c, r_kl), vscale(cij, r_ij));
+                const vec3   f_k = vsub(vscale(c, r_ij), vscale(ckl, r_kl));
+                addf(f, ia[1], f_i, 1);
+                addf(f, ia[2], f_i, -1);
+                addf(f, ia[3], f_k, 1);
+                addf(f, ia[4], f_k, -1);
+                add_fshift(fshift, t1, f_i, 1);
+                add_fshift(fshift, CENTRAL, f_i, -1);
+                add_fshift(fshift, t2, f_k, 1);
+                add_fshift(fshift, CENTRAL, f_k, -1);
             }
         }
         else if (ftype == LISTED_ANGLES || ftype == LISTED_UREY_BRADLEY)
@@ -236,6 +316,21 @@ void oracle_listed(int ftype, int n, const int* iatoms, const listed_iparams_t* 
                 *dvdl += (p[3] - p[1]) * v1 + cp * dph0 * sin(mdphi);
                 *epot += cp * v1;
             }
+            else if (ftype == LISTED_DIHRES)
+            {
+                const double phi0A = p[0] * DEG2RAD, dphiA = p[1] * DEG2RAD, kfacA = p[2];
+                const double phi0B = p[3] * DEG2RAD, dphiB = p[4] * DEG2RAD, kfacB = p[5];
+                const double phi0 = L1 * phi0A + lambda * phi0B, dphi = L1 * dphiA + lambda * dphiB, kfac = L1 * kfacA + lambda * kfacB;
+                double       dp   = phi - phi0;
+                if (dp >= M_PI) { dp -= 2 * M_PI; }
+                else if (dp < -M_PI) { dp += 2 * M_PI; }
+                const double ddp = (dp > dphi) ? dp - dphi : ((dp < -dphi) ? dp + dphi : 0.0);
+                *epot += 0.5 * kfac * ddp * ddp;
+                *dvdl += 0.5 * (kfacB - kfacA) * ddp * ddp;
+                if (ddp > 0) { *dvdl -= kfac * ddp * ((dphiB - dphiA) + (phi0B - phi0A)); }
+                else if (ddp < 0) { *dvdl += kfac * ddp * ((dphiB - dphiA) - (phi0B - phi0A)); }
+                ddphi = kfac * ddp;
+            }
             else if (ftype == LISTED_IDIHS)
             {
                 const double kk   = L1 * p[1] + lambda * p[3];
@@ -271,6 +366,34 @@ void oracle_listed(int ftype, int n, const int* iatoms, const listed_iparams_t* 
             }
             do_dih_fup(ia[1], ia[2], ia[3], ia[4], ddphi, r_ij, r_kj, r_kl, m, nn, f, fshift, x, box, npbcdim, t1, t2);
             (void)t3;
+        }
+    }
+}
+
+void oracle_listed_simple_pairs(int kind, int n, const int* iatoms, const listed_iparams_t* params, const double* x, const double* box,
+                                int npbcdim, double epsfac, double* f, double* fshift, double* eLJ, double* eCoul)
+{
+    for (int i = 0; i < n; i++)
+    {
+        const int*    ia = iatoms + (size_t)i * 3;
+        const double* p  = params[ia[0]].p;
+        const double  qq = (kind == 1) ? p[0] * p[1] * p[2] : p[0] * p[1];
+        const double  c6 = (kind == 1) ? p[3] : p[2], c12 = (kind == 1) ? p[4] : p[3];
+        vec3          dr;
+        const int     ki    = pbc_dx(box, npbcdim, getx(x, ia[1]), getx(x, ia[2]), &dr);
+        const double  r2    = vdot(dr, dr);
+        const double  rinv2 = 1.0 / r2, rinv = sqrt(rinv2), rinv6 = rinv2 * rinv2 * rinv2;
+        const double  velec = epsfac * qq * rinv;
+        const double  fr    = (12.0 * c12 * rinv6 - 6.0 * c6) * rinv6 + velec;
+        const vec3    fij   = vscale(fr * rinv2, dr);
+        *eLJ += (c12 * rinv6 - c6) * rinv6;
+        *eCoul += velec;
+        addf(f, ia[1], fij, 1);
+        addf(f, ia[2], fij, -1);
+        if (ki != CENTRAL)
+        {
+            add_fshift(fshift, ki, fij, 1);
+            add_fshift(fshift, CENTRAL, fij, -1);
         }
     }
 }

@@ -23,6 +23,11 @@ enum
     LISTED_PDIHS,        /* F_PDIHS/F_PIDIHS 4 atoms  p: phiA cpA phiB cpB, mult */
     LISTED_RBDIHS,       /* F_RBDIHS         4 atoms  p: rbcA[6] rbcB[6] */
     LISTED_IDIHS,        /* F_IDIHS          4 atoms  p: xA kA xB kB (degrees) */
+    /* restraints (lambda = the restraint lambda): bonded.cpp restraint_bonds :619-712, low_angres :2337-2420 (F_ANGRES),
+     * dihres :2472-2560; the fork's GPU twins listed_forces_gpu_internal.cu:1605-1872 */
+    LISTED_RESTRBONDS,   /* F_RESTRBONDS     2 atoms  p: lowA up1A up2A kA lowB up1B up2B kB */
+    LISTED_ANGRES,       /* F_ANGRES         4 atoms  p: phiA cpA phiB cpB, mult (angle between i->j and k->l) */
+    LISTED_DIHRES,       /* F_DIHRES         4 atoms  p: phiA dphiA kfacA phiB dphiB kfacB (degrees) */
     LISTED_NUM_TYPES
 };
 
@@ -51,6 +56,12 @@ typedef struct
     double sc_sigma6, sc_sigma6_min;
     double lambdaCoul, lambdaVdw;
 } listed_pairs_fep_t;
+
+/* Unperturbed pairs with their own parameters (pairs_gpu pType 1, 2; listed_forces/pairs.cpp do_pairs_simple / general):
+ * kind 1 = F_LJC14_Q   p: qi qj fqq c6 c12   qq = qi qj fqq
+ * kind 2 = F_LJC_PAIRS_NB p: qi qj c6 c12     qq = qi qj;   Coulomb scaled by epsfac in both */
+void oracle_listed_simple_pairs(int kind, int numPairs, const int* iatoms, const listed_iparams_t* params, const double* x,
+                                const double* box, int npbcdim, double epsfac, double* f, double* fshift, double* eLJ, double* eCoul);
 
 void oracle_listed_pairs(int numPairs, const int* iatoms, const listed_iparams_t* params, const double* x, const double* qA,
                          const double* qB, const double* box, int npbcdim, const listed_pairs_fep_t* fep, double elecScale,

@@ -37,8 +37,11 @@ CASES = [
     ("Dihedral", 3, "idihs", "IDIHS", dict(rA=100.15, krA=50.0, rB=95.0, krB=30.0)),
     ("Dihedral", 4, "rbdihs", "RBDIHS", dict(rbcA=RBC_A, rbcB=RBC_B)),
     ("Dihedral", 5, "rbdihs", "RBDIHS", dict(rbcA=RBC, rbcB=RBC)),
+    # bonded.cpp:709-716 (c_InputRestraints): angle restraints between the vectors i->j and k->l
+    ("Restraints", 0, "angres", "ANGRES", dict(phiA=-100.0, cpA=10.0, mult=2, phiB=-80.0, cpB=20.0)),
+    ("Restraints", 1, "angres", "ANGRES", dict(phiA=-105.0, cpA=15.0, mult=2, phiB=-105.0, cpB=15.0)),
 ]
-NRAL = {"bonds": 2, "angles": 3, "urey_bradley": 3, "pdihs": 4, "idihs": 4, "rbdihs": 4}
+NRAL = {"bonds": 2, "angles": 3, "urey_bradley": 3, "pdihs": 4, "idihs": 4, "rbdihs": 4, "angres": 4}
 IATOMS = {2: [[0, 1], [1, 2], [2, 3]], 3: [[0, 1, 2], [1, 2, 3]], 4: [[0, 1, 2, 3]]}
 
 

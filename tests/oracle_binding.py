@@ -186,8 +186,8 @@ def nbnxm_prune(sci, cjPacked, xq, shiftvec, rlist):
 
 
 # ---- listed (bonded) interactions with A/B parameters: oracle/listed_ref.h --------------------------------
-LISTED_TYPES = {"bonds": 0, "angles": 1, "urey_bradley": 2, "pdihs": 3, "rbdihs": 4, "idihs": 5}
-LISTED_NRAL = {"bonds": 2, "angles": 3, "urey_bradley": 3, "pdihs": 4, "rbdihs": 4, "idihs": 4}
+LISTED_TYPES = {"bonds": 0, "angles": 1, "urey_bradley": 2, "pdihs": 3, "rbdihs": 4, "idihs": 5, "restrbonds": 6, "angres": 7, "dihres": 8}
+LISTED_NRAL = {"bonds": 2, "angles": 3, "urey_bradley": 3, "pdihs": 4, "rbdihs": 4, "idihs": 4, "restrbonds": 2, "angres": 4, "dihres": 4}
 LISTED_IPARAMS = np.dtype([("p", np.float64, 12), ("mult", np.int32), ("pad", np.int32)])
 
 
@@ -198,12 +198,16 @@ def listed_iparams(type_name, prm):
         ip["p"][0, :4] = [prm["rA"], prm["krA"], prm["rB"], prm["krB"]]
     elif type_name == "urey_bradley":
         ip["p"][0, :8] = [prm[k] for k in ("thetaA", "kthetaA", "r13A", "kUBA", "thetaB", "kthetaB", "r13B", "kUBB")]
-    elif type_name == "pdihs":
+    elif type_name in ("pdihs", "angres"):
         ip["p"][0, :4] = [prm["phiA"], prm["cpA"], prm["phiB"], prm["cpB"]]
         ip["mult"][0] = prm["mult"]
     elif type_name == "rbdihs":
         ip["p"][0, :6] = prm["rbcA"]
         ip["p"][0, 6:] = prm["rbcB"]
+    elif type_name == "restrbonds":
+        ip["p"][0, :8] = [prm[k] for k in ("lowA", "up1A", "up2A", "kA", "lowB", "up1B", "up2B", "kB")]
+    elif type_name == "dihres":
+        ip["p"][0, :6] = [prm[k] for k in ("phiA", "dphiA", "kfacA", "phiB", "dphiB", "kfacB")]
     else:
         raise ValueError(type_name)
     return ip
@@ -223,6 +227,20 @@ def listed(type_name, iatoms, params, x, box, npbcdim, lam, want_fshift=True):
                         _ptr(prm), _ptr(x_), _ptr(box_), C.c_int(npbcdim), C.c_double(lam), _ptr(f),
                         _ptr(fshift) if want_fshift else None, C.byref(epot), C.byref(dvdl))
     return dict(f=f, fshift=fshift, epot=epot.value, dvdl=dvdl.value)
+
+
+def listed_simple_pairs(kind, iatoms, params, x, box, npbcdim, epsfac):
+    """kind 1 = F_LJC14_Q (p: qi qj fqq c6 c12), 2 = F_LJC_PAIRS_NB (p: qi qj c6 c12); returns dict(f, fshift, e_lj, e_coul)"""
+    ia = _arr(iatoms, np.int32)
+    prm = np.ascontiguousarray(params)
+    x_ = _arr(x, np.float64)
+    f = np.zeros((x_.reshape(-1, 3).shape[0], 3), np.float64)
+    fshift = np.zeros((45, 3), np.float64)
+    e_lj, e_coul = C.c_double(0), C.c_double(0)
+    lib().oracle_listed_simple_pairs(C.c_int(kind), C.c_int(ia.reshape(-1, 3).shape[0]), _ptr(ia), _ptr(prm), _ptr(x_),
+                                     _ptr(_arr(box, np.float64)), C.c_int(npbcdim), C.c_double(epsfac), _ptr(f), _ptr(fshift),
+                                     C.byref(e_lj), C.byref(e_coul))
+    return dict(f=f, fshift=fshift, e_lj=e_lj.value, e_coul=e_coul.value)
 
 
 class ListedPairsFep(C.Structure):

@@ -34,7 +34,7 @@ def test_hip_library_exports_every_listed_forces_symbol():
         assert hasattr(lib, n), "libnbnxm_hip.so does not export %s" % n
     assert sorted(names) == sorted(pkg.LISTED_SYMBOLS)
     assert pkg.LISTED_IPARAMS.itemsize == 52
-    assert ctypes.sizeof(pkg.ListedFepParams) == 32
+    assert ctypes.sizeof(pkg.ListedFepParams) == 36
 
 
 def test_hip_library_exports_every_update_symbol():

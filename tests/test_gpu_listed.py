@@ -25,13 +25,13 @@ def _gpu_params(prm64):
     return out
 
 
-def _fep(lam, alpha=0.3, power=1, sigma=0.3, sigma_min=0.3, lam_coul=None, lam_vdw=None):
+def _fep(lam, alpha=0.3, power=1, sigma=0.3, sigma_min=0.3, lam_coul=None, lam_vdw=None, lam_restraint=None):
     return pkg.ListedFepParams(alpha, alpha, power, sigma ** 6, sigma_min ** 6, lam, lam if lam_coul is None else lam_coul,
-                               lam if lam_vdw is None else lam_vdw)
+                               lam if lam_vdw is None else lam_vdw, lam if lam_restraint is None else lam_restraint)
 
 
-def _run_gpu(lists, params64, x, box3, pbc_type, lam, energy=True, virial=True, qA=None, qB=None, elec_scale=0.0, fep=None):
-    """lists: {type name: (n, 1 + nral) int32}; returns f, fshift, energy terms, dvdl (bonded part unless pairs are given)"""
+def _run_gpu(lists, params64, x, box3, pbc_type, lam, energy=True, virial=True, qA=None, qB=None, elec_scale=0.0, fep=None, epsfac=0.0):
+    """lists: {type name: (n, 1 + nral) int32}; returns f, fshift, energy terms, dvdl (bonded + restraint part), dvdl3 (all four)"""
     import torch
     n = x.shape[0]
     xq = np.zeros((n, 4), np.float32)
@@ -53,10 +53,10 @@ def _run_gpu(lists, params64, x, box3, pbc_type, lam, energy=True, virial=True, 
     box = np.diag(np.asarray(box3, np.float32))
     lg.launch_kernel(d_xq.data_ptr(), d_f.data_ptr(), d_fs.data_ptr(), box, pbc_type, fep or _fep(lam),
                      d_q4=d_q4.data_ptr() if d_q4 is not None else None, elec_scale=elec_scale, compute_energy=energy,
-                     compute_virial=virial)
+                     compute_virial=virial, epsfac=epsfac)
     epot, dvdl3 = lg.energies()
     torch.cuda.synchronize()
-    out = dict(f=d_f.cpu().numpy(), fshift=d_fs.cpu().numpy(), epot=epot, dvdl=dvdl3[0], dvdl3=dvdl3)
+    out = dict(f=d_f.cpu().numpy(), fshift=d_fs.cpu().numpy(), epot=epot, dvdl=dvdl3[0] + dvdl3[3], dvdl3=dvdl3)
     lg.free()
     return out
 
@@ -222,7 +222,7 @@ def test_listed_gpu_random_pairs_against_oracle(power):
     x[aj] = (x[ai] + rng.normal(0, 1, (8000, 3)) * 0.12 + 0.15) % box
     ia = np.stack([rng.integers(0, nprm, 8000), ai, aj], axis=1).astype(np.int32)
     fep64 = ob.ListedPairsFep(0.5, 0.3, power, 0, 0.3 ** 6, 0.28 ** 6, 0.35, 0.6)
-    fep32 = pkg.ListedFepParams(0.5, 0.3, power, 0.3 ** 6, 0.28 ** 6, 0.5, 0.35, 0.6)
+    fep32 = pkg.ListedFepParams(0.5, 0.3, power, 0.3 ** 6, 0.28 ** 6, 0.5, 0.35, 0.6, 0.0)
     xf = x.astype(np.float32).astype(np.float64)
     qAf, qBf = qA.astype(np.float32).astype(np.float64), qB.astype(np.float32).astype(np.float64)
     want = ob.listed_pairs(ia, prm, xf, qAf, qBf, np.full(3, box), 3, fep64, 138.935 * 0.5)
@@ -230,7 +230,80 @@ def test_listed_gpu_random_pairs_against_oracle(power):
     f = want["f"]
     rms = np.sqrt((f ** 2).sum(axis=1).mean())
     assert (np.abs(got["f"] - f) <= 1e-4 * np.maximum(np.linalg.norm(f, axis=1, keepdims=True), rms)).all()
-    assert abs(got["epot"][6] - want["eLJ"]) <= 1e-4 * max(abs(want["eLJ"]), 1.0)
-    assert abs(got["epot"][7] - want["eCoul"]) <= 1e-4 * max(abs(want["eCoul"]), 1.0)
+    assert abs(got["epot"][pkg.LISTED_TYPES["lj14"]] - want["eLJ"]) <= 1e-4 * max(abs(want["eLJ"]), 1.0)
+    assert abs(got["epot"][pkg.LISTED_ENERGY_COULOMB14] - want["eCoul"]) <= 1e-4 * max(abs(want["eCoul"]), 1.0)
     assert abs(got["dvdl3"][1] - want["dvdlCoul"]) <= 2e-4 * max(abs(want["dvdlCoul"]), abs(want["eCoul"]))
     assert abs(got["dvdl3"][2] - want["dvdlVdw"]) <= 2e-4 * max(abs(want["dvdlVdw"]), abs(want["eLJ"]))
+
+
+def test_restraints_and_simple_pairs_match_oracle():
+    """The remaining types of the fork's GPU list: flat-bottomed distance, angle and dihedral restraints (with their own
+    lambda and dV/dlambda component) and the unperturbed pair types with per-interaction charges.  F_RESTRBONDS and F_DIHRES have
+    no known answers in the reference's tests: the oracle they are compared with is checked by finite differences
+    (tests/test_oracle_golden.py), F_ANGRES additionally by the reference's known answers above."""
+    rng = np.random.default_rng(21)
+    nmol, box = 600, 3.0
+    x = np.zeros((4 * nmol, 3))
+    for m in range(nmol):
+        p = rng.uniform(0, box, 3)
+        for a in range(4):
+            x[4 * m + a] = p
+            p = p + rng.normal(0, 1, 3) * rng.choice([0.08, 0.2, 0.45])
+    x = (x % box).astype(np.float32).astype(np.float64)
+    nprm = 30
+    prm = np.zeros(nprm, ob.LISTED_IPARAMS)
+    kinds = ["restrbonds", "angres", "dihres", "ljc14_q", "ljc_pairs_nb"]
+    for i in range(nprm):
+        k = kinds[i % 5]
+        if k == "restrbonds":
+            low = rng.uniform(0.05, 0.3)
+            a = [low, low + rng.uniform(0.0, 0.1), low + rng.uniform(0.1, 0.3), rng.uniform(100, 900)]
+            prm["p"][i, :8] = a + [a[0] * 1.1, a[1] * 1.05, a[2] * 1.2, rng.uniform(100, 900)]
+        elif k == "angres":
+            prm["p"][i, :4] = [rng.uniform(-180, 180), rng.uniform(1, 20), rng.uniform(-180, 180), rng.uniform(1, 20)]
+            prm["mult"][i] = rng.integers(1, 4)
+        elif k == "dihres":
+            phi, dphi = rng.uniform(-180, 180), rng.uniform(0, 40)
+            prm["p"][i, :6] = [phi, dphi, rng.uniform(10, 80), phi + rng.uniform(-10, 10), dphi + rng.uniform(0, 5), rng.uniform(10, 80)]
+        elif k == "ljc14_q":
+            prm["p"][i, :5] = [rng.uniform(-0.8, 0.8), rng.uniform(-0.8, 0.8), rng.uniform(0.5, 1.0), rng.uniform(0, 3e-3), rng.uniform(0, 3e-6)]
+        else:
+            prm["p"][i, :4] = [rng.uniform(-0.8, 0.8), rng.uniform(-0.8, 0.8), rng.uniform(0, 3e-3), rng.uniform(0, 3e-6)]
+    prm["p"] = prm["p"].astype(np.float32).astype(np.float64)
+    lists = {k: [] for k in kinds}
+    for m in range(nmol):
+        b = 4 * m
+        t = lambda k: int(rng.choice([i for i in range(nprm) if kinds[i % 5] == k]))
+        lists["restrbonds"] += [[t("restrbonds"), b, b + 3], [t("restrbonds"), b + 2, b + 1]]
+        lists["angres"].append([t("angres"), b, b + 1, b + 2, b + 3])
+        lists["dihres"].append([t("dihres"), b, b + 1, b + 2, b + 3])
+        lists["ljc14_q"].append([t("ljc14_q"), b, b + 3])
+        lists["ljc_pairs_nb"].append([t("ljc_pairs_nb"), b + 1, b + 3])
+    lists = {k: np.array(v, np.int32) for k, v in lists.items()}
+    epsfac, lam_r = 138.935, 0.35
+    for pbc_type, npbc in ((3, 3), (0, 0)):
+        got = _run_gpu(lists, prm, x, [box] * 3, pbc_type, 0.9, fep=_fep(0.9, lam_restraint=lam_r), epsfac=epsfac)
+        f = np.zeros_like(x)
+        fs = np.zeros((45, 3))
+        dvdl_r = 0.0
+        for k in ("restrbonds", "angres", "dihres"):
+            r = ob.listed(k, lists[k], prm, x, np.full(3, box), npbc, lam_r)
+            f += r["f"]
+            fs += r["fshift"]
+            dvdl_r += r["dvdl"]
+            assert abs(got["epot"][pkg.LISTED_TYPES[k]] - r["epot"]) <= 2e-4 * max(1.0, abs(r["epot"])), k
+        e_coul = {}
+        for kind, k in ((1, "ljc14_q"), (2, "ljc_pairs_nb")):
+            r = ob.listed_simple_pairs(kind, lists[k], prm, x, np.full(3, box), npbc, epsfac)
+            f += r["f"]
+            fs += r["fshift"]
+            e_coul[k] = r["e_coul"]
+            assert abs(got["epot"][pkg.LISTED_TYPES[k]] - r["e_lj"]) <= 2e-4 * max(1.0, abs(r["e_lj"])), k
+        assert abs(got["epot"][pkg.LISTED_ENERGY_COULOMB14] - e_coul["ljc14_q"]) <= 2e-4 * max(1.0, abs(e_coul["ljc14_q"]))
+        assert abs(got["epot"][pkg.LISTED_ENERGY_COULOMB_PAIRS_NB] - e_coul["ljc_pairs_nb"]) <= 2e-4 * max(1.0, abs(e_coul["ljc_pairs_nb"]))
+        assert abs(got["dvdl3"][3] - dvdl_r) <= 2e-4 * max(1.0, abs(dvdl_r))
+        assert got["dvdl3"][0] == 0 and got["dvdl3"][1] == 0 and got["dvdl3"][2] == 0
+        scale = np.sqrt(np.mean(np.sum(f * f, axis=1)))
+        err = np.linalg.norm(got["f"] - f, axis=1)
+        assert (err <= 2e-4 * np.maximum(np.linalg.norm(f, axis=1), scale)).all()
+        assert np.abs(got["fshift"] - fs).max() <= 2e-4 * max(np.abs(fs).max(), scale)

@@ -235,3 +235,55 @@ def test_lincs_oracle_reproduces_reference_known_answers(idx):
         assert d0 @ d1 >= 0
     assert np.max(np.abs((c.masses[:, None] * (xp - c.xp)).sum(axis=0) / len(c.masses))) <= c.tol_x
     assert np.max(np.abs((c.masses[:, None] * (v - c.v)).sum(axis=0) / len(c.masses))) <= c.tol_v
+
+
+# ---- listed restraints without known answers in the reference (F_RESTRBONDS, F_DIHRES) and the simple pair types: the oracle's
+# forces and dV/dlambda must be the derivatives of its own energy (every branch of the flat-bottomed potentials is visited) ------
+def _restraint_systems():
+    rng = np.random.default_rng(11)
+    x = rng.uniform(0.2, 1.3, (4, 3))
+    out = []
+    for low, up1, up2 in ((0.9, 1.0, 1.1), (0.2, 0.3, 0.35), (0.05, 0.1, 0.6), (0.0, 0.05, 0.08)):
+        prm = dict(lowA=low, up1A=up1, up2A=up2, kA=800.0, lowB=low * 1.1, up1B=up1 * 1.05, up2B=up2 * 1.2, kB=500.0)
+        out.append(("restrbonds", np.array([[0, 0, 1], [0, 1, 3], [0, 2, 3]], np.int32), prm, x))
+    for phi, dphi in ((60.0, 10.0), (-150.0, 5.0), (170.0, 30.0), (0.0, 0.0)):
+        prm = dict(phiA=phi, dphiA=dphi, kfacA=40.0, phiB=phi + 7.0, dphiB=dphi + 3.0, kfacB=55.0)
+        out.append(("dihres", np.array([[0, 0, 1, 2, 3], [0, 3, 0, 2, 1]], np.int32), prm, x))
+    return out
+
+
+@pytest.mark.parametrize("idx", range(8))
+@pytest.mark.parametrize("npbc", [0, 3])
+def test_restraint_oracle_is_self_consistent(idx, npbc):
+    import oracle_binding as ob
+    name, ia, prm, x = _restraint_systems()[idx]
+    ip = ob.listed_iparams(name, prm)
+    box = np.full(3, 1.5)
+    rng = np.random.default_rng(idx)
+    d = rng.normal(0, 1, x.shape)
+    for lam in (0.0, 0.3, 1.0):
+        r = ob.listed(name, ia, ip, x, box, npbc, lam)
+        eps = 1e-6
+        ep = ob.listed(name, ia, ip, x + eps * d, box, npbc, lam)["epot"]
+        em = ob.listed(name, ia, ip, x - eps * d, box, npbc, lam)["epot"]
+        assert abs((ep - em) / (2 * eps) + np.sum(r["f"] * d)) <= 1e-5 * max(1.0, np.abs(r["f"]).max())
+        lp = ob.listed(name, ia, ip, x, box, npbc, lam + 1e-6)["epot"]
+        lm = ob.listed(name, ia, ip, x, box, npbc, lam - 1e-6)["epot"]
+        assert abs((lp - lm) / 2e-6 - r["dvdl"]) <= 1e-5 * max(1.0, abs(r["dvdl"]))
+        assert np.abs(r["f"].sum(axis=0)).max() <= 1e-9 * max(1.0, np.abs(r["f"]).max())
+
+
+@pytest.mark.parametrize("kind", [1, 2])
+def test_simple_pairs_oracle_is_self_consistent(kind):
+    import oracle_binding as ob
+    rng = np.random.default_rng(kind)
+    x = rng.uniform(0.2, 1.3, (4, 3))
+    ip = np.zeros(2, ob.LISTED_IPARAMS)
+    ip["p"][0, :5] = [0.4, -0.6, 0.8, 2.5e-3, 2.0e-6] if kind == 1 else [0.4, -0.6, 2.5e-3, 2.0e-6, 0]
+    ip["p"][1, :5] = [-0.3, -0.2, 0.5, 1.0e-3, 1.0e-6] if kind == 1 else [-0.3, -0.2, 1.0e-3, 1.0e-6, 0]
+    ia = np.array([[0, 0, 3], [1, 1, 2], [0, 2, 0]], np.int32)
+    box, d = np.full(3, 1.5), rng.normal(0, 1, x.shape)
+    for npbc in (0, 3):
+        r = ob.listed_simple_pairs(kind, ia, ip, x, box, npbc, 138.935)
+        e = [sum(ob.listed_simple_pairs(kind, ia, ip, x + s * 1e-6 * d, box, npbc, 138.935)[k] for k in ("e_lj", "e_coul")) for s in (1, -1)]
+        assert abs((e[0] - e[1]) / 2e-6 + np.sum(r["f"] * d)) <= 1e-5 * np.abs(r["f"]).max()
