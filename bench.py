@@ -152,11 +152,15 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (there is no CPU fallback for the product path)")
-    torch.cuda.set_device(local_rank)
+    # BENCH_REHEARSAL_GLOO=1: all ranks on cuda:0 with the gloo backend, to walk through the N > 1 code path on a one-GPU box
+    # (the numbers of such a run mean nothing)
+    rehearsal = os.environ.get("BENCH_REHEARSAL_GLOO") == "1"
+    torch.cuda.set_device(0 if rehearsal else local_rank)
+    reduce_device = "cpu" if rehearsal else "cuda"
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl")   # RCCL
+        dist.init_process_group("gloo" if rehearsal else "nccl")   # nccl = RCCL
 
     import fep_testlib as tl
     pkg = tl.pkg
@@ -209,7 +213,7 @@ def main():
         dist.barrier()
     elapsed = time.perf_counter() - t_start
     if world > 1:
-        elapsed = replica.max_over_ranks(elapsed, dist, device="cuda")
+        elapsed = replica.max_over_ranks(elapsed, dist, device=reduce_device)
 
     # kernel durations: a second, instrumented pass of the same steps with HIP events on the kernel's own stream
     # (inside the C-ABI library, nbnxm_gpu_set_timing); not part of the timed loop above
