@@ -513,3 +513,63 @@ def test_nve_energy_conservation_of_the_gpu_resident_loop():
     assert drift < 0.02 * exchange, (drift, exchange, etot.tolist())
     loop.free()
     nb.free()
+
+
+def test_update_edge_cases():
+    """empty constraint sets are no-ops, an update without any constraint is plain leap-frog (also through the fused path), lists
+    can be replaced by larger and smaller ones on the same objects (search steps)"""
+    import torch
+    n = 1000
+    x, v, f, im, tc = _system(n, 4)
+    d_x, d_xp, d_v = _dev(x), _dev(x + 0.01), _dev(v)
+    sg = pkg.SettleGpu(15.9994, 1.008, 0.09572, 0.15139)
+    sg.set(np.zeros((0, 3), np.int32))
+    vir = sg.apply(d_x.data_ptr(), d_xp.data_ptr(), d_v.data_ptr(), 500.0, True, 3, np.eye(3) * 5)
+    lg = pkg.LincsGpu(1, 4)
+    assert lg.set(np.zeros((0, 3), np.int32), [0.1], im)
+    vir2 = lg.apply(d_x.data_ptr(), d_xp.data_ptr(), d_v.data_ptr(), 500.0, True, 3, np.eye(3) * 5)
+    torch.cuda.synchronize()
+    assert not vir.any() and not vir2.any()
+    assert np.array_equal(d_xp.cpu().numpy(), (x + 0.01).astype(np.float32)) and np.array_equal(d_v.cpu().numpy(), v)
+    # growing and shrinking lists on the same objects
+    for count in (300, 40, 333):
+        iat = np.stack([np.zeros(count, np.int32), np.arange(count, dtype=np.int32) * 3, np.arange(count, dtype=np.int32) * 3 + 1], axis=1)
+        assert lg.set(iat, [0.1], im)
+        xx = x.copy()
+        xx[iat[:, 2]] = xx[iat[:, 1]] + np.array([0.1, 0, 0], np.float32)
+        xp = xx + np.random.default_rng(count).normal(0, 0.004, xx.shape).astype(np.float32)
+        d_a, d_b = _dev(xx), _dev(xp)
+        lg.apply(d_a.data_ptr(), d_b.data_ptr(), None, 500.0, False, 0, None)
+        torch.cuda.synchronize()
+        oxp, _, _ = ob.lincs(iat, [0.1], im, 1, 4, xx.astype(np.float64), xp.astype(np.float64), pbc_type=0)
+        assert np.max(np.abs(d_b.cpu().numpy() - oxp)) <= 2e-6 * max(1.0, np.abs(xp).max())
+    sg.free()
+    lg.free()
+    # no constraints at all: the composite is the integrator
+    up = pkg.UpdateConstrainGpu(0.002, num_temp_coupl_groups=3)
+    d_x, d_v, d_f = _dev(x), _dev(v), _dev(f)
+    assert up.set(d_x.data_ptr(), d_v.data_ptr(), d_f.data_ptr(), im, tc)
+    up.set_pbc(0, None)
+    lam = [0.9, 1.0, 1.1]
+    vir = up.integrate(0.002, compute_virial=True, tc_lambdas=lam)
+    xo, _, vo = ob.leapfrog(x, v, f, im, 0.002, lambdas=lam, groups=tc)
+    torch.cuda.synchronize()
+    assert not vir.any()
+    assert np.allclose(d_x.cpu().numpy(), xo, rtol=1e-6, atol=1e-6) and np.allclose(d_v.cpu().numpy(), vo, rtol=2e-6, atol=1e-6)
+    # the same through the fused kernel: grid slots = a permutation, forces in grid order
+    perm = np.random.default_rng(0).permutation(n).astype(np.int32)
+    d_xq = torch.zeros((n, 4), dtype=torch.float32, device="cuda")
+    f_grid = np.zeros((n, 3), np.float32)
+    f_grid[perm] = f
+    d_fg = _dev(f_grid)
+    d_x, d_v = _dev(x), _dev(v)
+    assert up.set(d_x.data_ptr(), d_v.data_ptr(), d_f.data_ptr(), im, tc)
+    assert not up.can_fuse()                      # the coupling belongs to a search: it is gone after set()
+    up.set_nbat_coupling(perm, d_xq.data_ptr(), d_fg.data_ptr())
+    assert up.can_fuse()
+    up.integrate_fused(0.002, tc_lambdas=lam)
+    torch.cuda.synchronize()
+    assert np.allclose(d_x.cpu().numpy(), xo, rtol=1e-6, atol=1e-6) and np.allclose(d_v.cpu().numpy(), vo, rtol=2e-6, atol=1e-6)
+    assert not d_fg.cpu().numpy().any()                                   # forces consumed and cleared
+    assert np.array_equal(d_xq.cpu().numpy()[perm, :3], d_x.cpu().numpy())  # next step's coordinates in grid order
+    up.free()
