@@ -346,6 +346,11 @@ class NbnxmGpu:
     def h(self):
         return C.c_void_p(self._h)
 
+    def pme_loadbal_update_param(self, ic):
+        """Nbnxm::gpu_pme_loadbal_update_param: new Coulomb cut-off / Ewald coefficient (and table) from PME load balancing"""
+        self._ic = ic
+        self._lib.nbnxm_gpu_pme_loadbal_update_param(self.h, C.byref(ic))
+
     def copy_fepparams(self, alpha_coul, alpha_vdw, lam_power, sc_sigma6_def, sc_sigma6_min, lambda_q,
                        lambda_v, all_lambda_coul=(), all_lambda_vdw=()):
         alc = _a(all_lambda_coul, np.float64)

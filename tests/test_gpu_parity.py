@@ -461,3 +461,20 @@ def test_forces_are_the_gradient_of_the_energy(elec, vdw, fused):
     want = -2 * eps * float(np.sum(base["f"] * d))
     scale = 2 * eps * float(np.sqrt(np.sum(base["f"] ** 2) * np.sum(d * d) / d.size))     # size of a typical projection
     assert abs(de - want) <= 0.02 * max(abs(want), scale), (de, want, scale)
+
+
+@pytest.mark.parametrize("fused", [False, True])
+@pytest.mark.parametrize("elec", ["ewald", "ewald_tab"])
+def test_pme_loadbal_update_param(elec, fused):
+    """PME load balancing moves the Coulomb cut-off and the Ewald coefficient on a living object (gpu_pme_loadbal_update_param):
+    scalars, the tabulated force and the LDS correction table must all follow.  Same box, same list (rlist unchanged)."""
+    c1 = tl.make_case(elec=elec, seed=91, rc=1.0, **SMALL)
+    c2 = tl.make_case(elec=elec, seed=91, rc=0.9, **SMALL)
+    assert abs(c1.beta - c2.beta) > 0.1 and np.array_equal(c1.plist.cjPacked["cj"], c2.plist.cjPacked["cj"])
+    nb = tl.setup_gpu(c1, fused=fused)
+    tl.assert_parity(tl.run_gpu(c1, energy=True, fused=fused, nb=nb), tl.run_oracle(c1, energy=True), rel=1e-4, label="before")
+    nb.pme_loadbal_update_param(tl.gpu_interaction_params(c2))
+    tl.assert_parity(tl.run_gpu(c2, energy=True, fused=fused, nb=nb), tl.run_oracle(c2, energy=True), rel=1e-4, label="after")
+    tl.assert_parity(tl.run_gpu(c2, energy=False, fused=fused, nb=nb), tl.run_oracle(c2, energy=False), rel=1e-4, energy=False,
+                     label="after, F only")
+    nb.free()
