@@ -453,9 +453,7 @@ class NbnxmGpu:
         assert f_out.dtype == np.float32 and f_out.size == 3 * self.num_atoms and f_out.flags["C_CONTIGUOUS"]
         self._lib.nbnxm_gpu_launch_cpyback(self.h, _p(f_out), C.byref(step_work), C.c_int(aloc))
 
-    def wait_finish_task(self, step_work, have_soft_core, aloc=LOCAL):
-        """Returns dict(e_lj, e_el, dvdl_lin, dvdl_nonlin, foreign_energies, foreign_dhdl_coul,
-        foreign_dhdl_vdw, fshift) — the caller-owned accumulators, zero-initialised here."""
+    def _finish_task(self, step_work, have_soft_core, aloc, wait):
         nl = self.n_lambda
         fe = np.zeros(nl + 1)
         fc = np.zeros(nl + 1)
@@ -466,10 +464,21 @@ class NbnxmGpu:
         ed.foreign_dhdl_coul = fc.ctypes.data_as(C.POINTER(C.c_double))
         ed.foreign_dhdl_vdw = fv.ctypes.data_as(C.POINTER(C.c_double))
         fshift = np.zeros((NUM_SHIFT_VECTORS, 3), np.float32)
-        self._lib.nbnxm_gpu_wait_finish_task(self.h, C.byref(step_work), C.c_int(aloc),
-                                             C.c_int(1 if have_soft_core else 0), C.byref(ed), _p(fshift))
+        fn = self._lib.nbnxm_gpu_wait_finish_task if wait else self._lib.nbnxm_gpu_try_finish_task
+        done = fn(self.h, C.byref(step_work), C.c_int(aloc), C.c_int(1 if have_soft_core else 0), C.byref(ed), _p(fshift))
+        if not wait and not done:
+            return None
         return dict(e_lj=ed.e_lj, e_el=ed.e_el, dvdl_lin=list(ed.dvdl_lin), dvdl_nonlin=list(ed.dvdl_nonlin),
                     foreign_energies=fe, foreign_dhdl_coul=fc, foreign_dhdl_vdw=fv, fshift=fshift)
+
+    def wait_finish_task(self, step_work, have_soft_core, aloc=LOCAL):
+        """Returns dict(e_lj, e_el, dvdl_lin, dvdl_nonlin, foreign_energies, foreign_dhdl_coul,
+        foreign_dhdl_vdw, fshift) — the caller-owned accumulators, zero-initialised here."""
+        return self._finish_task(step_work, have_soft_core, aloc, True)
+
+    def try_finish_task(self, step_work, have_soft_core, aloc=LOCAL):
+        """gpu_try_finish_task: None while the locality's work is still running, else the dict of wait_finish_task"""
+        return self._finish_task(step_work, have_soft_core, aloc, False)
 
     def set_timing(self, enable):
         self._lib.nbnxm_gpu_set_timing(self.h, C.c_int(1 if enable else 0))

@@ -478,3 +478,55 @@ def test_pme_loadbal_update_param(elec, fused):
     tl.assert_parity(tl.run_gpu(c2, energy=False, fused=fused, nb=nb), tl.run_oracle(c2, energy=False), rel=1e-4, energy=False,
                      label="after, F only")
     nb.free()
+
+
+def test_polling_finish_and_short_range_work_flags():
+    """gpu_try_finish_task polls without blocking and reduces exactly once; setupGpuShortRangeWork / haveGpuShortRangeWork follow
+    the lists and the listed-forces flag; the non-local dependency calls are accepted on both localities; gpu_get_fshift points at
+    the shift forces the virial step accumulated."""
+    import torch
+    c = tl.make_case(elec="rf", seed=45, **SMALL)
+    g = c.grid
+    lib = pkg.hip_lib()
+    nb = pkg.NbnxmGpu(tl.gpu_interaction_params(c), g.num_types, g.nbat_nbfp(c.sys["nbfp"]), local_and_nonlocal=True, fep=True, n_lambda=0)
+    sig6 = c.sc_sigma ** 6
+    nb.copy_fepparams(c.sc_alpha, c.sc_alpha, c.sc_power, sig6, sig6, c.lambda_coul, c.lambda_vdw)
+    nb.init_atomdata(g.num_atoms, g.type, qA=g.qA, qB=g.qB, typeA=g.typeA, typeB=g.typeB)
+    nb.init_pairlist(c.plist.sci, c.plist.cjPacked, c.plist.excl, iloc=pkg.LOCAL)
+    nb.init_pairlist(c.plist.sci[:0], c.plist.cjPacked[:0], c.plist.excl[:1], iloc=pkg.NONLOCAL)     # nothing non-local
+    empty = dict(iinr=np.zeros(0, np.int32), shift=np.zeros(0, np.int32), jindex=np.zeros(1, np.int32), jjnr=np.zeros(0, np.int32),
+                 excl_fep=np.zeros(0, np.int32))
+    nb.init_feppairlist(c.plist.fep, g.atomIndices, iloc=pkg.LOCAL)
+    nb.init_feppairlist(empty, g.atomIndices, iloc=pkg.NONLOCAL)
+    nb.upload_shiftvec(g.shift_vec)
+    for iloc, want in ((pkg.LOCAL, 1), (pkg.NONLOCAL, 0)):
+        nb.setup_short_range_work(False, iloc)
+        assert lib.nbnxm_gpu_have_short_range_work(nb.h, iloc) == want
+    nb.setup_short_range_work(True, pkg.NONLOCAL)          # listed forces on the GPU count as short-range work
+    assert lib.nbnxm_gpu_have_short_range_work(nb.h, pkg.NONLOCAL) == 1
+    nb.setup_short_range_work(False, pkg.NONLOCAL)
+    sw = pkg.step_workload(energy=True, virial=True)
+    nb.clear_outputs(True)
+    nb.copy_xq_to_gpu(g.xq, pkg.LOCAL)
+    nb.insert_nonlocal_dependency(pkg.LOCAL)
+    nb.launch_kernel(sw, pkg.LOCAL)
+    nb.insert_nonlocal_dependency(pkg.NONLOCAL)
+    nb.launch_kernel(sw, pkg.NONLOCAL)                     # no work: returns without a launch
+    f = np.zeros((g.num_atoms, 3), np.float32)
+    nb.launch_cpyback(f, sw, pkg.NONLOCAL)
+    nb.launch_cpyback(f, sw, pkg.LOCAL)
+    polls, res = 0, None
+    while res is None:
+        res = nb.try_finish_task(sw, c.have_soft_core, pkg.LOCAL)
+        polls += 1
+        assert polls < 10_000_000
+    dv = res["dvdl_nonlin"]
+    got = dict(f=f.astype(np.float64), fshift=res["fshift"].astype(np.float64), e_lj=res["e_lj"], e_el=res["e_el"], dvdl_coul=dv[0],
+               dvdl_vdw=dv[1])
+    tl.assert_parity(got, tl.run_oracle(c, energy=True), rel=1e-4, label="polled")
+    # the device shift forces are what was reduced
+    lib.nbnxm_gpu_get_fshift.restype = C.c_void_p
+    fs = np.zeros((45, 3), np.float32)
+    lib.nbnxm_gpu_debug_download(nb.h, C.c_void_p(lib.nbnxm_gpu_get_fshift(nb.h)), fs.ctypes.data_as(C.c_void_p), C.c_size_t(fs.nbytes))
+    assert np.array_equal(fs, res["fshift"])
+    nb.free()
