@@ -138,6 +138,8 @@ struct LincsKernelArgs
     const float* massFactors;    /* same layout */
     const int*   blockAtomStart; /* [numBlocks + 1] into blockAtoms */
     const int*   blockAtoms;     /* global indices of the atoms a work-group owns */
+    const int*   blockAtomSlots; /* their grid slots, or null: also write the constrained coordinates into xq (fused update) */
+    float*       xq;
     float*       virial;
     PbcAiuc      pbc;
 };
@@ -249,8 +251,16 @@ __global__ void lincsKernel(const LincsKernelArgs a, const float3* __restrict__ 
     {
         const int    g = a.blockAtoms[atomStart + k];
         const float3 d = make_float3(disp[k], disp[2 * B + k], disp[4 * B + k]);
-        xp[g]          = xp[g] + d;
+        const float3 xn = xp[g] + d;
+        xp[g]          = xn;
         if (updateVelocities) { v[g] = v[g] + invdt * d; }
+        if (a.blockAtomSlots != nullptr)
+        {
+            const int slot     = a.blockAtomSlots[atomStart + k];
+            a.xq[4 * slot + 0] = xn.x;
+            a.xq[4 * slot + 1] = xn.y;
+            a.xq[4 * slot + 2] = xn.z;
+        }
     }
     if (computeVirial)
     {
@@ -268,7 +278,8 @@ __global__ void lincsKernel(const LincsKernelArgs a, const float3* __restrict__ 
 struct FusedUpdateArgs
 {
     int                   numUnits;
-    const int*            units; /* per unit 3 atoms (second < 0: a single atom), then their 3 grid slots */
+    const int*            units; /* per unit 3 atoms (second -1: a single atom, -2: one with LINCS constraints), then their 3 grid slots */
+    float3*               xp;    /* coordinates before the update of the atoms LINCS will constrain */
     float3*               x;
     float3*               v;
     const float3*         fAtom; /* forces in atom order to add (listed, long-range), or null */
@@ -306,6 +317,7 @@ __launch_bounds__(c_fusedBlock) __global__ void fusedUpdateKernel(const FusedUpd
         int         at[3] = { u01.x, u01.y, u2s0.x };
         int         slot[3] = { u2s0.y, s12.x, s12.y };
         const bool  water = (at[1] >= 0);
+        const bool  keepOld = (at[1] == -2);
         if (!water)
         {
             at[1] = at[2] = at[0]; /* the extra two copies are computed and dropped */
@@ -319,6 +331,7 @@ __launch_bounds__(c_fusedBlock) __global__ void fusedUpdateKernel(const FusedUpd
             float3 f = a.fNbat[slot[k]];
             if (a.fAtom) { f = f + a.fAtom[at[k]]; }
             xOld[k]        = a.x[at[k]];
+            if (k == 0 && keepOld) { a.xp[at[0]] = xOld[0]; }
             const float3 v = a.v[at[k]];
             im[k]          = a.inverseMasses[at[k]];
             float3 vs      = v;
@@ -475,6 +488,11 @@ struct LincsGpu
     size_t       alloc[9] = { 0, 0, 0, 0, 0, 0, 0, 0, 0 };
     float*       d_virial = nullptr;
     PinnedBuffer<float> h_virial;
+    /* fused update: the constrained coordinates also go to the non-bonded xq buffer */
+    std::vector<int> h_blockAtoms;
+    int*             d_blockAtomSlots = nullptr;
+    size_t           slotsAlloc = 0;
+    float*           d_xq = nullptr;
 };
 
 struct UpdateConstrainGpu
@@ -691,6 +709,7 @@ void lincs_gpu_free(LincsGpu* lg)
     freeDeviceBuffer(&lg->d_massFactors);
     freeDeviceBuffer(&lg->d_blockAtomStart);
     freeDeviceBuffer(&lg->d_blockAtoms);
+    freeDeviceBuffer(&lg->d_blockAtomSlots);
     freeDeviceBuffer(&lg->d_virial);
     lg->stream.destroy();
     delete lg;
@@ -702,6 +721,8 @@ int lincs_gpu_set(LincsGpu* lg, int numConstraints, const int* iatoms, const flo
     if (numConstraints == 0)
     {
         lg->numBlocks = 0;
+        lg->h_blockAtoms.clear();
+        lg->d_xq = nullptr;
         return 0;
     }
     NBNXM_ASSERT(numAtoms > 0, "the number of atoms needs to be > 0 if there are constraints in the domain");
@@ -854,6 +875,8 @@ int lincs_gpu_set(LincsGpu* lg, int numConstraints, const int* iatoms, const flo
     uploadVector(&lg->d_massFactors, &lg->alloc[6], h_factors, s);
     uploadVector(&lg->d_blockAtomStart, &lg->alloc[7], h_blockAtomStart, s);
     uploadVector(&lg->d_blockAtoms, &lg->alloc[8], h_blockAtoms, s);
+    lg->h_blockAtoms = h_blockAtoms;
+    lg->d_xq         = nullptr; /* a coupling to the non-bonded buffers belongs to the previous search */
     lg->blockSize  = B;
     lg->numBlocks  = numBlocks;
     lg->maxCoupled = maxCoupled;
@@ -881,6 +904,8 @@ void lincs_gpu_apply(LincsGpu* lg, const void* d_x, void* d_xp, int updateVeloci
     a.massFactors    = lg->d_massFactors;
     a.blockAtomStart = lg->d_blockAtomStart;
     a.blockAtoms     = lg->d_blockAtoms;
+    a.blockAtomSlots = (lg->d_xq != nullptr) ? lg->d_blockAtomSlots : nullptr;
+    a.xq             = lg->d_xq;
     a.virial         = lg->d_virial;
     a.pbc            = makePbcAiuc(pbcType, box);
     auto k = updateVelocities ? (computeVirial ? lincsKernel<true, true> : lincsKernel<true, false>)
@@ -960,12 +985,22 @@ int update_constrain_gpu_set(UpdateConstrainGpu* uc, void* d_x, void* d_v, const
                 units.push_back(at);
             }
         }
+        std::vector<char> inLincs(t->numAtoms, 0);
+        for (int c = 0; c < t->numConstraints; c++)
+        {
+            for (int e = 1; e <= 2; e++)
+            {
+                const int at = t->constraints[3 * c + e];
+                NBNXM_ASSERT(at >= 0 && at < t->numAtoms && !inWater[at], "constrained atom outside the home atoms or part of a SETTLE water");
+                inLincs[at] = 1;
+            }
+        }
         for (int at = 0; at < t->numAtoms; at++)
         {
             if (!inWater[at])
             {
                 units.push_back(at);
-                units.push_back(-1);
+                units.push_back(inLincs[at] ? -2 : -1);
                 units.push_back(-1);
             }
         }
@@ -1034,25 +1069,34 @@ void update_constrain_gpu_set_nbat_coupling(UpdateConstrainGpu* uc, const int* c
         for (int k = 0; k < 3; k++)
         {
             const int at     = uc->h_unitAtoms[3 * u + k];
-            units[6 * u + k] = at;
+            units[6 * u + k] = at; /* second entry of a single atom: -1, or -2 when LINCS constrains it */
             units[6 * u + 3 + k] = (at >= 0) ? cell[at] : -1;
         }
     }
     uploadVector(&uc->d_units, &uc->unitsAlloc, units, uc->stream.stream);
+    /* LINCS writes the constrained coordinates of its atoms into xq as well */
+    {
+        LincsGpu*        lg = uc->lincs;
+        std::vector<int> slots(lg->h_blockAtoms.size());
+        for (size_t i = 0; i < slots.size(); i++) { slots[i] = cell[lg->h_blockAtoms[i]]; }
+        uploadVector(&lg->d_blockAtomSlots, &lg->slotsAlloc, slots, uc->stream.stream);
+        lg->d_xq = (lg->numBlocks > 0) ? static_cast<float*>(d_xq) : nullptr;
+    }
     uc->d_xq    = static_cast<float*>(d_xq);
     uc->d_fNbat = static_cast<float3*>(d_f_nbat);
 }
 
 int update_constrain_gpu_can_fuse(const UpdateConstrainGpu* uc)
 {
-    return (uc->numConstraints == 0 && uc->d_xq != nullptr) ? 1 : 0;
+    /* stochastic dynamics with LINCS needs the friction step between two constraint passes over memory: kernel sequence */
+    return (uc->d_xq != nullptr && (uc->numConstraints == 0 || uc->leapFrog != nullptr)) ? 1 : 0;
 }
 
 void update_constrain_gpu_integrate_fused(UpdateConstrainGpu* uc, void* fReadyEvent, float dt, int computeVirial, float* virial,
                                           int doTemperatureScaling, const float* tcLambdas, int doParrinelloRahman, float dtPressureCouple,
                                           const float* prVelocityScalingMatrix, int seed, int step, int addAtomOrderForces)
 {
-    NBNXM_ASSERT(update_constrain_gpu_can_fuse(uc), "the fused update needs the non-bonded coupling and a topology without LINCS constraints");
+    NBNXM_ASSERT(update_constrain_gpu_can_fuse(uc), "the fused update needs the non-bonded coupling (and leap-frog when there are LINCS constraints)");
     NBNXM_ASSERT(!computeVirial || virial != nullptr, "a virial tensor is needed to compute the virial");
     hipStream_t s = uc->stream.stream;
     if (virial) { std::fill(virial, virial + 9, 0.0F); }
@@ -1064,6 +1108,7 @@ void update_constrain_gpu_integrate_fused(UpdateConstrainGpu* uc, void* fReadyEv
         a.numUnits = uc->numUnits;
         a.units    = uc->d_units;
         a.x        = uc->d_x;
+        a.xp       = uc->d_xp;
         a.v        = uc->d_v;
         a.fAtom    = addAtomOrderForces ? uc->d_f : nullptr;
         a.fNbat    = uc->d_fNbat;
@@ -1097,6 +1142,8 @@ void update_constrain_gpu_integrate_fused(UpdateConstrainGpu* uc, void* fReadyEv
         const dim3 grid((uc->numUnits + c_fusedBlock - 1) / c_fusedBlock);
         hipLaunchKernelGGL(k, grid, dim3(c_fusedBlock), 0, s, a);
         NBNXM_HIP_CHECK(hipGetLastError());
+        /* the atoms LINCS constrains: old coordinates in d_xp, updated ones in d_x, as after the integrator kernel */
+        lincs_gpu_apply(uc->lincs, uc->d_xp, uc->d_x, 1, uc->d_v, 1.0F / dt, computeVirial, virial, uc->pbcType, uc->box);
         if (computeVirial)
         {
             NBNXM_HIP_CHECK(hipMemcpyAsync(uc->h_virial.data, uc->d_virial, 6 * sizeof(float), hipMemcpyDeviceToHost, s));

@@ -6,7 +6,8 @@ UpdateConstrainGpu::integrate).  Everything is one stream of C-ABI calls; Python
     x (atom order, HBM) --x_to_nbat_x--> xq (grid order) --cluster-pair + FEP kernels--> f (grid order)
       --force reduction--> f (atom order) --leap-frog | SD, LINCS, SETTLE--> x, v
 
-With fused_update (MI355X extension, waters + unconstrained atoms) the four kernels around the non-bonded ones collapse into one:
+With fused_update (MI355X extension; not for stochastic dynamics with LINCS constraints) the four kernels around the non-bonded ones
+collapse into one (+ the LINCS kernel when there are such constraints):
 
     xq, f (grid order) --cluster-pair + FEP kernels--> f --fused update: gather f, integrate, SETTLE, clear f, write x, v AND xq
 
@@ -48,7 +49,7 @@ class ShortRangeMdLoop:
         if fused_update:
             self.update.set_nbat_coupling(cell, nb.xq_device_pointer(), nb.f_device_pointer())
             if not self.update.can_fuse():
-                raise ValueError("the fused update needs a topology without LINCS constraints")
+                raise ValueError("stochastic dynamics with LINCS constraints needs the kernel sequence (fused_update=False)")
             self.fused_update = True
             # the state the fused kernel leaves behind: xq = current coordinates, non-bonded forces cleared
             nb.x_to_nbat_x(self.d_x.data_ptr(), 0, self.nslots)

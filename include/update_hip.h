@@ -136,8 +136,9 @@ void* update_constrain_gpu_x_updated_event(UpdateConstrainGpu* uc);
  * Between two searches the reference runs five kernels per step around the non-bonded ones: x -> xq (nbnxn_gpu_x_to_nbat_x),
  * clear, force reduction, integrator, SETTLE, each one pass over all atoms.  With the atom -> grid-slot map of the search the
  * update can read the non-bonded force buffer itself, clear it behind itself and write the new coordinates straight into xq:
- * ONE kernel, coordinates before the update live in registers only.  Available when the home atoms have no LINCS constraints
- * (waters and unconstrained atoms); otherwise use update_constrain_gpu_integrate. */
+ * ONE kernel, coordinates before the update live in registers only.  Atoms with LINCS constraints (leap-frog only) get their old
+ * coordinates stored for the LINCS kernel, which follows and also writes its result into xq.  Stochastic dynamics with LINCS
+ * constraints needs the friction step between two constraint passes over memory: use update_constrain_gpu_integrate there. */
 
 /* after update_constrain_gpu_set, every search: cell[numAtoms] = grid slot of each atom (inverse of gridSet.atomIndices()),
  * d_xq / d_f_nbat = nbnxm_gpu_get_xq / nbnxm_gpu_get_f of the non-bonded object */

@@ -573,3 +573,61 @@ def test_update_edge_cases():
     assert not d_fg.cpu().numpy().any()                                   # forces consumed and cleared
     assert np.array_equal(d_xq.cpu().numpy()[perm, :3], d_x.cpu().numpy())  # next step's coordinates in grid order
     up.free()
+
+
+def test_fused_update_with_lincs_molecules():
+    """waters (SETTLE in registers), molecules with LINCS constraints (old coordinates kept for the LINCS kernel, which also writes
+    xq) and free atoms: the fused path must reproduce the kernel sequence, including the virial and the next step's xq"""
+    import torch
+    box, dt = 5.0, 0.002
+    nw = 2000
+    xw, _, vw = _water_box(nw, 5, box)
+    xm, _, vm, imm, iatoms, lengths = _molecule_soup(6, 600, box, 0)
+    nfree = 500
+    rng = np.random.default_rng(7)
+    x = np.concatenate([xw, xm, rng.uniform(0, box, (nfree, 3))]).astype(np.float32)
+    v = np.concatenate([vw, vm, rng.normal(0, 0.5, (nfree, 3))]).astype(np.float32)
+    mO, mH, dOH, dHH = 15.9994, 1.008, 0.09572, 0.15139
+    im = np.concatenate([np.tile([1 / mO, 1 / mH, 1 / mH], nw), imm, np.full(nfree, 1 / 12.0)]).astype(np.float32)
+    iatoms = iatoms.copy()
+    iatoms[:, 1:] += 3 * nw
+    x64, _, _ = ob.lincs(iatoms, lengths, im, 4, 8, x.astype(np.float64), x.astype(np.float64), pbc_type=3, box=np.eye(3) * box)
+    x = x64.astype(np.float32)
+    n = len(im)
+    f = rng.normal(0, 300, (n, 3)).astype(np.float32)
+    tc = (np.arange(n) % 2).astype(np.uint16)
+    settles = np.arange(3 * nw, dtype=np.int32).reshape(-1, 3)
+    perm = rng.permutation(n + 64)[:n].astype(np.int32)          # grid slots, with holes (filler slots)
+    out = {}
+    for fused in (False, True):
+        up = pkg.UpdateConstrainGpu(dt, num_temp_coupl_groups=2, n_lincs_iter=1, n_proj_order=4, settle=(mO, mH, dOH, dHH))
+        d_x, d_v, d_f = _dev(x), _dev(v), _dev(f)
+        d_xq = torch.full((n + 64, 4), 7.0, dtype=torch.float32, device="cuda")
+        f_grid = np.zeros((n + 64, 3), np.float32)
+        f_grid[perm] = f
+        d_fg = _dev(f_grid)
+        assert up.set(d_x.data_ptr(), d_v.data_ptr(), d_f.data_ptr(), im, tc, iatoms, lengths, settles)
+        up.set_pbc(3, np.eye(3) * box)
+        if fused:
+            up.set_nbat_coupling(perm, d_xq.data_ptr(), d_fg.data_ptr())
+            assert up.can_fuse()
+            vir = up.integrate_fused(dt, compute_virial=True, tc_lambdas=[0.98, 1.03])
+        else:
+            vir = up.integrate(dt, compute_virial=True, tc_lambdas=[0.98, 1.03])
+        torch.cuda.synchronize()
+        out[fused] = (d_x.cpu().numpy(), d_v.cpu().numpy(), vir, d_xq.cpu().numpy(), d_fg.cpu().numpy())
+        up.free()
+    (x0, v0, vir0, _, _), (x1, v1, vir1, xq1, fg1) = out[False], out[True]
+    assert np.max(np.abs(x1 - x0)) <= 2e-6 and np.max(np.abs(v1 - v0)) <= 2e-3
+    assert np.max(np.abs(vir1 - vir0)) <= 1e-3 * np.max(np.abs(vir0))
+    assert np.array_equal(xq1[perm, :3], x1) and (xq1[:, 3] == 7.0).all()
+    holes = np.setdiff1d(np.arange(n + 64), perm)
+    assert (xq1[holes] == 7.0).all() and not fg1.any()
+    # stochastic dynamics with LINCS constraints is the one combination the fused path leaves to the kernel sequence
+    up = pkg.UpdateConstrainGpu(dt, num_temp_coupl_groups=2, stochastic_dynamics=True, ref_t=[300.0, 300.0], tau_t=[1.0, 1.0],
+                                settle=(mO, mH, dOH, dHH))
+    d_x, d_v, d_f = _dev(x), _dev(v), _dev(f)
+    assert up.set(d_x.data_ptr(), d_v.data_ptr(), d_f.data_ptr(), im, tc, iatoms, lengths, settles)
+    up.set_nbat_coupling(perm, d_xq.data_ptr(), d_fg.data_ptr())
+    assert not up.can_fuse()
+    up.free()
