@@ -92,7 +92,7 @@ HIP_SYMBOLS = [
     "nbnxm_gpu_try_finish_task", "nbnxm_gpu_wait_finish_task", "nbnxm_gpu_clear_outputs",
     "nbnxm_gpu_get_timings", "nbnxm_gpu_reset_timings", "nbnxm_gpu_set_timing",
     "nbnxm_gpu_min_ci_balanced", "nbnxm_gpu_is_kernel_ewald_analytical", "nbnxm_gpu_get_xq",
-    "nbnxm_gpu_get_f", "nbnxm_gpu_get_fshift", "nbnxm_gpu_get_stream",
+    "nbnxm_gpu_get_f", "nbnxm_gpu_get_fshift", "nbnxm_gpu_get_q4", "nbnxm_gpu_get_stream",
     "nbnxm_gpu_have_short_range_work", "nbnxm_gpu_set_fep_mode", "nbnxm_hip_abi_version",
     "nbnxm_hip_last_error", "nbnxm_gpu_debug_get_cjpacked", "nbnxm_gpu_debug_download", "nbnxm_gpu_debug_get_work_ranges",
     "nbnxm_gpu_debug_graph_steps", "nbnxm_gpu_debug_set_work_shares",
@@ -147,6 +147,7 @@ def hip_lib():
         lib.nbnxm_gpu_get_xq.restype = C.c_void_p
         lib.nbnxm_gpu_get_f.restype = C.c_void_p
         lib.nbnxm_gpu_get_fshift.restype = C.c_void_p
+        lib.nbnxm_gpu_get_q4.restype = C.c_void_p
         lib.nbnxm_gpu_get_stream.restype = C.c_void_p
         lib.nbnxm_hip_last_error.restype = C.c_char_p
         _hip = lib
@@ -412,6 +413,13 @@ class NbnxmGpu:
     def f_device_pointer(self):
         """gpu_get_f: float3 per grid slot"""
         return self._lib.nbnxm_gpu_get_f(self.h)
+
+    def fshift_device_pointer(self):
+        return self._lib.nbnxm_gpu_get_fshift(self.h)
+
+    def q4_device_pointer(self):
+        """gpuGetNBAtomData()->q4: (qA, qB, -, -) per grid slot"""
+        return self._lib.nbnxm_gpu_get_q4(self.h)
 
     def stream(self, iloc=LOCAL):
         """hipStream_t of a locality as an integer (e.g. for torch.cuda.ExternalStream)."""

@@ -1245,6 +1245,11 @@ void* nbnxm_gpu_get_fshift(NbnxmGpu* nb)
     return nb->atdat->fShift;
 }
 
+void* nbnxm_gpu_get_q4(NbnxmGpu* nb)
+{
+    return nb->atdat->q4;
+}
+
 void* nbnxm_gpu_get_stream(NbnxmGpu* nb, int iloc)
 {
     return nb->deviceStreams[iloc].stream;

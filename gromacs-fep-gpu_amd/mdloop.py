@@ -20,9 +20,12 @@ from . import UpdateConstrainGpu, step_workload
 class ShortRangeMdLoop:
     def __init__(self, nb, grid, x0, v0, inverse_masses, dt, box, settles=None, settle_params=None, constraints=None,
                  constraint_lengths=None, temp_coupl_groups=None, num_temp_coupl_groups=0, stochastic_dynamics=False, ref_t=None,
-                 tau_t=None, n_lincs_iter=1, n_proj_order=4, device="cuda", fused_update=False):
+                 tau_t=None, n_lincs_iter=1, n_proj_order=4, device="cuda", fused_update=False, listed=None, listed_fep=None,
+                 listed_elec_scale=0.0, listed_epsfac=0.0):
         """nb: NbnxmGpu with atom data and pair list uploaded; grid: the host grid the list was built on (atomIndices);
-        x0 / v0: atom order, x0 as the grid saw it (inside the unit cell); settle_params: (mO, mH, dOH, dHH)"""
+        x0 / v0: atom order, x0 as the grid saw it (inside the unit cell); settle_params: (mO, mH, dOH, dHH);
+        listed: a ListedGpu created on nb.stream() whose interaction lists hold GRID-order atom indices, as the reference's
+        ListedForcesGpu gets them (convertIlistToNbnxnOrder); it works on the non-bonded xq / f buffers, listed_fep: ListedFepParams"""
         import torch
         self.nb, self.grid, self.dt = nb, grid, float(dt)
         self.natoms, self.nslots = int(grid.natoms), int(grid.num_atoms)
@@ -54,8 +57,20 @@ class ShortRangeMdLoop:
             # the state the fused kernel leaves behind: xq = current coordinates, non-bonded forces cleared
             nb.x_to_nbat_x(self.d_x.data_ptr(), 0, self.nslots)
             nb.clear_outputs(True)
+        self.listed, self.listed_fep = listed, listed_fep
+        self.listed_scales = (float(listed_elec_scale), float(listed_epsfac))
+        self.box9 = np.ascontiguousarray(np.asarray(box, np.float32).reshape(3, 3) if np.asarray(box).size == 9 else np.diag(np.asarray(box, np.float32)))
         self.force_only = step_workload(energy=False, virial=False, dhdl=False)
         torch.cuda.synchronize()
+
+    def _launch_listed(self, sw):
+        """ListedForcesGpu::launchKernel on the non-bonded buffers, behind the non-bonded kernels of the same stream"""
+        if self.listed is None or not self.listed.have_interactions():
+            return
+        nb = self.nb
+        self.listed.launch_kernel(nb.xq_device_pointer(), nb.f_device_pointer(), nb.fshift_device_pointer(), self.box9, 3, self.listed_fep,
+                                  d_q4=nb.q4_device_pointer(), elec_scale=self.listed_scales[0], epsfac=self.listed_scales[1],
+                                  compute_energy=bool(sw.computeEnergy), compute_virial=bool(sw.computeVirial))
 
     def compute_forces(self, step_work=None):
         """x -> xq, clear, kernels, reduction: afterwards d_f holds the short-range forces in atom order (stream-ordered)"""
@@ -63,6 +78,7 @@ class ShortRangeMdLoop:
         self.nb.x_to_nbat_x(self.d_x.data_ptr(), 0, self.nslots)
         self.nb.clear_outputs(bool(sw.computeVirial))
         self.nb.launch_kernel(sw)
+        self._launch_listed(sw)
         self.nb.force_reduction_execute(self.d_f.data_ptr(), None, self.stream)
 
     def step(self, step_index=0, step_work=None, seed=0, compute_virial=False, tc_lambdas=None):
@@ -71,6 +87,7 @@ class ShortRangeMdLoop:
             if sw.computeEnergy or sw.computeVirial:
                 self.nb.clear_outputs(bool(sw.computeVirial))     # energies and shift forces; the forces are clear already
             self.nb.launch_kernel(sw)
+            self._launch_listed(sw)
             return self.update.integrate_fused(self.dt, compute_virial=compute_virial, tc_lambdas=tc_lambdas, seed=seed, step=step_index)
         self.compute_forces(step_work)
         return self.update.integrate(self.dt, update_velocities=True, compute_virial=compute_virial, tc_lambdas=tc_lambdas, seed=seed,

@@ -266,6 +266,9 @@ int nbnxm_gpu_is_kernel_ewald_analytical(const NbnxmGpu* nb);
 void* nbnxm_gpu_get_xq(NbnxmGpu* nb);
 void* nbnxm_gpu_get_f(NbnxmGpu* nb);
 void* nbnxm_gpu_get_fshift(NbnxmGpu* nb);
+/* gpuGetNBAtomData(nb)->q4: float4 per grid slot, .x = qA, .y = qB — what the perturbed 1-4 pairs of the listed forces read
+ * (mdlib/sim_util.cpp:1678-1689) */
+void* nbnxm_gpu_get_q4(NbnxmGpu* nb);
 /* stream of a locality (hipStream_t), for callers that order their own work after the kernels */
 void* nbnxm_gpu_get_stream(NbnxmGpu* nb, int iloc);
 /* Nbnxm::haveGpuShortRangeWork — nbnxm_gpu.h:300-311 */

@@ -631,3 +631,81 @@ def test_fused_update_with_lincs_molecules():
     up.set_nbat_coupling(perm, d_xq.data_ptr(), d_fg.data_ptr())
     assert not up.can_fuse()
     up.free()
+
+
+def test_md_loop_with_listed_forces_on_the_nonbonded_buffers():
+    """The whole short-range schedule on one stream: cluster-pair + perturbed-pair kernels, the listed-forces kernel working on
+    the non-bonded xq / f buffers in grid order (perturbed bonds, angles and soft-core 1-4 pairs with the A/B charges of q4),
+    force reduction or fused update.  Forces against the sum of the oracles; fused and kernel-sequence trajectories agree."""
+    import importlib
+    import torch
+    mdloop = importlib.import_module("gromacs_fep_gpu_amd.mdloop")
+    c = tl.make_case(nm=(8, 8, 8), num_perturbed_molecules=3, elec="rf", seed=19)
+    g = c.grid
+    n = c.natoms
+    ai = g.atomIndices
+    real = ai >= 0
+    cell = np.full(n, -1, np.int32)
+    cell[ai[real]] = np.nonzero(real)[0]
+    x0 = g.x_wrapped.astype(np.float64)
+    bx = np.diag(g.box.astype(np.float64))
+    # listed interactions among the oxygens of the first six waters (three of them perturbed) and 1-4 pairs between hydrogens
+    ox = np.arange(0, 18, 3)
+
+    def dist(a, b):
+        d = x0[a] - x0[b]
+        d -= np.rint(d / g.box) * g.box
+        return float(np.linalg.norm(d))
+
+    prm = np.zeros(3, ob.LISTED_IPARAMS)
+    prm["p"][0, :4] = [dist(ox[0], ox[1]) * 0.97, 3000.0, dist(ox[0], ox[1]) * 1.02, 2000.0]     # bond, A != B
+    prm["p"][1, :4] = [100.0, 300.0, 110.0, 200.0]                                                  # angle
+    prm["p"][2, :4] = [2.0e-3, 2.0e-6, 0.0, 0.0]                                                    # 1-4 pair vanishing in B
+    lists = {"bonds": np.array([[0, ox[i], ox[i + 1]] for i in range(5)], np.int32),
+             "angles": np.array([[1, ox[i], ox[i + 1], ox[i + 2]] for i in range(4)], np.int32),
+             "lj14": np.array([[2, 1, 4], [2, 2, 7], [2, 5, 8], [2, 10, 13]], np.int32)}
+    lam = dict(bonded=0.4, coul=0.5, vdw=0.5)
+    fep = pkg.ListedFepParams(c.sc_alpha, c.sc_alpha, c.sc_power, c.sc_sigma ** 6, c.sc_sigma ** 6, lam["bonded"], lam["coul"], lam["vdw"], 0.0)
+    elec_scale = c.epsfac * 0.8333
+    mO, mH = 15.9994, 1.008
+    im = np.tile([1 / mO, 1 / mH, 1 / mH], n // 3)
+    settles = np.arange(n, dtype=np.int32).reshape(-1, 3)
+    dt = 0.0005
+    gp = np.zeros(3, pkg.LISTED_IPARAMS)
+    gp["p"], gp["mult"] = prm["p"].astype(np.float32), prm["mult"]
+    traj = {}
+    for fused_update in (False, True):
+        nb = tl.setup_gpu(c, fused=True)
+        lg = pkg.ListedGpu(stream=nb.stream())
+        lg.set_force_params(gp)
+        for name, ia in lists.items():
+            ia_grid = ia.copy()
+            ia_grid[:, 1:] = cell[ia[:, 1:]]
+            lg.update_interaction_list(name, ia_grid, g.num_atoms)
+        loop = mdloop.ShortRangeMdLoop(nb, g, g.x_wrapped, np.zeros((n, 3)), im, dt, bx, settles=settles, settle_params=(mO, mH, 0.1, 0.16330),
+                                       fused_update=fused_update, listed=lg, listed_fep=fep, listed_elec_scale=elec_scale)
+        if not fused_update:
+            loop.compute_forces()
+            loop.synchronize()
+            want = tl.run_oracle(c, energy=False)
+            f = np.zeros((n, 3))
+            f[ai[real]] = want["f"][real]
+            f_listed = np.zeros((n, 3))
+            for name in ("bonds", "angles"):
+                f_listed += ob.listed(name, lists[name], prm, x0, g.box.astype(np.float64), 3, lam["bonded"])["f"]
+            pf = ob.ListedPairsFep(c.sc_alpha, c.sc_alpha, c.sc_power, 0, c.sc_sigma ** 6, c.sc_sigma ** 6, lam["coul"], lam["vdw"])
+            f_listed += ob.listed_pairs(lists["lj14"], prm, x0, c.sys["qA"], c.sys["qB"], g.box.astype(np.float64), 3, pf, elec_scale)["f"]
+            assert np.abs(f_listed).max() > 100.0                       # the listed part is not a rounding error of the test
+            got = loop.d_f.cpu().numpy()
+            tot = f + f_listed
+            frms = np.sqrt(np.mean(tot ** 2))
+            assert np.max(np.abs(got - tot)) <= 1e-4 * max(frms, 0.05 * np.abs(tot).max())
+        for step in range(3):
+            loop.step(step)
+        loop.synchronize()
+        traj[fused_update] = (loop.d_x.cpu().numpy(), loop.d_v.cpu().numpy())
+        loop.free()
+        lg.free()
+        nb.free()
+    assert np.max(np.abs(traj[True][0] - traj[False][0])) <= 2e-6
+    assert np.max(np.abs(traj[True][1] - traj[False][1])) <= 2e-3
