@@ -530,3 +530,40 @@ def test_polling_finish_and_short_range_work_flags():
     lib.nbnxm_gpu_debug_download(nb.h, C.c_void_p(lib.nbnxm_gpu_get_fshift(nb.h)), fs.ctypes.data_as(C.c_void_p), C.c_size_t(fs.nbytes))
     assert np.array_equal(fs, res["fshift"])
     nb.free()
+
+
+def _set_lambdas(nb, c, lam_q, lam_v):
+    sig6 = c.sc_sigma ** 6
+    nb.copy_fepparams(c.sc_alpha if c.sc_coul else 0.0, c.sc_alpha, c.sc_power, sig6, sig6 if c.sc_coul else 0.0, lam_q, lam_v, c.all_lambda,
+                      c.all_lambda)
+
+
+@pytest.mark.parametrize("fused", [False, True])
+@pytest.mark.parametrize("elec", ["rf", "ewald"])
+def test_free_energy_identities(elec, fused):
+    """What the free-energy estimators rest on, from the kernels' own outputs (no oracle):
+    thermodynamic integration — dV/dlambda (Coulomb and van der Waals separately) is the derivative of the energy the same
+    kernels report when lambda moves; and BAR / MBAR — the foreign-lambda energy differences equal the change of the total energy
+    when the simulation lambda itself is set to the foreign value."""
+    c = tl.make_case(elec=elec, seed=61, n_lambda=11, nm=(8, 8, 8), num_perturbed_molecules=3)
+    nb = tl.setup_gpu(c, fused=fused)
+
+    def energy(lam_q, lam_v, dhdl=False):
+        _set_lambdas(nb, c, lam_q, lam_v)
+        r = tl.run_gpu(c, energy=True, fused=fused, dhdl=dhdl, nb=nb)
+        return r["e_lj"] + r["e_el"], r
+
+    lam, d = 0.5, 0.01
+    _, base = energy(lam, lam, dhdl=True)
+    for which in ("coul", "vdw"):
+        ep, _ = energy(lam + d if which == "coul" else lam, lam + d if which == "vdw" else lam)
+        em, _ = energy(lam - d if which == "coul" else lam, lam - d if which == "vdw" else lam)
+        fd = (ep - em) / (2 * d)
+        want = base["dvdl_" + which]
+        assert abs(fd - want) <= 0.01 * max(abs(want), 1.0) + 0.5, (which, fd, want)     # 0.5: fp32 resolution of E / (2 d)
+    e0 = base["e_lj"] + base["e_el"]
+    fe = base["foreign"]["energies"]
+    for k, lk in enumerate(c.all_lambda):
+        ek, _ = energy(float(lk), float(lk))
+        assert abs((fe[k + 1] - fe[0]) - (ek - e0)) <= 2e-3 * max(abs(fe[k + 1] - fe[0]), 1.0) + 0.02, (k, fe[k + 1] - fe[0], ek - e0)
+    nb.free()
