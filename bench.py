@@ -248,7 +248,7 @@ def main():
 
     # GPU-resident MD steps between two searches (secondary figure): x -> xq, clear, kernels, force reduction, leap-frog and
     # SETTLE with coordinates, velocities and forces staying in HBM; 0.5 fs steps so that the list stays valid over the run
-    ms_md_step = ms_md_step_sequence = None
+    ms_md_step = ms_md_step_sequence = ms_md_step_prune = None
     if fused and world == 1:
         mdloop = importlib.import_module("gromacs_fep_gpu_amd.mdloop")
         nat = case.natoms
@@ -272,10 +272,13 @@ def main():
         loop = mdloop.ShortRangeMdLoop(nb, case.grid, x_now, v_now, im, 0.0005, np.diag(case.grid.box), fused_update=True,
                                        settles=np.arange(nat, dtype=np.int32).reshape(-1, 3), settle_params=(15.9994, 1.008, 0.1, 0.16330))
         ms_md_step = time_md(loop, 60)               # one fused update kernel
+        loop.rolling_prune_parts = 8                 # + dynamic pruning: one eighth of the list per step
+        ms_md_step_prune = time_md(loop, 120)
+        loop.rolling_prune_parts = 0
         md_finite = bool(torch.isfinite(loop.d_x).all().item())
         loop.free()
         if not md_finite:
-            ms_md_step = ms_md_step_sequence = None
+            ms_md_step = ms_md_step_sequence = ms_md_step_prune = None
         # put the object back into the state of the timed loop (coordinates of the search)
         nb.copy_xq_to_gpu(case.grid.xq)
 
@@ -314,6 +317,7 @@ def main():
         "ms_per_energy_step": ms_energy_step, "ms_per_dhdl_step_11_foreign_lambdas": ms_dhdl_step,
         "ms_per_virial_only_step": ms_virial_only, "ms_per_energy_only_step": ms_energy_only,
         "ms_per_gpu_resident_md_step": ms_md_step, "ms_per_gpu_resident_md_step_unfused_update": ms_md_step_sequence,
+        "ms_per_gpu_resident_md_step_with_rolling_prune_8": ms_md_step_prune,
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                      "kernel": "nbnxmKernel<EwaldAna,LJcut,F,%s>" % ("fused" if fused else "plain"),

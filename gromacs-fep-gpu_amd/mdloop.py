@@ -21,7 +21,7 @@ class ShortRangeMdLoop:
     def __init__(self, nb, grid, x0, v0, inverse_masses, dt, box, settles=None, settle_params=None, constraints=None,
                  constraint_lengths=None, temp_coupl_groups=None, num_temp_coupl_groups=0, stochastic_dynamics=False, ref_t=None,
                  tau_t=None, n_lincs_iter=1, n_proj_order=4, device="cuda", fused_update=False, listed=None, listed_fep=None,
-                 listed_elec_scale=0.0, listed_epsfac=0.0):
+                 listed_elec_scale=0.0, listed_epsfac=0.0, rolling_prune_parts=0):
         """nb: NbnxmGpu with atom data and pair list uploaded; grid: the host grid the list was built on (atomIndices);
         x0 / v0: atom order, x0 as the grid saw it (inside the unit cell); settle_params: (mO, mH, dOH, dHH);
         listed: a ListedGpu created on nb.stream() whose interaction lists hold GRID-order atom indices, as the reference's
@@ -57,6 +57,9 @@ class ShortRangeMdLoop:
             # the state the fused kernel leaves behind: xq = current coordinates, non-bonded forces cleared
             nb.x_to_nbat_x(self.d_x.data_ptr(), 0, self.nslots)
             nb.clear_outputs(True)
+        # dynamic pruning as mdrun does it between searches: every step one of rolling_prune_parts parts of the list is pruned to the
+        # inner radius (nonbonded_verlet_t::dispatchPruneKernelGpu); 0: the list stays as the first step left it
+        self.rolling_prune_parts = int(rolling_prune_parts)
         self.listed, self.listed_fep = listed, listed_fep
         self.listed_scales = (float(listed_elec_scale), float(listed_epsfac))
         self.box9 = np.ascontiguousarray(np.asarray(box, np.float32).reshape(3, 3) if np.asarray(box).size == 9 else np.diag(np.asarray(box, np.float32)))
@@ -82,6 +85,8 @@ class ShortRangeMdLoop:
         self.nb.force_reduction_execute(self.d_f.data_ptr(), None, self.stream)
 
     def step(self, step_index=0, step_work=None, seed=0, compute_virial=False, tc_lambdas=None):
+        if self.rolling_prune_parts > 0:
+            self.nb.launch_kernel_pruneonly(num_parts=self.rolling_prune_parts)
         if self.fused_update:
             sw = self.force_only if step_work is None else step_work
             if sw.computeEnergy or sw.computeVirial:
