@@ -9,7 +9,7 @@
  *   /root/reference/src/gromacs/nbnxm/cuda/nbnxm_cuda_kernel_pruneonly.cuh      (prune semantics)
  *
  * Pinning: the reference holds no known-answer vectors for this kernel (nbnxm/tests only checks
- * kernel selection).  It is pinned indirectly, see tests/test_oracle_consistency.py:
+ * kernel selection).  It is pinned indirectly, see tests/test_pairlist_cpu.py:
  *   (1) against the golden-pinned FEP oracle in the A == B limit on the same pairs, and
  *   (2) against an O(N^2) minimum-image evaluation of the same functional forms.
  * Flavours without such a cross-check are listed as "parity unpinned" in DESIGN.md §3.

@@ -174,6 +174,22 @@ def nbnxm_ref(sci, cjPacked, excl, xq, atype, ntype, nbfp, p, shiftvec, compute_
     return dict(f=f, fshift=fshift, Vc=Vc.value, Vv=Vv.value, npairs=npair.value)
 
 
+def nbnxm_simd(sci, cjPacked, excl, xq, atype, ntype, nbfp, p, shiftvec, num_threads=1):
+    """Throughput port of the force-only cluster kernel (oracle/nbnxm_simd.c, CPU baseline of bench.py); returns the forces in
+    grid order, or None when the CPU or the flavour is not supported."""
+    sci = np.ascontiguousarray(sci)
+    cjPacked = np.ascontiguousarray(cjPacked)
+    excl = np.ascontiguousarray(excl)
+    xq_ = _arr(xq, np.float32)
+    n = xq_.reshape(-1, 4).shape[0]
+    f = np.zeros((n, 3), np.float32)
+    nsci = sci.size if sci.dtype.names else sci.reshape(-1, 4).shape[0]
+    rc = lib().oracle_nbnxm_simd_f32(C.c_int(num_threads), C.c_int(n), C.c_int(nsci), _ptr(sci), _ptr(cjPacked), _ptr(excl), _ptr(xq_),
+                                     _ptr(_arr(atype, np.int32)), C.c_int(ntype), _ptr(_arr(nbfp, np.float32)), C.byref(p),
+                                     _ptr(_arr(shiftvec, np.float32)), _ptr(f))
+    return f if rc == 0 else None
+
+
 def nbnxm_prune(sci, cjPacked, xq, shiftvec, rlist):
     """Prunes cjPacked IN PLACE (imask bits); returns the number of cluster pairs left."""
     sci = np.ascontiguousarray(sci)

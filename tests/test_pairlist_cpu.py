@@ -152,3 +152,23 @@ def test_sci_splitting_keeps_the_list_content():
     ra, rb = tl.run_oracle(a), tl.run_oracle(b)
     assert np.allclose(ra["f"], rb["f"], rtol=0, atol=1e-9 * np.sqrt(np.mean(ra["f"] ** 2)))
     assert abs(ra["e_el"] - rb["e_el"]) < 1e-9 * abs(ra["e_el"])
+
+
+@pytest.mark.parametrize("elec", ["ewald", "rf", "cut"])
+def test_simd_port_of_the_cluster_kernel_matches_the_scalar_oracle(elec):
+    """oracle/nbnxm_simd.c (the CPU baseline of bench.py) against the scalar parity oracle on the same list: forces to fp32
+    round-off plus the 8e-7 relative error of the rational Ewald correction it shares with the GPU kernels"""
+    import oracle_binding as ob
+    c = tl.make_case(nm=(10, 10, 10), num_perturbed_molecules=3, elec=elec, seed=33)
+    g = c.grid
+    p = tl.oracle_ref_params(c)
+    nbfp = g.nbat_nbfp(c.sys["nbfp"])
+    want = ob.nbnxm_ref(c.plist.sci, c.plist.cjPacked, c.plist.excl, g.xq, g.type, g.num_types, nbfp, p, g.shift_vec, compute_energy=False,
+                        compute_fshift=False, precision="f64")["f"]
+    for threads in (1, 3):
+        got = ob.nbnxm_simd(c.plist.sci, c.plist.cjPacked, c.plist.excl, g.xq, g.type, g.num_types, nbfp, p, g.shift_vec, num_threads=threads)
+        if got is None:
+            pytest.skip("no AVX2 + FMA on this CPU")
+        frms = np.sqrt(np.mean(np.sum(want ** 2, axis=1)))
+        err = np.linalg.norm(got - want, axis=1)
+        assert (err <= 2e-5 * np.maximum(np.linalg.norm(want, axis=1), frms)).all()
