@@ -45,7 +45,7 @@ __global__ void nbnxmClearOutputsKernel(float4* __restrict__ f4, int numFloat4, 
     for (int i = gid; i < numFloat4; i += stride) { f4[i] = zero; }
     if (gid < numTail) { tail[gid] = 0.0F; }
     for (int i = gid; i < numScalars; i += stride) { scalars[i] = 0.0F; }
-    if (gid < numFshift) { fshift[gid] = 0.0F; }
+    for (int i = gid; i < numFshift; i += stride) { fshift[i] = 0.0F; }
 }
 
 namespace
@@ -283,7 +283,7 @@ NbnxmGpu* nbnxm_gpu_init(const nbnxm_interaction_params_t* ic, int numTypes, con
     nb->foreignSlotStride = (4 * (n_lambda + 1) + c_energySlotStride - 1) / c_energySlotStride * c_energySlotStride;
     nb->numScalarOutputs  = nb->foreignSlotOffset + c_numForeignSlots * nb->foreignSlotStride;
     pinned(&nb->nbst.scalars, nb->numScalarOutputs);
-    pinned(&nb->nbst.fShift, 3 * c_numShiftVectors);
+    pinned(&nb->nbst.fShift, c_fshiftBlockFloats);
     nb->nbst.eLJ             = nb->nbst.scalars + 0;
     nb->nbst.eElec           = nb->nbst.scalars + 1;
     nb->nbst.dvdlLJ          = nb->nbst.scalars + 2;
@@ -341,8 +341,13 @@ NbnxmGpu* nbnxm_gpu_init(const nbnxm_interaction_params_t* ic, int numTypes, con
     ad->energySlots     = nb->scalarOutputs + nb->slotOffset;
     ad->foreignSlots      = nb->scalarOutputs + nb->foreignSlotOffset;
     ad->foreignSlotStride = nb->foreignSlotStride;
-    allocateDeviceBuffer(&ad->fShift, c_numShiftVectors);
-    clearDeviceBufferAsync(&ad->fShift, 0, c_numShiftVectors, s);
+    {
+        /* primary shift forces + the cluster kernel's accumulator slots (c_fshiftBlockFloats floats) */
+        float* block = nullptr;
+        allocateDeviceBuffer(&block, c_fshiftBlockFloats);
+        clearDeviceBufferAsync(&block, 0, c_fshiftBlockFloats, s);
+        ad->fShift = reinterpret_cast<decltype(ad->fShift)>(block);
+    }
     clearDeviceBufferAsync(&nb->scalarOutputs, 0, nb->numScalarOutputs, s);
     ad->shiftVecUploaded = false;
     NBNXM_HIP_CHECK(hipStreamSynchronize(s));
@@ -771,7 +776,7 @@ void nbnxm_gpu_clear_outputs(NbnxmGpu* nb, int computeVirial)
     const int nblock    = std::max(1, std::min(2048, (numFloat4 + 255) / 256));
     hipLaunchKernelGGL(nbnxmClearOutputsKernel, dim3(nblock), dim3(256), 0, s, reinterpret_cast<float4*>(ad->f), numFloat4,
                        reinterpret_cast<float*>(ad->f) + 4 * static_cast<size_t>(numFloat4), numTail, nb->scalarOutputs,
-                       nb->numScalarOutputs, reinterpret_cast<float*>(ad->fShift), computeVirial ? 3 * c_numShiftVectors : 0);
+                       nb->numScalarOutputs, reinterpret_cast<float*>(ad->fShift), computeVirial ? c_fshiftBlockFloats : 0);
     NBNXM_HIP_CHECK(hipGetLastError());
 }
 
@@ -1115,7 +1120,7 @@ void nbnxm_gpu_launch_cpyback(NbnxmGpu* nb, float* f_out, const nbnxm_step_workl
     {
         if (stepWork->computeVirial)
         {
-            NBNXM_HIP_CHECK(hipMemcpyAsync(nb->nbst.fShift, ad->fShift, sizeof(float) * 3 * c_numShiftVectors, hipMemcpyDeviceToHost, s));
+            NBNXM_HIP_CHECK(hipMemcpyAsync(nb->nbst.fShift, ad->fShift, sizeof(float) * c_fshiftBlockFloats, hipMemcpyDeviceToHost, s));
         }
         /* one copy of the scalar-output block instead of the reference's 4 + 4 small ones (:1263-1294):
          * energy steps need the accumulator slots too, dH/dl-only steps just the head */
@@ -1162,7 +1167,12 @@ static int finishTask(NbnxmGpu* nb, const nbnxm_step_workload_t* stepWork, int a
             }
             if (stepWork->computeVirial && shiftForces != nullptr)
             {
-                for (int i = 0; i < 3 * c_numShiftVectors; i++) { shiftForces[i] += nb->nbst.fShift[i]; }
+                for (int i = 0; i < 3 * c_numShiftVectors; i++)
+                {
+                    float sum = nb->nbst.fShift[i];
+                    for (int k = 1; k <= c_numFshiftSlots; k++) { sum += nb->nbst.fShift[k * c_fshiftSlotStride + i]; }
+                    shiftForces[i] += sum;
+                }
             }
             /* gpu_reduce_staged_foreign_term, gpu_common.h:178-191 */
             if (nb->n_lambda > 0 && stepWork->computeDhdl && enerd != nullptr && enerd->foreign_energies != nullptr)

@@ -29,6 +29,13 @@ constexpr float c_nbnxnMinDistanceSquared = 3.82e-07F;
 /* nb_free_energy.cpp:107: cap on r^-6 in the perturbed-pair math */
 constexpr float c_maxRInvSix = 1.0e15F;
 constexpr int c_numEnergySlots   = 128;
+/* Shift forces of the cluster kernel: most i-entries off the central image use one of six shifts, and thousands of adds to the
+ * same few addresses serialise in one L2 channel (measured: +5.5 us on a virial step).  The kernel adds to one of
+ * c_numFshiftSlots copies behind the primary array (atdat.fShift + (1 + slot) * c_fshiftSlotStride floats, 1 KB apart);
+ * the host sums them with the primary array, which the atom-pair, perturbed-pair and listed kernels keep using. */
+constexpr int c_numFshiftSlots   = 32;
+constexpr int c_fshiftSlotStride = 256;
+constexpr int c_fshiftBlockFloats = (1 + c_numFshiftSlots) * c_fshiftSlotStride;
 constexpr int c_numForeignSlots  = 64;
 constexpr int c_energySlotStride = 32;
 

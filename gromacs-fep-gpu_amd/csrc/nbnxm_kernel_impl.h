@@ -485,7 +485,10 @@ __launch_bounds__(c_nbBlockSize) __attribute__((amdgpu_waves_per_eu(c_nbWavesPer
         if (lane < 3U)
         {
             const float v = (lane == 0U) ? sx : ((lane == 1U) ? sy : sz);
-            atomicAdd(reinterpret_cast<float*>(atdat.fShift) + 3 * shiftIdx + static_cast<int>(lane), v);
+            /* one of c_numFshiftSlots copies (nbnxm_hip_types.h): the same few shift indices from thousands of pieces */
+            atomicAdd(reinterpret_cast<float*>(atdat.fShift) + (1 + (sci & (c_numFshiftSlots - 1))) * c_fshiftSlotStride + 3 * shiftIdx
+                              + static_cast<int>(lane),
+                      v);
         }
     }
     } /* pieces */

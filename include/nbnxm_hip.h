@@ -265,6 +265,8 @@ int nbnxm_gpu_is_kernel_ewald_analytical(const NbnxmGpu* nb);
 /* Nbnxm::gpu_get_xq / gpu_get_f / gpuGetNBAtomData-style raw device pointers (nbnxm_gpu.h:238-311) */
 void* nbnxm_gpu_get_xq(NbnxmGpu* nb);
 void* nbnxm_gpu_get_f(NbnxmGpu* nb);
+/* (get_fshift: the primary array of 45 x 3 floats other kernels — listed forces — add to; the cluster kernel's own share sits in
+ * accumulator slots behind it and joins in gpu_try/wait_finish_task) */
 void* nbnxm_gpu_get_fshift(NbnxmGpu* nb);
 /* gpuGetNBAtomData(nb)->q4: float4 per grid slot, .x = qA, .y = qB — what the perturbed 1-4 pairs of the listed forces read
  * (mdlib/sim_util.cpp:1678-1689) */
