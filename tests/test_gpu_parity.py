@@ -569,3 +569,17 @@ def test_free_energy_identities(elec, fused):
         ek, _ = energy(float(lk), float(lk))
         assert abs((fe[k + 1] - fe[0]) - (ek - e0)) <= 2e-3 * max(abs(fe[k + 1] - fe[0]), 1.0) + 0.02, (k, fe[k + 1] - fe[0], ek - e0)
     nb.free()
+
+
+@pytest.mark.parametrize("seed,nm,npert", [(101, (7, 9, 11), 2), (102, (11, 7, 8), 5), (103, (6, 6, 13), 1), (104, (9, 12, 7), 8),
+                                           (105, (8, 8, 8), 0), (106, (13, 6, 6), 3)])
+def test_seed_and_shape_sweep(seed, nm, npert):
+    """Boxes that are not cubes and not multiples of the cluster size (filler atoms, ragged last super-clusters, every shift
+    pattern), 0 to 8 perturbed molecules, both perturbed-pair paths, Ewald and reaction field: forces, shift forces, energies and
+    dV/dlambda against the oracle"""
+    for elec in ("ewald", "rf"):
+        c = tl.make_case(elec=elec, seed=seed, nm=nm, num_perturbed_molecules=npert)
+        want = tl.run_oracle(c, energy=True)
+        for fused in (False, True):
+            tl.assert_parity(tl.run_gpu(c, energy=True, fused=fused), want, rel=1e-4, label="%s fused=%s VF" % (elec, fused))
+            tl.assert_parity(tl.run_gpu(c, energy=False, fused=fused), want, rel=1e-4, energy=False, label="%s fused=%s F" % (elec, fused))
