@@ -469,9 +469,11 @@ def test_fused_update_equals_the_kernel_sequence(sd):
 
 def test_nve_energy_conservation_of_the_gpu_resident_loop():
     """Forces and energies of the kernels must belong to one Hamiltonian, and the update + SETTLE must integrate it: total energy
-    (non-bonded potential from energy steps + kinetic energy, average of the two half-step values) over 300 steps of 0.1 fs of a
+    (non-bonded potential from energy steps + kinetic energy, average of the two half-step values) over 150 steps of 0.1 fs of a
     water box with a half-decoupled solute (reaction field, soft-core at lambda = 0.5) stays constant while kinetic and potential
-    energy exchange many times the allowed drift."""
+    energy exchange ten thousand times the allowed drift (measured: 0.3 kJ/mol of 10,300, tools/nve_probe.py).  15 fs only: the
+    start from a lattice heats the box to several hundred kelvin, and the pair list, built once with a 0.1 nm buffer, must stay
+    valid."""
     import importlib
     import torch
     mdloop = importlib.import_module("gromacs_fep_gpu_amd.mdloop")
@@ -488,12 +490,13 @@ def test_nve_energy_conservation_of_the_gpu_resident_loop():
     sw_e = pkg.step_workload(energy=True, virial=False, dhdl=False)
 
     def kinetic():
+        loop.synchronize()          # the loop runs on the non-bonded object's own stream: torch's copy alone does not wait for it
         v = loop.d_v.cpu().numpy().astype(np.float64)
         return 0.5 * float(np.sum(mass[:, None] * v * v))
 
     etot, ekin, epot = [], [], []
-    for step in range(300):
-        if step % 10 == 0:
+    for step in range(150):
+        if step % 5 == 0:
             k0 = kinetic()
             loop.step(step, step_work=sw_e)
             f = np.zeros((g.num_atoms, 3), np.float32)
@@ -510,7 +513,7 @@ def test_nve_energy_conservation_of_the_gpu_resident_loop():
     exchange = ekin.max() - ekin.min()
     drift = np.max(np.abs(etot - etot[0]))
     assert exchange > 50.0                       # kJ/mol: the lattice start relaxes, plenty of energy moves
-    assert drift < 0.02 * exchange, (drift, exchange, etot.tolist())
+    assert drift < 1e-3 * exchange, (drift, exchange, etot.tolist())
     loop.free()
     nb.free()
 
