@@ -140,6 +140,9 @@ def main():
     ap.add_argument("--max-cjpacked-per-sci", type=int, default=16)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-prune", action="store_true")
+    ap.add_argument("--primary-only", action="store_true",
+                    help="skip the secondary figures (energy / dH/dl / virial steps, MD loops): the profile of such a run holds "
+                         "the force-only kernels of the timed loop and nothing else")
     ap.add_argument("--perturbed-molecules", type=int, default=-1, help="override the ligand size (diagnostics)")
     ap.add_argument("--dd", action="store_true",
                     help="N > 1: one box decomposed over the ranks with a halo exchange (config 5, strong scaling) "
@@ -241,15 +244,17 @@ def main():
             nb.launch_kernel(sw)
         torch.cuda.synchronize()
         return 1e3 * (time.perf_counter() - t1) / n
-    ms_energy_step = timed(pkg.step_workload(energy=True, virial=True, dhdl=False))
-    ms_dhdl_step = timed(pkg.step_workload(energy=True, virial=True, dhdl=True))
-    ms_virial_only = timed(pkg.step_workload(energy=False, virial=True, dhdl=False))
-    ms_energy_only = timed(pkg.step_workload(energy=True, virial=False, dhdl=False))
+    ms_energy_step = ms_dhdl_step = ms_virial_only = ms_energy_only = None
+    if not args.primary_only:
+        ms_energy_step = timed(pkg.step_workload(energy=True, virial=True, dhdl=False))
+        ms_dhdl_step = timed(pkg.step_workload(energy=True, virial=True, dhdl=True))
+        ms_virial_only = timed(pkg.step_workload(energy=False, virial=True, dhdl=False))
+        ms_energy_only = timed(pkg.step_workload(energy=True, virial=False, dhdl=False))
 
     # GPU-resident MD steps between two searches (secondary figure): x -> xq, clear, kernels, force reduction, leap-frog and
     # SETTLE with coordinates, velocities and forces staying in HBM; 0.5 fs steps so that the list stays valid over the run
     ms_md_step = ms_md_step_sequence = ms_md_step_prune = None
-    if fused and world == 1:
+    if fused and world == 1 and not args.primary_only:
         mdloop = importlib.import_module("gromacs_fep_gpu_amd.mdloop")
         nat = case.natoms
         im = np.tile([1 / 15.9994, 1 / 1.008, 1 / 1.008], nat // 3)

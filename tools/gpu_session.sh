@@ -27,7 +27,7 @@ if [ "$MODE" = "all" ] || [ "$MODE" = "bench" ]; then
     step bench_fused 400 python bench.py --steps 200 --warmup 20
     step bench_split 300 python bench.py --steps 200 --warmup 20 --mode split --no-cpu-baseline
     rm -rf $OUT/prof
-    step rocprof_stats 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -- python3 bench.py --steps 100 --warmup 10 --no-cpu-baseline
+    step rocprof_stats 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -- python3 bench.py --steps 100 --warmup 10 --no-cpu-baseline --primary-only
     find $OUT/prof -name "*stats*" | head
 fi
 echo "=== done"
