@@ -639,8 +639,8 @@ SettleGpu* settle_gpu_create(void* stream, float mO, float mH, float dOH, float 
     sg->pars.rb       = static_cast<float>(h - ra);
     sg->pars.rc       = static_cast<float>(rc);
     sg->pars.irc2     = static_cast<float>(1.0 / dHH);
-    allocateDeviceBuffer(&sg->d_virial, 6);
-    sg->h_virial.resize(6);
+    allocateDeviceBuffer(&sg->d_virial, c_virialFloats);
+    sg->h_virial.resize(c_virialFloats);
     return sg;
 }
 
@@ -667,7 +667,7 @@ void settle_gpu_apply(SettleGpu* sg, const void* d_x, void* d_xp, int updateVelo
     if (sg->numSettles == 0) { return; }
     NBNXM_ASSERT(!updateVelocities || d_v != nullptr, "velocities are needed to update them");
     hipStream_t s = sg->stream.stream;
-    if (computeVirial) { NBNXM_HIP_CHECK(hipMemsetAsync(sg->d_virial, 0, 6 * sizeof(float), s)); }
+    if (computeVirial) { NBNXM_HIP_CHECK(hipMemsetAsync(sg->d_virial, 0, c_virialFloats * sizeof(float), s)); }
     auto k = updateVelocities ? (computeVirial ? settleKernel<true, true> : settleKernel<true, false>)
                               : (computeVirial ? settleKernel<false, true> : settleKernel<false, false>);
     const dim3 grid((sg->numSettles + c_updateBlock - 1) / c_updateBlock);
@@ -676,9 +676,11 @@ void settle_gpu_apply(SettleGpu* sg, const void* d_x, void* d_xp, int updateVelo
     NBNXM_HIP_CHECK(hipGetLastError());
     if (computeVirial)
     {
-        NBNXM_HIP_CHECK(hipMemcpyAsync(sg->h_virial.data, sg->d_virial, 6 * sizeof(float), hipMemcpyDeviceToHost, s));
+        NBNXM_HIP_CHECK(hipMemcpyAsync(sg->h_virial.data, sg->d_virial, c_virialFloats * sizeof(float), hipMemcpyDeviceToHost, s));
         NBNXM_HIP_CHECK(hipStreamSynchronize(s));
-        addSymmetricVirial(virialScaled, sg->h_virial.data);
+        float six[6];
+        sumVirialSlots(sg->h_virial.data, six);
+        addSymmetricVirial(virialScaled, six);
     }
 }
 
@@ -691,8 +693,8 @@ LincsGpu* lincs_gpu_create(void* stream, int numIterations, int expansionOrder)
     lg->stream.init(stream);
     lg->numIterations  = numIterations;
     lg->expansionOrder = expansionOrder;
-    allocateDeviceBuffer(&lg->d_virial, 6);
-    lg->h_virial.resize(6);
+    allocateDeviceBuffer(&lg->d_virial, c_virialFloats);
+    lg->h_virial.resize(c_virialFloats);
     return lg;
 }
 
@@ -889,7 +891,7 @@ void lincs_gpu_apply(LincsGpu* lg, const void* d_x, void* d_xp, int updateVeloci
     if (lg->numBlocks == 0) { return; }
     NBNXM_ASSERT(!updateVelocities || d_v != nullptr, "velocities are needed to update them");
     hipStream_t s = lg->stream.stream;
-    if (computeVirial) { NBNXM_HIP_CHECK(hipMemsetAsync(lg->d_virial, 0, 6 * sizeof(float), s)); }
+    if (computeVirial) { NBNXM_HIP_CHECK(hipMemsetAsync(lg->d_virial, 0, c_virialFloats * sizeof(float), s)); }
     LincsKernelArgs a;
     a.numThreads     = lg->numBlocks * lg->blockSize;
     a.numIterations  = lg->numIterations;
@@ -916,9 +918,11 @@ void lincs_gpu_apply(LincsGpu* lg, const void* d_x, void* d_xp, int updateVeloci
     NBNXM_HIP_CHECK(hipGetLastError());
     if (computeVirial)
     {
-        NBNXM_HIP_CHECK(hipMemcpyAsync(lg->h_virial.data, lg->d_virial, 6 * sizeof(float), hipMemcpyDeviceToHost, s));
+        NBNXM_HIP_CHECK(hipMemcpyAsync(lg->h_virial.data, lg->d_virial, c_virialFloats * sizeof(float), hipMemcpyDeviceToHost, s));
         NBNXM_HIP_CHECK(hipStreamSynchronize(s));
-        addSymmetricVirial(virialScaled, lg->h_virial.data);
+        float six[6];
+        sumVirialSlots(lg->h_virial.data, six);
+        addSymmetricVirial(virialScaled, six);
     }
 }
 
@@ -937,8 +941,8 @@ UpdateConstrainGpu* update_constrain_gpu_create(void* stream, const update_const
     uc->lincs = lincs_gpu_create(s, p->nLincsIter, p->nProjOrder);
     if (p->haveSettle) { uc->settle = settle_gpu_create(s, p->mO, p->mH, p->dOH, p->dHH); }
     NBNXM_HIP_CHECK(hipEventCreateWithFlags(&uc->xUpdated, hipEventDisableTiming));
-    allocateDeviceBuffer(&uc->d_virial, 6);
-    uc->h_virial.resize(6);
+    allocateDeviceBuffer(&uc->d_virial, c_virialFloats);
+    uc->h_virial.resize(c_virialFloats);
     return uc;
 }
 
@@ -1136,7 +1140,7 @@ void update_constrain_gpu_integrate_fused(UpdateConstrainGpu* uc, void* fReadyEv
             a.sdConstEm     = uc->langevin->d_sdConstEm;
             a.table         = uc->langevin->d_table;
         }
-        if (computeVirial) { NBNXM_HIP_CHECK(hipMemsetAsync(uc->d_virial, 0, 6 * sizeof(float), s)); }
+        if (computeVirial) { NBNXM_HIP_CHECK(hipMemsetAsync(uc->d_virial, 0, c_virialFloats * sizeof(float), s)); }
         auto k = uc->langevin ? (computeVirial ? fusedUpdateKernel<true, true> : fusedUpdateKernel<true, false>)
                               : (computeVirial ? fusedUpdateKernel<false, true> : fusedUpdateKernel<false, false>);
         const dim3 grid((uc->numUnits + c_fusedBlock - 1) / c_fusedBlock);
@@ -1146,9 +1150,11 @@ void update_constrain_gpu_integrate_fused(UpdateConstrainGpu* uc, void* fReadyEv
         lincs_gpu_apply(uc->lincs, uc->d_xp, uc->d_x, 1, uc->d_v, 1.0F / dt, computeVirial, virial, uc->pbcType, uc->box);
         if (computeVirial)
         {
-            NBNXM_HIP_CHECK(hipMemcpyAsync(uc->h_virial.data, uc->d_virial, 6 * sizeof(float), hipMemcpyDeviceToHost, s));
+            NBNXM_HIP_CHECK(hipMemcpyAsync(uc->h_virial.data, uc->d_virial, c_virialFloats * sizeof(float), hipMemcpyDeviceToHost, s));
             NBNXM_HIP_CHECK(hipStreamSynchronize(s));
-            addSymmetricVirial(virial, uc->h_virial.data);
+            float six[6];
+            sumVirialSlots(uc->h_virial.data, six);
+            addSymmetricVirial(virial, six);
             const float scale = 0.5F / (dt * dt);
             for (int i = 0; i < 9; i++) { virial[i] *= scale; }
         }

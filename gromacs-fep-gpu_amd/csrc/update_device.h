@@ -34,15 +34,35 @@ __device__ __forceinline__ float waveSum(float v)
     return v;
 }
 
-/* the six independent components of a symmetric tensor summed over the wave, added to virial[XX XY XZ YY YZ ZZ] once per wave */
+/* Virial accumulators: c_numVirialSlots copies of [XX XY XZ YY YZ ZZ - -], one 32-byte record each, summed on the host.
+ * Hundreds of waves adding to ONE set of six addresses serialise in L2 at ~10 ns per add: measured 41 us instead of 3.9 us
+ * for SETTLE on 32k waters (tools/settle_virial_probe.py). */
+constexpr int c_numVirialSlots   = 64;
+constexpr int c_virialSlotStride = 8;
+constexpr int c_virialFloats     = c_numVirialSlots * c_virialSlotStride;
+
+/* the six independent components of a symmetric tensor summed over the wave, added to one of the accumulator copies once per wave */
 __device__ __forceinline__ void addWaveVirial(float* virial, const float (&c)[6])
 {
     const int lane = static_cast<int>(threadIdx.x) & 63;
+    const int wave = static_cast<int>(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
+    float*    slot = virial + (wave & (c_numVirialSlots - 1)) * c_virialSlotStride;
 #pragma unroll
     for (int d = 0; d < 6; d++)
     {
         const float s = waveSum(c[d]);
-        if (lane == 0 && s != 0.0F) { atomicAdd(&virial[d], s); }
+        if (lane == 0 && s != 0.0F) { atomicAdd(&slot[d], s); }
+    }
+}
+
+/* host: sum of the accumulator copies into six numbers */
+inline void sumVirialSlots(const float* slots, float* six)
+{
+    for (int d = 0; d < 6; d++)
+    {
+        double s = 0;
+        for (int k = 0; k < c_numVirialSlots; k++) { s += slots[k * c_virialSlotStride + d]; }
+        six[d] = static_cast<float>(s);
     }
 }
 
