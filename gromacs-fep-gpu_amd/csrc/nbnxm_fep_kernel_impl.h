@@ -149,9 +149,9 @@ __launch_bounds__(c_fepBlockSize) __global__
             float s = 0.0F;
 #pragma unroll
             for (int k = 0; k < c_fepBlockSize / c_waveSize; k++) { s += red[k][threadIdx.x]; }
-            float* out = (threadIdx.x == 0U) ? atdat.eLJ
-                                             : ((threadIdx.x == 1U) ? atdat.eElec
-                                                                    : ((threadIdx.x == 2U) ? atdat.dvdlLJ : atdat.dvdlElec));
+            /* into one of the accumulator slots the cluster kernel uses (same layout: E_lj, E_el, dV/dl_lj, dV/dl_el; summed
+             * on the host with the staged scalars): hundreds of work-groups adding to ONE set of addresses serialise in L2 */
+            float* out = atdat.energySlots + (blockIdx.x & (c_numEnergySlots - 1)) * c_energySlotStride + threadIdx.x;
             if (s != 0.0F) { atomicAdd(out, s); }
         }
     }
@@ -200,11 +200,10 @@ __launch_bounds__(c_fepBlockSize) __global__
             float s = 0.0F;
 #pragma unroll
             for (int k = 0; k < c_fepBlockSize / c_waveSize; k++) { s += red[k][threadIdx.x]; }
-            float* out = (threadIdx.x == 0U) ? atdat.eLJForeign
-                                             : ((threadIdx.x == 1U) ? atdat.eElecForeign
-                                                                    : ((threadIdx.x == 2U) ? atdat.dvdlLJForeign
-                                                                                           : atdat.dvdlElecForeign));
-            if (s != 0.0F) { atomicAdd(out + idx, s); }
+            /* foreign-lambda accumulator slots, layout [E_lj | E_el | dV/dl_lj | dV/dl_el][lambda index] as in the fused mode */
+            float* out = atdat.foreignSlots + (blockIdx.x & (c_numForeignSlots - 1)) * atdat.foreignSlotStride
+                         + threadIdx.x * (n_lambda + 1) + idx;
+            if (s != 0.0F) { atomicAdd(out, s); }
         }
     }
 }
