@@ -137,6 +137,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--mode", choices=["fused", "split"], default="fused")
     ap.add_argument("--atoms", choices=["24k", "96k", "768k"], default="96k")
+    ap.add_argument("--elec", choices=["ewald", "rf"], default="ewald", help="rf: BASELINE configs[1] (with --atoms 24k)")
     ap.add_argument("--max-cjpacked-per-sci", type=int, default=16)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-prune", action="store_true")
@@ -179,7 +180,7 @@ def main():
         run_domain_decomposition(args, rank, world, dist, torch, tl, nm, npert)
         return
     t0 = time.time()
-    case = tl.make_case(nm=nm, num_perturbed_molecules=npert, elec="ewald", seed=2026, n_lambda=11,
+    case = tl.make_case(nm=nm, num_perturbed_molecules=npert, elec=args.elec, seed=2026, n_lambda=11,
                         lambda_coul=lam, lambda_vdw=lam, max_cjpacked_per_sci=args.max_cjpacked_per_sci)
     t_build = time.time() - t0
     fused = args.mode == "fused"
@@ -300,7 +301,7 @@ def main():
     # same command, tools/gpu_traffic.sh; FETCH_SIZE doubled as MI355X_MICROARCH.md §HBM prescribes for gfx950)
     traffic = None
     tpath = os.path.join(ROOT, "profiles", "r01", "g_traffic_fused.json")
-    if fused and args.atoms == "96k" and args.perturbed_molecules < 0 and os.path.exists(tpath):
+    if fused and args.atoms == "96k" and args.elec == "ewald" and args.perturbed_molecules < 0 and os.path.exists(tpath):
         try:
             traffic = json.load(open(tpath)).get("hbm_bytes_per_launch_corrected")
         except Exception:
@@ -312,7 +313,7 @@ def main():
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
         "data": "synthetic (seeded SPC/E-like water box + 48-atom decoupled ligand)",
         "config": {"workload": "configs[2]: 96k-atom water + 48 perturbed atoms, Ewald(analytical) + LJ cut, rc 1.0, rlist 1.1, lambda 0.5"
-                   if args.atoms == "96k" else args.atoms,
+                   if (args.atoms == "96k" and args.elec == "ewald") else "%s-atom box, %s" % (args.atoms, args.elec),
                    "mode": args.mode, "atoms": int(case.natoms), "perturbed_atoms": int(case.perturbed.sum()),
                    "nsci": stats["nsci"], "cj_slots": stats["cj_slots"], "cluster_pairs": stats["cluster_pairs"],
                    "fep_pairs": fep_pairs, "max_cjpacked_per_sci": args.max_cjpacked_per_sci,
@@ -325,7 +326,7 @@ def main():
         "ms_per_gpu_resident_md_step_with_rolling_prune_8": ms_md_step_prune,
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                     "kernel": "nbnxmKernel<EwaldAna,LJcut,F,%s>" % ("fused" if fused else "plain"),
+                     "kernel": "nbnxmKernel<%s,LJcut,F,%s>" % ("EwaldAna" if args.elec == "ewald" else "RF", "fused" if fused else "plain"),
                      "algorithmic_bytes_per_launch": bytes_nb,
                      "fp32_valu_frac_estimate": (pair_evals * 45.0 / (nb_k_us * 1e-6) / 1e12 / FP32_PEAK_TFLOPS)
                      if nb_k_us > 0 else None},
