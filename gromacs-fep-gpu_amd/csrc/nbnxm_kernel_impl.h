@@ -249,7 +249,7 @@ __launch_bounds__(c_nbBlockSize) __attribute__((amdgpu_waves_per_eu(c_nbWavesPer
     const void*    ljBase    = USE_TABLE ? static_cast<const void*>(atomTypes) : static_cast<const void*>(ljComb);
 
 /* W(g): list words of group g -> ring record g & 3 (lanes 0-7: the 8 dwords of nbnxn_cj_packed_t; FUSED: lane 8 adds
- * groupFepJ[g] behind them).  The lane id is recomputed in place on purpose: hoisted out of the loops it would be
+ * groupSlowMask[g] behind them).  The lane id is recomputed in place on purpose: hoisted out of the loops it would be
  * spilled, and a scratch reload in this loop is a VMEM load that drains the pipeline. */
 #define NBNXM_STAGE_WORDS(g)                                                                                    \
     {                                                                                                          \

@@ -259,7 +259,7 @@ def setup_gpu(c, fused=False, use_dynamic_pruning=False, list_override=None):
     else:
         nb.init_pairlist(pl.sci, pl.cjPacked, pl.excl)
     if fused:
-        # no atom-pair list at all: the cluster kernel's second pass covers forces, energies and foreign lambdas
+        # no atom-pair list at all: nbnxmFepClusterKernel covers forces, energies and foreign lambdas of the perturbed cluster pairs
         nb.init_fep_cluster_bits(g.fepBits)
         nb.set_fep_mode(True)
     else:

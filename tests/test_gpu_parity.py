@@ -60,7 +60,7 @@ def test_softcore_settings(sc_alpha, sc_power, sc_coul, lam, fused):
 @pytest.mark.parametrize("fused", [False, True])
 @pytest.mark.parametrize("elec,vdw", [("rf", "cut"), ("ewald", "cut"), ("ewald", "pswitch"), ("cut", "cut")])
 def test_foreign_lambda_energies(elec, vdw, fused):
-    # split: nbnxmFepForeignKernel on the atom-pair list; fused: the cluster kernel's second pass, no atom-pair list
+    # split: nbnxmFepForeignKernel on the atom-pair list; fused: nbnxmFepClusterKernel's FOREIGN flavour, no atom-pair list
     c = tl.make_case(elec=elec, vdw=vdw, seed=25, n_lambda=11, **SMALL)
     got = tl.run_gpu(c, energy=True, fused=fused, dhdl=True)
     want = tl.run_oracle(c, energy=True, foreign=True)
