@@ -50,7 +50,12 @@ class RankPlan:
 
 
 class SlabDecomposition:
-    def __init__(self, grid, plist, num_ranks, axis=0):
+    """molecule_ids (one id per atom, optional): keep molecules whole — every atom is owned by the rank that owns the
+    super-cluster of its molecule's first atom (the reference's update groups, domdec/updategroups.cpp, needed as soon as a
+    rank constrains and integrates its home atoms).  Without it an atom belongs to the owner of its own super-cluster.  The
+    WORK is decomposed by super-cluster either way; ownership only decides who sends coordinates and who collects forces."""
+
+    def __init__(self, grid, plist, num_ranks, axis=0, molecule_ids=None):
         self.grid, self.plist, self.num_ranks = grid, plist, int(num_ranks)
         self.owner_sc = owners_by_slab(grid, num_ranks, axis)
         sci, cj = plist.sci, plist.cjPacked
@@ -61,21 +66,34 @@ class SlabDecomposition:
         group_index = np.concatenate([np.arange(b, e) for b, e in zip(sci["cjPackedBegin"], sci["cjPackedEnd"])]) \
             if len(sci) else np.zeros(0, np.int64)
         self._group_entry, self._group_index = group_entry, group_index
+        # owner of every atom (topology order)
+        ai = grid.atomIndices
+        real = ai >= 0
+        natoms = int(grid.natoms)
+        self.owner_atom = np.zeros(natoms, np.int32)
+        self.owner_atom[ai[real]] = self.owner_sc[np.nonzero(real)[0] // SUPERCLUSTER]
+        if molecule_ids is not None:
+            mol = np.asarray(molecule_ids)
+            first = np.full(int(mol.max()) + 1, natoms, np.int64)
+            np.minimum.at(first, mol, np.arange(natoms))
+            self.owner_atom = self.owner_atom[first[mol]]
+        # the clusters a rank's entries touch: the 8 i-clusters of each entry and the j-clusters of its groups
         cjs = cj["cj"][group_index]                                    # (ngroupsTotal, 4) j-cluster indices
-        own_i = self._entry_owner[group_entry][:, None].repeat(4, axis=1)
-        own_j = self.owner_sc[cjs // CLUSTER]
-        foreign = own_i != own_j
-        # (needing rank, owning rank, j-cluster) triples, unique
-        trip = np.stack([own_i[foreign], own_j[foreign], cjs[foreign]], axis=1)
-        trip = np.unique(trip, axis=0) if len(trip) else trip.reshape(0, 3)
-        ai = grid.atomIndices.reshape(-1, CLUSTER)
+        own_g = self._entry_owner[group_entry]
+        ai_cl = ai.reshape(-1, CLUSTER)
         self._needs = {}
         for r in range(self.num_ranks):
+            jcl = np.unique(cjs[own_g == r]) if len(cjs) else np.zeros(0, np.int64)
+            isc = np.unique(sci["sci"][self._entry_owner == r]) if len(sci) else np.zeros(0, np.int64)
+            icl = (isc[:, None] * (SUPERCLUSTER // CLUSTER) + np.arange(SUPERCLUSTER // CLUSTER)[None, :]).reshape(-1)
+            atoms = ai_cl[np.union1d(jcl, icl).astype(np.int64)].reshape(-1)
+            atoms = np.unique(atoms[atoms >= 0])
+            own = self.owner_atom[atoms]
             for q in range(self.num_ranks):
-                sel = trip[(trip[:, 0] == r) & (trip[:, 1] == q), 2] if len(trip) else np.zeros(0, np.int64)
-                if len(sel):
-                    atoms = ai[sel].reshape(-1)
-                    self._needs[(r, q)] = np.sort(atoms[atoms >= 0]).astype(np.int32)
+                if q != r:
+                    sel = atoms[own == q]
+                    if len(sel):
+                        self._needs[(r, q)] = sel.astype(np.int32)
 
     def plan(self, rank):
         sci, cj = self.plist.sci, self.plist.cjPacked
@@ -90,9 +108,7 @@ class SlabDecomposition:
         new_cj = np.ascontiguousarray(cj[idx]) if len(idx) else cj[:0].copy()
         recv = {q: a for (r, q), a in self._needs.items() if r == rank}
         send = {r: a for (r, q), a in self._needs.items() if q == rank}
-        ai = self.grid.atomIndices.reshape(-1, SUPERCLUSTER)
-        home = ai[self.owner_sc == rank].reshape(-1)
-        home = np.sort(home[home >= 0]).astype(np.int32)
+        home = np.nonzero(self.owner_atom == rank)[0].astype(np.int32)
         return RankPlan(rank, new_sci, new_cj, recv, send, home)
 
 
@@ -241,3 +257,44 @@ class DomainStep:
             self.compute(step_work)
             comm.exchange_f(self.halo)
             self.unpack_f()
+
+
+class DomainMdStep(DomainStep):
+    """DomainStep plus the update of the rank's home atoms: halo x, kernels, halo f, then leap-frog | SD, LINCS, SETTLE on the
+    molecules this rank owns (the decomposition must keep molecules whole: SlabDecomposition(molecule_ids=...)).  The update
+    objects see the whole atom range — the coordinate and force arrays are global — with zero inverse mass and zero velocity
+    outside the home atoms, so nothing else moves; settles / constraints are the home molecules' only."""
+
+    def __init__(self, nb, grid, plan, halo, x0, v0, inverse_masses, dt, box, settles=None, settle_params=None, constraints=None,
+                 constraint_lengths=None, **update_args):
+        import torch
+        from . import UpdateConstrainGpu
+        super().__init__(nb, grid, plan, halo)
+        home = np.zeros(self.natoms, bool)
+        home[plan.home_atoms] = True
+        im = np.where(home, np.asarray(inverse_masses, np.float64), 0.0)
+        self.d_x.copy_(torch.from_numpy(np.ascontiguousarray(x0, np.float32)))
+        v = np.where(home[:, None], np.asarray(v0, np.float64), 0.0)
+        self.d_v = torch.from_numpy(np.ascontiguousarray(v, np.float32)).to(self.d_x.device)
+        keep = lambda rows: None if rows is None else np.asarray(rows, np.int32)[home[np.asarray(rows, np.int32)[:, -1]]]
+        st, cs = keep(settles), keep(constraints)
+        for rows in (st, cs):
+            if rows is not None and len(rows):
+                atoms = rows[:, 1:] if rows is cs else rows
+                assert home[atoms].all(), "a molecule is split over ranks: decompose with molecule_ids"
+        self.dt = float(dt)
+        self.update = UpdateConstrainGpu(dt, settle=settle_params, stream=self.stream, **update_args)
+        ok = self.update.set(self.d_x.data_ptr(), self.d_v.data_ptr(), self.d_f.data_ptr(), im, None, cs, constraint_lengths, st)
+        if not ok:
+            raise ValueError("a group of coupled constraints is too large for the GPU LINCS")
+        self.update.set_pbc(3, box)
+        torch.cuda.synchronize()
+
+    def integrate(self, step_index=0, seed=0, tc_lambdas=None):
+        return self.update.integrate(self.dt, update_velocities=True, tc_lambdas=tc_lambdas, seed=seed, step=step_index)
+
+    def md_step(self, comm, step_work, step_index=0):
+        import torch
+        self.step(comm, step_work)
+        with torch.cuda.stream(self.torch_stream()):
+            self.integrate(step_index)

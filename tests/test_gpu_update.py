@@ -712,3 +712,71 @@ def test_md_loop_with_listed_forces_on_the_nonbonded_buffers():
         nb.free()
     assert np.max(np.abs(traj[True][0] - traj[False][0])) <= 2e-6
     assert np.max(np.abs(traj[True][1] - traj[False][1])) <= 2e-3
+
+
+@pytest.mark.parametrize("num_ranks", [2, 3])
+def test_domain_decomposed_md_steps_with_whole_molecules(num_ranks):
+    """Config 5 end to end on one GPU (all ranks in this process, LoopbackComm): per step halo x, kernels on the rank's share of
+    the list, halo f, then leap-frog + SETTLE on the molecules the rank owns.  Molecules are kept whole by the decomposition
+    (update groups); the trajectory of every atom, taken from its owner, equals the single-domain GPU-resident loop."""
+    import importlib
+    import torch
+    domdec = importlib.import_module("gromacs_fep_gpu_amd.domdec")
+    mdloop = importlib.import_module("gromacs_fep_gpu_amd.mdloop")
+    c = tl.make_case(nm=(12, 8, 8), num_perturbed_molecules=3, elec="ewald", seed=52)
+    g = c.grid
+    n = c.natoms
+    mO, mH = 15.9994, 1.008
+    im = np.tile([1 / mO, 1 / mH, 1 / mH], n // 3)
+    settles = np.arange(n, dtype=np.int32).reshape(-1, 3)
+    rng = np.random.default_rng(3)
+    v0 = np.repeat(rng.normal(0, 0.3, (n // 3, 3)), 3, axis=0)
+    dt, bx = 0.001, np.diag(g.box.astype(np.float64))
+    sw = pkg.step_workload(energy=False, virial=False, dhdl=False)
+    # single domain
+    nb0 = tl.setup_gpu(c, fused=True)
+    ref = mdloop.ShortRangeMdLoop(nb0, g, g.x_wrapped, v0, im, dt, bx, settles=settles, settle_params=(mO, mH, 0.1, 0.16330))
+    for step in range(3):
+        ref.step(step)
+    ref.synchronize()
+    x_ref, v_ref = ref.d_x.cpu().numpy(), ref.d_v.cpu().numpy()
+    ref.free()
+    nb0.free()
+    # decomposed
+    dd = domdec.SlabDecomposition(g, c.plist_fused, num_ranks, molecule_ids=c.sys["molId"])
+    plans = [dd.plan(r) for r in range(num_ranks)]
+    owners = np.full(n, -1)
+    for p in plans:
+        assert (owners[p.home_atoms] == -1).all()
+        owners[p.home_atoms] = p.rank
+    assert (owners >= 0).all() and (owners.reshape(-1, 3) == owners.reshape(-1, 3)[:, :1]).all()      # whole waters
+    steps = []
+    for p in plans:
+        nb = tl.setup_gpu(c, fused=True, list_override=(p.sci, p.cjPacked, c.plist_fused.excl))
+        steps.append(domdec.DomainMdStep(nb, g, p, domdec.HaloExchange(p, "cuda"), g.x_wrapped, v0, im, dt, bx, settles=settles,
+                                         settle_params=(mO, mH, 0.1, 0.16330)))
+    comm = domdec.LoopbackComm([s.halo for s in steps])
+    for step in range(3):
+        for s in steps:
+            s.pack_x()
+        torch.cuda.synchronize()
+        comm.exchange_all_x()
+        torch.cuda.synchronize()
+        for s in steps:
+            s.compute(sw)
+        torch.cuda.synchronize()
+        comm.exchange_all_f()
+        torch.cuda.synchronize()
+        for s in steps:
+            s.unpack_f()
+            s.integrate(step)
+        torch.cuda.synchronize()
+    x_dd, v_dd = np.zeros((n, 3), np.float32), np.zeros((n, 3), np.float32)
+    for s, p in zip(steps, plans):
+        x_dd[p.home_atoms] = s.d_x.cpu().numpy()[p.home_atoms]
+        v_dd[p.home_atoms] = s.d_v.cpu().numpy()[p.home_atoms]
+    assert np.max(np.abs(x_dd - x_ref)) <= 3e-6
+    assert np.max(np.abs(v_dd - v_ref)) <= 3e-3
+    for s in steps:
+        s.update.free()
+        s.nb.free()
