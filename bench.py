@@ -288,6 +288,40 @@ def main():
         # put the object back into the state of the timed loop (coordinates of the search)
         nb.copy_xq_to_gpu(case.grid.xq)
 
+    # lambda windows batched into one object (secondary figure; BASELINE configs[3]: 11 windows — more than the GPUs of a node):
+    # one list over 11 x N slots, per-window lambdas in the perturbed-pair kernel (nbnxm_gpu_set_window_lambdas)
+    batched = None
+    if fused and world == 1 and not args.primary_only and args.atoms != "768k":
+        R = 11
+        b = replica.batch_windows(case.grid, pl, R)
+        nbw = pkg.NbnxmGpu(tl.gpu_interaction_params(case, not args.no_prune), case.grid.num_types, case.grid.nbat_nbfp(case.sys["nbfp"]),
+                           fep=True, n_lambda=0)
+        sig6 = case.sc_sigma ** 6
+        nbw.copy_fepparams(case.sc_alpha if case.sc_coul else 0.0, case.sc_alpha, case.sc_power, sig6, sig6 if case.sc_coul else 0.0, 0.5, 0.5)
+        nbw.init_atomdata(len(b["type"]), b["type"], qA=b["qA"], qB=b["qB"], typeA=b["typeA"], typeB=b["typeB"])
+        nbw.init_pairlist(b["sci"], b["cjPacked"], b["excl"])
+        nbw.init_fep_cluster_bits(b["fepBits"])
+        nbw.set_fep_mode(True)
+        lam_w = replica.lambda_schedule(R)
+        nbw.set_window_lambdas(b["clusters_per_window"], lam_w, lam_w)
+        nbw.upload_shiftvec(case.grid.shift_vec)
+        nbw.copy_xq_to_gpu(b["xq"])
+        nbw.set_timing(False)
+        for _ in range(5):
+            nbw.clear_outputs(False)
+            nbw.launch_kernel(sw_f)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(30):
+            nbw.clear_outputs(False)
+            nbw.launch_kernel(sw_f)
+        torch.cuda.synchronize()
+        ms_batched = 1e3 * (time.perf_counter() - t1) / 30
+        nbw.free()
+        batched = {"windows": R, "ms_per_step_all_windows": ms_batched,
+                   "pair_interactions_per_s": R * 64 * stats["cluster_pairs"] / (ms_batched * 1e-3),
+                   "speedup_over_one_window_at_a_time": R * (elapsed / args.steps) / (ms_batched * 1e-3)}
+
     ms_per_step = 1e3 * elapsed / args.steps
     pair_evals = 64 * stats["cluster_pairs"]          # atom pairs in the (pruned) list, SURVEY §8d
     fep_pairs = len(case.plist.fep["jjnr"])
@@ -330,6 +364,7 @@ def main():
                      "algorithmic_bytes_per_launch": bytes_nb,
                      "fp32_valu_frac_estimate": (pair_evals * 45.0 / (nb_k_us * 1e-6) / 1e12 / FP32_PEAK_TFLOPS)
                      if nb_k_us > 0 else None},
+        "lambda_windows_batched": batched,
         "host_list_build_s": t_build,
     }
 

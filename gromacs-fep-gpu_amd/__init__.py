@@ -92,7 +92,7 @@ HIP_SYMBOLS = [
     "nbnxm_gpu_try_finish_task", "nbnxm_gpu_wait_finish_task", "nbnxm_gpu_clear_outputs",
     "nbnxm_gpu_get_timings", "nbnxm_gpu_reset_timings", "nbnxm_gpu_set_timing",
     "nbnxm_gpu_min_ci_balanced", "nbnxm_gpu_is_kernel_ewald_analytical", "nbnxm_gpu_get_xq",
-    "nbnxm_gpu_get_f", "nbnxm_gpu_get_fshift", "nbnxm_gpu_get_q4", "nbnxm_gpu_get_stream",
+    "nbnxm_gpu_get_f", "nbnxm_gpu_get_fshift", "nbnxm_gpu_get_q4", "nbnxm_gpu_get_stream", "nbnxm_gpu_set_window_lambdas",
     "nbnxm_gpu_have_short_range_work", "nbnxm_gpu_set_fep_mode", "nbnxm_hip_abi_version",
     "nbnxm_hip_last_error", "nbnxm_gpu_debug_get_cjpacked", "nbnxm_gpu_debug_download", "nbnxm_gpu_debug_get_work_ranges",
     "nbnxm_gpu_debug_graph_steps", "nbnxm_gpu_debug_set_work_shares",
@@ -392,6 +392,12 @@ class NbnxmGpu:
     def init_fep_cluster_bits(self, fep_bits):
         fb = _a(fep_bits, np.uint8)
         self._lib.nbnxm_gpu_init_fep_cluster_bits(self.h, C.c_int(len(fb)), _p(fb))
+
+    def set_window_lambdas(self, clusters_per_window, lambda_q, lambda_v):
+        """several lambda windows batched into this object (see include/nbnxm_hip.h); empty arrays switch it off"""
+        lq, lv = _a(lambda_q, np.float32), _a(lambda_v, np.float32)
+        assert lq.size == lv.size
+        self._lib.nbnxm_gpu_set_window_lambdas(self.h, C.c_int(lq.size), C.c_int(clusters_per_window), _p(lq), _p(lv))
 
     def set_fep_mode(self, fused):
         self._lib.nbnxm_gpu_set_fep_mode(self.h, C.c_int(1 if fused else 0))

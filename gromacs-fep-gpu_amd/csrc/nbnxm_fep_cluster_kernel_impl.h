@@ -116,6 +116,15 @@ __launch_bounds__(c_fepClusterWavesPerBlock* c_waveSize) __global__
     /* the self term of i-atom tidxi: the lanes tidxj == tidxi of the cluster's pair with itself */
     [[maybe_unused]] const bool selfLane = ENERGY && EXCL_FORCES && diagPair && (tidxj == tidxi) && ((iBits >> tidxi) & 1U);
 
+    /* this pair's lambdas: the object's, or its window's when several windows are batched into the object */
+    float lambdaQ = nbp.lambda_q, lambdaV = nbp.lambda_v;
+    if (nbp.clustersPerWindow > 0)
+    {
+        const float2 wl = nbp.windowLambda[ci / nbp.clustersPerWindow];
+        lambdaQ         = wl.x;
+        lambdaV         = wl.y;
+    }
+
     float E_lj = 0.0F, E_el = 0.0F, DVDL_lj = 0.0F, DVDL_el = 0.0F;
     float F_invr = 0.0F;
     if constexpr (ENERGY && EXCL_FORCES)
@@ -126,7 +135,7 @@ __launch_bounds__(c_fepClusterWavesPerBlock* c_waveSize) __global__
         {
             const float sA = qABi.x * qABi.x / nbp.epsfac * selfCoef;
             const float sB = qABi.y * qABi.y / nbp.epsfac * selfCoef;
-            E_el += (1.0F - nbp.lambda_q) * sA + nbp.lambda_q * sB;
+            E_el += (1.0F - lambdaQ) * sA + lambdaQ * sB;
             DVDL_el += sB - sA;
         }
     }
@@ -136,7 +145,7 @@ __launch_bounds__(c_fepClusterWavesPerBlock* c_waveSize) __global__
         {
             if (!subDiag)
             {
-                const FepLambda L     = makeFepLambda(nbp.lambda_q, nbp.lambda_v, nbp.lam_power, nbp.alpha_coul, nbp.alpha_vdw);
+                const FepLambda L     = makeFepLambda(lambdaQ, lambdaV, nbp.lam_power, nbp.alpha_coul, nbp.alpha_vdw);
                 float           fscal = 0.0F;
                 const bool      done  = fepPair<FEP_ELEC, VDW == VDK_PSWITCH, true, ENERGY>(nbp, L, r2, included, false, qq, c6AB, c12AB, fscal,
                                                                                            E_lj, E_el, DVDL_lj, DVDL_el);
@@ -213,8 +222,8 @@ __launch_bounds__(c_fepClusterWavesPerBlock* c_waveSize) __global__
     {
         for (int fidx = 0; fidx <= numForeignLambda; fidx++)
         {
-            const float     lc = (fidx == 0) ? nbp.lambda_q : nbp.allLambdaCoul[fidx - 1];
-            const float     lv = (fidx == 0) ? nbp.lambda_v : nbp.allLambdaVdw[fidx - 1];
+            const float     lc = (fidx == 0) ? lambdaQ : nbp.allLambdaCoul[fidx - 1];
+            const float     lv = (fidx == 0) ? lambdaV : nbp.allLambdaVdw[fidx - 1];
             const FepLambda Lf = makeFepLambda(lc, lv, nbp.lam_power, nbp.alpha_coul, nbp.alpha_vdw);
             float fE_lj = 0.0F, fE_el = 0.0F, fDVDL_lj = 0.0F, fDVDL_el = 0.0F, fscal = 0.0F;
             if (selfLane)

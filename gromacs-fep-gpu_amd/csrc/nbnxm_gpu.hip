@@ -381,6 +381,7 @@ void nbnxm_gpu_free(NbnxmGpu* nb)
     freeDeviceBuffer(&nb->atomIndices);
     freeDeviceBuffer(&nb->cell);
     freeDeviceBuffer(&nbp->allLambdaCoul);
+    freeDeviceBuffer(const_cast<float2**>(&nbp->windowLambda));
     freeDeviceBuffer(&nbp->allLambdaVdw);
     for (int i = 0; i < 2; i++)
     {
@@ -1259,6 +1260,25 @@ void* nbnxm_gpu_get_f(NbnxmGpu* nb)
 void* nbnxm_gpu_get_fshift(NbnxmGpu* nb)
 {
     return nb->atdat->fShift;
+}
+
+void nbnxm_gpu_set_window_lambdas(NbnxmGpu* nb, int numWindows, int clustersPerWindow, const float* lambda_q, const float* lambda_v)
+{
+    NBParamGpu* nbp = nb->nbparam;
+    freeDeviceBuffer(const_cast<float2**>(&nbp->windowLambda));
+    nbp->clustersPerWindow = 0;
+    if (numWindows <= 0) { return; }
+    NBNXM_ASSERT(clustersPerWindow > 0 && clustersPerWindow % c_numClPerSupercl == 0, "a window is a whole number of super-clusters");
+    NBNXM_ASSERT(static_cast<long long>(numWindows) * clustersPerWindow * c_clSize >= nb->atdat->numAtoms,
+                 "the windows do not cover the atoms (set the atom data first)");
+    std::vector<float2> h(numWindows);
+    for (int w = 0; w < numWindows; w++) { h[w] = make_float2(lambda_q[w], lambda_v[w]); }
+    float2* d = nullptr;
+    allocateDeviceBuffer(&d, numWindows);
+    NBNXM_HIP_CHECK(hipStreamSynchronize(nb->deviceStreams[0].stream));
+    NBNXM_HIP_CHECK(hipMemcpy(d, h.data(), sizeof(float2) * numWindows, hipMemcpyHostToDevice));
+    nbp->windowLambda      = d;
+    nbp->clustersPerWindow = clustersPerWindow;
 }
 
 void* nbnxm_gpu_get_q4(NbnxmGpu* nb)

@@ -125,6 +125,10 @@ struct NBParamGpu
     float lambda_v;
     float* allLambdaCoul; /* n_lambda */
     float* allLambdaVdw;  /* n_lambda */
+    /* MI355X extension: several lambda windows of the same system batched into one object (R x N atoms, one list): the window of
+     * an i-cluster is cluster / clustersPerWindow and its (lambda_q, lambda_v) come from this table; 0: one window, the scalars */
+    const float2* windowLambda;
+    int           clustersPerWindow;
 
     /* MI355X extension: rvdw (not squared) and rcoulomb for the per-interaction soft-core cut-offs
      * of the CPU kernel (nb_free_energy.cpp:804-812,880-890) */

@@ -32,3 +32,33 @@ def max_over_ranks(value, dist=None, device="cpu"):
 def aggregate_throughput(units_per_step_per_rank, steps, elapsed_max, world_size):
     """Whole-job throughput of a weak-scaling replica set: every rank processes the same number of units."""
     return world_size * units_per_step_per_rank * steps / elapsed_max
+
+
+def batch_windows(grid, plist, num_windows):
+    """R lambda windows of one system as ONE set of non-bonded inputs (nbnxm_gpu_set_window_lambdas): the grid
+    arrays tiled R times, the fused-mode list concatenated with cluster, group and exclusion indices shifted per window — no pair
+    connects two windows.  The windows start from the same list (same search); their coordinates are free to differ.
+    Returns a dict with the arrays NbnxmGpu.init_atomdata / init_pairlist / init_fep_cluster_bits / init_x_to_nbat_x take and
+    `clusters_per_window`, `slots_per_window`, `atoms_per_window`."""
+    R = int(num_windows)
+    ns = int(grid.num_atoms)
+    ncl, nsc = ns // 8, ns // 64
+    natoms = int(grid.natoms)
+    sci = np.tile(plist.sci, R)
+    cj = np.tile(plist.cjPacked, R)
+    excl = np.tile(plist.excl, R)
+    ng, nx, ne = len(plist.cjPacked), len(plist.excl), len(plist.sci)
+    w_sci = np.repeat(np.arange(R), ne)
+    w_cj = np.repeat(np.arange(R), ng)
+    sci["sci"] += (w_sci * nsc).astype(sci["sci"].dtype)
+    sci["cjPackedBegin"] += (w_sci * ng).astype(np.int32)
+    sci["cjPackedEnd"] += (w_sci * ng).astype(np.int32)
+    cj["cj"] += (w_cj * ncl).astype(np.int32)[:, None]
+    cj["imei"]["excl_ind"] += (w_cj * nx).astype(np.int32)[:, None]
+    ai = np.tile(grid.atomIndices, R)
+    shift = np.repeat(np.arange(R) * natoms, ns)
+    ai = np.where(ai >= 0, ai + shift, ai).astype(np.int32)
+    tile = lambda a: np.tile(np.asarray(a), R)
+    return dict(sci=sci, cjPacked=cj, excl=excl, xq=np.tile(grid.xq.reshape(-1, 4), (R, 1)), type=tile(grid.type), qA=tile(grid.qA), qB=tile(grid.qB),
+                typeA=tile(grid.typeA), typeB=tile(grid.typeB), fepBits=tile(grid.fepBits), atomIndices=ai, clusters_per_window=ncl,
+                slots_per_window=ns, atoms_per_window=natoms, num_windows=R)

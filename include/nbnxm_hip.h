@@ -318,6 +318,14 @@ void nbnxm_gpu_halo_unpack_f(void* stream, void* d_f, const int* d_map, int mapS
  *       cluster-pair FEP kernel from the same packed list (needs nbnxm_gpu_init_fep_cluster_bits). */
 void nbnxm_gpu_set_fep_mode(NbnxmGpu* nb, int fused);
 
+/* MI355X extension: lambda windows batched into one object.  With more windows than GPUs (or one GPU) R independent windows of
+ * the same system become ONE object over R x N grid slots with one concatenated list (no pair between windows): the cluster
+ * kernel does not depend on lambda, and one long list runs at a higher rate than R short ones (DESIGN §4.1 size table).
+ * The perturbed-pair kernel of the fused mode takes the lambdas of a pair from this table, window = i-cluster /
+ * clustersPerWindow.  Force-only steps only: energies and dV/dlambda of such an object are sums over the windows — energy steps
+ * are run per window.  numWindows = 0 switches back to the scalars of nbnxm_gpu_copy_fepparams. */
+void nbnxm_gpu_set_window_lambdas(NbnxmGpu* nb, int numWindows, int clustersPerWindow, const float* lambda_q, const float* lambda_v);
+
 /* Diagnostics for tests: device pointer of the packed j-list of a locality, and a synchronous
  * device-to-host copy on that object's local stream. */
 void* nbnxm_gpu_debug_get_cjpacked(NbnxmGpu* nb, int iloc);

@@ -583,3 +583,61 @@ def test_seed_and_shape_sweep(seed, nm, npert):
         for fused in (False, True):
             tl.assert_parity(tl.run_gpu(c, energy=True, fused=fused), want, rel=1e-4, label="%s fused=%s VF" % (elec, fused))
             tl.assert_parity(tl.run_gpu(c, energy=False, fused=fused), want, rel=1e-4, energy=False, label="%s fused=%s F" % (elec, fused))
+
+
+def test_lambda_windows_batched_into_one_object():
+    """Three lambda windows of one system as ONE object (one list over 3 x N slots, per-window lambdas from a table): the forces
+    of every window equal those of the window run alone with its own lambda and coordinates."""
+    import importlib
+    replica = importlib.import_module("gromacs_fep_gpu_amd.replica")
+    c = tl.make_case(elec="ewald", seed=71, n_lambda=0, **SMALL)
+    g = c.grid
+    lambdas = [(0.15, 0.3), (0.5, 0.5), (0.9, 0.75)]              # (coulomb, van der Waals) per window
+    rng = np.random.default_rng(12)
+    real = g.atomIndices >= 0
+    xqs = []
+    for _ in lambdas:
+        xq = g.xq.reshape(-1, 4).copy()
+        xq[real, :3] += rng.normal(0, 0.004, (int(real.sum()), 3)).astype(np.float32)     # the windows have drifted apart
+        xqs.append(xq)
+    sw = pkg.step_workload(energy=False, virial=True, dhdl=False)
+    # every window alone
+    alone = []
+    for (lq, lv), xq in zip(lambdas, xqs):
+        nb = tl.setup_gpu(c, fused=True)
+        _set_lambdas(nb, c, lq, lv)
+        nb.copy_xq_to_gpu(xq)
+        nb.clear_outputs(True)
+        nb.launch_kernel(sw)
+        f = np.zeros((g.num_atoms, 3), np.float32)
+        nb.launch_cpyback(f, sw)
+        res = nb.wait_finish_task(sw, c.have_soft_core)
+        alone.append((f, res["fshift"]))
+        nb.free()
+    # all windows in one object
+    b = replica.batch_windows(g, c.plist_fused, len(lambdas))
+    nb = pkg.NbnxmGpu(tl.gpu_interaction_params(c), g.num_types, g.nbat_nbfp(c.sys["nbfp"]), fep=True, n_lambda=0)
+    _set_lambdas(nb, c, 0.0, 0.0)                                 # the scalars are not used once the table is set
+    nb.init_atomdata(len(b["type"]), b["type"], qA=b["qA"], qB=b["qB"], typeA=b["typeA"], typeB=b["typeB"])
+    nb.init_pairlist(b["sci"], b["cjPacked"], b["excl"])
+    nb.init_fep_cluster_bits(b["fepBits"])
+    nb.set_fep_mode(True)
+    nb.set_window_lambdas(b["clusters_per_window"], [l[0] for l in lambdas], [l[1] for l in lambdas])
+    nb.upload_shiftvec(g.shift_vec)
+    nb.copy_xq_to_gpu(np.concatenate(xqs))
+    nb.clear_outputs(True)
+    nb.launch_kernel(sw)
+    f = np.zeros((len(b["type"]), 3), np.float32)
+    nb.launch_cpyback(f, sw)
+    res = nb.wait_finish_task(sw, c.have_soft_core)
+    ns = b["slots_per_window"]
+    for w, (fw, _) in enumerate(alone):
+        got = f[w * ns:(w + 1) * ns].astype(np.float64)
+        frms = np.sqrt(np.mean(np.sum(fw.astype(np.float64) ** 2, axis=1)))
+        err = np.linalg.norm(got - fw, axis=1)
+        assert (err <= 1e-4 * np.maximum(np.linalg.norm(fw, axis=1), frms)).all(), "window %d" % w
+    fs_sum = sum(a[1].astype(np.float64) for a in alone)
+    assert np.max(np.abs(res["fshift"] - fs_sum)) <= 1e-3 * max(1.0, np.abs(fs_sum).max())
+    # and the windows do differ: the same coordinates with another window's lambdas give other forces
+    assert np.max(np.abs(alone[0][0] - alone[2][0])) > 1.0
+    nb.free()
