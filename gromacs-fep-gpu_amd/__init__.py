@@ -93,6 +93,7 @@ HIP_SYMBOLS = [
     "nbnxm_gpu_get_timings", "nbnxm_gpu_reset_timings", "nbnxm_gpu_set_timing",
     "nbnxm_gpu_min_ci_balanced", "nbnxm_gpu_is_kernel_ewald_analytical", "nbnxm_gpu_get_xq",
     "nbnxm_gpu_get_f", "nbnxm_gpu_get_fshift", "nbnxm_gpu_get_q4", "nbnxm_gpu_get_stream", "nbnxm_gpu_set_window_lambdas",
+    "nbnxm_gpu_get_window_energies",
     "nbnxm_gpu_have_short_range_work", "nbnxm_gpu_set_fep_mode", "nbnxm_hip_abi_version",
     "nbnxm_hip_last_error", "nbnxm_gpu_debug_get_cjpacked", "nbnxm_gpu_debug_download", "nbnxm_gpu_debug_get_work_ranges",
     "nbnxm_gpu_debug_graph_steps", "nbnxm_gpu_debug_set_work_shares",
@@ -398,6 +399,21 @@ class NbnxmGpu:
         lq, lv = _a(lambda_q, np.float32), _a(lambda_v, np.float32)
         assert lq.size == lv.size
         self._lib.nbnxm_gpu_set_window_lambdas(self.h, C.c_int(lq.size), C.c_int(clusters_per_window), _p(lq), _p(lv))
+
+    def get_window_energies(self, window, have_soft_core):
+        """one window's share of the last finished energy / dH/dlambda step of an object with batched windows"""
+        nl = self.n_lambda
+        fe, fc, fv = np.zeros(nl + 1), np.zeros(nl + 1), np.zeros(nl + 1)
+        ed = EnerData()
+        ed.n_lambda = nl
+        ed.foreign_energies = fe.ctypes.data_as(C.POINTER(C.c_double))
+        ed.foreign_dhdl_coul = fc.ctypes.data_as(C.POINTER(C.c_double))
+        ed.foreign_dhdl_vdw = fv.ctypes.data_as(C.POINTER(C.c_double))
+        rc = self._lib.nbnxm_gpu_get_window_energies(self.h, C.c_int(window), C.byref(ed), C.c_int(1 if have_soft_core else 0))
+        if rc != 0:
+            raise IndexError("no such window")
+        return dict(e_lj=ed.e_lj, e_el=ed.e_el, dvdl_lin=list(ed.dvdl_lin), dvdl_nonlin=list(ed.dvdl_nonlin), foreign_energies=fe,
+                    foreign_dhdl_coul=fc, foreign_dhdl_vdw=fv)
 
     def set_fep_mode(self, fused):
         self._lib.nbnxm_gpu_set_fep_mode(self.h, C.c_int(1 if fused else 0))

@@ -117,12 +117,17 @@ __launch_bounds__(c_fepClusterWavesPerBlock* c_waveSize) __global__
     [[maybe_unused]] const bool selfLane = ENERGY && EXCL_FORCES && diagPair && (tidxj == tidxi) && ((iBits >> tidxi) & 1U);
 
     /* this pair's lambdas: the object's, or its window's when several windows are batched into the object */
-    float lambdaQ = nbp.lambda_q, lambdaV = nbp.lambda_v;
+    float  lambdaQ = nbp.lambda_q, lambdaV = nbp.lambda_v;
+    float* energySlots  = atdat.energySlots;
+    float* foreignSlots = atdat.foreignSlots;
     if (nbp.clustersPerWindow > 0)
     {
-        const float2 wl = nbp.windowLambda[ci / nbp.clustersPerWindow];
-        lambdaQ         = wl.x;
-        lambdaV         = wl.y;
+        const int    window = ci / nbp.clustersPerWindow;
+        const float2 wl     = nbp.windowLambda[window];
+        lambdaQ             = wl.x;
+        lambdaV             = wl.y;
+        energySlots         = atdat.windowSlots + window * atdat.windowSlotStride;
+        foreignSlots        = energySlots + atdat.windowForeignOffset;
     }
 
     float E_lj = 0.0F, E_el = 0.0F, DVDL_lj = 0.0F, DVDL_el = 0.0F;
@@ -214,7 +219,7 @@ __launch_bounds__(c_fepClusterWavesPerBlock* c_waveSize) __global__
         DVDL_el = waveSum(DVDL_el);
         const int   slot = item & (c_numEnergySlots - 1);
         const float v    = (lane == 0U) ? E_lj : ((lane == 1U) ? E_el : ((lane == 2U) ? DVDL_lj : DVDL_el));
-        if (lane < 4U) { atomicAdd(atdat.energySlots + slot * c_energySlotStride + static_cast<int>(lane), v); }
+        if (lane < 4U) { atomicAdd(energySlots + slot * c_energySlotStride + static_cast<int>(lane), v); }
     }
 
     /* ---- foreign lambdas (dH/dl steps): the same pair's energies at every lambda index */
@@ -247,7 +252,7 @@ __launch_bounds__(c_fepClusterWavesPerBlock* c_waveSize) __global__
                 /* into this wave's accumulator slot (NBAtomDataGpu::foreignSlots): thousands of waves adding to the same
                  * 48 addresses serialise in L2 (measured +0.28 ms per dH/dl step) */
                 const float v    = (lane == 0U) ? s0 : ((lane == 1U) ? s1 : ((lane == 2U) ? s2 : s3));
-                float*      slot = atdat.foreignSlots + (item & (c_numForeignSlots - 1)) * atdat.foreignSlotStride;
+                float*      slot = foreignSlots + (item & (c_numForeignSlots - 1)) * atdat.foreignSlotStride;
                 if (v != 0.0F) { atomicAdd(slot + static_cast<int>(lane) * (numForeignLambda + 1) + fidx, v); }
             }
         }

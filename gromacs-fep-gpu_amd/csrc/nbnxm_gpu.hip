@@ -37,7 +37,8 @@ void setLastError(const char* msg)
 /* Clears the force array and the block of scalar outputs (energies, dV/dl, foreign terms, shift forces)
  * in one launch; replaces the 5-10 separate memsets of gpu_clear_outputs (nbnxm_gpu_data_mgmt.cpp:1047-1070). */
 __global__ void nbnxmClearOutputsKernel(float4* __restrict__ f4, int numFloat4, float* __restrict__ tail, int numTail,
-                                        float* __restrict__ scalars, int numScalars, float* __restrict__ fshift, int numFshift)
+                                        float* __restrict__ scalars, int numScalars, float* __restrict__ fshift, int numFshift,
+                                        float* __restrict__ windowSlots, int numWindowFloats)
 {
     const int    gid    = static_cast<int>(blockIdx.x * blockDim.x + threadIdx.x);
     const int    stride = static_cast<int>(gridDim.x * blockDim.x);
@@ -46,6 +47,7 @@ __global__ void nbnxmClearOutputsKernel(float4* __restrict__ f4, int numFloat4, 
     if (gid < numTail) { tail[gid] = 0.0F; }
     for (int i = gid; i < numScalars; i += stride) { scalars[i] = 0.0F; }
     for (int i = gid; i < numFshift; i += stride) { fshift[i] = 0.0F; }
+    for (int i = gid; i < numWindowFloats; i += stride) { windowSlots[i] = 0.0F; }
 }
 
 namespace
@@ -382,6 +384,7 @@ void nbnxm_gpu_free(NbnxmGpu* nb)
     freeDeviceBuffer(&nb->cell);
     freeDeviceBuffer(&nbp->allLambdaCoul);
     freeDeviceBuffer(const_cast<float2**>(&nbp->windowLambda));
+    freeDeviceBuffer(&nb->atdat->windowSlots);
     freeDeviceBuffer(&nbp->allLambdaVdw);
     for (int i = 0; i < 2; i++)
     {
@@ -777,7 +780,8 @@ void nbnxm_gpu_clear_outputs(NbnxmGpu* nb, int computeVirial)
     const int nblock    = std::max(1, std::min(2048, (numFloat4 + 255) / 256));
     hipLaunchKernelGGL(nbnxmClearOutputsKernel, dim3(nblock), dim3(256), 0, s, reinterpret_cast<float4*>(ad->f), numFloat4,
                        reinterpret_cast<float*>(ad->f) + 4 * static_cast<size_t>(numFloat4), numTail, nb->scalarOutputs,
-                       nb->numScalarOutputs, reinterpret_cast<float*>(ad->fShift), computeVirial ? c_fshiftBlockFloats : 0);
+                       nb->numScalarOutputs, reinterpret_cast<float*>(ad->fShift), computeVirial ? c_fshiftBlockFloats : 0, ad->windowSlots,
+                       nb->numWindows * ad->windowSlotStride);
     NBNXM_HIP_CHECK(hipGetLastError());
 }
 
@@ -1131,6 +1135,11 @@ void nbnxm_gpu_launch_cpyback(NbnxmGpu* nb, float* f_out, const nbnxm_step_workl
             /* (dH/dl steps bring the foreign-lambda slots, which lie behind the energy slots) */
             const int n = wantForeign ? nb->numScalarOutputs : (stepWork->computeEnergy ? nb->foreignSlotOffset : nb->numHeadScalars);
             NBNXM_HIP_CHECK(hipMemcpyAsync(nb->nbst.scalars, nb->scalarOutputs, sizeof(float) * n, hipMemcpyDeviceToHost, s));
+            if (nb->numWindows > 0)
+            {
+                NBNXM_HIP_CHECK(hipMemcpyAsync(nb->h_windowSlots.data, ad->windowSlots,
+                                               sizeof(float) * static_cast<size_t>(nb->numWindows) * ad->windowSlotStride, hipMemcpyDeviceToHost, s));
+            }
         }
     }
 }
@@ -1165,6 +1174,38 @@ static int finishTask(NbnxmGpu* nb, const nbnxm_step_workload_t* stepWork, int a
                 double* dvdl = haveSoftCore ? enerd->dvdl_nonlin : enerd->dvdl_lin; /* gpu_common.h:420-428 */
                 dvdl[0] += sum[3];
                 dvdl[1] += sum[2];
+            }
+            if (nb->numWindows > 0 && (stepWork->computeEnergy || (nb->n_lambda > 0 && stepWork->computeDhdl)))
+            {
+                /* batched lambda windows: every window's own sums (nbnxm_gpu_get_window_energies); the caller's accumulators get
+                 * the sum over the windows, like everything else of such an object */
+                const NBAtomDataGpu* ad = nb->atdat;
+                const int            n1 = nb->n_lambda + 1, per = 4 + 4 * n1;
+                for (int w = 0; w < nb->numWindows; w++)
+                {
+                    double*      sums = nb->windowSums.data() + static_cast<size_t>(w) * per;
+                    const float* base = nb->h_windowSlots.data + static_cast<size_t>(w) * ad->windowSlotStride;
+                    std::fill(sums, sums + per, 0.0);
+                    if (stepWork->computeEnergy)
+                    {
+                        for (int k = 0; k < c_numEnergySlots; k++)
+                        {
+                            for (int c = 0; c < 4; c++) { sums[c] += base[k * c_energySlotStride + c]; }
+                        }
+                    }
+                    if (nb->n_lambda > 0 && stepWork->computeDhdl)
+                    {
+                        for (int k = 0; k < c_numForeignSlots; k++)
+                        {
+                            const float* slot = base + ad->windowForeignOffset + k * nb->foreignSlotStride;
+                            for (int c = 0; c < 4; c++)
+                            {
+                                for (int idx = 0; idx < n1; idx++) { sums[4 + c * n1 + idx] += slot[c * n1 + idx]; }
+                            }
+                        }
+                    }
+                    if (enerd != nullptr) { nbnxm_gpu_get_window_energies(nb, w, enerd, haveSoftCore); }
+                }
             }
             if (stepWork->computeVirial && shiftForces != nullptr)
             {
@@ -1266,7 +1307,9 @@ void nbnxm_gpu_set_window_lambdas(NbnxmGpu* nb, int numWindows, int clustersPerW
 {
     NBParamGpu* nbp = nb->nbparam;
     freeDeviceBuffer(const_cast<float2**>(&nbp->windowLambda));
+    freeDeviceBuffer(&nb->atdat->windowSlots);
     nbp->clustersPerWindow = 0;
+    nb->numWindows         = 0;
     if (numWindows <= 0) { return; }
     NBNXM_ASSERT(clustersPerWindow > 0 && clustersPerWindow % c_numClPerSupercl == 0, "a window is a whole number of super-clusters");
     NBNXM_ASSERT(static_cast<long long>(numWindows) * clustersPerWindow * c_clSize >= nb->atdat->numAtoms,
@@ -1279,6 +1322,38 @@ void nbnxm_gpu_set_window_lambdas(NbnxmGpu* nb, int numWindows, int clustersPerW
     NBNXM_HIP_CHECK(hipMemcpy(d, h.data(), sizeof(float2) * numWindows, hipMemcpyHostToDevice));
     nbp->windowLambda      = d;
     nbp->clustersPerWindow = clustersPerWindow;
+    /* per-window accumulators: [energy slots | foreign-lambda slots] */
+    NBAtomDataGpu* ad       = nb->atdat;
+    ad->windowForeignOffset = c_numEnergySlots * c_energySlotStride;
+    ad->windowSlotStride    = ad->windowForeignOffset + c_numForeignSlots * nb->foreignSlotStride;
+    nb->numWindows          = numWindows;
+    const size_t total      = static_cast<size_t>(numWindows) * ad->windowSlotStride;
+    allocateDeviceBuffer(&ad->windowSlots, total);
+    NBNXM_HIP_CHECK(hipMemset(ad->windowSlots, 0, sizeof(float) * total));
+    nb->h_windowSlots.resize(total);
+    nb->windowSums.assign(static_cast<size_t>(numWindows) * (4 + 4 * (nb->n_lambda + 1)), 0.0);
+}
+
+int nbnxm_gpu_get_window_energies(NbnxmGpu* nb, int window, nbnxm_enerdata_t* enerd, int haveSoftCore)
+{
+    if (window < 0 || window >= nb->numWindows || enerd == nullptr) { return -1; }
+    const int     n1 = nb->n_lambda + 1;
+    const double* w  = nb->windowSums.data() + static_cast<size_t>(window) * (4 + 4 * n1);
+    enerd->e_lj += w[0];
+    enerd->e_el += w[1];
+    double* dvdl = haveSoftCore ? enerd->dvdl_nonlin : enerd->dvdl_lin;
+    dvdl[0] += w[3];
+    dvdl[1] += w[2];
+    if (nb->n_lambda > 0 && enerd->foreign_energies != nullptr)
+    {
+        for (int idx = 0; idx < n1; idx++)
+        {
+            enerd->foreign_energies[idx] += w[4 + idx] + w[4 + n1 + idx];
+            enerd->foreign_dhdl_vdw[idx] += w[4 + 2 * n1 + idx];
+            enerd->foreign_dhdl_coul[idx] += w[4 + 3 * n1 + idx];
+        }
+    }
+    return 0;
 }
 
 void* nbnxm_gpu_get_q4(NbnxmGpu* nb)

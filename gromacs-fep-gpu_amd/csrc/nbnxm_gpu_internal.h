@@ -90,6 +90,10 @@ struct NbnxmGpu
     PinnedBuffer<float2>      h_ewaldCorrTab;
 
     float* scalarOutputs    = nullptr; /* device block behind atdat->eLJ ... dvdlElecForeign, energySlots */
+    /* batched lambda windows: device accumulators (atdat->windowSlots), pinned mirror, per-window sums of the last energy step */
+    int                 numWindows = 0;
+    PinnedBuffer<float> h_windowSlots;
+    std::vector<double> windowSums; /* per window: e_lj, e_el, dvdl_lj, dvdl_el, then 4 x (n_lambda + 1) foreign terms */
     int    numHeadScalars   = 0;       /* scalars + foreign arrays */
     int    slotOffset       = 0;       /* first float of the energy slots */
     int    foreignSlotOffset = 0;      /* first float of the foreign-lambda slots */

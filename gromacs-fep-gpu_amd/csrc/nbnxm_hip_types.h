@@ -82,6 +82,11 @@ struct NBAtomDataGpu
      * foreignSlotStride floats, [eLJ[n+1], eElec[n+1], dvdlLJ[n+1], dvdlElec[n+1], pad] each */
     float* foreignSlots;
     int    foreignSlotStride;
+    /* batched lambda windows (NBParamGpu::clustersPerWindow > 0): every window has its own energy and foreign-lambda
+     * accumulators, windowSlots + window * windowSlotStride = [energy slots | foreign slots] in the layouts above */
+    float* windowSlots;
+    int    windowSlotStride;
+    int    windowForeignOffset;
 };
 
 /* nbnxm/gpu_types_common.h:160-237 */

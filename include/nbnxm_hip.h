@@ -322,9 +322,12 @@ void nbnxm_gpu_set_fep_mode(NbnxmGpu* nb, int fused);
  * the same system become ONE object over R x N grid slots with one concatenated list (no pair between windows): the cluster
  * kernel does not depend on lambda, and one long list runs at a higher rate than R short ones (DESIGN §4.1 size table).
  * The perturbed-pair kernel of the fused mode takes the lambdas of a pair from this table, window = i-cluster /
- * clustersPerWindow.  Force-only steps only: energies and dV/dlambda of such an object are sums over the windows — energy steps
- * are run per window.  numWindows = 0 switches back to the scalars of nbnxm_gpu_copy_fepparams. */
+ * clustersPerWindow.  Energies, dV/dlambda and foreign-lambda terms are kept per window: gpu_try/wait_finish_task adds the sum
+ * over the windows to its accumulators, and nbnxm_gpu_get_window_energies ADDS window w's own share of the last finished energy
+ * step to *enerd (returns -1 for a bad window).  Shift forces (virial) are a sum over the windows.  numWindows = 0 switches back
+ * to the scalars of nbnxm_gpu_copy_fepparams. */
 void nbnxm_gpu_set_window_lambdas(NbnxmGpu* nb, int numWindows, int clustersPerWindow, const float* lambda_q, const float* lambda_v);
+int  nbnxm_gpu_get_window_energies(NbnxmGpu* nb, int window, nbnxm_enerdata_t* enerd, int haveSoftCore);
 
 /* Diagnostics for tests: device pointer of the packed j-list of a locality, and a synchronous
  * device-to-host copy on that object's local stream. */

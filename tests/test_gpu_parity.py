@@ -586,11 +586,12 @@ def test_seed_and_shape_sweep(seed, nm, npert):
 
 
 def test_lambda_windows_batched_into_one_object():
-    """Three lambda windows of one system as ONE object (one list over 3 x N slots, per-window lambdas from a table): the forces
-    of every window equal those of the window run alone with its own lambda and coordinates."""
+    """Three lambda windows of one system as ONE object (one list over 3 x N slots, per-window lambdas from a table): forces,
+    energies, dV/dlambda and foreign-lambda terms of every window equal those of the window run alone with its own lambda and
+    coordinates; the object's own accumulators hold the sums over the windows."""
     import importlib
     replica = importlib.import_module("gromacs_fep_gpu_amd.replica")
-    c = tl.make_case(elec="ewald", seed=71, n_lambda=0, **SMALL)
+    c = tl.make_case(elec="ewald", seed=71, n_lambda=11, **SMALL)
     g = c.grid
     lambdas = [(0.15, 0.3), (0.5, 0.5), (0.9, 0.75)]              # (coulomb, van der Waals) per window
     rng = np.random.default_rng(12)
@@ -600,24 +601,30 @@ def test_lambda_windows_batched_into_one_object():
         xq = g.xq.reshape(-1, 4).copy()
         xq[real, :3] += rng.normal(0, 0.004, (int(real.sum()), 3)).astype(np.float32)     # the windows have drifted apart
         xqs.append(xq)
-    sw = pkg.step_workload(energy=False, virial=True, dhdl=False)
+
+    def run(nb, natoms, sw):
+        nb.clear_outputs(True)
+        nb.launch_kernel(sw)
+        f = np.zeros((natoms, 3), np.float32)
+        nb.launch_cpyback(f, sw)
+        return f, nb.wait_finish_task(sw, c.have_soft_core)
+
+    sw_f = pkg.step_workload(energy=False, virial=True, dhdl=False)
+    sw_e = pkg.step_workload(energy=True, virial=True, dhdl=True)
     # every window alone
     alone = []
     for (lq, lv), xq in zip(lambdas, xqs):
         nb = tl.setup_gpu(c, fused=True)
         _set_lambdas(nb, c, lq, lv)
         nb.copy_xq_to_gpu(xq)
-        nb.clear_outputs(True)
-        nb.launch_kernel(sw)
-        f = np.zeros((g.num_atoms, 3), np.float32)
-        nb.launch_cpyback(f, sw)
-        res = nb.wait_finish_task(sw, c.have_soft_core)
-        alone.append((f, res["fshift"]))
+        f, res = run(nb, g.num_atoms, sw_f)
+        _, res_e = run(nb, g.num_atoms, sw_e)
+        alone.append((f, res["fshift"], res_e))
         nb.free()
     # all windows in one object
     b = replica.batch_windows(g, c.plist_fused, len(lambdas))
-    nb = pkg.NbnxmGpu(tl.gpu_interaction_params(c), g.num_types, g.nbat_nbfp(c.sys["nbfp"]), fep=True, n_lambda=0)
-    _set_lambdas(nb, c, 0.0, 0.0)                                 # the scalars are not used once the table is set
+    nb = pkg.NbnxmGpu(tl.gpu_interaction_params(c), g.num_types, g.nbat_nbfp(c.sys["nbfp"]), fep=True, n_lambda=c.n_lambda)
+    _set_lambdas(nb, c, 0.0, 0.0)                                 # the scalar lambdas are not used once the table is set
     nb.init_atomdata(len(b["type"]), b["type"], qA=b["qA"], qB=b["qB"], typeA=b["typeA"], typeB=b["typeB"])
     nb.init_pairlist(b["sci"], b["cjPacked"], b["excl"])
     nb.init_fep_cluster_bits(b["fepBits"])
@@ -625,19 +632,34 @@ def test_lambda_windows_batched_into_one_object():
     nb.set_window_lambdas(b["clusters_per_window"], [l[0] for l in lambdas], [l[1] for l in lambdas])
     nb.upload_shiftvec(g.shift_vec)
     nb.copy_xq_to_gpu(np.concatenate(xqs))
-    nb.clear_outputs(True)
-    nb.launch_kernel(sw)
-    f = np.zeros((len(b["type"]), 3), np.float32)
-    nb.launch_cpyback(f, sw)
-    res = nb.wait_finish_task(sw, c.have_soft_core)
+    f, res = run(nb, len(b["type"]), sw_f)
     ns = b["slots_per_window"]
-    for w, (fw, _) in enumerate(alone):
+    for w, (fw, _, _) in enumerate(alone):
         got = f[w * ns:(w + 1) * ns].astype(np.float64)
         frms = np.sqrt(np.mean(np.sum(fw.astype(np.float64) ** 2, axis=1)))
         err = np.linalg.norm(got - fw, axis=1)
         assert (err <= 1e-4 * np.maximum(np.linalg.norm(fw, axis=1), frms)).all(), "window %d" % w
     fs_sum = sum(a[1].astype(np.float64) for a in alone)
     assert np.max(np.abs(res["fshift"] - fs_sum)) <= 1e-3 * max(1.0, np.abs(fs_sum).max())
-    # and the windows do differ: the same coordinates with another window's lambdas give other forces
+    # the windows do differ: the same coordinates with another window's lambdas give other forces
     assert np.max(np.abs(alone[0][0] - alone[2][0])) > 1.0
+    # energy + dH/dlambda step: per-window shares, and their sum in the object's accumulators
+    _, tot = run(nb, len(b["type"]), sw_e)
+    close = lambda a, b_, scale: abs(a - b_) <= 1e-4 * max(abs(scale), 1.0)
+    sums = dict(e_lj=0.0, e_el=0.0)
+    for w, (_, _, want) in enumerate(alone):
+        got = nb.get_window_energies(w, c.have_soft_core)
+        escale = abs(want["e_lj"]) + abs(want["e_el"])
+        assert close(got["e_lj"], want["e_lj"], escale) and close(got["e_el"], want["e_el"], escale), w
+        for k in range(2):
+            assert close(got["dvdl_nonlin"][k], want["dvdl_nonlin"][k], max(abs(v) for v in want["dvdl_nonlin"])), (w, k)
+        fscale = np.max(np.abs(want["foreign_energies"]))
+        assert np.max(np.abs(got["foreign_energies"] - want["foreign_energies"])) <= 1e-4 * max(fscale, 1.0), w
+        assert np.max(np.abs(got["foreign_dhdl_coul"] - want["foreign_dhdl_coul"])) <= 1e-4 * max(np.max(np.abs(want["foreign_dhdl_coul"])), 1.0)
+        assert np.max(np.abs(got["foreign_dhdl_vdw"] - want["foreign_dhdl_vdw"])) <= 1e-4 * max(np.max(np.abs(want["foreign_dhdl_vdw"])), 1.0)
+        sums["e_lj"] += want["e_lj"]
+        sums["e_el"] += want["e_el"]
+    assert close(tot["e_lj"], sums["e_lj"], abs(sums["e_lj"]) + abs(sums["e_el"])) and close(tot["e_el"], sums["e_el"], abs(sums["e_lj"]) + abs(sums["e_el"]))
+    with pytest.raises(IndexError):
+        nb.get_window_energies(len(lambdas), c.have_soft_core)
     nb.free()
