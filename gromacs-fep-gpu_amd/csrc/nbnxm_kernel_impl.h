@@ -307,8 +307,6 @@ __launch_bounds__(c_nbBlockSize) __attribute__((amdgpu_waves_per_eu(c_nbWavesPer
     int stagedGroup = -1;
 
     float E_lj = 0.0F, E_el = 0.0F;
-    /* batched lambda windows: the window whose energies E_lj / E_el currently hold (-1: one window, the object's own slots) */
-    [[maybe_unused]] int energyWindow = -1;
 
     /* ---- the pieces of this wave's range: one per i-entry it touches ---------------------------------- */
 #pragma unroll 1
@@ -322,30 +320,6 @@ __launch_bounds__(c_nbBlockSize) __attribute__((amdgpu_waves_per_eu(c_nbWavesPer
     const int         sci           = nb_sci.sci;
     const int         shiftIdx      = nb_sci.shift & NBNXM_CI_SHIFT_MASK;
     const bool        central       = (shiftIdx == c_centralShiftIndex);
-    if constexpr (ENERGY)
-    {
-        if (nbp.clustersPerWindow > 0)
-        {
-            /* a range can run across the border of two windows: hand the energies of the one it leaves over */
-            const int w = (sci * c_numClPerSupercl) / nbp.clustersPerWindow;
-            if (w != energyWindow)
-            {
-                if (energyWindow >= 0)
-                {
-                    const float sLj = waveSum(E_lj), sEl = waveSum(E_el);
-                    const float v   = (lane == 0U) ? sLj : sEl;
-                    if (lane < 2U)
-                    {
-                        atomicAdd(atdat.windowSlots + energyWindow * atdat.windowSlotStride + (workItem & (c_numEnergySlots - 1)) * c_energySlotStride
-                                          + static_cast<int>(lane),
-                                  v);
-                    }
-                    E_lj = E_el = 0.0F;
-                }
-                energyWindow = w;
-            }
-        }
-    }
 
 #ifdef NBNXM_WAVE_TIMELINE
     tlMain -= wall_clock64();
@@ -517,6 +491,23 @@ __launch_bounds__(c_nbBlockSize) __attribute__((amdgpu_waves_per_eu(c_nbWavesPer
                       v);
         }
     }
+    if constexpr (ENERGY)
+    {
+        if (nbp.clustersPerWindow > 0)
+        {
+            /* batched lambda windows: a range can run across the border of two windows, so the energies go to the window of the
+             * i-entry piece by piece (a wave has one or two pieces) */
+            const float sLj = waveSum(E_lj), sEl = waveSum(E_el);
+            const float v   = (lane == 0U) ? sLj : sEl;
+            if (lane < 2U)
+            {
+                atomicAdd(atdat.windowSlots + ((sci * c_numClPerSupercl) / nbp.clustersPerWindow) * atdat.windowSlotStride
+                                  + (workItem & (c_numEnergySlots - 1)) * c_energySlotStride + static_cast<int>(lane),
+                          v);
+            }
+            E_lj = E_el = 0.0F;
+        }
+    }
     } /* pieces */
 #undef NBNXM_STAGE_GROUP
 #undef NBNXM_STAGE_WORDS
@@ -544,8 +535,8 @@ __launch_bounds__(c_nbBlockSize) __attribute__((amdgpu_waves_per_eu(c_nbWavesPer
         E_el = waveSum(E_el);
         const int   slot = workItem & (c_numEnergySlots - 1);
         const float v    = (lane == 0U) ? E_lj : E_el;
-        float*      base = (energyWindow >= 0) ? atdat.windowSlots + energyWindow * atdat.windowSlotStride : atdat.energySlots;
-        if (lane < 2U) { atomicAdd(base + slot * c_energySlotStride + static_cast<int>(lane), v); }
+        /* (with batched lambda windows the pieces have delivered everything: the sums are zero) */
+        if (lane < 2U && nbp.clustersPerWindow == 0) { atomicAdd(atdat.energySlots + slot * c_energySlotStride + static_cast<int>(lane), v); }
     }
 }
 
