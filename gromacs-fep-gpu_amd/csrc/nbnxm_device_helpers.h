@@ -28,7 +28,9 @@ enum
     VDK_COMB_GEOM,
     VDK_COMB_LB,
     VDK_FSWITCH,
-    VDK_PSWITCH
+    VDK_PSWITCH,
+    VDK_EWALD_GEOM, /* nbfp table + LJ-PME grid correction, geometric combination of the grid C6 (nbfp_comb) */
+    VDK_EWALD_LB    /* ... Lorentz-Berthelot combination */
 };
 
 #define NB_DEVINL __device__ __forceinline__
@@ -138,7 +140,8 @@ NB_DEVINL void nbPair(const NBParamGpu& nbp,
                       float             c12,
                       float&            F_invr,
                       float&            E_lj,
-                      float&            E_el)
+                      float&            E_el,
+                      [[maybe_unused]] float c6grid = 0.0F /* LJ-PME flavours: C6 of the grid part for this pair */)
 {
     r2                 = fmaxf(r2, c_nbnxnMinDistanceSquared);
     const float inv_r  = __frsqrt_rn(r2);
@@ -174,6 +177,22 @@ NB_DEVINL void nbPair(const NBParamGpu& nbp,
             E_lj_p += (c6 * (nbp.dispersion_shift.c2 * (1.0F / 3.0F) + nbp.dispersion_shift.c3 * 0.25F * rs)
                        - c12 * (nbp.repulsion_shift.c2 * (1.0F / 3.0F) + nbp.repulsion_shift.c3 * 0.25F * rs))
                       * rs * rs * rs;
+        }
+    }
+    if constexpr (VDW == VDK_EWALD_GEOM || VDW == VDK_EWALD_LB)
+    {
+        /* real-space part of the LJ-PME grid term (nbnxm_cuda_kernel_utils.cuh:231-330, calculate_lj_ewald_comb_*_F / _F_E):
+         * not masked by the exclusion bit — an excluded pair within the cut-off keeps the correction for what the grid adds */
+        const float inv_r6_nm = inv_r2 * inv_r2 * inv_r2;
+        const float lje2      = nbp.ewaldcoeff_lj * nbp.ewaldcoeff_lj;
+        const float lje6_6    = lje2 * lje2 * lje2 * c_oneSixth;
+        const float cr2       = lje2 * r2;
+        const float expmcr2   = __expf(-cr2);
+        const float poly      = 1.0F + cr2 + 0.5F * cr2 * cr2;
+        F_invr += c6grid * (inv_r6_nm - expmcr2 * (inv_r6_nm * poly + lje6_6)) * inv_r2;
+        if constexpr (ENERGY)
+        {
+            E_lj_p += c_oneSixth * c6grid * (inv_r6_nm * (1.0F - expmcr2 * poly) + nbp.sh_lj_ewald * int_bit);
         }
     }
     if constexpr (VDW == VDK_PSWITCH)

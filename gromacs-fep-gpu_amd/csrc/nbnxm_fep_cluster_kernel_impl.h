@@ -36,7 +36,8 @@ __launch_bounds__(c_fepClusterWavesPerBlock* c_waveSize) __global__
                                    const int numForeignLambda /* FOREIGN: lambda indices 0 .. numForeignLambda */)
 {
     static_assert(!FOREIGN || ENERGY, "the foreign-lambda flavour is an energy flavour");
-    constexpr bool EXCL_FORCES = (ELEC != ELK_CUT) || ENERGY;
+    constexpr bool LJ_EWALD    = VdwTraits<VDW>::ljEwald; /* plain pairs only: perturbed pairs keep plain shifted LJ */
+    constexpr bool EXCL_FORCES = (ELEC != ELK_CUT) || ENERGY || LJ_EWALD;
     constexpr bool USE_TABLE   = VdwTraits<VDW>::useTable;
     constexpr int  FEP_ELEC    = (ELEC == ELK_CUT) ? ELK_RF : ELEC;
 
@@ -174,10 +175,11 @@ __launch_bounds__(c_fepClusterWavesPerBlock* c_waveSize) __global__
                     c12 = pA.y;
                 }
                 else { ljFromComb(VDW, ljComb[ai], ljComb[aj], c6, c12); }
-                float E_lj_p = 0.0F, E_el_p = 0.0F;
+                float E_lj_p = 0.0F, E_el_p = 0.0F, c6grid = 0.0F;
+                if constexpr (LJ_EWALD) { c6grid = ljGridC6(VDW, nbp.nbfp_comb[t4i.x], nbp.nbfp_comb[t4j.x]); }
                 /* no Ewald table in this kernel's LDS: the rational form of the correction */
                 nbPair<ELEC, TWIN, VDW, ENERGY, EXCL_FORCES, true, false>(nbp, nullptr, r2, intMask, xi.w * nbp.epsfac * xqj.w, c6, c12, F_invr,
-                                                                         E_lj_p, E_el_p);
+                                                                         E_lj_p, E_el_p, c6grid);
                 if constexpr (ENERGY)
                 {
                     E_lj += E_lj_p;

@@ -1028,7 +1028,7 @@ void nbnxm_gpu_launch_kernel(NbnxmGpu* nb, const nbnxm_step_workload_t* stepWork
         const NbKernelPtr kernel        = selectNbKernel(nbp->elecType, nbp->vdwType, energyFlavour, fused);
         if (kernel == nullptr)
         {
-            fatal(__FILE__, __LINE__, "nbnxm_gpu_launch_kernel", "no kernel for this electrostatics / VdW combination (LJ-PME grid flavours are not built)");
+            fatal(__FILE__, __LINE__, "nbnxm_gpu_launch_kernel", "no kernel for this electrostatics / VdW combination");
         }
         if (plist->workRangesDirty) { updateWorkPartition(nb, iloc); }
 
@@ -1049,7 +1049,8 @@ void nbnxm_gpu_launch_kernel(NbnxmGpu* nb, const nbnxm_step_workload_t* stepWork
                 NBNXM_HIP_CHECK(hipStreamWaitEvent(fs, nb->fepFork[iloc], 0));
                 fepForked = true;
             }
-            const bool fepUseTable = (nbp->vdwType == NBNXM_VDW_CUT || nbp->vdwType == NBNXM_VDW_FSWITCH || nbp->vdwType == NBNXM_VDW_PSWITCH);
+            const bool fepUseTable = (nbp->vdwType == NBNXM_VDW_CUT || nbp->vdwType == NBNXM_VDW_FSWITCH || nbp->vdwType == NBNXM_VDW_PSWITCH
+                                      || nbp->vdwType == NBNXM_VDW_EWALD_GEOM || nbp->vdwType == NBNXM_VDW_EWALD_LB);
             const int  fepLds      = fepUseTable ? ((adat->numTypes * adat->numTypes * 8 + 15) & ~15) : 0;
             NBNXM_ASSERT(fepLds <= 160 * 1024, "too many atom types: the LJ parameter table does not fit the 160 KB LDS");
             if (fepLds > 64 * 1024)
@@ -1068,12 +1069,14 @@ void nbnxm_gpu_launch_kernel(NbnxmGpu* nb, const nbnxm_step_workload_t* stepWork
         }
         if (nb->bDoTime) { t.nb_k.openTimingRegion(s); }
         /* The LJ table lives in LDS (up to ~140 types in the 160 KB; large tables cost occupancy) */
-        const bool useTable = (nbp->vdwType == NBNXM_VDW_CUT || nbp->vdwType == NBNXM_VDW_FSWITCH || nbp->vdwType == NBNXM_VDW_PSWITCH);
+        const bool ljEwald  = (nbp->vdwType == NBNXM_VDW_EWALD_GEOM || nbp->vdwType == NBNXM_VDW_EWALD_LB);
+        const bool useTable = (nbp->vdwType == NBNXM_VDW_CUT || nbp->vdwType == NBNXM_VDW_FSWITCH || nbp->vdwType == NBNXM_VDW_PSWITCH || ljEwald);
+        NBNXM_ASSERT(!ljEwald || nbp->nbfp_comb != nullptr, "LJ-PME kernel selected without the grid parameters (nbfp_comb)");
         int        wavesPerBlock = nb->nbWavesPerBlock;
         const int  tableBytes    = useTable ? adat->numTypes * adat->numTypes * 8 : 0;
         if (tableBytes > 8 * 1024) { wavesPerBlock = c_nbWavesPerBlock; } /* one table copy per 4 waves */
         const bool ewaldCorrTable = (nbp->elecType == NBNXM_ELEC_EWALD_ANA || nbp->elecType == NBNXM_ELEC_EWALD_ANA_TWIN);
-        const int  ldsBytes       = nbLdsBytes(adat->numTypes, useTable, ewaldCorrTable, fused, wavesPerBlock);
+        const int  ldsBytes       = nbLdsBytes(adat->numTypes, useTable, ljEwald, ewaldCorrTable, fused, wavesPerBlock);
         NBNXM_ASSERT(ldsBytes <= 160 * 1024, "too many atom types: the LJ parameter table does not fit the 160 KB LDS");
         if (ldsBytes > 64 * 1024)
         {

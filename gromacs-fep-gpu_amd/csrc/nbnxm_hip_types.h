@@ -242,9 +242,9 @@ constexpr int c_ringRecordBytes  = 64;
 constexpr int c_jRingBytes       = 4 * c_ringRecordBytes;
 
 /* Dynamic LDS bytes of one workgroup of the cluster-pair kernel (must match the carve-up in the kernel). */
-inline int nbLdsBytes(int numTypes, bool useTable, bool ewaldCorrTable, bool fused, int wavesPerBlock)
+inline int nbLdsBytes(int numTypes, bool useTable, bool ljEwald, bool ewaldCorrTable, bool fused, int wavesPerBlock)
 {
-    const int tableBytes = (useTable ? ((numTypes * numTypes * static_cast<int>(sizeof(float2)) + 15) & ~15) : 0)
+    const int tableBytes = (useTable ? (((numTypes * numTypes + (ljEwald ? numTypes : 0)) * static_cast<int>(sizeof(float2)) + 15) & ~15) : 0)
                            + (ewaldCorrTable ? c_ewaldCorrTabSize * static_cast<int>(sizeof(float2)) : 0);
     (void)fused;
     return tableBytes + wavesPerBlock * (2 * c_jStageBytes + c_jRingBytes);

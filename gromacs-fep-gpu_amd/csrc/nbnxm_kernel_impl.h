@@ -35,7 +35,8 @@
 template<int VDW>
 struct VdwTraits
 {
-    static constexpr bool useTable = (VDW == VDK_CUT || VDW == VDK_FSWITCH || VDW == VDK_PSWITCH);
+    static constexpr bool ljEwald  = (VDW == VDK_EWALD_GEOM || VDW == VDK_EWALD_LB);
+    static constexpr bool useTable = (VDW == VDK_CUT || VDW == VDK_FSWITCH || VDW == VDK_PSWITCH || ljEwald);
 };
 
 /* LDS-direct loads (global -> LDS without VGPRs; completion is counted by vmcnt): every active lane moves 16
@@ -84,6 +85,15 @@ NB_DEVINL void ljFromComb(int vdwKind, const float2& a, const float2& b, float& 
     }
 }
 
+/* LJ-PME: C6 of the grid part from the per-type parameters NBParamGpu::nbfp_comb (nbnxm_cuda_kernel_utils.cuh:221-229, 283-297) */
+NB_DEVINL float ljGridC6(int vdwKind, const float2& a, const float2& b)
+{
+    if (vdwKind == VDK_EWALD_GEOM) { return a.x * b.x; }
+    const float sigma  = a.x + b.x;
+    const float sigma2 = sigma * sigma;
+    return a.y * b.y * sigma2 * sigma2 * sigma2;
+}
+
 /* The unrolled loop over the 8 i-clusters of one j-cluster, as a macro so that both instances index the
  * kernel's register arrays (xqi, trow, fci_buf) directly: a lambda capturing them by reference sends them to
  * scratch memory.  Diagonal rule: on the central image a cluster paired with itself keeps only j > i
@@ -121,9 +131,10 @@ NB_DEVINL void ljFromComb(int vdwKind, const float2& a, const float2& b, float& 
                                     c12                = c6c12.y; \
                                 } \
                                 else { ljFromComb(VDW, ljcpi[i], ljcp_j, c6, c12); } \
-                                float F_invr, E_lj_p = 0.0F, E_el_p = 0.0F; \
+                                float F_invr, E_lj_p = 0.0F, E_el_p = 0.0F, c6grid = 0.0F; \
+                                if constexpr (LJ_EWALD) { c6grid = ljGridC6(VDW, ljcpi[i], ljcp_j); } \
                                 nbPair<ELEC, TWIN, VDW, ENERGY, EXCL_FORCES, HAS_EXCL>(nbp, ewaldCorrLds, r2, intMask, xqi[i].w * xqj.w, c6, c12, \
-                                                                                       F_invr, E_lj_p, E_el_p); \
+                                                                                       F_invr, E_lj_p, E_el_p, c6grid); \
                                 if constexpr (ENERGY) \
                                 { \
                                     E_lj += E_lj_p; \
@@ -170,7 +181,8 @@ __launch_bounds__(c_nbBlockSize) __attribute__((amdgpu_waves_per_eu(c_nbWavesPer
                          const int numWorkRanges,
                          const unsigned* __restrict__ groupSlowMask /* FUSED: perturbed cluster pairs of each group */)
 {
-    constexpr bool EXCL_FORCES = (ELEC != ELK_CUT) || ENERGY; /* nbnxm_cuda_kernel.cuh:69-78 */
+    constexpr bool LJ_EWALD    = VdwTraits<VDW>::ljEwald;
+    constexpr bool EXCL_FORCES = (ELEC != ELK_CUT) || ENERGY || LJ_EWALD; /* nbnxm_cuda_kernel.cuh:69-78 */
     constexpr bool USE_TABLE   = VdwTraits<VDW>::useTable;
 
     /* wave-uniform values are pinned to SGPRs with readfirstlane so that everything derived from them
@@ -188,13 +200,19 @@ __launch_bounds__(c_nbBlockSize) __attribute__((amdgpu_waves_per_eu(c_nbWavesPer
     const int numTypes   = atdat.numTypes;
     float2*   nbfpLds    = reinterpret_cast<float2*>(nbLds);
     constexpr bool EWALD_CORR_TABLE = (ELEC == ELK_EWALD_ANA);
-    const int      nbfpBytes  = USE_TABLE ? ((numTypes * numTypes * static_cast<int>(sizeof(float2)) + 15) & ~15) : 0;
+    /* LJ-PME: the per-type grid parameters (nbfp_comb) follow the pair table */
+    const int      nbfpEntries = numTypes * numTypes + (LJ_EWALD ? numTypes : 0);
+    const int      nbfpBytes   = USE_TABLE ? ((nbfpEntries * static_cast<int>(sizeof(float2)) + 15) & ~15) : 0;
     const int      tableBytes = nbfpBytes + (EWALD_CORR_TABLE ? c_ewaldCorrTabSize * static_cast<int>(sizeof(float2)) : 0);
     [[maybe_unused]] const float2* ewaldCorrLds = reinterpret_cast<const float2*>(nbLds + nbfpBytes);
     unsigned char* jStage = nbLds + tableBytes + wave * (2 * c_jStageBytes + c_jRingBytes);
     if constexpr (USE_TABLE)
     {
         for (int t = threadIdx.x; t < numTypes * numTypes; t += blockSize) { nbfpLds[t] = nbp.nbfp[t]; }
+        if constexpr (LJ_EWALD)
+        {
+            for (int t = threadIdx.x; t < numTypes; t += blockSize) { nbfpLds[numTypes * numTypes + t] = nbp.nbfp_comb[t]; }
+        }
     }
     if constexpr (EWALD_CORR_TABLE)
     {
@@ -354,7 +372,12 @@ __launch_bounds__(c_nbBlockSize) __attribute__((amdgpu_waves_per_eu(c_nbWavesPer
             v.z += sh.z;
             v.w *= nbp.epsfac;
             xqi[i] = v;
-            if constexpr (USE_TABLE) { trow[i] = numTypes * atomTypes[ai] * static_cast<int>(sizeof(float2)); }
+            if constexpr (USE_TABLE)
+            {
+                const int ti = atomTypes[ai];
+                trow[i]      = numTypes * ti * static_cast<int>(sizeof(float2));
+                if constexpr (LJ_EWALD) { ljcpi[i] = nbfpLds[numTypes * numTypes + ti]; }
+            }
             else { ljcpi[i] = ljComb[ai]; }
         }
     }
@@ -369,6 +392,13 @@ __launch_bounds__(c_nbBlockSize) __attribute__((amdgpu_waves_per_eu(c_nbWavesPer
             const float coef = (ELEC == ELK_CUT || ELEC == ELK_RF) ? -0.5F * nbp.c_rf : -nbp.ewald_beta * c_oneOverSqrtPi;
             const float qi   = xq[sci * c_superClSize + static_cast<int>(lane)].w * nbp.epsfac;
             E_el += qi * qi / nbp.epsfac * coef;
+            if constexpr (LJ_EWALD)
+            {
+                /* nbnxm_cuda_kernel.cuh:374-380: the grid part counts every atom's pair with itself */
+                const float lje2 = nbp.ewaldcoeff_lj * nbp.ewaldcoeff_lj;
+                const int   ti   = atomTypes[sci * c_superClSize + static_cast<int>(lane)];
+                E_lj += nbfpLds[ti * (numTypes + 1)].x * 0.5F * c_oneSixth * (lje2 * lje2 * lje2 * c_oneSixth);
+            }
         }
     }
 
@@ -424,7 +454,11 @@ __launch_bounds__(c_nbBlockSize) __attribute__((amdgpu_waves_per_eu(c_nbWavesPer
                 const float4   xqj    = *reinterpret_cast<const float4*>(jData + jAtom * 16U);
                 int            typej  = 0;
                 float2         ljcp_j = make_float2(0.0F, 0.0F);
-                if constexpr (USE_TABLE) { typej = *reinterpret_cast<const int*>(jData + c_jStageLjOffset + jAtom * 4U); }
+                if constexpr (USE_TABLE)
+                {
+                    typej = *reinterpret_cast<const int*>(jData + c_jStageLjOffset + jAtom * 4U);
+                    if constexpr (LJ_EWALD) { ljcp_j = nbfpLds[numTypes * numTypes + typej]; }
+                }
                 else
                 {
                     ljcp_j.x = *reinterpret_cast<const float*>(jData + c_jStageLjOffset + jAtom * 4U);

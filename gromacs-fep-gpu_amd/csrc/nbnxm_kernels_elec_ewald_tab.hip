@@ -19,6 +19,8 @@ NbKernelPtr nbKernelElecEwaldTab(int vdwKind, bool energy, bool fused)
         case VDK_COMB_LB: return pick<VDK_COMB_LB>(energy, fused);
         case VDK_FSWITCH: return pick<VDK_FSWITCH>(energy, fused);
         case VDK_PSWITCH: return pick<VDK_PSWITCH>(energy, fused);
+        case VDK_EWALD_GEOM: return pick<VDK_EWALD_GEOM>(energy, fused);
+        case VDK_EWALD_LB: return pick<VDK_EWALD_LB>(energy, fused);
         default: return nullptr;
     }
 }
@@ -39,6 +41,8 @@ FepClusterKernelPtr nbKernelElecEwaldTabFepCluster(int vdwKind, bool energy, boo
         case VDK_COMB_LB: return pickFepCluster<VDK_COMB_LB>(energy, foreign);
         case VDK_FSWITCH: return pickFepCluster<VDK_FSWITCH>(energy, foreign);
         case VDK_PSWITCH: return pickFepCluster<VDK_PSWITCH>(energy, foreign);
+        case VDK_EWALD_GEOM: return pickFepCluster<VDK_EWALD_GEOM>(energy, foreign);
+        case VDK_EWALD_LB: return pickFepCluster<VDK_EWALD_LB>(energy, foreign);
         default: return nullptr;
     }
 }

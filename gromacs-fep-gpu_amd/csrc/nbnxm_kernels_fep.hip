@@ -12,7 +12,9 @@ static int vdwKindOf(int vdwType)
         case NBNXM_VDW_CUT_COMB_LB: return VDK_COMB_LB;
         case NBNXM_VDW_FSWITCH: return VDK_FSWITCH;
         case NBNXM_VDW_PSWITCH: return VDK_PSWITCH;
-        default: return -1; /* LJ-PME grid flavours: not built yet */
+        case NBNXM_VDW_EWALD_GEOM: return VDK_EWALD_GEOM;
+        case NBNXM_VDW_EWALD_LB: return VDK_EWALD_LB;
+        default: return -1;
     }
 }
 

@@ -30,8 +30,9 @@ ONE_4PI_EPS0 = ob.ONE_4PI_EPS0
 def make_case(nm=(8, 8, 8), num_perturbed_molecules=3, elec="rf", vdw="cut", seed=2026, rc=1.0, rlist=1.1,
               rlist_fep=None, sc_alpha=0.5, sc_power=1, sc_sigma=0.3, sc_coul=True, lambda_coul=0.5,
               lambda_vdw=0.5, n_lambda=0, max_cjpacked_per_sci=0, identical_states=False, rvdw_switch=0.8,
-              spacing=0.310736, jitter=0.03, num_extra_types=0):
-    """elec: 'rf' | 'cut' | 'ewald' | 'ewald_tab';  vdw: 'cut' | 'pswitch' | 'fswitch'."""
+              spacing=0.310736, jitter=0.03, num_extra_types=0, rvdw=None):
+    """elec: 'rf' | 'cut' | 'ewald' | 'ewald_tab';  vdw: 'cut' | 'pswitch' | 'fswitch' | 'comb_geom' | 'comb_lb' |
+    'ewald_geom' | 'ewald_lb' (LJ-PME real-space part; perturbed pairs keep plain shifted LJ, as in the reference's GPU path)."""
     sysd = pkg.make_water_box(nm[0], nm[1], nm[2], spacing=spacing, jitter=jitter, seed=seed,
                               num_perturbed_molecules=num_perturbed_molecules)
     n = len(sysd["qA"])
@@ -59,6 +60,9 @@ def make_case(nm=(8, 8, 8), num_perturbed_molecules=3, elec="rf", vdw="cut", see
     c.perturbed = perturbed
     c.excl_index, c.excl_atoms = excl_index, excl_atoms
     c.rc, c.rlist, c.rlist_fep = rc, rlist, rlist_fep
+    # rvdw < rcoulomb: the twin-range flavours of the Ewald kernels (ElecType::EwaldAnaTwin / EwaldTabTwin)
+    c.rvdw = rc if rvdw is None else float(rvdw)
+    assert c.rvdw == rc or (c.rvdw < rc and elec in ("ewald", "ewald_tab"))
     c.elec, c.vdw = elec, vdw
     c.epsfac = ONE_4PI_EPS0
     c.k_rf = c.c_rf = c.beta = c.sh_ewald = 0.0
@@ -73,26 +77,36 @@ def make_case(nm=(8, 8, 8), num_perturbed_molecules=3, elec="rf", vdw="cut", see
         c.beta = ob.lib().oracle_calc_ewaldcoeff_q(rc, 1e-5)
         c.sh_ewald = math.erfc(c.beta * rc) / rc
         c.elec_type = pkg.ELEC_EWALD_ANA if elec == "ewald" else pkg.ELEC_EWALD_TAB
-    # potential-shift modifier (GROMACS default): V(rc) = 0
-    c.disp_shift = (0.0, 0.0, -rc ** -6)
-    c.rep_shift = (0.0, 0.0, -rc ** -12)
+        if c.rvdw < rc:
+            c.elec_type = pkg.ELEC_EWALD_ANA_TWIN if elec == "ewald" else pkg.ELEC_EWALD_TAB_TWIN
+    # potential-shift modifier (GROMACS default): V(rvdw) = 0
+    rv = c.rvdw
+    c.disp_shift = (0.0, 0.0, -rv ** -6)
+    c.rep_shift = (0.0, 0.0, -rv ** -12)
     c.vdw_switch = (0.0, 0.0, 0.0)
     c.rvdw_switch = 0.0
+    c.beta_lj = c.sh_lj_ewald = 0.0
     c.vdw_type = pkg.VDW_CUT
     if vdw == "pswitch":
         c.vdw_type = pkg.VDW_PSWITCH
         c.rvdw_switch = rvdw_switch
-        d = rc - rvdw_switch
+        d = rv - rvdw_switch
         c.vdw_switch = (-10.0 / d ** 3, 15.0 / d ** 4, -6.0 / d ** 5)   # potential_switch_constants, forcerec/interaction_const
         c.disp_shift = (0.0, 0.0, 0.0)
         c.rep_shift = (0.0, 0.0, 0.0)
     elif vdw in ("comb_geom", "comb_lb"):
         c.vdw_type = pkg.VDW_CUT_COMB_GEOM if vdw == "comb_geom" else pkg.VDW_CUT_COMB_LB
+    elif vdw in ("ewald_geom", "ewald_lb"):
+        c.vdw_type = pkg.VDW_EWALD_GEOM if vdw == "ewald_geom" else pkg.VDW_EWALD_LB
+        c.beta_lj = ob.lib().oracle_calc_ewaldcoeff_lj(rv, 1e-3)
+        crc2 = (c.beta_lj * rv) ** 2
+        # forcerec: the grid part's potential shift, sh_lj_ewald = (exp(-b^2 rc^2) (1 + b^2 rc^2 + b^4 rc^4 / 2) - 1) / rc^6
+        c.sh_lj_ewald = (math.exp(-crc2) * (1 + crc2 + 0.5 * crc2 * crc2) - 1) / rv ** 6
     elif vdw == "fswitch":
         c.vdw_type = pkg.VDW_FSWITCH
         c.rvdw_switch = rvdw_switch
-        c.disp_shift = force_switch_constants(6.0, rvdw_switch, rc)
-        c.rep_shift = force_switch_constants(12.0, rvdw_switch, rc)
+        c.disp_shift = force_switch_constants(6.0, rvdw_switch, rv)
+        c.rep_shift = force_switch_constants(12.0, rvdw_switch, rv)
     c.sc_alpha, c.sc_power, c.sc_sigma, c.sc_coul = sc_alpha, sc_power, sc_sigma, sc_coul
     c.lambda_coul, c.lambda_vdw = lambda_coul, lambda_vdw
     c.n_lambda = n_lambda
@@ -126,6 +140,11 @@ def add_oxygen_type_variants(sysd, k, seed):
     sysd["typeB"][ox] = np.where(same, newt, sysd["typeB"][ox])
 
 
+def lj_type_params(c):
+    """The per-TYPE table of the same parameters (numTypes = ntype + 1 rows): NBParamGpu::nbfp_comb of the LJ-PME flavours"""
+    return lj_comb_params(c, np.arange(c.ntype + 1))
+
+
 def lj_comb_params(c, atype):
     """Per-atom combination-rule parameters in the kernels' convention (nbnxm_cuda_kernel.cuh:504-516):
     geometric: (sqrt(6 C6), sqrt(12 C12)); Lorentz-Berthelot: (sigma/2, sqrt(eps)) with
@@ -137,7 +156,7 @@ def lj_comb_params(c, atype):
     out = np.zeros((len(atype), 2), np.float32)
     c6, c12 = tab[atype, 0], tab[atype, 1]
     has = (c6 > 0) & (c12 > 0)
-    if c.vdw == "comb_geom":
+    if c.vdw in ("comb_geom", "ewald_geom"):
         out[:, 0] = np.sqrt(c6)
         out[:, 1] = np.sqrt(c12)
     else:
@@ -163,7 +182,7 @@ def oracle_fep_params(c):
     p.vdwIsEwald = 0
     p.vdwPotSwitch = 1 if c.vdw == "pswitch" else 0
     p.epsfac = c.epsfac
-    p.rcoulomb = p.rvdw = c.rc
+    p.rcoulomb, p.rvdw = c.rc, c.rvdw
     p.rvdw_switch = c.rvdw_switch
     p.k_rf, p.c_rf = c.k_rf, c.c_rf
     p.ewaldcoeff_q, p.sh_ewald = c.beta, c.sh_ewald
@@ -177,11 +196,12 @@ def oracle_ref_params(c):
     p.elecType, p.vdwType = c.elec_type, c.vdw_type
     p.epsfac, p.c_rf, p.k_rf = c.epsfac, c.c_rf, c.k_rf
     p.ewaldcoeff_q, p.sh_ewald = c.beta, c.sh_ewald
-    p.rcoulomb = p.rvdw = c.rc
+    p.rcoulomb, p.rvdw = c.rc, c.rvdw
     p.rvdw_switch, p.rlist = c.rvdw_switch, c.rlist
     p.disp_c2, p.disp_c3, p.disp_cpot = c.disp_shift
     p.rep_c2, p.rep_c3, p.rep_cpot = c.rep_shift
     p.sw_c3, p.sw_c4, p.sw_c5 = c.vdw_switch
+    p.ewaldcoeff_lj, p.sh_lj_ewald = c.beta_lj, c.sh_lj_ewald
     return p
 
 
@@ -193,7 +213,9 @@ def run_oracle(c, energy=True, precision="f64", foreign=False, cjPacked=None, nu
     ljc = lj_comb_params(c, g.type) if c.vdw in ("comb_geom", "comb_lb") else None
     ref = ob.nbnxm_ref(c.plist.sci, c.plist.cjPacked if cjPacked is None else cjPacked, c.plist.excl, g.xq,
                        g.type, g.num_types, g.nbat_nbfp(c.sys["nbfp"]), oracle_ref_params(c), g.shift_vec,
-                       compute_energy=energy, compute_fshift=True, lj_comb=ljc, precision=precision, num_threads=num_threads)
+                       compute_energy=energy, compute_fshift=True, lj_comb=ljc,
+                       nbfp_comb=lj_type_params(c) if c.vdw in ("ewald_geom", "ewald_lb") else None, precision=precision,
+                       num_threads=num_threads)
     fp = oracle_fep_params(c)
     fep = ob.fep_kernel(c.plist.fep, g.x_wrapped, c.ntype, fp, g.shift_vec, c.sys["nbfp"], None, c.sys["qA"],
                         c.sys["qB"], c.sys["typeA"], c.sys["typeB"], flags, c.lambda_coul, c.lambda_vdw, precision)
@@ -220,12 +242,12 @@ def gpu_interaction_params(c, use_dynamic_pruning=False):
     tab, scale = None, 0.0
     if c.elec == "ewald_tab":
         tab, scale = ewald_force_table(c.beta, c.rc + 0.3)
-    return pkg.make_interaction_params(c.elec_type, c.vdw_type, c.epsfac, c.rc, c.rc, c.rlist, c.rlist,
+    return pkg.make_interaction_params(c.elec_type, c.vdw_type, c.epsfac, c.rc, c.rvdw, c.rlist, c.rlist,
                                        k_rf=c.k_rf, c_rf=c.c_rf, ewaldcoeff_q=c.beta, sh_ewald=c.sh_ewald,
                                        rvdw_switch=c.rvdw_switch, dispersion_shift=c.disp_shift,
                                        repulsion_shift=c.rep_shift, vdw_switch=c.vdw_switch,
                                        use_dynamic_pruning=use_dynamic_pruning, coulomb_tab=tab,
-                                       coulomb_tab_scale=scale)
+                                       coulomb_tab_scale=scale, ewaldcoeff_lj=c.beta_lj, sh_lj_ewald=c.sh_lj_ewald)
 
 
 def ewald_force_table(beta, rmax, scale=2000.0):
@@ -245,7 +267,8 @@ def setup_gpu(c, fused=False, use_dynamic_pruning=False, list_override=None):
     """list_override: (sci, cjPacked, excl) to upload instead of the case's own list (domain decomposition)."""
     g = c.grid
     ic = gpu_interaction_params(c, use_dynamic_pruning)
-    nb = pkg.NbnxmGpu(ic, g.num_types, g.nbat_nbfp(c.sys["nbfp"]), fep=True, n_lambda=c.n_lambda)
+    nb = pkg.NbnxmGpu(ic, g.num_types, g.nbat_nbfp(c.sys["nbfp"]),
+                      nbfp_comb=lj_type_params(c) if c.vdw in ("ewald_geom", "ewald_lb") else None, fep=True, n_lambda=c.n_lambda)
     sig6 = c.sc_sigma ** 6
     alpha_coul = c.sc_alpha if c.sc_coul else 0.0
     sig6_min = sig6 if c.sc_coul else 0.0
@@ -328,6 +351,7 @@ def brute_force(c, use_state="A"):
     mol = c.sys["molId"]
     f = np.zeros((n, 3))
     e_lj = e_el = 0.0
+    ljt = lj_type_params(c).astype(np.float64) if c.vdw in ("ewald_geom", "ewald_lb") else None
     erf = np.vectorize(math.erf)
     rc2 = c.rc * c.rc
     for i in range(n - 1):
@@ -358,6 +382,22 @@ def brute_force(c, use_state="A"):
                 dsw = (3 * c.vdw_switch[0] + (4 * c.vdw_switch[1] + 5 * c.vdw_switch[2] * rsw) * rsw) * rsw ** 2
                 F = F * sw - rinv * E * dsw
                 E = E * sw
+        if c.vdw in ("ewald_geom", "ewald_lb"):
+            # real-space part of the LJ-PME grid term, E = c6grid / 6 (g(r) + shift), g = (1 - exp(-b^2 r^2) P(b^2 r^2)) / r^6,
+            # for excluded pairs too (without the shift); the force as -dE/dr / r with dg/dr = -6 g / r + exp(-b^2 r^2) b^6 / r
+            ca, cb = ljt[t[i]], ljt[t[idx]]
+            if c.vdw == "ewald_geom":
+                c6g = ca[0] * cb[:, 0]
+            else:
+                c6g = ca[1] * cb[:, 1] * (ca[0] + cb[:, 0]) ** 6
+            b2 = c.beta_lj ** 2
+            ex = np.exp(-b2 * r2)
+            gr = (1 - ex * (1 + b2 * r2 + 0.5 * (b2 * r2) ** 2)) / r2 ** 3
+            E += c6g / 6 * (gr + c.sh_lj_ewald * inc)
+            F += c6g / 6 * (6 * gr / r2 - ex * b2 ** 3 / r2)
+        if c.rvdw < c.rc:
+            inside = (r2 < c.rvdw ** 2).astype(np.float64)
+            F, E = F * inside, E * inside
         if c.elec in ("ewald", "ewald_tab"):
             br = c.beta * r
             F += qq * (inc * rinv ** 3 + (2 / math.sqrt(math.pi) * br * np.exp(-br * br) - erf(br)) / (br ** 3) * c.beta ** 3)
@@ -372,6 +412,9 @@ def brute_force(c, use_state="A"):
         fv = d * F[:, None]
         f[i] += fv.sum(axis=0)
         np.subtract.at(f, idx, fv)
+    if c.vdw in ("ewald_geom", "ewald_lb"):
+        # every atom's pair with itself on the grid: g(0) = b^6 / 6
+        e_lj += float(np.sum(nbfp[t, t, 0])) * 0.5 / 6 * c.beta_lj ** 6 / 6
     q2 = float(np.sum(q * q)) * c.epsfac
     if c.elec in ("ewald", "ewald_tab"):
         e_el += -q2 * c.beta / math.sqrt(math.pi)

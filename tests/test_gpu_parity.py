@@ -154,6 +154,50 @@ def test_full_size_properties_100k():
     tl.assert_parity(fused, want, rel=1e-4, label="96k fused")
 
 
+@pytest.mark.parametrize("elec", ["ewald", "ewald_tab"])
+@pytest.mark.parametrize("vdw", ["cut", "pswitch", "fswitch", "comb_lb"])
+@pytest.mark.parametrize("fused", [False, True])
+def test_twin_range_kernels(elec, vdw, fused):
+    # rvdw < rcoulomb: ElecType::EwaldAnaTwin / EwaldTabTwin (nbnxm_cuda_kernel.cuh VDW_CUTOFF_CHECK); the perturbed pairs
+    # follow the CPU kernel's separate rvdw / rcoulomb
+    c = tl.make_case(elec=elec, vdw=vdw, seed=44, rvdw=0.85, rvdw_switch=0.7, **SMALL)
+    want = tl.run_oracle(c, energy=True)
+    got = tl.run_gpu(c, energy=True, fused=fused)
+    tl.assert_parity(got, want, rel=1e-4, label="twin %s %s" % (elec, vdw))
+    got_f = tl.run_gpu(c, energy=False, fused=fused)
+    tl.assert_parity(got_f, want, rel=1e-4, energy=False, label="twin F %s %s" % (elec, vdw))
+
+
+@pytest.mark.parametrize("elec", ["ewald", "rf", "cut", "ewald_tab"])
+@pytest.mark.parametrize("vdw", ["ewald_geom", "ewald_lb"])
+@pytest.mark.parametrize("fused", [False, True])
+def test_lj_pme_kernels(elec, vdw, fused):
+    # VdwType::EwaldGeom / EwaldLB: the real-space part of the LJ-PME grid term in the cluster kernel (several oxygen types: with
+    # Lorentz-Berthelot the grid C6 of a pair is not the table's C6); perturbed pairs keep plain shifted LJ as in the reference's
+    # GPU path, so the atom-pair FEP kernels run unchanged beside it; fused: the plain pairs inside perturbed cluster pairs carry
+    # the grid term too
+    c = tl.make_case(elec=elec, vdw=vdw, seed=43, num_extra_types=3, **SMALL)
+    want = tl.run_oracle(c, energy=True)
+    got = tl.run_gpu(c, energy=True, fused=fused)
+    tl.assert_parity(got, want, rel=1e-4, label="LJ-PME %s %s" % (elec, vdw))
+    got_f = tl.run_gpu(c, energy=False, fused=fused)
+    tl.assert_parity(got_f, want, rel=1e-4, energy=False, label="LJ-PME F %s %s" % (elec, vdw))
+    if fused and elec == "ewald":
+        # dH/dlambda step: foreign-lambda energies of the perturbed cluster pairs
+        cf = tl.make_case(elec=elec, vdw=vdw, seed=43, num_extra_types=3, n_lambda=5, **SMALL)
+        wf = tl.run_oracle(cf, energy=True, foreign=True)
+        gf = tl.run_gpu(cf, energy=True, fused=True, dhdl=True)
+        tl.assert_parity(gf, wf, rel=1e-4, label="LJ-PME dhdl")
+
+
+def test_lj_pme_twin_range_kernel():
+    c = tl.make_case(elec="ewald", vdw="ewald_geom", seed=45, num_extra_types=2, rvdw=0.85, **SMALL)
+    want = tl.run_oracle(c, energy=True)
+    for fused in (False, True):
+        got = tl.run_gpu(c, energy=True, fused=fused)
+        tl.assert_parity(got, want, rel=1e-4, label="LJ-PME twin")
+
+
 @pytest.mark.parametrize("vdw", ["comb_geom", "comb_lb"])
 @pytest.mark.parametrize("fused", [False, True])
 def test_combination_rule_kernels(vdw, fused):

@@ -82,12 +82,16 @@ def test_cluster_list_covers_every_pair_within_rlist_once(tiny):
 
 
 @pytest.mark.parametrize("elec,vdw", [("rf", "cut"), ("ewald", "cut"), ("cut", "cut"), ("rf", "pswitch"),
-                                      ("ewald", "fswitch")])
+                                      ("ewald", "fswitch"), ("ewald", "ewald_geom"), ("ewald", "ewald_lb"),
+                                      ("rf", "ewald_geom")])
 def test_nbnxm_ref_matches_all_pairs(elec, vdw):
-    c = tl.make_case(nm=(8, 8, 8), num_perturbed_molecules=0, elec=elec, vdw=vdw, seed=5)
+    # (LJ-PME cases: several oxygen types, so that the grid C6 of a pair is not the table's C6 with Lorentz-Berthelot)
+    c = tl.make_case(nm=(8, 8, 8), num_perturbed_molecules=0, elec=elec, vdw=vdw, seed=5,
+                     num_extra_types=3 if vdw.startswith("ewald") else 0)
     g = c.grid
     ref = ob.nbnxm_ref(c.plist_fused.sci, c.plist_fused.cjPacked, c.plist_fused.excl, g.xq, g.type, g.num_types,
-                       g.nbat_nbfp(c.sys["nbfp"]), tl.oracle_ref_params(c), g.shift_vec)
+                       g.nbat_nbfp(c.sys["nbfp"]), tl.oracle_ref_params(c), g.shift_vec,
+                       nbfp_comb=tl.lj_type_params(c) if vdw.startswith("ewald") else None)
     bf = tl.brute_force(c)
     real = g.atomIndices >= 0
     f = np.zeros((c.natoms, 3))
@@ -98,6 +102,40 @@ def test_nbnxm_ref_matches_all_pairs(elec, vdw):
     assert abs(ref["Vv"] - bf["e_lj"]) < 1e-9 * max(1.0, abs(bf["e_lj"]))
     assert abs(ref["Vc"] - bf["e_el"]) < 1e-9 * max(1.0, abs(bf["e_el"]))
     assert np.all(ref["f"][~real] == 0)
+
+
+@pytest.mark.parametrize("elec,vdw", [("ewald", "cut"), ("ewald_tab", "pswitch"), ("ewald", "fswitch"), ("ewald", "ewald_lb")])
+def test_nbnxm_ref_twin_range_matches_all_pairs(elec, vdw):
+    # rvdw < rcoulomb: the *_TWIN electrostatics flavours (LJ only inside rvdw, its shift / switch constants built on rvdw)
+    c = tl.make_case(nm=(8, 8, 8), num_perturbed_molecules=0, elec=elec, vdw=vdw, seed=6, rvdw=0.85, rvdw_switch=0.7,
+                     num_extra_types=3 if vdw.startswith("ewald") else 0)
+    g = c.grid
+    ref = ob.nbnxm_ref(c.plist_fused.sci, c.plist_fused.cjPacked, c.plist_fused.excl, g.xq, g.type, g.num_types,
+                       g.nbat_nbfp(c.sys["nbfp"]), tl.oracle_ref_params(c), g.shift_vec,
+                       nbfp_comb=tl.lj_type_params(c) if vdw.startswith("ewald") else None)
+    bf = tl.brute_force(c)
+    real = g.atomIndices >= 0
+    f = np.zeros((c.natoms, 3))
+    f[g.atomIndices[real]] = ref["f"][real]
+    scale = np.sqrt(np.mean(bf["f"] ** 2))
+    assert np.max(np.abs(f - bf["f"])) < 1e-9 * scale
+    assert abs(ref["Vv"] - bf["e_lj"]) < 1e-9 * max(1.0, abs(bf["e_lj"]))
+    assert abs(ref["Vc"] - bf["e_el"]) < 1e-9 * max(1.0, abs(bf["e_el"]))
+
+
+def test_twin_range_carved_plus_fep_list_equals_uncarved_when_states_are_identical():
+    c = tl.make_case(nm=(8, 8, 8), num_perturbed_molecules=4, elec="ewald", vdw="cut", seed=3, sc_alpha=0.0,
+                     identical_states=True, lambda_coul=0.3, lambda_vdw=0.7, rvdw=0.85)
+    g = c.grid
+    split = tl.run_oracle(c, energy=True)
+    xq_full = g.xq.copy()
+    xq_full[:, 3] = g.qA
+    full = ob.nbnxm_ref(c.plist_fused.sci, c.plist_fused.cjPacked, c.plist_fused.excl, xq_full, g.typeA,
+                        g.num_types, g.nbat_nbfp(c.sys["nbfp"]), tl.oracle_ref_params(c), g.shift_vec)
+    scale = np.sqrt(np.mean(full["f"] ** 2))
+    assert np.max(np.abs(split["f"] - full["f"])) < 1e-9 * scale
+    assert abs(split["e_lj"] - full["Vv"]) < 1e-9 * max(1.0, abs(full["Vv"]))
+    assert abs(split["e_el"] - full["Vc"]) < 1e-9 * max(1.0, abs(full["Vc"]))
 
 
 @pytest.mark.parametrize("elec,vdw", [("rf", "cut"), ("ewald", "cut"), ("cut", "cut"), ("rf", "pswitch")])
