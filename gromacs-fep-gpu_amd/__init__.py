@@ -26,6 +26,7 @@ JGROUP_SIZE = 4
 NUM_SHIFT_VECTORS = 45
 CENTRAL_SHIFT_INDEX = 22
 ELEC_CUT, ELEC_RF, ELEC_EWALD_TAB, ELEC_EWALD_TAB_TWIN, ELEC_EWALD_ANA, ELEC_EWALD_ANA_TWIN = range(6)
+SOFTCORE_BEUTLER, SOFTCORE_GAPSYS = 0, 1
 VDW_CUT, VDW_CUT_COMB_GEOM, VDW_CUT_COMB_LB, VDW_FSWITCH, VDW_PSWITCH, VDW_EWALD_GEOM, VDW_EWALD_LB = range(7)
 LOCAL, NONLOCAL = 0, 1
 
@@ -85,7 +86,7 @@ class GpuTimings(C.Structure):
 
 # Every symbol include/nbnxm_hip.h declares (checked by tests/test_abi_symbols.py).
 HIP_SYMBOLS = [
-    "nbnxm_gpu_init", "nbnxm_gpu_free", "nbnxm_gpu_copy_fepparams", "nbnxm_gpu_pme_loadbal_update_param",
+    "nbnxm_gpu_init", "nbnxm_gpu_free", "nbnxm_gpu_copy_fepparams", "nbnxm_gpu_set_softcore", "nbnxm_gpu_pme_loadbal_update_param",
     "nbnxm_gpu_init_atomdata", "nbnxm_gpu_init_pairlist", "nbnxm_gpu_init_feppairlist",
     "nbnxm_gpu_init_fep_cluster_bits", "nbnxm_gpu_upload_shiftvec", "nbnxm_gpu_copy_xq_to_gpu",
     "nbnxm_gpu_launch_kernel", "nbnxm_gpu_launch_kernel_pruneonly", "nbnxm_gpu_launch_cpyback",
@@ -362,6 +363,12 @@ class NbnxmGpu:
                                            C.c_int(lam_power), C.c_float(sc_sigma6_def), C.c_float(sc_sigma6_min),
                                            C.c_float(lambda_q), C.c_float(lambda_v), C.c_int(self.n_lambda),
                                            _p(alc), _p(alv))
+
+    def set_softcore(self, softcore_type, gapsys_scale_linpoint_vdw=0.85, gapsys_scale_linpoint_coul=0.3, gapsys_sigma_vdw=0.3):
+        """SOFTCORE_BEUTLER (default after init) | SOFTCORE_GAPSYS; the Gapsys parameters are mdp's sc-gapsys-scale-linpoint-lj / -q
+        and sc-gapsys-sigma-lj (the C ABI takes sigma^6, as interaction_const_t does)"""
+        self._lib.nbnxm_gpu_set_softcore(self.h, C.c_int(softcore_type), C.c_float(gapsys_scale_linpoint_vdw),
+                                         C.c_float(gapsys_scale_linpoint_coul), C.c_float(gapsys_sigma_vdw ** 6))
 
     def init_atomdata(self, num_atoms, atype, lj_comb=None, qA=None, qB=None, typeA=None, typeB=None,
                       lj_combA=None, lj_combB=None, num_atoms_local=None):

@@ -263,7 +263,7 @@ NB_DEVINL void nbPair(const NBParamGpu& nbp,
 
 /* ---- perturbed atom pair ------------------------------------------------------------------------
  * Semantics: the CPU kernel nb_free_energy_kernel<> (gmxlib/nonbonded/nb_free_energy.cpp:723-1136),
- * Beutler soft-core or none, RF/cut-off or Ewald, LJ cut-off with optional potential switch;
+ * Beutler or Gapsys soft-core or none, RF/cut-off or Ewald, LJ cut-off with optional potential switch;
  * per-interaction cut-offs on the soft-core radii (:804-812,880-890) and the r^-6 cap (:907) as on the
  * CPU, which is where the reference's own CUDA kernel deviates.
  */
@@ -297,6 +297,65 @@ NB_DEVINL FepLambda makeFepLambda(float lambdaCoul, float lambdaVdw, int lamPowe
     return L;
 }
 
+/* Gapsys soft-core (gmxlib/nonbonded/nb_softcore.h:44-279; the reference's GPU kernels have Beutler only, its CPU kernel both):
+ * inside a lambda-dependent radius rQ the Coulomb / LJ interaction of one end state is replaced by its quadratic expansion around rQ.
+ * force / potential are overwritten, dvdl is added to, exactly where the CPU kernel does it. */
+template<bool EWALD, bool ENERGY>
+NB_DEVINL void gapsysCoulomb(float qq, float facel, float r, float rCutoff, float lambdaFac, float dLambdaFac, float alphaEff,
+                             float twoKrf, float potentialShift, float& force, float& potential, float& dvdl)
+{
+    if (!(lambdaFac < 1.0F && 0.0F < alphaEff && facel != 0.0F)) { return; }
+    float rQ = sqrtf(cbrtf(1.0F - lambdaFac)) * (1.0F + fabsf(qq / facel)) * alphaEff;
+    const bool withinCutoff = (rQ <= rCutoff);
+    rQ                      = fminf(rQ, rCutoff);
+    if (!(r < rQ)) { return; }
+    const float rInvQ    = 1.0F / rQ;
+    const float constFac = qq * rInvQ;
+    const float linFac   = constFac * r * rInvQ;
+    const float quadrFac = linFac * r * rInvQ;
+    float       fq       = -2.0F * quadrFac + 3.0F * linFac;
+    float       vq       = quadrFac - 3.0F * (linFac - constFac);
+    if constexpr (EWALD) { vq -= qq * potentialShift; }
+    else
+    {
+        fq -= qq * twoKrf * r * r;
+        vq += qq * (0.5F * twoKrf * r * r - potentialShift);
+    }
+    force     = fq;
+    potential = vq;
+    if constexpr (ENERGY)
+    {
+        if (withinCutoff) { dvdl += dLambdaFac * 0.5F * (lambdaFac / (1.0F - lambdaFac)) * (quadrFac - 2.0F * linFac + constFac); }
+    }
+}
+
+template<bool ENERGY>
+NB_DEVINL void gapsysLJ(float c6, float c12, float r, float rsq, float lambdaFac, float dLambdaFac, float sigma6, float alphaEff,
+                        float repulsionShift, float dispersionShift, float& force, float& potential, float& dvdl)
+{
+    if (!(lambdaFac < 1.0F && 0.0F < alphaEff)) { return; }
+    const float lambdaFacRev = 1.0F - lambdaFac;
+    const float rQ           = sqrtf(cbrtf((26.0F / 7.0F) * sigma6 * lambdaFacRev)) * alphaEff;
+    if (!(r < rQ)) { return; }
+    const float c6s = c6 * c_oneSixth, c12s = c12 * c_oneTwelfth;
+    const float rInvQ = 1.0F / rQ;
+    float       i6    = rInvQ * rInvQ * rInvQ;
+    i6                = i6 * i6;
+    const float i7 = i6 * rInvQ, i8 = i7 * rInvQ;
+    const float rInv14C = c12s * i7 * i7 * rsq, rInv13C = c12s * i7 * i6 * r, rInv12C = c12s * i6 * i6;
+    const float rInv8C = i8 * c6s * rsq, rInv7C = i7 * c6s * r, rInv6C = i6 * c6s;
+    const float quadrFac  = 156.0F * rInv14C - 42.0F * rInv8C;
+    const float linearFac = 168.0F * rInv13C - 48.0F * rInv7C;
+    const float constFac  = 91.0F * rInv12C - 28.0F * rInv6C;
+    force     = -quadrFac + linearFac;
+    potential = 0.5F * quadrFac - linearFac + constFac + (c12s * repulsionShift - c6s * dispersionShift);
+    if constexpr (ENERGY)
+    {
+        dvdl += dLambdaFac * 28.0F * (lambdaFac / lambdaFacRev)
+                * ((6.5F * rInv14C - rInv8C) - (13.0F * rInv13C - 2.0F * rInv7C) + (6.5F * rInv12C - rInv6C));
+    }
+}
+
 /* Returns false when the pair is skipped (beyond the cut-off and not an exclusion, :665-678). */
 template<int ELEC, bool PSWITCH, bool FORCE, bool ENERGY>
 NB_DEVINL bool fepPair(const NBParamGpu& nbp,
@@ -316,7 +375,10 @@ NB_DEVINL bool fepPair(const NBParamGpu& nbp,
     const float rcMax2 = fmaxf(nbp.rcoulomb_sq, nbp.rvdw_sq);
     if (included && !(r2raw < rcMax2)) { return false; }
 
-    const bool  useSoftCore = (nbp.alpha_coul != 0.0F || nbp.alpha_vdw != 0.0F); /* dispatchKernel :1326 */
+    /* dispatchKernel :1315-1364: Beutler without alphas, Gapsys without linearisation points = no soft-core */
+    const bool gapsys      = (nbp.softcoreType == NBNXM_SOFTCORE_GAPSYS);
+    const bool useSoftCore = !gapsys && (nbp.alpha_coul != 0.0F || nbp.alpha_vdw != 0.0F);
+    const bool useGapsys   = gapsys && (nbp.gapsysLinpointCoul != 0.0F || nbp.gapsysLinpointVdw != 0.0F);
     const float r2          = fmaxf(r2raw, c_nbnxnMinDistanceSquared);
     const float rInv        = __frsqrt_rn(r2);
     const float r           = r2 * rInv;
@@ -335,19 +397,26 @@ NB_DEVINL bool fepPair(const NBParamGpu& nbp,
             rpm2 = rInv * rInv;
             rp   = 1.0F;
         }
-        float sigma6[2];
+        float sigma6[2], gapsysSigma6[2];
 #pragma unroll
         for (int k = 0; k < 2; k++)
         {
             if (c6[k] > 0.0F && c12[k] > 0.0F)
             {
-                sigma6[k] = fmaxf(0.5F * c12[k] / c6[k], nbp.sc_sigma6_min);
+                gapsysSigma6[k] = 0.5F * c12[k] / c6[k];
+                sigma6[k]       = fmaxf(gapsysSigma6[k], nbp.sc_sigma6_min);
             }
-            else { sigma6[k] = nbp.sc_sigma6; }
+            else
+            {
+                sigma6[k]       = nbp.sc_sigma6;
+                gapsysSigma6[k] = nbp.gapsysSigma6Vdw;
+            }
         }
-        const bool  hardCore  = (c12[0] > 0.0F && c12[1] > 0.0F);
-        const float alphaVEff = hardCore ? 0.0F : nbp.alpha_vdw;
-        const float alphaCEff = hardCore ? 0.0F : nbp.alpha_coul;
+        const bool  hardCore   = (c12[0] > 0.0F && c12[1] > 0.0F);
+        const float alphaVEff  = hardCore ? 0.0F : nbp.alpha_vdw;
+        const float alphaCEff  = hardCore ? 0.0F : nbp.alpha_coul;
+        const float gapsysLinV = hardCore ? 0.0F : nbp.gapsysLinpointVdw;
+        const float gapsysLinC = hardCore ? 0.0F : nbp.gapsysLinpointCoul;
 
         float fC[2] = { 0.0F, 0.0F }, fV[2] = { 0.0F, 0.0F }, vC[2] = { 0.0F, 0.0F }, vV[2] = { 0.0F, 0.0F };
 #pragma unroll
@@ -394,12 +463,22 @@ NB_DEVINL bool fepPair(const NBParamGpu& nbp,
                     {
                         vC[k] = qq[k] * (rInvC - nbp.sh_ewald);
                         fC[k] = qq[k] * rInvC;
+                        if (useGapsys)
+                        {
+                            gapsysCoulomb<true, ENERGY>(qq[k], nbp.epsfac, rC, nbp.rcoulomb, L.LFC[k], (k == 0) ? -1.0F : 1.0F, gapsysLinC, 0.0F,
+                                                        nbp.sh_ewald, fC[k], vC[k], dvdlEl);
+                        }
                     }
                     else
                     {
                         /* plain cut-off is reaction-field with k_rf = 0 (:377-386) */
                         vC[k] = qq[k] * (rInvC + 0.5F * nbp.two_k_rf * rC * rC - nbp.c_rf);
                         fC[k] = qq[k] * (rInvC - nbp.two_k_rf * rC * rC);
+                        if (useGapsys)
+                        {
+                            gapsysCoulomb<false, ENERGY>(qq[k], nbp.epsfac, rC, nbp.rcoulomb, L.LFC[k], (k == 0) ? -1.0F : 1.0F, gapsysLinC,
+                                                         nbp.two_k_rf, nbp.c_rf, fC[k], vC[k], dvdlEl);
+                        }
                     }
                 }
                 const bool doVdw = (c6[k] != 0.0F || c12[k] != 0.0F) && (rV < nbp.rvdw);
@@ -418,6 +497,11 @@ NB_DEVINL bool fepPair(const NBParamGpu& nbp,
                     vV[k]           = (v12 + c12[k] * nbp.repulsion_shift.cpot) * c_oneTwelfth
                             - (v6 + c6[k] * nbp.dispersion_shift.cpot) * c_oneSixth;
                     fV[k] = v12 - v6;
+                    if (useGapsys)
+                    {
+                        gapsysLJ<ENERGY>(c6[k], c12[k], r, r2, L.LFV[k], (k == 0) ? -1.0F : 1.0F, gapsysSigma6[k], gapsysLinV,
+                                         nbp.repulsion_shift.cpot, nbp.dispersion_shift.cpot, fV[k], vV[k], dvdlLJ);
+                    }
                     if constexpr (PSWITCH)
                     {
                         float d        = rV - nbp.rvdw_switch;

@@ -448,6 +448,17 @@ void nbnxm_gpu_free(NbnxmGpu* nb)
     delete nb;
 }
 
+void nbnxm_gpu_set_softcore(NbnxmGpu* nb, int softcoreType, float gapsysScaleLinpointVdW, float gapsysScaleLinpointCoul,
+                            float gapsysSigma6VdW)
+{
+    NBNXM_ASSERT(softcoreType == NBNXM_SOFTCORE_BEUTLER || softcoreType == NBNXM_SOFTCORE_GAPSYS, "unknown soft-core type");
+    NBParamGpu* nbp         = nb->nbparam;
+    nbp->softcoreType       = softcoreType;
+    nbp->gapsysLinpointVdw  = gapsysScaleLinpointVdW;
+    nbp->gapsysLinpointCoul = gapsysScaleLinpointCoul;
+    nbp->gapsysSigma6Vdw    = gapsysSigma6VdW;
+}
+
 void nbnxm_gpu_copy_fepparams(NbnxmGpu* nb, int bFEP, float alpha_coul, float alpha_vdw,
                               int lam_power, float sc_sigma6_def, float sc_sigma6_min,
                               float lambda_q, float lambda_v, int n_lambda,

@@ -128,6 +128,12 @@ struct NBParamGpu
     float sc_sigma6_min;
     float lambda_q;
     float lambda_v;
+    /* MI355X extension: the CPU kernel's second soft-core function (interaction_const_t::SoftCoreParameters,
+     * mdtypes/interaction_const.h; nb_softcore.h); the reference's GPU kernels have Beutler only */
+    int   softcoreType; /* nbnxm_softcore_type */
+    float gapsysLinpointVdw;
+    float gapsysLinpointCoul;
+    float gapsysSigma6Vdw;
     float* allLambdaCoul; /* n_lambda */
     float* allLambdaVdw;  /* n_lambda */
     /* MI355X extension: several lambda windows of the same system batched into one object (R x N atoms, one list): the window of

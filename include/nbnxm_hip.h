@@ -183,6 +183,19 @@ void nbnxm_gpu_copy_fepparams(NbnxmGpu* nb, int bFEP, float alpha_coul, float al
                               float lambda_q, float lambda_v, int n_lambda,
                               const double* all_lambda_coul, const double* all_lambda_vdw);
 
+/* MI355X extension: the soft-core function of the perturbed pairs.  The reference's GPU kernels implement Beutler only (the
+ * caller falls back to the CPU for anything else); its CPU kernel also has Gapsys (SoftcoreType, mdtypes/md_enums.h;
+ * interaction_const_t::SoftCoreParameters{softcoreType, gapsysScaleLinpointVdW, gapsysScaleLinpointCoul, gapsysSigma6VdW},
+ * mdtypes/interaction_const.h; gmxlib/nonbonded/nb_softcore.h).  Beutler (the state after nbnxm_gpu_init) uses the alphas of
+ * nbnxm_gpu_copy_fepparams and ignores the three Gapsys parameters; Gapsys ignores the alphas. */
+enum nbnxm_softcore_type
+{
+    NBNXM_SOFTCORE_BEUTLER = 0,
+    NBNXM_SOFTCORE_GAPSYS  = 1
+};
+void nbnxm_gpu_set_softcore(NbnxmGpu* nb, int softcoreType, float gapsysScaleLinpointVdW, float gapsysScaleLinpointCoul,
+                            float gapsysSigma6VdW);
+
 /* Nbnxm::gpu_pme_loadbal_update_param — nbnxm_gpu_data_mgmt.cpp (cut-off/Ewald update) */
 void nbnxm_gpu_pme_loadbal_update_param(NbnxmGpu* nb, const nbnxm_interaction_params_t* ic);
 

@@ -30,7 +30,8 @@ ONE_4PI_EPS0 = ob.ONE_4PI_EPS0
 def make_case(nm=(8, 8, 8), num_perturbed_molecules=3, elec="rf", vdw="cut", seed=2026, rc=1.0, rlist=1.1,
               rlist_fep=None, sc_alpha=0.5, sc_power=1, sc_sigma=0.3, sc_coul=True, lambda_coul=0.5,
               lambda_vdw=0.5, n_lambda=0, max_cjpacked_per_sci=0, identical_states=False, rvdw_switch=0.8,
-              spacing=0.310736, jitter=0.03, num_extra_types=0, rvdw=None):
+              spacing=0.310736, jitter=0.03, num_extra_types=0, rvdw=None, softcore="beutler",
+              gapsys=(0.85, 0.3, 0.3)):
     """elec: 'rf' | 'cut' | 'ewald' | 'ewald_tab';  vdw: 'cut' | 'pswitch' | 'fswitch' | 'comb_geom' | 'comb_lb' |
     'ewald_geom' | 'ewald_lb' (LJ-PME real-space part; perturbed pairs keep plain shifted LJ, as in the reference's GPU path)."""
     sysd = pkg.make_water_box(nm[0], nm[1], nm[2], spacing=spacing, jitter=jitter, seed=seed,
@@ -108,10 +109,12 @@ def make_case(nm=(8, 8, 8), num_perturbed_molecules=3, elec="rf", vdw="cut", see
         c.disp_shift = force_switch_constants(6.0, rvdw_switch, rv)
         c.rep_shift = force_switch_constants(12.0, rvdw_switch, rv)
     c.sc_alpha, c.sc_power, c.sc_sigma, c.sc_coul = sc_alpha, sc_power, sc_sigma, sc_coul
+    # softcore "gapsys": (sc-gapsys-scale-linpoint-lj, -q, sc-gapsys-sigma-lj); the alphas are not used then
+    c.softcore, c.gapsys = softcore, tuple(gapsys)
     c.lambda_coul, c.lambda_vdw = lambda_coul, lambda_vdw
     c.n_lambda = n_lambda
     c.all_lambda = np.linspace(0.0, 1.0, n_lambda) if n_lambda > 0 else np.zeros(0)
-    c.have_soft_core = sc_alpha != 0
+    c.have_soft_core = (sc_alpha != 0) if softcore == "beutler" else (gapsys[0] != 0 or gapsys[1] != 0)
     return c
 
 
@@ -187,7 +190,11 @@ def oracle_fep_params(c):
     p.k_rf, p.c_rf = c.k_rf, c.c_rf
     p.ewaldcoeff_q, p.sh_ewald = c.beta, c.sh_ewald
     p.dispersion_shift_cpot, p.repulsion_shift_cpot = c.disp_shift[2], c.rep_shift[2]
-    ob.softcore_params(p, c.sc_alpha, c.sc_power, c.sc_sigma, c.sc_sigma, c.sc_coul)
+    if c.softcore == "gapsys":
+        ob.softcore_params(p, c.sc_alpha, c.sc_power, c.sc_sigma, c.sc_sigma, c.sc_coul, softcore_type=ob.SOFTCORE_GAPSYS,
+                           gapsys_lj=c.gapsys[0], gapsys_q=c.gapsys[1], gapsys_sigma=c.gapsys[2])
+    else:
+        ob.softcore_params(p, c.sc_alpha, c.sc_power, c.sc_sigma, c.sc_sigma, c.sc_coul)
     return p
 
 
@@ -274,6 +281,8 @@ def setup_gpu(c, fused=False, use_dynamic_pruning=False, list_override=None):
     sig6_min = sig6 if c.sc_coul else 0.0
     nb.copy_fepparams(alpha_coul, c.sc_alpha, c.sc_power, sig6, sig6_min, c.lambda_coul, c.lambda_vdw,
                       c.all_lambda, c.all_lambda)
+    if c.softcore == "gapsys":
+        nb.set_softcore(pkg.SOFTCORE_GAPSYS, *c.gapsys)
     ljc = lj_comb_params(c, g.type) if c.vdw in ("comb_geom", "comb_lb") else None
     nb.init_atomdata(g.num_atoms, g.type, lj_comb=ljc, qA=g.qA, qB=g.qB, typeA=g.typeA, typeB=g.typeB)
     pl = c.plist_fused if fused else c.plist
@@ -334,6 +343,16 @@ def assert_parity(got, want, rel=1e-4, energy=True, label=""):
         for k in ("e_lj", "e_el", "dvdl_coul", "dvdl_vdw"):
             scale = max(abs(want[k]), 1e-3 * (abs(want["e_lj"]) + abs(want["e_el"])), 1.0)
             assert abs(got[k] - want[k]) <= rel * scale, "%s %s got %.8g want %.8g" % (label, k, got[k], want[k])
+
+
+def assert_foreign(got, want, rel=1e-4):
+    """foreign-lambda energies and dV/dlambda of a dH/dlambda step against run_oracle(..., foreign=True)"""
+    fw = want["foreign"]
+    e_want = fw["eVdw"] + fw["eCoul"]
+    scale = max(1.0, float(np.max(np.abs(fw["eVdw"])) + np.max(np.abs(fw["eCoul"]))))
+    assert np.max(np.abs(got["foreign"]["energies"] - e_want)) <= rel * scale
+    assert np.max(np.abs(got["foreign"]["dvdlCoul"] - fw["dvdlCoul"])) <= rel * max(1.0, float(np.max(np.abs(fw["dvdlCoul"]))))
+    assert np.max(np.abs(got["foreign"]["dvdlVdw"] - fw["dvdlVdw"])) <= rel * max(1.0, float(np.max(np.abs(fw["dvdlVdw"]))))
 
 
 # ---- O(N^2) evaluation (tiny systems) ------------------------------------------------------------------------

@@ -168,6 +168,33 @@ def test_twin_range_kernels(elec, vdw, fused):
     tl.assert_parity(got_f, want, rel=1e-4, energy=False, label="twin F %s %s" % (elec, vdw))
 
 
+@pytest.mark.parametrize("elec,vdw", [("rf", "cut"), ("ewald", "cut"), ("cut", "cut"), ("ewald_tab", "cut"), ("ewald", "pswitch"),
+                                      ("rf", "pswitch")])
+@pytest.mark.parametrize("fused", [False, True])
+def test_gapsys_softcore(elec, vdw, fused):
+    # the CPU kernel's second soft-core function on the GPU (the reference's GPU kernels stop at Beutler); the oracle's Gapsys
+    # branch is pinned by 36 of the reference's known answers (tests/test_oracle_golden.py)
+    c = tl.make_case(elec=elec, vdw=vdw, seed=46, softcore="gapsys", n_lambda=5, lambda_coul=0.4, lambda_vdw=0.6, **SMALL)
+    want = tl.run_oracle(c, energy=True, foreign=True)
+    got = tl.run_gpu(c, energy=True, fused=fused, dhdl=True)
+    tl.assert_parity(got, want, rel=1e-4, label="gapsys %s %s" % (elec, vdw))
+    tl.assert_foreign(got, want, rel=1e-4)
+    got_f = tl.run_gpu(c, energy=False, fused=fused)
+    tl.assert_parity(got_f, want, rel=1e-4, energy=False, label="gapsys F %s %s" % (elec, vdw))
+
+
+def test_gapsys_softcore_changes_the_result_and_zero_linpoints_switch_it_off():
+    c = tl.make_case(elec="rf", seed=46, softcore="gapsys", **SMALL)
+    b = tl.make_case(elec="rf", seed=46, softcore="beutler", sc_alpha=0.0, **SMALL)      # no soft-core at all
+    z = tl.make_case(elec="rf", seed=46, softcore="gapsys", gapsys=(0.0, 0.0, 0.3), **SMALL)
+    g, gb, gz = (tl.run_gpu(x, energy=True, fused=True) for x in (c, b, z))
+    assert abs(g["dvdl_vdw"] - gb["dvdl_vdw"]) > 1e-3 * abs(gb["dvdl_vdw"])
+    # (float atomics: equal up to the order of the sums)
+    assert np.max(np.abs(gz["f"] - gb["f"])) <= 1e-5 * np.max(np.abs(gb["f"]))
+    assert abs(gz["e_lj"] - gb["e_lj"]) <= 1e-5 * abs(gb["e_lj"]) and abs(gz["dvdl_vdw"] - gb["dvdl_vdw"]) <= 1e-5 * abs(gb["dvdl_vdw"])
+    tl.assert_parity(gz, tl.run_oracle(z, energy=True), rel=1e-4, label="gapsys off")
+
+
 @pytest.mark.parametrize("elec", ["ewald", "rf", "cut", "ewald_tab"])
 @pytest.mark.parametrize("vdw", ["ewald_geom", "ewald_lb"])
 @pytest.mark.parametrize("fused", [False, True])
@@ -188,6 +215,7 @@ def test_lj_pme_kernels(elec, vdw, fused):
         wf = tl.run_oracle(cf, energy=True, foreign=True)
         gf = tl.run_gpu(cf, energy=True, fused=True, dhdl=True)
         tl.assert_parity(gf, wf, rel=1e-4, label="LJ-PME dhdl")
+        tl.assert_foreign(gf, wf, rel=1e-4)
 
 
 def test_lj_pme_twin_range_kernel():
