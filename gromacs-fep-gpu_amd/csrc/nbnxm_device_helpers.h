@@ -128,6 +128,31 @@ NB_DEVINL float interpolateCoulombForceR(const NBParamGpu& nbp, float r)
     return fmaf(fraction, d1, fmaf(-fraction, d0, d0));
 }
 
+/* LJ-PME: C6 of the grid part from the per-type parameters NBParamGpu::nbfp_comb (nbnxm_cuda_kernel_utils.cuh:221-229, 283-297) */
+NB_DEVINL float ljGridC6(int vdwKind, const float2& a, const float2& b)
+{
+    if (vdwKind == VDK_EWALD_GEOM) { return a.x * b.x; }
+    const float sigma  = a.x + b.x;
+    const float sigma2 = sigma * sigma;
+    return a.y * b.y * sigma2 * sigma2 * sigma2;
+}
+
+/* the perturbed-pair kernels have no VdW template parameter: grid C6 of the A and B states of a pair, zero without LJ-PME */
+NB_DEVINL bool isLjPme(const NBParamGpu& nbp)
+{
+    return nbp.vdwType == NBNXM_VDW_EWALD_GEOM || nbp.vdwType == NBNXM_VDW_EWALD_LB;
+}
+NB_DEVINL void ljGridC6AB(const NBParamGpu& nbp, const int4& t4i, const int4& t4j, float (&c6grid)[2])
+{
+    c6grid[0] = c6grid[1] = 0.0F;
+    if (isLjPme(nbp))
+    {
+        const int kind = (nbp.vdwType == NBNXM_VDW_EWALD_GEOM) ? VDK_EWALD_GEOM : VDK_EWALD_LB;
+        c6grid[0]      = ljGridC6(kind, nbp.nbfp_comb[t4i.x], nbp.nbfp_comb[t4j.x]);
+        c6grid[1]      = ljGridC6(kind, nbp.nbfp_comb[t4i.y], nbp.nbfp_comb[t4j.y]);
+    }
+}
+
 /* ---- non-perturbed atom pair (nbnxm_cuda_kernel.cuh:518-645) ---------------------------------- */
 
 template<int ELEC, bool TWIN, int VDW, bool ENERGY, bool EXCL_FORCES, bool HAS_EXCL = true, bool CORR_TABLE = true>
@@ -263,7 +288,8 @@ NB_DEVINL void nbPair(const NBParamGpu& nbp,
 
 /* ---- perturbed atom pair ------------------------------------------------------------------------
  * Semantics: the CPU kernel nb_free_energy_kernel<> (gmxlib/nonbonded/nb_free_energy.cpp:723-1136),
- * Beutler or Gapsys soft-core or none, RF/cut-off or Ewald, LJ cut-off with optional potential switch;
+ * Beutler or Gapsys soft-core or none, RF/cut-off or Ewald, LJ cut-off with optional potential switch or LJ-PME
+ * (grid correction :121-163, :1103-1136 — the reference's own GPU kernels evaluate plain shifted LJ there);
  * per-interaction cut-offs on the soft-core radii (:804-812,880-890) and the r^-6 cap (:907) as on the
  * CPU, which is where the reference's own CUDA kernel deviates.
  */
@@ -370,8 +396,10 @@ NB_DEVINL bool fepPair(const NBParamGpu& nbp,
                        float&            eLJ,
                        float&            eEl,
                        float&            dvdlLJ,
-                       float&            dvdlEl)
+                       float&            dvdlEl,
+                       const float (&c6grid)[2] /* LJ-PME: grid C6 of the two states (ljGridC6AB) */)
 {
+    const bool  ljPme  = isLjPme(nbp);
     const float rcMax2 = fmaxf(nbp.rcoulomb_sq, nbp.rvdw_sq);
     if (included && !(r2raw < rcMax2)) { return false; }
 
@@ -481,7 +509,7 @@ NB_DEVINL bool fepPair(const NBParamGpu& nbp,
                         }
                     }
                 }
-                const bool doVdw = (c6[k] != 0.0F || c12[k] != 0.0F) && (rV < nbp.rvdw);
+                const bool doVdw = (c6[k] != 0.0F || c12[k] != 0.0F) && ((ljPme ? r : rV) < nbp.rvdw); /* :880-890 */
                 if (doVdw)
                 {
                     float rInv6;
@@ -502,6 +530,7 @@ NB_DEVINL bool fepPair(const NBParamGpu& nbp,
                         gapsysLJ<ENERGY>(c6[k], c12[k], r, r2, L.LFV[k], (k == 0) ? -1.0F : 1.0F, gapsysSigma6[k], gapsysLinV,
                                          nbp.repulsion_shift.cpot, nbp.dispersion_shift.cpot, fV[k], vV[k], dvdlLJ);
                     }
+                    if (ljPme) { vV[k] += c6grid[k] * nbp.sh_lj_ewald * c_oneSixth; } /* :937-944 */
                     if constexpr (PSWITCH)
                     {
                         float d        = rV - nbp.rvdw_switch;
@@ -586,6 +615,32 @@ NB_DEVINL bool fepPair(const NBParamGpu& nbp,
                     eEl -= L.LFC[k] * qq[k] * v_lr;
                     dvdlEl -= dlf * qq[k] * v_lr;
                 }
+            }
+        }
+    }
+    if (ljPme && (!included || r < nbp.rvdw))
+    {
+        /* remove the grid part (:1103-1136, ewaldLennardJonesGridSubtract :121-163) */
+        const float lje2    = nbp.ewaldcoeff_lj * nbp.ewaldcoeff_lj;
+        const float lje6_6  = lje2 * lje2 * lje2 * c_oneSixth;
+        const float rInvSq  = rInv * rInv;
+        const float rInvSix = rInvSq * rInvSq * rInvSq;
+        const float x       = lje2 * r2;
+        const float expNegX = __expf(-x);
+        const float poly    = 1.0F + x + 0.5F * x * x;
+        /* below (8 eps)^(1/6) the series: the closed form cancels */
+        const float term = (x < 0.09921257F) ? lje6_6 * (1.0F + x * (-0.75F + 0.3F * x)) : rInvSix * (1.0F - expNegX * poly);
+        const float f_lr = (term - expNegX * lje6_6) * rInvSq;
+        const float v_lr = (iEqJ ? 0.5F * lje6_6 : term) * c_oneSixth;
+#pragma unroll
+        for (int k = 0; k < 2; k++)
+        {
+            const float dlf = (k == 0) ? -1.0F : 1.0F;
+            if constexpr (FORCE) { fs += L.LFV[k] * c6grid[k] * f_lr; }
+            if constexpr (ENERGY)
+            {
+                eLJ += L.LFV[k] * c6grid[k] * v_lr;
+                dvdlLJ += dlf * c6grid[k] * v_lr;
             }
         }
     }

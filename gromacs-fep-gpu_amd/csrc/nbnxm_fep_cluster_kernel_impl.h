@@ -36,7 +36,7 @@ __launch_bounds__(c_fepClusterWavesPerBlock* c_waveSize) __global__
                                    const int numForeignLambda /* FOREIGN: lambda indices 0 .. numForeignLambda */)
 {
     static_assert(!FOREIGN || ENERGY, "the foreign-lambda flavour is an energy flavour");
-    constexpr bool LJ_EWALD    = VdwTraits<VDW>::ljEwald; /* plain pairs only: perturbed pairs keep plain shifted LJ */
+    constexpr bool LJ_EWALD    = VdwTraits<VDW>::ljEwald;
     constexpr bool EXCL_FORCES = (ELEC != ELK_CUT) || ENERGY || LJ_EWALD;
     constexpr bool USE_TABLE   = VdwTraits<VDW>::useTable;
     constexpr int  FEP_ELEC    = (ELEC == ELK_CUT) ? ELK_RF : ELEC;
@@ -113,6 +113,12 @@ __launch_bounds__(c_fepClusterWavesPerBlock* c_waveSize) __global__
     const float2   pB       = USE_TABLE ? nbfpLds[numTypes * t4i.y + t4j.y] : nbfp[numTypes * t4i.y + t4j.y];
     const float    c6AB[2]  = { pA.x, pB.x };
     const float    c12AB[2] = { pA.y, pB.y };
+    float          c6gridAB[2];
+    ljGridC6AB(nbp, t4i, t4j, c6gridAB); /* zero without LJ-PME */
+    /* LJ-PME: what the grid counts for an atom's pair with itself, removed like the Coulomb self term (:1103-1136 with i == j) */
+    [[maybe_unused]] const float ljSelfCoef = LJ_EWALD ? 0.5F * c_oneSixth * c_oneSixth * nbp.ewaldcoeff_lj * nbp.ewaldcoeff_lj * nbp.ewaldcoeff_lj
+                                                                * nbp.ewaldcoeff_lj * nbp.ewaldcoeff_lj * nbp.ewaldcoeff_lj
+                                                       : 0.0F;
     [[maybe_unused]] const float selfCoef = (ELEC == ELK_CUT || ELEC == ELK_RF) ? -0.5F * nbp.c_rf : -nbp.ewald_beta * c_oneOverSqrtPi;
     /* the self term of i-atom tidxi: the lanes tidxj == tidxi of the cluster's pair with itself */
     [[maybe_unused]] const bool selfLane = ENERGY && EXCL_FORCES && diagPair && (tidxj == tidxi) && ((iBits >> tidxi) & 1U);
@@ -143,6 +149,12 @@ __launch_bounds__(c_fepClusterWavesPerBlock* c_waveSize) __global__
             const float sB = qABi.y * qABi.y / nbp.epsfac * selfCoef;
             E_el += (1.0F - lambdaQ) * sA + lambdaQ * sB;
             DVDL_el += sB - sA;
+            if constexpr (LJ_EWALD)
+            {
+                /* (this lane is the atom's pair with itself: c6gridAB are its own grid C6 in the two states) */
+                E_lj += ((1.0F - lambdaV) * c6gridAB[0] + lambdaV * c6gridAB[1]) * ljSelfCoef;
+                DVDL_lj += (c6gridAB[1] - c6gridAB[0]) * ljSelfCoef;
+            }
         }
     }
     if (inList)
@@ -154,7 +166,7 @@ __launch_bounds__(c_fepClusterWavesPerBlock* c_waveSize) __global__
                 const FepLambda L     = makeFepLambda(lambdaQ, lambdaV, nbp.lam_power, nbp.alpha_coul, nbp.alpha_vdw);
                 float           fscal = 0.0F;
                 const bool      done  = fepPair<FEP_ELEC, VDW == VDK_PSWITCH, true, ENERGY>(nbp, L, r2, included, false, qq, c6AB, c12AB, fscal,
-                                                                                           E_lj, E_el, DVDL_lj, DVDL_el);
+                                                                                           E_lj, E_el, DVDL_lj, DVDL_el, c6gridAB);
                 F_invr = done ? fscal : 0.0F;
             }
         }
@@ -239,11 +251,16 @@ __launch_bounds__(c_fepClusterWavesPerBlock* c_waveSize) __global__
                 const float sB = qABi.y * qABi.y / nbp.epsfac * selfCoef;
                 fE_el += (1.0F - lc) * sA + lc * sB;
                 fDVDL_el += sB - sA;
+                if constexpr (LJ_EWALD)
+                {
+                    fE_lj += ((1.0F - lv) * c6gridAB[0] + lv * c6gridAB[1]) * ljSelfCoef;
+                    fDVDL_lj += (c6gridAB[1] - c6gridAB[0]) * ljSelfCoef;
+                }
             }
             if (inList && pert && !subDiag)
             {
                 fepPair<FEP_ELEC, VDW == VDK_PSWITCH, false, true>(nbp, Lf, r2, included, false, qq, c6AB, c12AB, fscal, fE_lj, fE_el, fDVDL_lj,
-                                                                   fDVDL_el);
+                                                                   fDVDL_el, c6gridAB);
             }
             const float s0 = waveSum(fE_lj);
             const float s1 = waveSum(fE_el);

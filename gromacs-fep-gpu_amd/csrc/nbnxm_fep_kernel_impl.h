@@ -39,7 +39,7 @@ struct FepPairData
     bool   included;
     float3 rv;
     float  r2;
-    float  qq[2], c6[2], c12[2];
+    float  qq[2], c6[2], c12[2], c6grid[2];
 };
 
 NB_DEVINL FepPairData loadFepPair(const NBAtomDataGpu& atdat, const NBParamGpu& nbp, const gpu_feplist& feplist, int p)
@@ -52,7 +52,7 @@ NB_DEVINL FepPairData loadFepPair(const NBAtomDataGpu& atdat, const NBParamGpu& 
     d.included  = true;
     d.rv        = make_float3(0.0F, 0.0F, 0.0F);
     d.r2        = 0.0F;
-    d.qq[0] = d.qq[1] = d.c6[0] = d.c6[1] = d.c12[0] = d.c12[1] = 0.0F;
+    d.qq[0] = d.qq[1] = d.c6[0] = d.c6[1] = d.c12[0] = d.c12[1] = d.c6grid[0] = d.c6grid[1] = 0.0F;
     if (d.valid)
     {
         d.entry    = feplist.pairEntry[p];
@@ -77,6 +77,7 @@ NB_DEVINL FepPairData loadFepPair(const NBAtomDataGpu& atdat, const NBParamGpu& 
         d.c12[0]         = pA.y;
         d.c6[1]          = pB.x;
         d.c12[1]         = pB.y;
+        ljGridC6AB(nbp, t4i, t4j, d.c6grid);
     }
     return d;
 }
@@ -98,7 +99,7 @@ __launch_bounds__(c_fepBlockSize) __global__
     {
         float      fs   = 0.0F;
         const bool done = fepPair<ELEC, PSWITCH, true, ENERGY>(nbp, L, d.r2, d.included, d.ai == d.aj, d.qq, d.c6,
-                                                               d.c12, fs, E_lj, E_el, DVDL_lj, DVDL_el);
+                                                               d.c12, fs, E_lj, E_el, DVDL_lj, DVDL_el, d.c6grid);
         fscal           = done ? fs : 0.0F;
     }
     const float3 f_ij = make_float3(d.rv.x * fscal, d.rv.y * fscal, d.rv.z * fscal);
@@ -180,7 +181,7 @@ __launch_bounds__(c_fepBlockSize) __global__
         if (d.valid)
         {
             fepPair<ELEC, PSWITCH, false, true>(nbp, L, d.r2, d.included, d.ai == d.aj, d.qq, d.c6, d.c12, fs, E_lj,
-                                                E_el, DVDL_lj, DVDL_el);
+                                                E_el, DVDL_lj, DVDL_el, d.c6grid);
         }
         E_lj    = waveSum(E_lj);
         E_el    = waveSum(E_el);

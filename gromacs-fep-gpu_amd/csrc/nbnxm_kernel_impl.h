@@ -85,15 +85,6 @@ NB_DEVINL void ljFromComb(int vdwKind, const float2& a, const float2& b, float& 
     }
 }
 
-/* LJ-PME: C6 of the grid part from the per-type parameters NBParamGpu::nbfp_comb (nbnxm_cuda_kernel_utils.cuh:221-229, 283-297) */
-NB_DEVINL float ljGridC6(int vdwKind, const float2& a, const float2& b)
-{
-    if (vdwKind == VDK_EWALD_GEOM) { return a.x * b.x; }
-    const float sigma  = a.x + b.x;
-    const float sigma2 = sigma * sigma;
-    return a.y * b.y * sigma2 * sigma2 * sigma2;
-}
-
 /* The unrolled loop over the 8 i-clusters of one j-cluster, as a macro so that both instances index the
  * kernel's register arrays (xqi, trow, fci_buf) directly: a lambda capturing them by reference sends them to
  * scratch memory.  Diagonal rule: on the central image a cluster paired with itself keeps only j > i

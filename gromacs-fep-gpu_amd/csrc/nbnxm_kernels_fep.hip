@@ -51,8 +51,8 @@ FepClusterKernelPtr selectFepClusterKernel(int elecType, int vdwType, bool energ
 }
 
 /* The perturbed-pair math has three electrostatics forms (cut-off == RF with k_rf 0, nb_free_energy.cpp:377-386)
- * and LJ with or without potential switch; force switch and LJ-PME evaluate plain shifted LJ for perturbed
- * pairs, as in the reference. */
+ * and LJ with or without potential switch; force switch evaluates plain shifted LJ for perturbed pairs, as in the
+ * reference; LJ-PME is a run-time branch of fepPair (NBParamGpu::vdwType). */
 template<int ELEC>
 static FepKernelPtr pickFep(bool pswitch, bool energy)
 {

@@ -33,7 +33,7 @@ def make_case(nm=(8, 8, 8), num_perturbed_molecules=3, elec="rf", vdw="cut", see
               spacing=0.310736, jitter=0.03, num_extra_types=0, rvdw=None, softcore="beutler",
               gapsys=(0.85, 0.3, 0.3)):
     """elec: 'rf' | 'cut' | 'ewald' | 'ewald_tab';  vdw: 'cut' | 'pswitch' | 'fswitch' | 'comb_geom' | 'comb_lb' |
-    'ewald_geom' | 'ewald_lb' (LJ-PME real-space part; perturbed pairs keep plain shifted LJ, as in the reference's GPU path)."""
+    'ewald_geom' | 'ewald_lb' (LJ-PME real-space part; perturbed pairs as in the CPU kernel, with the grid correction)."""
     sysd = pkg.make_water_box(nm[0], nm[1], nm[2], spacing=spacing, jitter=jitter, seed=seed,
                               num_perturbed_molecules=num_perturbed_molecules)
     n = len(sysd["qA"])
@@ -143,6 +143,20 @@ def add_oxygen_type_variants(sysd, k, seed):
     sysd["typeB"][ox] = np.where(same, newt, sysd["typeB"][ox])
 
 
+def lj_grid_table(c):
+    """ntype x ntype x 2 table of the grid C6 (the CPU kernel's fr->ljpme_c6grid, nb_free_energy.cpp:560-566; second component unused)"""
+    if c.vdw not in ("ewald_geom", "ewald_lb"):
+        return None
+    t = lj_type_params(c).astype(np.float64)[:c.ntype]
+    if c.vdw == "ewald_geom":
+        c6 = np.outer(t[:, 0], t[:, 0])
+    else:
+        c6 = np.outer(t[:, 1], t[:, 1]) * (t[:, 0][:, None] + t[:, 0][None, :]) ** 6
+    out = np.zeros((c.ntype, c.ntype, 2))
+    out[..., 0] = c6
+    return out.reshape(-1)
+
+
 def lj_type_params(c):
     """The per-TYPE table of the same parameters (numTypes = ntype + 1 rows): NBParamGpu::nbfp_comb of the LJ-PME flavours"""
     return lj_comb_params(c, np.arange(c.ntype + 1))
@@ -182,7 +196,8 @@ def force_switch_constants(p, rsw, rc):
 def oracle_fep_params(c):
     p = ob.FepParams()
     p.elecIsEwald = 1 if c.elec in ("ewald", "ewald_tab") else 0
-    p.vdwIsEwald = 0
+    p.vdwIsEwald = 1 if c.vdw in ("ewald_geom", "ewald_lb") else 0
+    p.ewaldcoeff_lj, p.sh_lj_ewald = c.beta_lj, c.sh_lj_ewald
     p.vdwPotSwitch = 1 if c.vdw == "pswitch" else 0
     p.epsfac = c.epsfac
     p.rcoulomb, p.rvdw = c.rc, c.rvdw
@@ -224,7 +239,7 @@ def run_oracle(c, energy=True, precision="f64", foreign=False, cjPacked=None, nu
                        nbfp_comb=lj_type_params(c) if c.vdw in ("ewald_geom", "ewald_lb") else None, precision=precision,
                        num_threads=num_threads)
     fp = oracle_fep_params(c)
-    fep = ob.fep_kernel(c.plist.fep, g.x_wrapped, c.ntype, fp, g.shift_vec, c.sys["nbfp"], None, c.sys["qA"],
+    fep = ob.fep_kernel(c.plist.fep, g.x_wrapped, c.ntype, fp, g.shift_vec, c.sys["nbfp"], lj_grid_table(c), c.sys["qA"],
                         c.sys["qB"], c.sys["typeA"], c.sys["typeB"], flags, c.lambda_coul, c.lambda_vdw, precision)
     f = np.array(ref["f"], dtype=np.float64)
     real = g.atomIndices >= 0
@@ -237,7 +252,7 @@ def run_oracle(c, energy=True, precision="f64", foreign=False, cjPacked=None, nu
                dvdl_coul=fep["dvdl_coul"], dvdl_vdw=fep["dvdl_vdw"], npairs=ref["npairs"],
                parts=dict(ref=ref, fep=fep))
     if foreign and c.n_lambda > 0:
-        out["foreign"] = ob.fep_foreign(c.plist.fep, g.x_wrapped, c.ntype, fp, g.shift_vec, c.sys["nbfp"], None,
+        out["foreign"] = ob.fep_foreign(c.plist.fep, g.x_wrapped, c.ntype, fp, g.shift_vec, c.sys["nbfp"], lj_grid_table(c),
                                         c.sys["qA"], c.sys["qB"], c.sys["typeA"], c.sys["typeB"], c.lambda_coul,
                                         c.lambda_vdw, c.all_lambda, c.all_lambda, precision)
     return out

@@ -200,9 +200,8 @@ def test_gapsys_softcore_changes_the_result_and_zero_linpoints_switch_it_off():
 @pytest.mark.parametrize("fused", [False, True])
 def test_lj_pme_kernels(elec, vdw, fused):
     # VdwType::EwaldGeom / EwaldLB: the real-space part of the LJ-PME grid term in the cluster kernel (several oxygen types: with
-    # Lorentz-Berthelot the grid C6 of a pair is not the table's C6); perturbed pairs keep plain shifted LJ as in the reference's
-    # GPU path, so the atom-pair FEP kernels run unchanged beside it; fused: the plain pairs inside perturbed cluster pairs carry
-    # the grid term too
+    # Lorentz-Berthelot the grid C6 of a pair is not the table's C6); perturbed pairs follow the CPU kernel (grid correction with
+    # the A / B grid C6, nb_free_energy.cpp:1103-1136) — the reference's own GPU kernels evaluate plain shifted LJ there
     c = tl.make_case(elec=elec, vdw=vdw, seed=43, num_extra_types=3, **SMALL)
     want = tl.run_oracle(c, energy=True)
     got = tl.run_gpu(c, energy=True, fused=fused)

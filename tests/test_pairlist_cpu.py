@@ -123,6 +123,26 @@ def test_nbnxm_ref_twin_range_matches_all_pairs(elec, vdw):
     assert abs(ref["Vc"] - bf["e_el"]) < 1e-9 * max(1.0, abs(bf["e_el"]))
 
 
+@pytest.mark.parametrize("vdw", ["ewald_geom", "ewald_lb"])
+def test_lj_pme_carved_plus_fep_list_equals_uncarved_when_states_are_identical(vdw):
+    # the LJ-PME real-space term of the cluster kernel (nbnxm_ref.c) and the grid correction of the perturbed-pair kernel
+    # (fep_oracle.c, pinned by the reference's LJ-PME known answers) are two restatements of one function
+    c = tl.make_case(nm=(8, 8, 8), num_perturbed_molecules=4, elec="ewald", vdw=vdw, seed=3, sc_alpha=0.0,
+                     identical_states=True, lambda_coul=0.3, lambda_vdw=0.7, num_extra_types=2)
+    g = c.grid
+    split = tl.run_oracle(c, energy=True)
+    xq_full = g.xq.copy()
+    xq_full[:, 3] = g.qA
+    full = ob.nbnxm_ref(c.plist_fused.sci, c.plist_fused.cjPacked, c.plist_fused.excl, xq_full, g.typeA,
+                        g.num_types, g.nbat_nbfp(c.sys["nbfp"]), tl.oracle_ref_params(c), g.shift_vec,
+                        nbfp_comb=tl.lj_type_params(c))
+    scale = np.sqrt(np.mean(full["f"] ** 2))
+    assert np.max(np.abs(split["f"] - full["f"])) < 1e-9 * scale
+    assert abs(split["e_lj"] - full["Vv"]) < 1e-9 * max(1.0, abs(full["Vv"]))
+    assert abs(split["e_el"] - full["Vc"]) < 1e-8 * max(1.0, abs(full["Vc"]))
+    assert abs(split["dvdl_vdw"]) < 1e-8 * max(1.0, abs(full["Vv"]))
+
+
 def test_twin_range_carved_plus_fep_list_equals_uncarved_when_states_are_identical():
     c = tl.make_case(nm=(8, 8, 8), num_perturbed_molecules=4, elec="ewald", vdw="cut", seed=3, sc_alpha=0.0,
                      identical_states=True, lambda_coul=0.3, lambda_vdw=0.7, rvdw=0.85)
