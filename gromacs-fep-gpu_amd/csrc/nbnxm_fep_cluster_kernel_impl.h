@@ -16,7 +16,7 @@
 #ifndef NBNXM_FEP_CLUSTER_KERNEL_IMPL_H
 #define NBNXM_FEP_CLUSTER_KERNEL_IMPL_H
 
-#include "nbnxm_kernel_impl.h"
+#include "nbnxm_kernel_impl.h" /* includes nbnxm_fep_cluster_body.h */
 
 constexpr int c_fepClusterWavesPerBlock = c_fepClusterWavesPerBlockDef;
 
@@ -35,17 +35,8 @@ __launch_bounds__(c_fepClusterWavesPerBlock* c_waveSize) __global__
                                    const unsigned* __restrict__ fepWords,
                                    const int numForeignLambda /* FOREIGN: lambda indices 0 .. numForeignLambda */)
 {
-    static_assert(!FOREIGN || ENERGY, "the foreign-lambda flavour is an energy flavour");
-    constexpr bool LJ_EWALD    = VdwTraits<VDW>::ljEwald;
-    constexpr bool EXCL_FORCES = (ELEC != ELK_CUT) || ENERGY || LJ_EWALD;
-    constexpr bool USE_TABLE   = VdwTraits<VDW>::useTable;
-    constexpr int  FEP_ELEC    = (ELEC == ELK_CUT) ? ELK_RF : ELEC;
-
-    const unsigned lane  = threadIdx.x & (c_waveSize - 1);
-    const unsigned wave  = __builtin_amdgcn_readfirstlane(threadIdx.x / c_waveSize);
-    const unsigned tidxi = lane & 7U;
-    const unsigned tidxj = lane >> 3;
-    const unsigned half  = lane >> 5;
+    constexpr bool USE_TABLE = VdwTraits<VDW>::useTable;
+    const unsigned wave      = __builtin_amdgcn_readfirstlane(threadIdx.x / c_waveSize);
 
     /* LDS: the LJ parameter table of the workgroup */
     extern __shared__ __align__(16) unsigned char fepLds[];
@@ -61,221 +52,8 @@ __launch_bounds__(c_fepClusterWavesPerBlock* c_waveSize) __global__
     __builtin_amdgcn_s_setprio(3);
     const int item = __builtin_amdgcn_readfirstlane(static_cast<int>(blockIdx.x) * c_fepClusterWavesPerBlock + static_cast<int>(wave));
     if (item >= plist.numSlowPairs) { return; }
-    /* one wave per perturbed cluster pair: the waves are latency-bound chains, so the kernel lasts as long as its
-     * longest wave, and one cluster pair is the shortest unit there is */
-    const int         entry    = __builtin_amdgcn_readfirstlane(plist.slowPairs[item]); /* group * 32 + jm * 8 + i */
-    const int         group    = entry >> 5;
-    const int         jm       = (entry >> 3) & 3;
-    const int         i        = entry & 7;
-    const int         sciShift = __builtin_amdgcn_readfirstlane(plist.slowPairSci[item]); /* sci * 64 + shift index */
-    const int         sci      = sciShift >> 6;
-    const int         shiftIdx = sciShift & 63;
-    const bool        central  = (shiftIdx == c_centralShiftIndex);
-
-    const nbnxn_cj_packed_t* __restrict__ grp = &cjPackedList[group];
-    const int  cj       = grp->cj[jm];
-    const int  ci       = sci * c_numClPerSupercl + i;
-    const bool inList   = ((grp->imei[0].imask >> (jm * c_numClPerSupercl + i)) & 1U) != 0U; /* survives the current pruning */
-    const bool diagPair = central && (ci == cj);
-    /* the atoms' own (i == j) terms belong to the cluster's pair with itself, whether or not that pair is in range */
-    if (!inList && !(ENERGY && EXCL_FORCES && diagPair)) { return; }
-
-    const unsigned iBits    = (fepWords[ci >> 2] >> ((ci & 3) * 8)) & 0xFFU;
-    const unsigned jFepBits = (fepWords[cj >> 2] >> ((cj & 3) * 8)) & 0xFFU;
-
-    float* __restrict__ f = reinterpret_cast<float*>(atdat.f);
-    const __amdgpu_buffer_rsrc_t fRsrc =
-            __builtin_amdgcn_make_buffer_rsrc(f, 0, atdat.numAtoms * 3 * static_cast<int>(sizeof(float)), 0x00020000);
-    const float2* __restrict__ nbfp = nbp.nbfp;
-
-    /* lane (tidxj, tidxi) owns the pair (i-atom tidxi, j-atom tidxj) */
-    const int    ai  = ci * c_clSize + static_cast<int>(tidxi);
-    const int    aj  = cj * c_clSize + static_cast<int>(tidxj);
-    const float3 sh  = atdat.shiftVec[shiftIdx];
-    float4       xi  = xq[ai];
-    const float4 q4i = atdat.q4[ai];
-    const int4   t4i = atdat.atomTypes4[ai];
-    const float4 xqj = xq[aj];
-    const float4 q4j = atdat.q4[aj];
-    const int4   t4j = atdat.atomTypes4[aj];
-    xi.x += sh.x;
-    xi.y += sh.y;
-    xi.z += sh.z;
-    const float2   qABi     = make_float2(q4i.x * nbp.epsfac, q4i.y * nbp.epsfac);
-    const unsigned wexcl    = exclList[half ? grp->imei[1].excl_ind : grp->imei[0].excl_ind].pair[lane & 31U];
-    const bool     included = ((wexcl >> (jm * c_numClPerSupercl + i)) & 1U) != 0U;
-    const float3   rv       = make_float3(xi.x - xqj.x, xi.y - xqj.y, xi.z - xqj.z);
-    const float    r2       = rv.x * rv.x + rv.y * rv.y + rv.z * rv.z;
-    const bool     subDiag  = diagPair && (tidxj <= tidxi);
-    const bool     pert     = (((iBits >> tidxi) | (jFepBits >> tidxj)) & 1U) != 0U;
-    const float    qq[2]    = { qABi.x * q4j.x, qABi.y * q4j.y };
-    const float2   pA       = USE_TABLE ? nbfpLds[numTypes * t4i.x + t4j.x] : nbfp[numTypes * t4i.x + t4j.x];
-    const float2   pB       = USE_TABLE ? nbfpLds[numTypes * t4i.y + t4j.y] : nbfp[numTypes * t4i.y + t4j.y];
-    const float    c6AB[2]  = { pA.x, pB.x };
-    const float    c12AB[2] = { pA.y, pB.y };
-    float          c6gridAB[2];
-    ljGridC6AB(nbp, t4i, t4j, c6gridAB); /* zero without LJ-PME */
-    /* LJ-PME: what the grid counts for an atom's pair with itself, removed like the Coulomb self term (:1103-1136 with i == j) */
-    [[maybe_unused]] const float ljSelfCoef = LJ_EWALD ? 0.5F * c_oneSixth * c_oneSixth * nbp.ewaldcoeff_lj * nbp.ewaldcoeff_lj * nbp.ewaldcoeff_lj
-                                                                * nbp.ewaldcoeff_lj * nbp.ewaldcoeff_lj * nbp.ewaldcoeff_lj
-                                                       : 0.0F;
-    [[maybe_unused]] const float selfCoef = (ELEC == ELK_CUT || ELEC == ELK_RF) ? -0.5F * nbp.c_rf : -nbp.ewald_beta * c_oneOverSqrtPi;
-    /* the self term of i-atom tidxi: the lanes tidxj == tidxi of the cluster's pair with itself */
-    [[maybe_unused]] const bool selfLane = ENERGY && EXCL_FORCES && diagPair && (tidxj == tidxi) && ((iBits >> tidxi) & 1U);
-
-    /* this pair's lambdas: the object's, or its window's when several windows are batched into the object */
-    float  lambdaQ = nbp.lambda_q, lambdaV = nbp.lambda_v;
-    float* energySlots  = atdat.energySlots;
-    float* foreignSlots = atdat.foreignSlots;
-    if (nbp.clustersPerWindow > 0)
-    {
-        const int    window = ci / nbp.clustersPerWindow;
-        const float2 wl     = nbp.windowLambda[window];
-        lambdaQ             = wl.x;
-        lambdaV             = wl.y;
-        energySlots         = atdat.windowSlots + window * atdat.windowSlotStride;
-        foreignSlots        = energySlots + atdat.windowForeignOffset;
-    }
-
-    float E_lj = 0.0F, E_el = 0.0F, DVDL_lj = 0.0F, DVDL_el = 0.0F;
-    float F_invr = 0.0F;
-    if constexpr (ENERGY && EXCL_FORCES)
-    {
-        /* perturbed atoms carry q = 0 in xq; their lambda-dependent self term is what the i == j entry of the
-         * atom-pair list contributes (nb_free_energy.cpp:1035-1052,1079-1100) */
-        if (selfLane)
-        {
-            const float sA = qABi.x * qABi.x / nbp.epsfac * selfCoef;
-            const float sB = qABi.y * qABi.y / nbp.epsfac * selfCoef;
-            E_el += (1.0F - lambdaQ) * sA + lambdaQ * sB;
-            DVDL_el += sB - sA;
-            if constexpr (LJ_EWALD)
-            {
-                /* (this lane is the atom's pair with itself: c6gridAB are its own grid C6 in the two states) */
-                E_lj += ((1.0F - lambdaV) * c6gridAB[0] + lambdaV * c6gridAB[1]) * ljSelfCoef;
-                DVDL_lj += (c6gridAB[1] - c6gridAB[0]) * ljSelfCoef;
-            }
-        }
-    }
-    if (inList)
-    {
-        if (pert)
-        {
-            if (!subDiag)
-            {
-                const FepLambda L     = makeFepLambda(lambdaQ, lambdaV, nbp.lam_power, nbp.alpha_coul, nbp.alpha_vdw);
-                float           fscal = 0.0F;
-                const bool      done  = fepPair<FEP_ELEC, VDW == VDK_PSWITCH, true, ENERGY>(nbp, L, r2, included, false, qq, c6AB, c12AB, fscal,
-                                                                                           E_lj, E_el, DVDL_lj, DVDL_el, c6gridAB);
-                F_invr = done ? fscal : 0.0F;
-            }
-        }
-        else
-        {
-            /* a plain pair inside a perturbed cluster pair */
-            const int intMask = included ? -1 : 0;
-            bool      active;
-            if constexpr (EXCL_FORCES) { active = (r2 < nbp.rcoulomb_sq) && !subDiag; }
-            else { active = (r2 < nbp.rcoulomb_sq) && included; }
-            if (active)
-            {
-                float c6, c12;
-                if constexpr (USE_TABLE)
-                {
-                    /* non-perturbed atoms: the A-state type is the type */
-                    c6  = pA.x;
-                    c12 = pA.y;
-                }
-                else { ljFromComb(VDW, ljComb[ai], ljComb[aj], c6, c12); }
-                float E_lj_p = 0.0F, E_el_p = 0.0F, c6grid = 0.0F;
-                if constexpr (LJ_EWALD) { c6grid = ljGridC6(VDW, nbp.nbfp_comb[t4i.x], nbp.nbfp_comb[t4j.x]); }
-                /* no Ewald table in this kernel's LDS: the rational form of the correction */
-                nbPair<ELEC, TWIN, VDW, ENERGY, EXCL_FORCES, true, false>(nbp, nullptr, r2, intMask, xi.w * nbp.epsfac * xqj.w, c6, c12, F_invr,
-                                                                         E_lj_p, E_el_p, c6grid);
-                if constexpr (ENERGY)
-                {
-                    E_lj += E_lj_p;
-                    E_el += E_el_p;
-                }
-            }
-        }
-    }
-    const float3 f_ij = make_float3(rv.x * F_invr, rv.y * F_invr, rv.z * F_invr);
-    {
-        /* i-forces: sum over tidxj, lanes tidxj 0..2 carry x, y, z; j-forces: sum over tidxi, lanes tidxi 0..2 */
-        const float fix = reduceOverTidxj(f_ij.x), fiy = reduceOverTidxj(f_ij.y), fiz = reduceOverTidxj(f_ij.z);
-        const float vi  = (tidxj == 0U) ? fix : ((tidxj == 1U) ? fiy : fiz);
-        const int   oi  = (tidxj < 3U) ? (3 * ai + static_cast<int>(tidxj)) * static_cast<int>(sizeof(float)) : c_dropLane;
-        __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(vi, fRsrc, oi, 0, 0);
-        const float fjx = reduceOver8Lanes(-f_ij.x), fjy = reduceOver8Lanes(-f_ij.y), fjz = reduceOver8Lanes(-f_ij.z);
-        const float vj  = (tidxi == 0U) ? fjx : ((tidxi == 1U) ? fjy : fjz);
-        const int   oj  = (tidxi < 3U) ? (3 * aj + static_cast<int>(tidxi)) * static_cast<int>(sizeof(float)) : c_dropLane;
-        __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(vj, fRsrc, oj, 0, 0);
-    }
-
-    if (bCalcFshift && !central)
-    {
-        const float sx = waveSum(f_ij.x);
-        const float sy = waveSum(f_ij.y);
-        const float sz = waveSum(f_ij.z);
-        if (lane < 3U)
-        {
-            const float v = (lane == 0U) ? sx : ((lane == 1U) ? sy : sz);
-            atomicAdd(reinterpret_cast<float*>(atdat.fShift) + 3 * shiftIdx + static_cast<int>(lane), v);
-        }
-    }
-
-    if constexpr (ENERGY)
-    {
-        E_lj    = waveSum(E_lj);
-        E_el    = waveSum(E_el);
-        DVDL_lj = waveSum(DVDL_lj);
-        DVDL_el = waveSum(DVDL_el);
-        const int   slot = item & (c_numEnergySlots - 1);
-        const float v    = (lane == 0U) ? E_lj : ((lane == 1U) ? E_el : ((lane == 2U) ? DVDL_lj : DVDL_el));
-        if (lane < 4U) { atomicAdd(energySlots + slot * c_energySlotStride + static_cast<int>(lane), v); }
-    }
-
-    /* ---- foreign lambdas (dH/dl steps): the same pair's energies at every lambda index */
-    if constexpr (FOREIGN)
-    {
-        for (int fidx = 0; fidx <= numForeignLambda; fidx++)
-        {
-            const float     lc = (fidx == 0) ? lambdaQ : nbp.allLambdaCoul[fidx - 1];
-            const float     lv = (fidx == 0) ? lambdaV : nbp.allLambdaVdw[fidx - 1];
-            const FepLambda Lf = makeFepLambda(lc, lv, nbp.lam_power, nbp.alpha_coul, nbp.alpha_vdw);
-            float fE_lj = 0.0F, fE_el = 0.0F, fDVDL_lj = 0.0F, fDVDL_el = 0.0F, fscal = 0.0F;
-            if (selfLane)
-            {
-                const float sA = qABi.x * qABi.x / nbp.epsfac * selfCoef;
-                const float sB = qABi.y * qABi.y / nbp.epsfac * selfCoef;
-                fE_el += (1.0F - lc) * sA + lc * sB;
-                fDVDL_el += sB - sA;
-                if constexpr (LJ_EWALD)
-                {
-                    fE_lj += ((1.0F - lv) * c6gridAB[0] + lv * c6gridAB[1]) * ljSelfCoef;
-                    fDVDL_lj += (c6gridAB[1] - c6gridAB[0]) * ljSelfCoef;
-                }
-            }
-            if (inList && pert && !subDiag)
-            {
-                fepPair<FEP_ELEC, VDW == VDK_PSWITCH, false, true>(nbp, Lf, r2, included, false, qq, c6AB, c12AB, fscal, fE_lj, fE_el, fDVDL_lj,
-                                                                   fDVDL_el, c6gridAB);
-            }
-            const float s0 = waveSum(fE_lj);
-            const float s1 = waveSum(fE_el);
-            const float s2 = waveSum(fDVDL_lj);
-            const float s3 = waveSum(fDVDL_el);
-            if (lane < 4U)
-            {
-                /* into this wave's accumulator slot (NBAtomDataGpu::foreignSlots): thousands of waves adding to the same
-                 * 48 addresses serialise in L2 (measured +0.28 ms per dH/dl step) */
-                const float v    = (lane == 0U) ? s0 : ((lane == 1U) ? s1 : ((lane == 2U) ? s2 : s3));
-                float*      slot = foreignSlots + (item & (c_numForeignSlots - 1)) * atdat.foreignSlotStride;
-                if (v != 0.0F) { atomicAdd(slot + static_cast<int>(lane) * (numForeignLambda + 1) + fidx, v); }
-            }
-        }
-    }
+    fepClusterPair<ELEC, TWIN, VDW, ENERGY, FOREIGN>(atdat, nbp, plist, bCalcFshift, cjPackedList, exclList, xq, ljComb, fepWords,
+                                                     numForeignLambda, item, nbfpLds);
 }
 
 #endif

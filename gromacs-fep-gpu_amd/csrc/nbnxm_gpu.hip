@@ -234,6 +234,10 @@ NbnxmGpu* nbnxm_gpu_init(const nbnxm_interaction_params_t* ic, int numTypes, con
         nb->fepConcurrent      = (std::atoi(env) != 0);
         nb->fepConcurrentFused = (std::atoi(env) == 2);
     }
+    if (const char* env = std::getenv("NBNXM_HIP_FEP_MERGED"))
+    {
+        nb->fepMergedFused = (std::atoi(env) != 0);
+    }
     if (bFEP && nb->fepConcurrent)
     {
         for (int i = 0; i < (nb->bUseTwoStreams ? 2 : 1); i++)
@@ -988,7 +992,9 @@ void nbnxm_gpu_launch_kernel(NbnxmGpu* nb, const nbnxm_step_workload_t* stepWork
     const bool fused = nb->fusedFep && nbp->bFEP;
     /* foreign-lambda energies are wanted on dH/dl steps of soft-core runs (nbnxm_cuda.cu:817-856).  In fused mode
      * nbnxmFepClusterKernel accumulates them itself: no atom-pair list is needed at all. */
-    const bool wantForeign = nbp->bFEP && nb->n_lambda > 0 && stepWork->computeDhdl && (nbp->alpha_coul != 0.0F || nbp->alpha_vdw != 0.0F);
+    const bool wantForeign = nbp->bFEP && nb->n_lambda > 0 && stepWork->computeDhdl
+                             && ((nbp->softcoreType == NBNXM_SOFTCORE_GAPSYS) ? (nbp->gapsysLinpointCoul != 0.0F || nbp->gapsysLinpointVdw != 0.0F)
+                                                                               : (nbp->alpha_coul != 0.0F || nbp->alpha_vdw != 0.0F));
     bool       fepForked = false;
     if (nbp->bFEP && !fused)
     {
@@ -1043,7 +1049,9 @@ void nbnxm_gpu_launch_kernel(NbnxmGpu* nb, const nbnxm_step_workload_t* stepWork
         }
         if (plist->workRangesDirty) { updateWorkPartition(nb, iloc); }
 
-        if (fused && plist->numSlowPairs > 0)
+        /* force-only steps: the perturbed cluster pairs ride in trailing workgroups of the cluster kernel (nbnxm_kernel_impl.h) */
+        const bool mergeFep = fused && plist->numSlowPairs > 0 && nb->fepMergedFused && !energyFlavour && !wantForeign;
+        if (fused && plist->numSlowPairs > 0 && !mergeFep)
         {
             /* the cluster pairs that touch a perturbed atom: a few thousand short latency-bound waves, ~13 us on the 96k
              * box.  On the same stream, ahead of the cluster kernel: measured on MI355X a second stream does not help here
@@ -1097,10 +1105,12 @@ void nbnxm_gpu_launch_kernel(NbnxmGpu* nb, const nbnxm_step_workload_t* stepWork
         const int p         = nbKernelWavesPerEu(nbp->vdwType, energyFlavour, fused) - 4;
         const int numRanges = plist->numWorkRanges[p];
         NBNXM_ASSERT(numRanges > 0, "work partition missing");
-        hipLaunchKernelGGL(kernel, dim3((numRanges + wavesPerBlock - 1) / wavesPerBlock), dim3(wavesPerBlock * c_waveSize), ldsBytes, s,
+        const int mergedFepItems = mergeFep ? plist->numSlowPairs : 0;
+        const int numBlocks      = (numRanges + wavesPerBlock - 1) / wavesPerBlock + (mergedFepItems + wavesPerBlock - 1) / wavesPerBlock;
+        hipLaunchKernelGGL(kernel, dim3(numBlocks), dim3(wavesPerBlock * c_waveSize), ldsBytes, s,
                            *adat, *nbp, *plist, stepWork->computeVirial, plist->sciSorted, plist->cjPacked, plist->excl, adat->xq,
                            adat->atomTypes, adat->ljComb, reinterpret_cast<const unsigned*>(adat->fepBits),
-                           plist->workRangeStart[p], plist->workFirstSci[p], numRanges, plist->groupSlowMask);
+                           plist->workRangeStart[p], plist->workFirstSci[p], numRanges, plist->groupSlowMask, mergedFepItems);
         NBNXM_HIP_CHECK(hipGetLastError());
         if (nb->bDoTime) { t.nb_k.closeTimingRegion(s); }
     }

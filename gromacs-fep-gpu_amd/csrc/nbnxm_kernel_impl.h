@@ -85,6 +85,8 @@ NB_DEVINL void ljFromComb(int vdwKind, const float2& a, const float2& b, float& 
     }
 }
 
+#include "nbnxm_fep_cluster_body.h"
+
 /* The unrolled loop over the 8 i-clusters of one j-cluster, as a macro so that both instances index the
  * kernel's register arrays (xqi, trow, fci_buf) directly: a lambda capturing them by reference sends them to
  * scratch memory.  Diagonal rule: on the central image a cluster paired with itself keeps only j > i
@@ -170,7 +172,8 @@ __launch_bounds__(c_nbBlockSize) __attribute__((amdgpu_waves_per_eu(c_nbWavesPer
                          const int* __restrict__ workRangeStart,
                          const int* __restrict__ workFirstSci,
                          const int numWorkRanges,
-                         const unsigned* __restrict__ groupSlowMask /* FUSED: perturbed cluster pairs of each group */)
+                         const unsigned* __restrict__ groupSlowMask, /* FUSED: perturbed cluster pairs of each group */
+                         const int mergedFepItems /* FUSED force flavour: perturbed cluster pairs for the trailing workgroups, or 0 */)
 {
     constexpr bool LJ_EWALD    = VdwTraits<VDW>::ljEwald;
     constexpr bool EXCL_FORCES = (ELEC != ELK_CUT) || ENERGY || LJ_EWALD; /* nbnxm_cuda_kernel.cuh:69-78 */
@@ -190,6 +193,30 @@ __launch_bounds__(c_nbBlockSize) __attribute__((amdgpu_waves_per_eu(c_nbWavesPer
     extern __shared__ __align__(16) unsigned char nbLds[];
     const int numTypes   = atdat.numTypes;
     float2*   nbfpLds    = reinterpret_cast<float2*>(nbLds);
+    if constexpr (FUSED && !ENERGY)
+    {
+        /* Trailing workgroups (launched with mergedFepItems > 0): one perturbed cluster pair per wave, what nbnxmFepClusterKernel
+         * does.  The dispatcher hands them out as the ranges' waves retire, so these short latency-bound waves run in the wave
+         * slots — and issue slots — that the end of the kernel leaves idle (one wave per SIMD finishes alone), instead of in a
+         * kernel of their own ahead of this one.  Lowest priority: they must not take issue slots from the ranges. */
+        const unsigned mainBlocks = (static_cast<unsigned>(numWorkRanges) + blockSize / c_waveSize - 1U) / (blockSize / c_waveSize);
+        if (blockIdx.x >= mainBlocks)
+        {
+            if constexpr (VdwTraits<VDW>::useTable)
+            {
+                for (int t = threadIdx.x; t < numTypes * numTypes; t += blockSize) { nbfpLds[t] = nbp.nbfp[t]; }
+                __syncthreads();
+            }
+            __builtin_amdgcn_s_setprio(0);
+            const int item = __builtin_amdgcn_readfirstlane(static_cast<int>((blockIdx.x - mainBlocks) * (blockSize / c_waveSize) + wave));
+            if (item < mergedFepItems)
+            {
+                fepClusterPair<ELEC, TWIN, VDW, false, false>(atdat, nbp, plist, bCalcFshiftIn, cjPackedList, exclList, xq, ljComb, fepWords,
+                                                              -1, item, nbfpLds);
+            }
+            return;
+        }
+    }
     constexpr bool EWALD_CORR_TABLE = (ELEC == ELK_EWALD_ANA);
     /* LJ-PME: the per-type grid parameters (nbfp_comb) follow the pair table */
     const int      nbfpEntries = numTypes * numTypes + (LJ_EWALD ? numTypes : 0);
