@@ -234,6 +234,10 @@ NbnxmGpu* nbnxm_gpu_init(const nbnxm_interaction_params_t* ic, int numTypes, con
         nb->fepConcurrent      = (std::atoi(env) != 0);
         nb->fepConcurrentFused = (std::atoi(env) == 2);
     }
+    if (const char* env = std::getenv("NBNXM_HIP_PRUNE_MERGED"))
+    {
+        nb->pruneMerged = (std::atoi(env) != 0);
+    }
     if (const char* env = std::getenv("NBNXM_HIP_FEP_MERGED"))
     {
         nb->fepMergedFused = (std::atoi(env) != 0);
@@ -641,6 +645,8 @@ void nbnxm_gpu_init_pairlist(NbnxmGpu* nb, int iloc, int na_c, int nsci, const n
     d->haveFreshList          = true;
     d->rollingPruningNumParts = 0;
     d->rollingPruningPart     = 0;
+    d->pendingPrunePart       = -1;
+    d->pendingPruneEntries    = 0;
     nb->haveWork[iloc]        = nsci > 0;
 }
 
@@ -923,6 +929,21 @@ static void updateWorkPartition(NbnxmGpu* nb, int iloc)
     NBNXM_HIP_CHECK(hipGetLastError());
 }
 
+/* a deferred rolling-prune part in its own kernel, now */
+static void flushPendingPrune(NbnxmGpu* nb, int iloc)
+{
+    gpu_plist* plist = nb->plist[iloc];
+    if (plist->pendingPrunePart < 0) { return; }
+    hipStream_t        s = nb->deviceStreams[iloc].stream;
+    InteractionTimers& t = nb->timers[iloc];
+    if (nb->bDoTime) { t.prune_k.openTimingRegion(s); }
+    hipLaunchKernelGGL(selectPruneKernel(false), dim3(plist->pendingPruneEntries), dim3(c_waveSize), 0, s, *nb->atdat, *nb->nbparam, *plist,
+                       plist->rollingPruningNumParts, plist->pendingPrunePart);
+    NBNXM_HIP_CHECK(hipGetLastError());
+    if (nb->bDoTime) { t.prune_k.closeTimingRegion(s); }
+    plist->pendingPrunePart = -1;
+}
+
 void nbnxm_gpu_launch_kernel_pruneonly(NbnxmGpu* nb, int iloc, int numParts)
 {
     gpu_plist*  plist = nb->plist[iloc];
@@ -945,11 +966,22 @@ void nbnxm_gpu_launch_kernel_pruneonly(NbnxmGpu* nb, int iloc, int numParts)
         return;
     }
     InteractionTimers& t = nb->timers[iloc];
-    if (nb->bDoTime) { t.prune_k.openTimingRegion(s); }
-    const PruneKernelPtr kernel = selectPruneKernel(plist->haveFreshList);
-    hipLaunchKernelGGL(kernel, dim3(numSciInPart), dim3(c_waveSize), 0, s, *nb->atdat, *nb->nbparam, *plist, numParts, part);
-    NBNXM_HIP_CHECK(hipGetLastError());
-    if (nb->bDoTime) { t.prune_k.closeTimingRegion(s); }
+    flushPendingPrune(nb, iloc); /* an earlier part that no force-only launch has picked up */
+    if (!plist->haveFreshList && nb->pruneMerged)
+    {
+        /* rolling pruning: the part runs in trailing workgroups of the next force-only cluster kernel (nbnxm_kernel_impl.h),
+         * or in its own kernel ahead of any other flavour (nbnxm_gpu_launch_kernel) */
+        plist->pendingPrunePart    = part;
+        plist->pendingPruneEntries = numSciInPart;
+    }
+    else
+    {
+        if (nb->bDoTime) { t.prune_k.openTimingRegion(s); }
+        const PruneKernelPtr kernel = selectPruneKernel(plist->haveFreshList);
+        hipLaunchKernelGGL(kernel, dim3(numSciInPart), dim3(c_waveSize), 0, s, *nb->atdat, *nb->nbparam, *plist, numParts, part);
+        NBNXM_HIP_CHECK(hipGetLastError());
+        if (nb->bDoTime) { t.prune_k.closeTimingRegion(s); }
+    }
     if (plist->haveFreshList)
     {
         plist->haveFreshList   = false;
@@ -1047,6 +1079,7 @@ void nbnxm_gpu_launch_kernel(NbnxmGpu* nb, const nbnxm_step_workload_t* stepWork
         {
             fatal(__FILE__, __LINE__, "nbnxm_gpu_launch_kernel", "no kernel for this electrostatics / VdW combination");
         }
+        if (energyFlavour) { flushPendingPrune(nb, iloc); } /* only the force flavour has trailing workgroups */
         if (plist->workRangesDirty) { updateWorkPartition(nb, iloc); }
 
         /* force-only steps: the perturbed cluster pairs ride in trailing workgroups of the cluster kernel (nbnxm_kernel_impl.h) */
@@ -1106,11 +1139,16 @@ void nbnxm_gpu_launch_kernel(NbnxmGpu* nb, const nbnxm_step_workload_t* stepWork
         const int numRanges = plist->numWorkRanges[p];
         NBNXM_ASSERT(numRanges > 0, "work partition missing");
         const int mergedFepItems = mergeFep ? plist->numSlowPairs : 0;
-        const int numBlocks      = (numRanges + wavesPerBlock - 1) / wavesPerBlock + (mergedFepItems + wavesPerBlock - 1) / wavesPerBlock;
+        const int pruneEntries   = (plist->pendingPrunePart >= 0) ? plist->pendingPruneEntries : 0;
+        const int prunePart      = std::max(plist->pendingPrunePart, 0);
+        plist->pendingPrunePart  = -1;
+        const int numBlocks      = (numRanges + wavesPerBlock - 1) / wavesPerBlock + (mergedFepItems + wavesPerBlock - 1) / wavesPerBlock
+                              + (pruneEntries + wavesPerBlock - 1) / wavesPerBlock;
         hipLaunchKernelGGL(kernel, dim3(numBlocks), dim3(wavesPerBlock * c_waveSize), ldsBytes, s,
                            *adat, *nbp, *plist, stepWork->computeVirial, plist->sciSorted, plist->cjPacked, plist->excl, adat->xq,
                            adat->atomTypes, adat->ljComb, reinterpret_cast<const unsigned*>(adat->fepBits),
-                           plist->workRangeStart[p], plist->workFirstSci[p], numRanges, plist->groupSlowMask, mergedFepItems);
+                           plist->workRangeStart[p], plist->workFirstSci[p], numRanges, plist->groupSlowMask, mergedFepItems,
+                           std::max(plist->rollingPruningNumParts, 1), prunePart, pruneEntries);
         NBNXM_HIP_CHECK(hipGetLastError());
         if (nb->bDoTime) { t.nb_k.closeTimingRegion(s); }
     }
@@ -1397,6 +1435,7 @@ int nbnxm_gpu_have_short_range_work(const NbnxmGpu* nb, int iloc)
 
 void* nbnxm_gpu_debug_get_cjpacked(NbnxmGpu* nb, int iloc)
 {
+    flushPendingPrune(nb, iloc); /* the caller is about to look at the masks */
     return nb->plist[iloc]->cjPacked;
 }
 

@@ -57,6 +57,8 @@ struct NbnxmGpu
     bool           fepConcurrent               = true;  /* split mode: atom-pair kernels on the FEP stream */
     bool           fepMergedFused              = true;  /* fused mode, force-only steps: the perturbed cluster pairs run in trailing
                                                           * workgroups of the cluster kernel (NBNXM_HIP_FEP_MERGED=0: own kernel) */
+    bool           pruneMerged                 = true;  /* rolling pruning rides in trailing workgroups of the next force-only
+                                                          * cluster kernel (NBNXM_HIP_PRUNE_MERGED=0: own kernel, at once) */
     bool           fepConcurrentFused          = false; /* fused mode: perturbed-cluster-pair kernel on the FEP stream */
     hipEvent_t     nonlocal_done               = nullptr;
     hipEvent_t     misc_ops_and_local_H2D_done = nullptr;

@@ -87,6 +87,88 @@ NB_DEVINL void ljFromComb(int vdwKind, const float2& a, const float2& b, float& 
 
 #include "nbnxm_fep_cluster_body.h"
 
+/* First-pass / rolling list pruning of ONE i-entry by one wavefront (nbnxm/cuda/nbnxm_cuda_kernel_pruneonly.cuh:100-316): a cluster
+ * pair is kept when any of its 64 atom pairs is within range, and the same mask is written to both halves of the split-2 entry.
+ * The i-atoms a lane meets (atom tidxi of the 8 i-clusters) stay in registers: no LDS, no barrier, so the function serves the
+ * prune kernel and the trailing workgroups of the force kernel alike. */
+template<bool haveFreshList>
+NB_DEVINL void pruneEntry(const NBAtomDataGpu& atdat, const NBParamGpu& nbp, const gpu_plist& plist, const int entry)
+{
+    const unsigned lane  = threadIdx.x & (c_waveSize - 1);
+    const unsigned tidxi = lane & 7U;
+    const unsigned tidxj = lane >> 3;
+
+    const nbnxn_sci_t nb_sci   = plist.sci[entry];
+    const int         shiftIdx = nb_sci.shift & NBNXM_CI_SHIFT_MASK;
+    float4            xi[c_numClPerSupercl];
+    {
+        const float3 sh = atdat.shiftVec[shiftIdx];
+#pragma unroll
+        for (int i = 0; i < c_numClPerSupercl; i++)
+        {
+            float4 v = atdat.xq[nb_sci.sci * c_superClSize + i * c_clSize + static_cast<int>(tidxi)];
+            v.x += sh.x;
+            v.y += sh.y;
+            v.z += sh.z;
+            xi[i] = v;
+        }
+    }
+
+    const float rlistOuter_sq = nbp.rlistOuter_sq;
+    const float rlistInner_sq = nbp.rlistInner_sq;
+
+    for (int jPacked = nb_sci.cjPackedBegin; jPacked < nb_sci.cjPackedEnd; jPacked++)
+    {
+        unsigned imaskFull, imaskCheck, imaskNew;
+        if constexpr (haveFreshList)
+        {
+            imaskFull  = plist.cjPacked[jPacked].imei[0].imask;
+            imaskCheck = imaskFull;
+            imaskNew   = 0U;
+        }
+        else
+        {
+            imaskFull  = plist.imask[jPacked * NBNXM_GPU_CLUSTERPAIR_SPLIT];
+            imaskNew   = plist.cjPacked[jPacked].imei[0].imask;
+            imaskCheck = imaskNew ^ imaskFull;
+        }
+        if (imaskCheck == 0U) { continue; }
+#pragma unroll 1
+        for (int jm = 0; jm < c_jGroupSize; jm++)
+        {
+            if (!(imaskCheck & (0xFFU << (jm * c_numClPerSupercl)))) { continue; }
+            const int    cj = plist.cjPacked[jPacked].cj[jm];
+            const float4 xj = atdat.xq[cj * c_clSize + static_cast<int>(tidxj)];
+#pragma unroll
+            for (int i = 0; i < c_numClPerSupercl; i++)
+            {
+                const unsigned mask_ji = 1U << (jm * c_numClPerSupercl + i);
+                if (imaskCheck & mask_ji)
+                {
+                    const float dx = xi[i].x - xj.x, dy = xi[i].y - xj.y, dz = xi[i].z - xj.z;
+                    const float r2 = dx * dx + dy * dy + dz * dz;
+                    if constexpr (haveFreshList)
+                    {
+                        if (__ballot(r2 < rlistOuter_sq) == 0ULL) { imaskFull &= ~mask_ji; }
+                    }
+                    if (__ballot(r2 < rlistInner_sq) != 0ULL) { imaskNew |= mask_ji; }
+                }
+            }
+        }
+        if (lane == 0U)
+        {
+            if constexpr (haveFreshList)
+            {
+                plist.imask[jPacked * NBNXM_GPU_CLUSTERPAIR_SPLIT]     = imaskFull;
+                plist.imask[jPacked * NBNXM_GPU_CLUSTERPAIR_SPLIT + 1] = imaskFull;
+            }
+            plist.cjPacked[jPacked].imei[0].imask = imaskNew;
+            plist.cjPacked[jPacked].imei[1].imask = imaskNew;
+        }
+    }
+}
+
+
 /* The unrolled loop over the 8 i-clusters of one j-cluster, as a macro so that both instances index the
  * kernel's register arrays (xqi, trow, fci_buf) directly: a lambda capturing them by reference sends them to
  * scratch memory.  Diagonal rule: on the central image a cluster paired with itself keeps only j > i
@@ -173,7 +255,11 @@ __launch_bounds__(c_nbBlockSize) __attribute__((amdgpu_waves_per_eu(c_nbWavesPer
                          const int* __restrict__ workFirstSci,
                          const int numWorkRanges,
                          const unsigned* __restrict__ groupSlowMask, /* FUSED: perturbed cluster pairs of each group */
-                         const int mergedFepItems /* FUSED force flavour: perturbed cluster pairs for the trailing workgroups, or 0 */)
+                         const int mergedFepItems, /* FUSED force flavour: perturbed cluster pairs for the trailing workgroups, or 0 */
+                         /* force flavour: i-entries idx * pruneNumParts + prunePart, idx < pruneEntries, are rolling-pruned by trailing workgroups */
+                         const int pruneNumParts,
+                         const int prunePart,
+                         const int pruneEntries)
 {
     constexpr bool LJ_EWALD    = VdwTraits<VDW>::ljEwald;
     constexpr bool EXCL_FORCES = (ELEC != ELK_CUT) || ENERGY || LJ_EWALD; /* nbnxm_cuda_kernel.cuh:69-78 */
@@ -193,26 +279,42 @@ __launch_bounds__(c_nbBlockSize) __attribute__((amdgpu_waves_per_eu(c_nbWavesPer
     extern __shared__ __align__(16) unsigned char nbLds[];
     const int numTypes   = atdat.numTypes;
     float2*   nbfpLds    = reinterpret_cast<float2*>(nbLds);
-    if constexpr (FUSED && !ENERGY)
+    if constexpr (!ENERGY)
     {
-        /* Trailing workgroups (launched with mergedFepItems > 0): one perturbed cluster pair per wave, what nbnxmFepClusterKernel
-         * does.  The dispatcher hands them out as the ranges' waves retire, so these short latency-bound waves run in the wave
-         * slots — and issue slots — that the end of the kernel leaves idle (one wave per SIMD finishes alone), instead of in a
-         * kernel of their own ahead of this one.  Lowest priority: they must not take issue slots from the ranges. */
-        const unsigned mainBlocks = (static_cast<unsigned>(numWorkRanges) + blockSize / c_waveSize - 1U) / (blockSize / c_waveSize);
+        /* Trailing workgroups, behind the ones of the ranges.  The dispatcher hands workgroups out in order, so their waves start
+         * as the ranges' waves retire and run in the wave slots — and issue slots — that the end of the kernel leaves idle (one
+         * wave per SIMD finishes alone), at the lowest priority: they must not take issue slots from the ranges.
+         *  1. pruneEntries > 0: one i-entry of this step's rolling-prune part per wave, what nbnxmPruneKernel<false> does.  It
+         *     rewrites list masks that the ranges may be reading: either value is right for this step (a cluster pair that is
+         *     pruned has no atom pair within the inner list radius, so it adds exactly zero);
+         *  2. FUSED, mergedFepItems > 0: one perturbed cluster pair per wave, what nbnxmFepClusterKernel does in a kernel of its own. */
+        const unsigned wavesPerBlock = blockSize / c_waveSize;
+        const unsigned mainBlocks    = (static_cast<unsigned>(numWorkRanges) + wavesPerBlock - 1U) / wavesPerBlock;
         if (blockIdx.x >= mainBlocks)
         {
-            if constexpr (VdwTraits<VDW>::useTable)
-            {
-                for (int t = threadIdx.x; t < numTypes * numTypes; t += blockSize) { nbfpLds[t] = nbp.nbfp[t]; }
-                __syncthreads();
-            }
             __builtin_amdgcn_s_setprio(0);
-            const int item = __builtin_amdgcn_readfirstlane(static_cast<int>((blockIdx.x - mainBlocks) * (blockSize / c_waveSize) + wave));
-            if (item < mergedFepItems)
+            /* the rolling-prune waves first: they are the longer chains (a loop over the entry's j-groups); the perturbed-pair
+             * waves are short and fill what is left */
+            const unsigned pruneBlocks = (static_cast<unsigned>(pruneEntries) + wavesPerBlock - 1U) / wavesPerBlock;
+            if (blockIdx.x < mainBlocks + pruneBlocks)
             {
-                fepClusterPair<ELEC, TWIN, VDW, false, false>(atdat, nbp, plist, bCalcFshiftIn, cjPackedList, exclList, xq, ljComb, fepWords,
-                                                              -1, item, nbfpLds);
+                const int idx   = __builtin_amdgcn_readfirstlane(static_cast<int>((blockIdx.x - mainBlocks) * wavesPerBlock + wave));
+                const int entry = idx * pruneNumParts + prunePart;
+                if (idx < pruneEntries && entry < plist.nsci) { pruneEntry<false>(atdat, nbp, plist, entry); }
+            }
+            else if constexpr (FUSED)
+            {
+                if constexpr (VdwTraits<VDW>::useTable)
+                {
+                    for (int t = threadIdx.x; t < numTypes * numTypes; t += blockSize) { nbfpLds[t] = nbp.nbfp[t]; }
+                    __syncthreads();
+                }
+                const int item = __builtin_amdgcn_readfirstlane(static_cast<int>((blockIdx.x - mainBlocks - pruneBlocks) * wavesPerBlock + wave));
+                if (item < mergedFepItems)
+                {
+                    fepClusterPair<ELEC, TWIN, VDW, false, false>(atdat, nbp, plist, bCalcFshiftIn, cjPackedList, exclList, xq, ljComb, fepWords,
+                                                                  -1, item, nbfpLds);
+                }
             }
             return;
         }
@@ -592,86 +694,14 @@ __launch_bounds__(c_nbBlockSize) __attribute__((amdgpu_waves_per_eu(c_nbWavesPer
     }
 }
 
-/* First-pass / rolling list pruning (nbnxm/cuda/nbnxm_cuda_kernel_pruneonly.cuh:100-316).
- * One wavefront per i-entry `blockIdx.x * numParts + part`; a cluster pair is kept when any of its 64
- * atom pairs is within range, and the same mask is written to both halves of the split-2 entry. */
+/* One wavefront per i-entry `blockIdx.x * numParts + part` (pruneEntry above). */
 template<bool haveFreshList>
 __launch_bounds__(c_waveSize) __global__
         void nbnxmPruneKernel(const NBAtomDataGpu atdat, const NBParamGpu nbp, const gpu_plist plist, const int numParts, const int part)
 {
     const int entry = static_cast<int>(blockIdx.x) * numParts + part;
     if (entry >= plist.nsci) { return; }
-    const unsigned lane  = threadIdx.x;
-    const unsigned tidxi = lane & 7U;
-    const unsigned tidxj = lane >> 3;
-
-    __shared__ float4 xib[c_superClSize];
-
-    const nbnxn_sci_t nb_sci   = plist.sci[entry];
-    const int         shiftIdx = nb_sci.shift & NBNXM_CI_SHIFT_MASK;
-    {
-        const float3 sh = atdat.shiftVec[shiftIdx];
-        float4       xi = atdat.xq[nb_sci.sci * c_superClSize + static_cast<int>(lane)];
-        xi.x += sh.x;
-        xi.y += sh.y;
-        xi.z += sh.z;
-        xib[lane] = xi;
-    }
-    __syncthreads();
-
-    const float rlistOuter_sq = nbp.rlistOuter_sq;
-    const float rlistInner_sq = nbp.rlistInner_sq;
-
-    for (int jPacked = nb_sci.cjPackedBegin; jPacked < nb_sci.cjPackedEnd; jPacked++)
-    {
-        unsigned imaskFull, imaskCheck, imaskNew;
-        if constexpr (haveFreshList)
-        {
-            imaskFull  = plist.cjPacked[jPacked].imei[0].imask;
-            imaskCheck = imaskFull;
-            imaskNew   = 0U;
-        }
-        else
-        {
-            imaskFull  = plist.imask[jPacked * NBNXM_GPU_CLUSTERPAIR_SPLIT];
-            imaskNew   = plist.cjPacked[jPacked].imei[0].imask;
-            imaskCheck = imaskNew ^ imaskFull;
-        }
-        if (imaskCheck == 0U) { continue; }
-#pragma unroll 1
-        for (int jm = 0; jm < c_jGroupSize; jm++)
-        {
-            if (!(imaskCheck & (0xFFU << (jm * c_numClPerSupercl)))) { continue; }
-            const int    cj = plist.cjPacked[jPacked].cj[jm];
-            const float4 xj = atdat.xq[cj * c_clSize + static_cast<int>(tidxj)];
-#pragma unroll
-            for (int i = 0; i < c_numClPerSupercl; i++)
-            {
-                const unsigned mask_ji = 1U << (jm * c_numClPerSupercl + i);
-                if (imaskCheck & mask_ji)
-                {
-                    const float4 xi = xib[i * c_clSize + tidxi];
-                    const float  dx = xi.x - xj.x, dy = xi.y - xj.y, dz = xi.z - xj.z;
-                    const float  r2 = dx * dx + dy * dy + dz * dz;
-                    if constexpr (haveFreshList)
-                    {
-                        if (__ballot(r2 < rlistOuter_sq) == 0ULL) { imaskFull &= ~mask_ji; }
-                    }
-                    if (__ballot(r2 < rlistInner_sq) != 0ULL) { imaskNew |= mask_ji; }
-                }
-            }
-        }
-        if (lane == 0U)
-        {
-            if constexpr (haveFreshList)
-            {
-                plist.imask[jPacked * NBNXM_GPU_CLUSTERPAIR_SPLIT]     = imaskFull;
-                plist.imask[jPacked * NBNXM_GPU_CLUSTERPAIR_SPLIT + 1] = imaskFull;
-            }
-            plist.cjPacked[jPacked].imei[0].imask = imaskNew;
-            plist.cjPacked[jPacked].imei[1].imask = imaskNew;
-        }
-    }
+    pruneEntry<haveFreshList>(atdat, nbp, plist, entry);
 }
 
 #endif

@@ -241,7 +241,11 @@ void nbnxm_gpu_copy_xq_to_gpu(NbnxmGpu* nb, const float* xq, int atomLocality);
 /* Nbnxm::gpu_launch_kernel — nbnxm/nbnxm_gpu.h:108-111, nbnxm/cuda/nbnxm_cuda.cu:642-858 */
 void nbnxm_gpu_launch_kernel(NbnxmGpu* nb, const nbnxm_step_workload_t* stepWork, int iloc);
 
-/* Nbnxm::gpu_launch_kernel_pruneonly — nbnxm/nbnxm_gpu.h:148-151, nbnxm_cuda.cu:873-994 */
+/* Nbnxm::gpu_launch_kernel_pruneonly — nbnxm/nbnxm_gpu.h:148-151, nbnxm_cuda.cu:873-994.
+ * First pruning of a fresh list: a kernel, at once.  Rolling pruning (numParts parts, one per call): the part is noted and runs in
+ * trailing workgroups of the next force-only nbnxm_gpu_launch_kernel of the locality (in its own kernel ahead of any other
+ * flavour, before the next prune call, and before nbnxm_gpu_debug_get_cjpacked hands out the masks); results of a step do not
+ * depend on which of the two mask values its kernel reads.  NBNXM_HIP_PRUNE_MERGED=0: always at once. */
 void nbnxm_gpu_launch_kernel_pruneonly(NbnxmGpu* nb, int iloc, int numParts);
 
 /* Nbnxm::gpu_launch_cpyback — nbnxm/nbnxm_gpu.h:157-161, nbnxm_gpu_data_mgmt.cpp:1117-1303.
