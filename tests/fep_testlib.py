@@ -264,7 +264,7 @@ def gpu_interaction_params(c, use_dynamic_pruning=False):
     tab, scale = None, 0.0
     if c.elec == "ewald_tab":
         tab, scale = ewald_force_table(c.beta, c.rc + 0.3)
-    return pkg.make_interaction_params(c.elec_type, c.vdw_type, c.epsfac, c.rc, c.rvdw, c.rlist, c.rlist,
+    return pkg.make_interaction_params(c.elec_type, c.vdw_type, c.epsfac, c.rc, c.rvdw, c.rlist, getattr(c, "rlist_inner", c.rlist),
                                        k_rf=c.k_rf, c_rf=c.c_rf, ewaldcoeff_q=c.beta, sh_ewald=c.sh_ewald,
                                        rvdw_switch=c.rvdw_switch, dispersion_shift=c.disp_shift,
                                        repulsion_shift=c.rep_shift, vdw_switch=c.vdw_switch,

@@ -136,6 +136,57 @@ def test_prune_kernel_matches_oracle_and_keeps_forces():
     nb.free()
 
 
+@pytest.mark.parametrize("fused", [False, True])
+@pytest.mark.parametrize("merged", [True, False])
+def test_rolling_prune_with_moving_atoms(fused, merged, monkeypatch):
+    """Dynamic pruning as mdrun drives it: the first launch prunes the fresh list to the outer radius (kept in gpu_plist::imask) and
+    to the inner radius (the working masks); afterwards every step re-checks one of numParts parts of the list for cluster pairs that
+    have come inside the inner radius (nbnxm_cuda_kernel_pruneonly.cuh:100-316).  merged: the part runs in trailing workgroups of the
+    force-only cluster kernel; otherwise in the prune kernel, at once.  Masks against the oracle's pruning, forces against the oracle."""
+    import oracle_binding as ob
+    monkeypatch.setenv("NBNXM_HIP_PRUNE_MERGED", "1" if merged else "0")
+    c = tl.make_case(elec="ewald", seed=33, **SMALL)
+    c.rlist_inner = 1.03
+    g = c.grid
+    pl = c.plist_fused if fused else c.plist
+    nb = tl.setup_gpu(c, fused=fused, use_dynamic_pruning=True)
+    tl.run_gpu(c, energy=False, fused=fused, nb=nb)            # first launch: prunes the fresh list
+    outer = pl.cjPacked.copy()
+    ob.nbnxm_prune(pl.sci, outer, g.xq, g.shift_vec, c.rlist)
+    inner = outer.copy()
+    n_inner = ob.nbnxm_prune(pl.sci, inner, g.xq, g.shift_vec, c.rlist_inner)
+    dev = pkg.download_cjpacked(nb, len(outer))
+    assert np.array_equal(dev["imei"]["imask"], inner["imei"]["imask"])
+    # the atoms move (the list stays valid: displacements far below the buffer)
+    rng = np.random.default_rng(5)
+    xq_new = g.xq.reshape(-1, 4).copy()
+    xq_new[:, :3] += rng.normal(0.0, 0.012, size=(len(xq_new), 3)).astype(np.float32) * (g.atomIndices >= 0)[:, None]
+    nb.copy_xq_to_gpu(xq_new)
+    came_in = outer.copy()
+    ob.nbnxm_prune(pl.sci, came_in, xq_new, g.shift_vec, c.rlist_inner)
+    want_mask = inner["imei"]["imask"] | came_in["imei"]["imask"]
+    assert (want_mask != inner["imei"]["imask"]).any()          # the test moves something across the inner radius
+    # reference forces at the new coordinates (the oracle on the full outer list: pruned pairs add nothing)
+    xq_old = g.xq
+    g.xq = xq_new
+    x_wrapped_old = g.x_wrapped
+    xw = g.x_wrapped.copy()
+    real = g.atomIndices >= 0
+    xw[g.atomIndices[real]] = xq_new[real, :3]
+    g.x_wrapped = xw
+    try:
+        want = tl.run_oracle(c, energy=False)
+    finally:
+        g.xq, g.x_wrapped = xq_old, x_wrapped_old
+    for _ in range(4):
+        nb.launch_kernel_pruneonly(num_parts=4)
+        got = tl.run_gpu(c, energy=False, fused=fused, nb=nb)
+        tl.assert_parity(got, want, rel=1e-4, energy=False, label="rolling prune")
+    dev = pkg.download_cjpacked(nb, len(outer))
+    assert np.array_equal(dev["imei"]["imask"], want_mask)
+    nb.free()
+
+
 def test_full_size_properties_100k():
     """BASELINE size (96k atoms, 48 perturbed): properties that need no full oracle pass —
     Newton's third law (zero net force incl. shift bookkeeping), fused == split, F-only == VF forces."""
