@@ -11,7 +11,8 @@
  *
  * One wavefront per perturbed cluster pair (gpu_plist::slowPairs, a few thousand for a ligand-sized perturbed region, built
  * on the device once per list), lane = tidxj*8 + tidxi as in the cluster kernel: every lane owns one atom pair, nothing is
- * staged.  The waves are short latency-bound chains (~6 us on MI355X), queued ahead of the cluster kernel on its stream.
+ * staged.  The waves are short latency-bound chains.  On force-only steps the body (nbnxm_fep_cluster_body.h) runs in trailing
+ * workgroups of the cluster kernel instead; this kernel serves the energy and dH/dl steps, queued ahead of the cluster kernel.
  */
 #ifndef NBNXM_FEP_CLUSTER_KERNEL_IMPL_H
 #define NBNXM_FEP_CLUSTER_KERNEL_IMPL_H

@@ -1086,7 +1086,8 @@ void nbnxm_gpu_launch_kernel(NbnxmGpu* nb, const nbnxm_step_workload_t* stepWork
         const bool mergeFep = fused && plist->numSlowPairs > 0 && nb->fepMergedFused && !energyFlavour && !wantForeign;
         if (fused && plist->numSlowPairs > 0 && !mergeFep)
         {
-            /* the cluster pairs that touch a perturbed atom: a few thousand short latency-bound waves, ~13 us on the 96k
+            /* (energy / dH/dl steps, or NBNXM_HIP_FEP_MERGED=0; force-only steps: trailing workgroups of the cluster kernel, below)
+             * the cluster pairs that touch a perturbed atom: a few thousand short latency-bound waves, ~10 us on the 96k
              * box.  On the same stream, ahead of the cluster kernel: measured on MI355X a second stream does not help here
              * (the cluster kernel fills every wave slot, so the other kernel's waves only start when those retire, and
              * the fork / join events cost more than the overlap gains: 0.101 vs 0.099 ms per step); the option stays
