@@ -647,6 +647,7 @@ void nbnxm_gpu_init_pairlist(NbnxmGpu* nb, int iloc, int na_c, int nsci, const n
     d->rollingPruningPart     = 0;
     d->pendingPrunePart       = -1;
     d->pendingPruneEntries    = 0;
+    d->pruneCallsSinceRebalance = 0;
     nb->haveWork[iloc]        = nsci > 0;
 }
 
@@ -991,8 +992,15 @@ void nbnxm_gpu_launch_kernel_pruneonly(NbnxmGpu* nb, int iloc, int numParts)
     else
     {
         plist->rollingPruningPart = (part + 1) % numParts;
-        /* a rolling pass changes a part of the masks, by little: re-balance once per full cycle */
-        if (plist->rollingPruningPart == 0) { plist->workRangesDirty = true; }
+        /* a rolling pass adds cluster pairs to a part of the masks, few and evenly spread: re-balance at the end of a full cycle,
+         * and not more often than every c_rebalanceMinPruneCalls steps (the three partition kernels cost ~30 us together) */
+        constexpr int c_rebalanceMinPruneCalls = 32;
+        plist->pruneCallsSinceRebalance++;
+        if (plist->rollingPruningPart == 0 && plist->pruneCallsSinceRebalance >= c_rebalanceMinPruneCalls)
+        {
+            plist->workRangesDirty          = true;
+            plist->pruneCallsSinceRebalance = 0;
+        }
         t.didRollingPrune = true;
     }
 }

@@ -184,6 +184,7 @@ struct gpu_plist
     /* host bookkeeping: a rolling-prune part that waits for the next force-only launch to run in its trailing workgroups */
     int  pendingPrunePart;    /* -1: none */
     int  pendingPruneEntries;
+    int  pruneCallsSinceRebalance; /* rolling-prune calls since the work partition was last recomputed */
 
     /* MI355X extension: work partition of the cluster-pair kernel.  The launch has one wave per resident wave
      * slot of the device; wave w evaluates the packed j-groups [workRangeStart[p][w], workRangeStart[p][w+1]),

@@ -117,22 +117,8 @@ NB_DEVINL void pruneEntry(const NBAtomDataGpu& atdat, const NBParamGpu& nbp, con
     const float rlistOuter_sq = nbp.rlistOuter_sq;
     const float rlistInner_sq = nbp.rlistInner_sq;
 
-    for (int jPacked = nb_sci.cjPackedBegin; jPacked < nb_sci.cjPackedEnd; jPacked++)
-    {
-        unsigned imaskFull, imaskCheck, imaskNew;
-        if constexpr (haveFreshList)
-        {
-            imaskFull  = plist.cjPacked[jPacked].imei[0].imask;
-            imaskCheck = imaskFull;
-            imaskNew   = 0U;
-        }
-        else
-        {
-            imaskFull  = plist.imask[jPacked * NBNXM_GPU_CLUSTERPAIR_SPLIT];
-            imaskNew   = plist.cjPacked[jPacked].imei[0].imask;
-            imaskCheck = imaskNew ^ imaskFull;
-        }
-        if (imaskCheck == 0U) { continue; }
+    /* the pair checks of one packed group; returns the new working mask */
+    auto checkGroup = [&](const int jPacked, unsigned& imaskFull, const unsigned imaskCheck, unsigned imaskNew) {
 #pragma unroll 1
         for (int jm = 0; jm < c_jGroupSize; jm++)
         {
@@ -155,19 +141,55 @@ NB_DEVINL void pruneEntry(const NBAtomDataGpu& atdat, const NBParamGpu& nbp, con
                 }
             }
         }
-        if (lane == 0U)
+        return imaskNew;
+    };
+
+    if constexpr (haveFreshList)
+    {
+        for (int jPacked = nb_sci.cjPackedBegin; jPacked < nb_sci.cjPackedEnd; jPacked++)
         {
-            if constexpr (haveFreshList)
+            unsigned       imaskFull = plist.cjPacked[jPacked].imei[0].imask;
+            const unsigned imaskNew  = checkGroup(jPacked, imaskFull, imaskFull, 0U);
+            if (lane == 0U)
             {
                 plist.imask[jPacked * NBNXM_GPU_CLUSTERPAIR_SPLIT]     = imaskFull;
                 plist.imask[jPacked * NBNXM_GPU_CLUSTERPAIR_SPLIT + 1] = imaskFull;
+                plist.cjPacked[jPacked].imei[0].imask                  = imaskNew;
+                plist.cjPacked[jPacked].imei[1].imask                  = imaskNew;
             }
-            plist.cjPacked[jPacked].imei[0].imask = imaskNew;
-            plist.cjPacked[jPacked].imei[1].imask = imaskNew;
+        }
+    }
+    else
+    {
+        /* rolling pass: only cluster pairs of the outer list that are not in the working list are looked at, and in most groups
+         * there is none.  64 groups at a time: lane l reads the two masks of group base + l (one round trip for the whole
+         * entry instead of one per group), a ballot finds the groups with something to check. */
+        for (int base = nb_sci.cjPackedBegin; base < nb_sci.cjPackedEnd; base += c_waveSize)
+        {
+            const int g    = base + static_cast<int>(lane);
+            unsigned  full = 0U, cur = 0U;
+            if (g < nb_sci.cjPackedEnd)
+            {
+                full = plist.imask[g * NBNXM_GPU_CLUSTERPAIR_SPLIT];
+                cur  = plist.cjPacked[g].imei[0].imask;
+            }
+            unsigned long long need = __ballot((full ^ cur) != 0U);
+            while (need != 0ULL)
+            {
+                const int l = __builtin_ctzll(need);
+                need &= need - 1ULL;
+                unsigned       imaskFull = static_cast<unsigned>(__builtin_amdgcn_readlane(static_cast<int>(full), l));
+                const unsigned imaskCur  = static_cast<unsigned>(__builtin_amdgcn_readlane(static_cast<int>(cur), l));
+                const unsigned imaskNew  = checkGroup(base + l, imaskFull, imaskCur ^ imaskFull, imaskCur);
+                if (lane == 0U && imaskNew != imaskCur)
+                {
+                    plist.cjPacked[base + l].imei[0].imask = imaskNew;
+                    plist.cjPacked[base + l].imei[1].imask = imaskNew;
+                }
+            }
         }
     }
 }
-
 
 /* The unrolled loop over the 8 i-clusters of one j-cluster, as a macro so that both instances index the
  * kernel's register arrays (xqi, trow, fci_buf) directly: a lambda capturing them by reference sends them to
