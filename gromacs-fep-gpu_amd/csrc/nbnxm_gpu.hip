@@ -234,6 +234,10 @@ NbnxmGpu* nbnxm_gpu_init(const nbnxm_interaction_params_t* ic, int numTypes, con
         nb->fepConcurrent      = (std::atoi(env) != 0);
         nb->fepConcurrentFused = (std::atoi(env) == 2);
     }
+    if (const char* env = std::getenv("NBNXM_HIP_F_DOUBLE_BUFFER"))
+    {
+        nb->fDoubleBuffer = (std::atoi(env) != 0);
+    }
     if (const char* env = std::getenv("NBNXM_HIP_PRUNE_MERGED"))
     {
         nb->pruneMerged = (std::atoi(env) != 0);
@@ -376,6 +380,7 @@ void nbnxm_gpu_free(NbnxmGpu* nb)
     freeDeviceBuffer(&ad->xq);
     freeDeviceBuffer(&ad->q4);
     freeDeviceBuffer(&ad->f);
+    freeDeviceBuffer(&nb->fSpare);
     freeDeviceBuffer(&nb->scalarOutputs);
     freeDeviceBuffer(&ad->fShift);
     freeDeviceBuffer(&ad->atomTypes);
@@ -537,9 +542,13 @@ void nbnxm_gpu_init_atomdata(NbnxmGpu* nb, int numAtoms, int numAtomsLocal, cons
         allocateDeviceBuffer(&ad->ljComb4, nalloc);
         ad->numAtomsAlloc = nalloc;
         clearDeviceBufferAsync(&ad->f, 0, nalloc, s); /* first use: no stale forces */
+        freeDeviceBuffer(&nb->fSpare);
+        nb->fSpareAlloc   = 0;
+        nb->fSpareCleared = false;
     }
     ad->numAtoms      = numAtoms;
     ad->numAtomsLocal = numAtomsLocal;
+    nb->fSpareCleared = false; /* the spare force buffer was zeroed for the previous atom count */
 
     nb->h_atomTypes.resize(numAtoms);
     std::memcpy(nb->h_atomTypes.data, type, sizeof(int) * numAtoms);
@@ -794,16 +803,27 @@ void nbnxm_gpu_clear_outputs(NbnxmGpu* nb, int computeVirial)
 {
     NBAtomDataGpu* ad = nb->atdat;
     hipStream_t    s  = nb->deviceStreams[0].stream;
-    /* A.4: the reference clears E / dV/dl only on virial steps; they are accumulated with atomics,
-     * so they are cleared on every call here (one launch for everything). */
+    /* A.4: the reference clears E / dV/dl only on virial steps; they are accumulated with atomics, so they are cleared on every
+     * call that follows a launch which wrote them (one launch for everything; none at all when the forces come from the swap). */
     const int numFloats = 3 * ad->numAtoms;
-    const int numFloat4 = numFloats / 4;
-    const int numTail   = numFloats - 4 * numFloat4;
-    const int nblock    = std::max(1, std::min(2048, (numFloat4 + 255) / 256));
+    int       numFloat4 = numFloats / 4;
+    int       numTail   = numFloats - 4 * numFloat4;
+    if (nb->fDoubleBuffer && nb->fSpareCleared)
+    {
+        /* the last force-only kernel has zeroed the other force buffer in its trailing workgroups: swap */
+        std::swap(ad->f, nb->fSpare);
+        nb->fSpareCleared = false;
+        numFloat4         = 0;
+        numTail           = 0;
+    }
+    const int numScalars = nb->scalarsDirty ? nb->numScalarOutputs : 0;
+    const int numWindow  = nb->scalarsDirty ? nb->numWindows * ad->windowSlotStride : 0;
+    nb->scalarsDirty     = false;
+    if (numFloat4 == 0 && numTail == 0 && numScalars == 0 && numWindow == 0 && !computeVirial) { return; } /* nothing to clear */
+    const int nblock = std::max(1, std::min(2048, (numFloat4 + 255) / 256));
     hipLaunchKernelGGL(nbnxmClearOutputsKernel, dim3(nblock), dim3(256), 0, s, reinterpret_cast<float4*>(ad->f), numFloat4,
-                       reinterpret_cast<float*>(ad->f) + 4 * static_cast<size_t>(numFloat4), numTail, nb->scalarOutputs,
-                       nb->numScalarOutputs, reinterpret_cast<float*>(ad->fShift), computeVirial ? c_fshiftBlockFloats : 0, ad->windowSlots,
-                       nb->numWindows * ad->windowSlotStride);
+                       reinterpret_cast<float*>(ad->f) + 4 * static_cast<size_t>(numFloat4), numTail, nb->scalarOutputs, numScalars,
+                       reinterpret_cast<float*>(ad->fShift), computeVirial ? c_fshiftBlockFloats : 0, ad->windowSlots, numWindow);
     NBNXM_HIP_CHECK(hipGetLastError());
 }
 
@@ -1014,6 +1034,7 @@ void nbnxm_gpu_launch_kernel(NbnxmGpu* nb, const nbnxm_step_workload_t* stepWork
     hipStream_t        s     = nb->deviceStreams[iloc].stream;
     InteractionTimers& t     = nb->timers[iloc];
     NBNXM_ASSERT(adat->shiftVecUploaded, "shift vectors have not been uploaded");
+    if (stepWork->computeEnergy || stepWork->computeDhdl) { nb->scalarsDirty = true; } /* see nbnxm_gpu_clear_outputs */
 
     if (canSkipNonbondedWork(*nb, iloc))
     {
@@ -1151,13 +1172,28 @@ void nbnxm_gpu_launch_kernel(NbnxmGpu* nb, const nbnxm_step_workload_t* stepWork
         const int pruneEntries   = (plist->pendingPrunePart >= 0) ? plist->pendingPruneEntries : 0;
         const int prunePart      = std::max(plist->pendingPrunePart, 0);
         plist->pendingPrunePart  = -1;
+        /* the force flavour zeroes the spare force buffer for the next step (nbnxm_gpu_clear_outputs swaps) */
+        int clearNumFloat4 = 0;
+        if (nb->fDoubleBuffer && !energyFlavour && (3 * adat->numAtoms) % 4 == 0)
+        {
+            if (nb->fSpareAlloc < adat->numAtomsAlloc)
+            {
+                freeDeviceBuffer(&nb->fSpare);
+                allocateDeviceBuffer(&nb->fSpare, adat->numAtomsAlloc);
+                nb->fSpareAlloc = adat->numAtomsAlloc;
+            }
+            clearNumFloat4    = 3 * adat->numAtoms / 4;
+            nb->fSpareCleared = true;
+        }
+        const int clearChunk     = wavesPerBlock * c_waveSize * static_cast<int>(c_clearFloat4PerThread);
         const int numBlocks      = (numRanges + wavesPerBlock - 1) / wavesPerBlock + (mergedFepItems + wavesPerBlock - 1) / wavesPerBlock
-                              + (pruneEntries + wavesPerBlock - 1) / wavesPerBlock;
+                              + (pruneEntries + wavesPerBlock - 1) / wavesPerBlock + (clearNumFloat4 + clearChunk - 1) / clearChunk;
         hipLaunchKernelGGL(kernel, dim3(numBlocks), dim3(wavesPerBlock * c_waveSize), ldsBytes, s,
                            *adat, *nbp, *plist, stepWork->computeVirial, plist->sciSorted, plist->cjPacked, plist->excl, adat->xq,
                            adat->atomTypes, adat->ljComb, reinterpret_cast<const unsigned*>(adat->fepBits),
                            plist->workRangeStart[p], plist->workFirstSci[p], numRanges, plist->groupSlowMask, mergedFepItems,
-                           std::max(plist->rollingPruningNumParts, 1), prunePart, pruneEntries);
+                           std::max(plist->rollingPruningNumParts, 1), prunePart, pruneEntries, reinterpret_cast<float4*>(nb->fSpare),
+                           clearNumFloat4);
         NBNXM_HIP_CHECK(hipGetLastError());
         if (nb->bDoTime) { t.nb_k.closeTimingRegion(s); }
     }
@@ -1366,6 +1402,7 @@ void* nbnxm_gpu_get_xq(NbnxmGpu* nb)
 
 void* nbnxm_gpu_get_f(NbnxmGpu* nb)
 {
+    nb->fDoubleBuffer = false; /* the caller may keep the pointer: no more swaps */
     return nb->atdat->f;
 }
 

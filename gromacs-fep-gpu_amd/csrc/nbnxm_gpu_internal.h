@@ -57,6 +57,14 @@ struct NbnxmGpu
     bool           fepConcurrent               = true;  /* split mode: atom-pair kernels on the FEP stream */
     bool           fepMergedFused              = true;  /* fused mode, force-only steps: the perturbed cluster pairs run in trailing
                                                           * workgroups of the cluster kernel (NBNXM_HIP_FEP_MERGED=0: own kernel) */
+    /* Double-buffered force array: the force-only cluster kernel zeroes the buffer that is NOT in use in its last trailing
+     * workgroups, and nbnxm_gpu_clear_outputs swaps the two instead of launching a clear kernel.  Switched off for good as soon
+     * as the caller asks for the device pointer (nbnxm_gpu_get_f: it may keep it), or with NBNXM_HIP_F_DOUBLE_BUFFER=0. */
+    bool           fDoubleBuffer               = true;
+    float3*        fSpare                      = nullptr;
+    int            fSpareAlloc                 = 0;
+    bool           fSpareCleared               = false;
+    bool           scalarsDirty                = true;  /* energies / dV/dl / foreign / window slots written since the last clear */
     bool           pruneMerged                 = true;  /* rolling pruning rides in trailing workgroups of the next force-only
                                                           * cluster kernel (NBNXM_HIP_PRUNE_MERGED=0: own kernel, at once) */
     bool           fepConcurrentFused          = false; /* fused mode: perturbed-cluster-pair kernel on the FEP stream */

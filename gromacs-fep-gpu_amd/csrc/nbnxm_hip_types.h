@@ -158,6 +158,7 @@ struct NBParamGpu
 constexpr int c_ewaldCorrTabSize = 2048;
 /* waves per workgroup of nbnxmFepClusterKernel */
 constexpr int c_fepClusterWavesPerBlockDef = 4;
+constexpr unsigned c_clearFloat4PerThread = 4; /* trailing clear workgroups of the cluster kernel: float4 stores per thread */
 
 /* nbnxm/gpu_types_common.h:297-341 */
 struct gpu_plist

@@ -281,7 +281,10 @@ __launch_bounds__(c_nbBlockSize) __attribute__((amdgpu_waves_per_eu(c_nbWavesPer
                          /* force flavour: i-entries idx * pruneNumParts + prunePart, idx < pruneEntries, are rolling-pruned by trailing workgroups */
                          const int pruneNumParts,
                          const int prunePart,
-                         const int pruneEntries)
+                         const int pruneEntries,
+                         /* force flavour: the spare force buffer, zeroed by the last trailing workgroups (or 0 float4) */
+                         float4* __restrict__ clearF4,
+                         const int clearNumFloat4)
 {
     constexpr bool LJ_EWALD    = VdwTraits<VDW>::ljEwald;
     constexpr bool EXCL_FORCES = (ELEC != ELK_CUT) || ENERGY || LJ_EWALD; /* nbnxm_cuda_kernel.cuh:69-78 */
@@ -318,25 +321,38 @@ __launch_bounds__(c_nbBlockSize) __attribute__((amdgpu_waves_per_eu(c_nbWavesPer
             /* the rolling-prune waves first: they are the longer chains (a loop over the entry's j-groups); the perturbed-pair
              * waves are short and fill what is left */
             const unsigned pruneBlocks = (static_cast<unsigned>(pruneEntries) + wavesPerBlock - 1U) / wavesPerBlock;
+            const unsigned fepBlocks   = FUSED ? (static_cast<unsigned>(mergedFepItems) + wavesPerBlock - 1U) / wavesPerBlock : 0U;
             if (blockIdx.x < mainBlocks + pruneBlocks)
             {
                 const int idx   = __builtin_amdgcn_readfirstlane(static_cast<int>((blockIdx.x - mainBlocks) * wavesPerBlock + wave));
                 const int entry = idx * pruneNumParts + prunePart;
                 if (idx < pruneEntries && entry < plist.nsci) { pruneEntry<false>(atdat, nbp, plist, entry); }
             }
-            else if constexpr (FUSED)
+            else if (blockIdx.x < mainBlocks + pruneBlocks + fepBlocks)
             {
-                if constexpr (VdwTraits<VDW>::useTable)
+                if constexpr (FUSED)
                 {
-                    for (int t = threadIdx.x; t < numTypes * numTypes; t += blockSize) { nbfpLds[t] = nbp.nbfp[t]; }
-                    __syncthreads();
+                    if constexpr (VdwTraits<VDW>::useTable)
+                    {
+                        for (int t = threadIdx.x; t < numTypes * numTypes; t += blockSize) { nbfpLds[t] = nbp.nbfp[t]; }
+                        __syncthreads();
+                    }
+                    const int item = __builtin_amdgcn_readfirstlane(static_cast<int>((blockIdx.x - mainBlocks - pruneBlocks) * wavesPerBlock + wave));
+                    if (item < mergedFepItems)
+                    {
+                        fepClusterPair<ELEC, TWIN, VDW, false, false>(atdat, nbp, plist, bCalcFshiftIn, cjPackedList, exclList, xq, ljComb, fepWords,
+                                                                      -1, item, nbfpLds);
+                    }
                 }
-                const int item = __builtin_amdgcn_readfirstlane(static_cast<int>((blockIdx.x - mainBlocks - pruneBlocks) * wavesPerBlock + wave));
-                if (item < mergedFepItems)
-                {
-                    fepClusterPair<ELEC, TWIN, VDW, false, false>(atdat, nbp, plist, bCalcFshiftIn, cjPackedList, exclList, xq, ljComb, fepWords,
-                                                                  -1, item, nbfpLds);
-                }
+            }
+            else
+            {
+                /* 3. the OTHER force buffer (clearNumFloat4 > 0), zeroed for the next step: nbnxm_gpu_clear_outputs then swaps the
+                 *    two buffers instead of launching a kernel */
+                const unsigned idx   = blockIdx.x - mainBlocks - pruneBlocks - fepBlocks;
+                const unsigned chunk = blockSize * c_clearFloat4PerThread;
+                const unsigned end   = min((idx + 1U) * chunk, static_cast<unsigned>(clearNumFloat4));
+                for (unsigned i = idx * chunk + threadIdx.x; i < end; i += blockSize) { clearF4[i] = make_float4(0.0F, 0.0F, 0.0F, 0.0F); }
             }
             return;
         }

@@ -264,7 +264,10 @@ void nbnxm_gpu_wait_finish_task(NbnxmGpu* nb, const nbnxm_step_workload_t* stepW
                                 float* shiftForces);
 
 /* Nbnxm::gpu_clear_outputs — nbnxm/gpu_data_mgmt.h:126, nbnxm_gpu_data_mgmt.cpp:1047-1070.
- * (Unlike the reference, energies and dV/dl are cleared on every call) */
+ * (Unlike the reference, energies and dV/dl are cleared on every call that follows a launch which wrote them)
+ * The forces are double-buffered inside the module: after a force-only launch this call swaps to a buffer that launch has already
+ * zeroed and starts no kernel.  The device address of the forces therefore changes from step to step, until nbnxm_gpu_get_f is
+ * called: from then on it stays fixed (and every call clears with a kernel). */
 void nbnxm_gpu_clear_outputs(NbnxmGpu* nb, int computeVirial);
 
 /* ---- queries / plumbing -------------------------------------------------------------------- */
@@ -281,7 +284,7 @@ int nbnxm_gpu_min_ci_balanced(NbnxmGpu* nb);
 int nbnxm_gpu_is_kernel_ewald_analytical(const NbnxmGpu* nb);
 /* Nbnxm::gpu_get_xq / gpu_get_f / gpuGetNBAtomData-style raw device pointers (nbnxm_gpu.h:238-311) */
 void* nbnxm_gpu_get_xq(NbnxmGpu* nb);
-void* nbnxm_gpu_get_f(NbnxmGpu* nb);
+void* nbnxm_gpu_get_f(NbnxmGpu* nb); /* also pins the force buffer, see nbnxm_gpu_clear_outputs */
 /* (get_fshift: the primary array of 45 x 3 floats other kernels — listed forces — add to; the cluster kernel's own share sits in
  * accumulator slots behind it and joins in gpu_try/wait_finish_task) */
 void* nbnxm_gpu_get_fshift(NbnxmGpu* nb);
