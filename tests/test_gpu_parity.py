@@ -187,6 +187,24 @@ def test_rolling_prune_with_moving_atoms(fused, merged, monkeypatch):
     nb.free()
 
 
+def test_force_buffer_swap_and_pinning():
+    """nbnxm_gpu_clear_outputs swaps to the force buffer that the last force-only kernel zeroed in its tail; an energy-step kernel has
+    no tail (the next clear is a kernel again); nbnxm_gpu_get_f pins the buffer.  Every step of a mixed sequence must give the
+    oracle's forces — a stale or doubly used buffer would show as doubled or missing forces."""
+    c = tl.make_case(elec="ewald", seed=51, **SMALL)
+    want = tl.run_oracle(c, energy=True)
+    nb = tl.setup_gpu(c, fused=True)
+    for energy in (False, False, False, True, False, True, True, False, False):
+        got = tl.run_gpu(c, energy=energy, fused=True, nb=nb)
+        tl.assert_parity(got, want, rel=1e-4, energy=energy, label="swap sequence")
+    p1 = nb.f_device_pointer()
+    for energy in (False, False, True, False):
+        got = tl.run_gpu(c, energy=energy, fused=True, nb=nb)
+        tl.assert_parity(got, want, rel=1e-4, energy=energy, label="pinned")
+        assert nb.f_device_pointer() == p1
+    nb.free()
+
+
 def test_full_size_properties_100k():
     """BASELINE size (96k atoms, 48 perturbed): properties that need no full oracle pass —
     Newton's third law (zero net force incl. shift bookkeeping), fused == split, F-only == VF forces."""
