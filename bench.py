@@ -133,8 +133,8 @@ def run_domain_decomposition(args, rank, world, dist, torch, tl, nm, npert):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=500)
+    ap.add_argument("--warmup", type=int, default=50)
     ap.add_argument("--mode", choices=["fused", "split"], default="fused")
     ap.add_argument("--atoms", choices=["24k", "96k", "768k"], default="96k")
     ap.add_argument("--elec", choices=["ewald", "rf"], default="ewald", help="rf: BASELINE configs[1] (with --atoms 24k)")
