@@ -1499,6 +1499,9 @@ void nbnxm_gpu_debug_timeline(NbnxmGpu* nb, unsigned long long* out, int numWave
 void nbnxm_gpu_debug_graph_steps(NbnxmGpu* nb, const nbnxm_step_workload_t* stepWork, int numSteps)
 {
     hipStream_t s = nb->deviceStreams[0].stream;
+    /* a captured step replays with the buffer addresses of the capture: no swapping of force buffers here (and no allocation
+     * inside the capture) */
+    nb->fDoubleBuffer = false;
     /* steady state only: no fresh list, no dirty partition */
     nbnxm_gpu_clear_outputs(nb, stepWork->computeVirial);
     nbnxm_gpu_launch_kernel(nb, stepWork, NBNXM_LOCAL);
