@@ -11,38 +11,107 @@ One "step" = one pass of the hot path over the resident inputs: clear outputs + 
 (fused cluster-pair kernel with in-line perturbed pairs; forces only, as in a normal MD step).
 Inputs (xq, parameters, lists) are in HBM before the timed region.  Synthetic data, seeded.
 
-N > 1 (config 4): one process per GPU, each an independent lambda replica of the same box
-(lambda index = rank mod 11); no data-path collective, RCCL only for init/barrier/timing -> weak scaling.
+N > 1: `python bench.py --gpus N` starts the N ranks itself (torch.distributed.run, one process per GPU, RCCL);
+under a launcher that has already set RANK / WORLD_SIZE it is one of the ranks.  Default (BASELINE configs[3]):
+every rank an independent lambda replica of the same box (window = rank mod 11), no data-path collective ->
+weak scaling.  --dd (configs[4]): one box decomposed over the ranks on a 3-D domain grid with a halo exchange
+(gromacs-fep-gpu_amd/domdec.py) -> strong scaling.
+
+The product legs (everything but `cpu_baseline`) use only gromacs-fep-gpu_amd/ (libnbnxm_hip.so, libnbnxm_host.so);
+the CPU baseline leg alone loads the oracle.
 """
 import argparse
 import json
-import math
 import os
+import socket
+import subprocess
 import sys
 import time
 
-import numpy as np
-
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8 TB/s
 FP32_PEAK_TFLOPS = 157.3   # vector fp32
 DT_FS = 2.0                # MD time step for the kernel-bound ns/day figure
 METRIC = "ns/day + pair-interactions/s, 100k-atom FEP box @ λ=0.5, 1/2/4/8 MI355X"
+COUNTERS_FILE = os.path.join("profiles", "r02", "counters_fused_force_kernel.json")   # written by tools/summarize_counters.py
 
 
-def list_statistics(pl):
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=500)
+    ap.add_argument("--warmup", type=int, default=50)
+    ap.add_argument("--mode", choices=["fused", "split"], default="fused")
+    ap.add_argument("--atoms", choices=["24k", "96k", "768k"], default="96k")
+    ap.add_argument("--elec", choices=["ewald", "rf"], default="ewald", help="rf: BASELINE configs[1] (with --atoms 24k)")
+    ap.add_argument("--max-cjpacked-per-sci", type=int, default=16)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-prune", action="store_true")
+    ap.add_argument("--primary-only", action="store_true",
+                    help="skip the secondary figures (energy / dH/dl / virial steps, MD loops): the profile of such a run holds "
+                         "the force-only kernels of the timed loop and nothing else")
+    ap.add_argument("--perturbed-molecules", type=int, default=-1, help="override the ligand size (diagnostics)")
+    ap.add_argument("--dd", action="store_true",
+                    help="N > 1: one box decomposed over the ranks with a halo exchange (config 5, strong scaling) "
+                         "instead of the default independent lambda replicas (config 4, weak scaling)")
+    ap.add_argument("--dd-grid", default="", help="domain grid of --dd as AxBxC (default: 2x2x2 for 8 ranks, else slabs)")
+    return ap.parse_args(argv)
+
+
+# ---- N > 1 from one command: the parent starts the ranks and never touches a GPU itself ----------------------------
+
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def launch_ranks(args, argv):
+    """`python bench.py --gpus N` without a launcher: N fresh rank processes under torch.distributed.run (which sets
+    RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*), rank 0's JSON line forwarded, exit code of the job returned.  Runs before
+    torch is imported: this process never initialises a GPU (a process that has must not exec or fork ranks)."""
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // args.gpus)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(free_port()), os.path.abspath(__file__)] + list(argv)
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, env=env, text=True)
+    line = None
+    for out in proc.stdout:
+        s = out.strip()
+        if s.startswith("{") and '"metric"' in s:
+            line = s
+        else:
+            sys.stderr.write(out)
+    rc = proc.wait()
+    if line is not None:
+        rec = json.loads(line)
+        if rec.get("n_gpus") != args.gpus:
+            sys.stderr.write("bench.py: the ranks report n_gpus %r, asked for %d\n" % (rec.get("n_gpus"), args.gpus))
+            rc = rc or 1
+        print(line, flush=True)
+    elif rc == 0:
+        sys.stderr.write("bench.py: the ranks printed no result line\n")
+        rc = 1
+    return rc
+
+
+# ---- list statistics and byte counts ---------------------------------------------------------------------------------
+
+def list_statistics(sci, cjPacked):
     """Counts used for the algorithmic-byte and pair figures."""
-    imask = pl.cjPacked["imei"][:, 0]["imask"]
-    cluster_pairs = int(sum(bin(int(m)).count("1") for m in imask))
+    import numpy as np
+    imask = np.ascontiguousarray(cjPacked["imei"][:, 0]["imask"])
+    cluster_pairs = int(np.unpackbits(imask.view(np.uint8)).sum())
     cj_slots = 0
     for sh in range(4):
         cj_slots += int(np.count_nonzero((imask >> (8 * sh)) & 0xFF))
-    used_excl = np.unique(pl.cjPacked["imei"]["excl_ind"])
-    return dict(nsci=len(pl.sci), ncjPacked=len(pl.cjPacked), cj_slots=cj_slots, cluster_pairs=cluster_pairs,
-                nexcl=int(len(used_excl)))
+    used_excl = np.unique(cjPacked["imei"]["excl_ind"])
+    return dict(nsci=len(sci), ncjPacked=len(cjPacked), cj_slots=cj_slots, cluster_pairs=cluster_pairs, nexcl=int(len(used_excl)))
 
 
 def host_cores():
@@ -76,118 +145,105 @@ def algorithmic_bytes(stats, fused, fep_nri=0, fep_nrj=0):
     return b, b_fep
 
 
-def run_domain_decomposition(args, rank, world, dist, torch, tl, nm, npert):
-    """--dd: the box is decomposed into `world` slabs (gromacs-fep-gpu_amd/domdec.py); a step = halo x (pack, RCCL
-    point-to-point, unpack), x -> xq, fused cluster kernel on the rank's share of the list, force reduction, halo f.
-    value = pair interactions of the WHOLE list per second (strong scaling)."""
+def committed_counters(fused, args):
+    """PMC-derived figures of the dominant kernel from the committed rocprofv3 summary (separate --pmc passes of this same
+    command, tools/gpu_pmc.sh + tools/gpu_traffic.sh -> tools/summarize_counters.py).  NOT measured in this run: the record
+    says so (`source`, with the commit the profile was taken at)."""
+    path = os.path.join(ROOT, COUNTERS_FILE)
+    if not (fused and args.atoms == "96k" and args.elec == "ewald" and args.perturbed_molecules < 0 and os.path.exists(path)):
+        return None
+    try:
+        rec = json.load(open(path))
+    except Exception:
+        return None
+    rec["source"] = "%s (profiled at commit %s; not measured in this run)" % (COUNTERS_FILE, rec.get("commit", "?"))
+    return rec
+
+
+# ---- the ranks -------------------------------------------------------------------------------------------------------
+
+def dry_run(args, rank, world, dist):
+    """BENCH_DRY_RUN=1: the launcher, the rendezvous, the barriers and the JSON contract without any GPU work (CPU test
+    of the N > 1 start-up path).  The numbers of such a line mean nothing and it says so."""
     import importlib
-    pkg = tl.pkg
-    domdec = importlib.import_module("gromacs_fep_gpu_amd.domdec")
-    t0 = time.time()
-    case = tl.make_case(nm=nm, num_perturbed_molecules=npert, elec="ewald", seed=2026, n_lambda=11)
-    dd = domdec.SlabDecomposition(case.grid, case.plist_fused, world)
-    plan = dd.plan(rank)
-    t_build = time.time() - t0
-    nb = tl.setup_gpu(case, fused=True, use_dynamic_pruning=not args.no_prune,
-                      list_override=(plan.sci, plan.cjPacked, case.plist_fused.excl))
-    halo = domdec.HaloExchange(plan, "cuda")
-    st = domdec.DomainStep(nb, case.grid, plan, halo)
-    g = case.grid
-    real = g.atomIndices >= 0
-    x = np.zeros((case.natoms, 3), np.float32)
-    x[g.atomIndices[real]] = g.xq.reshape(-1, 4)[real, :3]
-    st.d_x.copy_(torch.from_numpy(x))
-    comm = domdec.TorchDistComm(dist)
-    sw = pkg.step_workload(energy=False, virial=False, dhdl=False)
-    for _ in range(1 + args.warmup):
-        st.step(comm, sw)
-    torch.cuda.synchronize()
-    cj_dev = pkg.download_cjpacked(nb, len(plan.cjPacked))
-    my_pairs = torch.tensor([float(sum(bin(int(m)).count("1") for m in cj_dev["imei"][:, 0]["imask"]))], device="cuda",
-                            dtype=torch.float64)
-    dist.all_reduce(my_pairs)
-    dist.barrier()
-    torch.cuda.synchronize()
-    t_start = time.perf_counter()
-    for _ in range(args.steps):
-        st.step(comm, sw)
-    torch.cuda.synchronize()
-    dist.barrier()
-    elapsed = importlib.import_module("gromacs_fep_gpu_amd.replica").max_over_ranks(time.perf_counter() - t_start, dist, device="cuda")
+    replica = importlib.import_module("gromacs_fep_gpu_amd.replica")
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    if world > 1:
+        dist.barrier()
+    elapsed = replica.max_over_ranks(time.perf_counter() - t0, dist if world > 1 else None, device="cpu")
     if rank == 0:
-        pairs = 64.0 * float(my_pairs.item())
-        print(json.dumps({
-            "metric": METRIC, "value": pairs * args.steps / elapsed, "unit": "pair-interactions/s", "n_gpus": world,
-            "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
-            "scaling": "strong", "vs_baseline": None, "dtype": "f32",
-            "data": "synthetic (seeded SPC/E-like water box + 48-atom decoupled ligand)",
-            "config": {"workload": "configs[4]-style: %d-atom box decomposed into %d slabs, halo exchange over RCCL" % (case.natoms, world),
-                       "mode": "fused", "atoms": int(case.natoms), "cluster_pairs": int(my_pairs.item()),
-                       "halo_bytes_per_step_rank0": halo.bytes_per_step(), "parallelism": "dd%d" % world},
-            "ns_per_day_kernel_bound": 86400.0 / (elapsed / args.steps) * DT_FS * 1e-6,
-            "roofline": None, "host_list_build_s": t_build}))
-    nb.free()
-    dist.destroy_process_group()
+        print(json.dumps({"metric": METRIC, "value": 0.0, "unit": "pair-interactions/s", "n_gpus": world, "steps": args.steps,
+                          "warmup": args.warmup, "ms_per_step": 1e3 * elapsed, "higher_is_better": True, "scaling": "weak",
+                          "vs_baseline": None, "dtype": "f32", "data": "none", "dry_run": True,
+                          "rccl_ranks": dist.get_world_size() if world > 1 else 1,
+                          "config": {"workload": "dry run of the launch path: no GPU work"}}), flush=True)
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=500)
-    ap.add_argument("--warmup", type=int, default=50)
-    ap.add_argument("--mode", choices=["fused", "split"], default="fused")
-    ap.add_argument("--atoms", choices=["24k", "96k", "768k"], default="96k")
-    ap.add_argument("--elec", choices=["ewald", "rf"], default="ewald", help="rf: BASELINE configs[1] (with --atoms 24k)")
-    ap.add_argument("--max-cjpacked-per-sci", type=int, default=16)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-prune", action="store_true")
-    ap.add_argument("--primary-only", action="store_true",
-                    help="skip the secondary figures (energy / dH/dl / virial steps, MD loops): the profile of such a run holds "
-                         "the force-only kernels of the timed loop and nothing else")
-    ap.add_argument("--perturbed-molecules", type=int, default=-1, help="override the ligand size (diagnostics)")
-    ap.add_argument("--dd", action="store_true",
-                    help="N > 1: one box decomposed over the ranks with a halo exchange (config 5, strong scaling) "
-                         "instead of the default independent lambda replicas (config 4, weak scaling)")
-    args = ap.parse_args()
+def main(argv=None):
+    argv = sys.argv[1:] if argv is None else argv
+    args = parse_args(argv)
+    if args.gpus > 1 and "RANK" not in os.environ:
+        return launch_ranks(args, argv)
 
-    import torch
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU (there is no CPU fallback for the product path)")
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but the launcher started %d ranks" % (args.gpus, world))
     # BENCH_REHEARSAL_GLOO=1: all ranks on cuda:0 with the gloo backend, to walk through the N > 1 code path on a one-GPU box
     # (the numbers of such a run mean nothing)
     rehearsal = os.environ.get("BENCH_REHEARSAL_GLOO") == "1"
-    torch.cuda.set_device(0 if rehearsal else local_rank)
-    reduce_device = "cpu" if rehearsal else "cuda"
+    dry = os.environ.get("BENCH_DRY_RUN") == "1"
+    import torch
+    dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    if dry:
+        if world > 1:
+            dist.init_process_group("gloo")
+        from __graft_entry__ import load_package
+        load_package()
+        dry_run(args, rank, world, dist)
+        if world > 1:
+            dist.destroy_process_group()
+        return 0
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (there is no CPU fallback for the product path)")
+    torch.cuda.set_device(0 if rehearsal else local_rank)
+    reduce_device = "cpu" if rehearsal else "cuda"
+    if world > 1:
         dist.init_process_group("gloo" if rehearsal else "nccl")   # nccl = RCCL
+    rccl_ranks = dist.get_world_size() if world > 1 else 1
 
-    import fep_testlib as tl
-    pkg = tl.pkg
+    import importlib
+    import numpy as np
+    from __graft_entry__ import load_package
+    pkg = load_package()
+    wl = importlib.import_module("gromacs_fep_gpu_amd.workload")
+    replica = importlib.import_module("gromacs_fep_gpu_amd.replica")
 
     nm = {"24k": (20, 20, 20), "96k": (40, 40, 20), "768k": (80, 80, 40)}[args.atoms]
     npert = {"24k": 3, "96k": 16, "768k": 16}[args.atoms]
     if args.perturbed_molecules >= 0:
         npert = args.perturbed_molecules
-    import importlib
-    replica = importlib.import_module("gromacs_fep_gpu_amd.replica")
-    lam = replica.replica_lambda(rank, world)   # 0.5 on one GPU; window rank mod 11 in the replica set (config 4)
     if args.dd and world > 1:
-        run_domain_decomposition(args, rank, world, dist, torch, tl, nm, npert)
-        return
+        bench_dd = importlib.import_module("gromacs_fep_gpu_amd.bench_dd")
+        bench_dd.run(args, rank, world, dist, torch, nm, npert, METRIC, DT_FS, rehearsal, rccl_ranks)
+        return 0
+    lam = replica.replica_lambda(rank, world)   # 0.5 on one GPU; window rank mod 11 in the replica set (config 4)
     t0 = time.time()
-    case = tl.make_case(nm=nm, num_perturbed_molecules=npert, elec=args.elec, seed=2026, n_lambda=11,
+    case = wl.make_case(nm=nm, num_perturbed_molecules=npert, elec=args.elec, seed=2026, n_lambda=11,
                         lambda_coul=lam, lambda_vdw=lam, max_cjpacked_per_sci=args.max_cjpacked_per_sci)
     t_build = time.time() - t0
     fused = args.mode == "fused"
-    nb = tl.setup_gpu(case, fused=fused, use_dynamic_pruning=not args.no_prune)
-    nb.set_timing(False)   # the timed loop runs without the HIP-event regions: they cost ~15 us per step in stream bubbles
+    nb = wl.setup_gpu(case, fused=fused, use_dynamic_pruning=not args.no_prune)
+    nb.set_timing(False)   # no per-launch HIP-event regions anywhere in this file: they cost ~15 us per step in stream bubbles
     pl = case.plist_fused if fused else case.plist
     sw_f = pkg.step_workload(energy=False, virial=False, dhdl=False)
+    kernel_stream = torch.cuda.ExternalStream(nb.stream())   # the stream the library launches on (not torch's current one)
 
     def one_step():
         nb.clear_outputs(False)
@@ -197,41 +253,31 @@ def main():
     one_step()
     torch.cuda.synchronize()
     cj_dev = pkg.download_cjpacked(nb, len(pl.cjPacked))
-    import copy
-    pruned = copy.copy(pl)
-    pruned.cjPacked = cj_dev
-    stats = list_statistics(pruned)
+    stats = list_statistics(pl.sci, cj_dev)
     for _ in range(args.warmup):
         one_step()
     torch.cuda.synchronize()
-    nb.reset_timings()
 
+    # the timed region: K steps between barrier + synchronize on both sides; ONE HIP-event pair on the kernel's own stream
+    # around the same K launches gives the device-side time of the loop (kernel durations + launch gaps): it cannot exceed
+    # the wall time of the loop
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t_start = time.perf_counter()
+    ev0.record(kernel_stream)
     for _ in range(args.steps):
         one_step()
+    ev1.record(kernel_stream)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     elapsed = time.perf_counter() - t_start
     if world > 1:
         elapsed = replica.max_over_ranks(elapsed, dist, device=reduce_device)
-
-    # kernel durations: a second, instrumented pass of the same steps with HIP events on the kernel's own stream
-    # (inside the C-ABI library, nbnxm_gpu_set_timing); not part of the timed loop above
-    nb.set_timing(True)
-    nb.reset_timings()
-    for _ in range(max(20, min(args.steps, 100))):
-        one_step()
-    f = np.zeros((case.grid.num_atoms, 3), np.float32)
-    nb.launch_cpyback(f, sw_f)
-    nb.wait_finish_task(sw_f, case.have_soft_core)
-    tm = nb.get_timings()
-    nb.set_timing(False)
-    nb_k_us = 1e3 * tm.nb_k_ms / max(1, tm.nb_k_count)
-    fep_k_us = 1e3 * tm.fep_k_ms / max(1, tm.fep_k_count) if tm.fep_k_count else 0.0
+    nb_k_us = 1e3 * ev0.elapsed_time(ev1) / args.steps   # per launch, device side, inside the timed loop
+    fep_k_us = 0.0                                       # fused: the perturbed pairs ride in the same launch
 
     # secondary figures (not part of `value`): an energy+virial step and a dH/dlambda step with 11 foreign lambdas
     def timed(sw, n=20):
@@ -294,7 +340,7 @@ def main():
     if fused and world == 1 and not args.primary_only and args.atoms != "768k":
         R = 11
         b = replica.batch_windows(case.grid, pl, R)
-        nbw = pkg.NbnxmGpu(tl.gpu_interaction_params(case, not args.no_prune), case.grid.num_types, case.grid.nbat_nbfp(case.sys["nbfp"]),
+        nbw = pkg.NbnxmGpu(wl.gpu_interaction_params(case, not args.no_prune), case.grid.num_types, case.grid.nbat_nbfp(case.sys["nbfp"]),
                            fep=True, n_lambda=0)
         sig6 = case.sc_sigma ** 6
         nbw.copy_fepparams(case.sc_alpha if case.sc_coul else 0.0, case.sc_alpha, case.sc_power, sig6, sig6 if case.sc_coul else 0.0, 0.5, 0.5)
@@ -327,25 +373,18 @@ def main():
     fep_pairs = len(case.plist.fep["jjnr"])
     pairs_per_step = pair_evals + (0 if fused else fep_pairs)
     value = replica.aggregate_throughput(pairs_per_step, args.steps, elapsed, world)
+    useful_pairs = wl.count_pairs_within(case) if rank == 0 else 0   # r < rc, not excluded, each pair once (host count)
     ns_per_day = world * 86400.0 / (elapsed / args.steps) * DT_FS * 1e-6
     bytes_nb, bytes_fep = algorithmic_bytes(stats, fused, len(case.plist.fep["iinr"]), fep_pairs)
     achieved = bytes_nb / (nb_k_us * 1e-6) / 1e9 if nb_k_us > 0 else 0.0
-
-    # HBM bytes per launch of the dominant kernel from rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE; separate runs of this
-    # same command, tools/gpu_traffic.sh; FETCH_SIZE doubled as MI355X_MICROARCH.md §HBM prescribes for gfx950)
-    traffic = None
-    tpath = os.path.join(ROOT, "profiles", "r01", "i_traffic_fused.json")
-    if fused and args.atoms == "96k" and args.elec == "ewald" and args.perturbed_molecules < 0 and os.path.exists(tpath):
-        try:
-            traffic = json.load(open(tpath)).get("hbm_bytes_per_launch_corrected")
-        except Exception:
-            traffic = None
+    counters = committed_counters(fused, args)
 
     out = {
         "metric": METRIC, "value": value, "unit": "pair-interactions/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
         "data": "synthetic (seeded SPC/E-like water box + 48-atom decoupled ligand)",
+        "rccl_ranks": rccl_ranks,
         "config": {"workload": "configs[2]: 96k-atom water + 48 perturbed atoms, Ewald(analytical) + LJ cut, rc 1.0, rlist 1.1, lambda 0.5"
                    if (args.atoms == "96k" and args.elec == "ewald") else "%s-atom box, %s" % (args.atoms, args.elec),
                    "mode": args.mode, "atoms": int(case.natoms), "perturbed_atoms": int(case.perturbed.sum()),
@@ -353,67 +392,81 @@ def main():
                    "fep_pairs": fep_pairs, "max_cjpacked_per_sci": args.max_cjpacked_per_sci,
                    "parallelism": "1 lambda replica per GPU" if world > 1 else "single GPU"},
         "ns_per_day_kernel_bound": ns_per_day,
-        "kernel_us": {"k_calc_nb": nb_k_us, "k_calc_nb_fep": fep_k_us},
+        # pairs with r < rc (what the physics needs) next to the pairs the list makes the kernel evaluate (`value`)
+        "useful_pairs_per_step": useful_pairs,
+        "useful_pair_interactions_per_s": world * useful_pairs * args.steps / elapsed,
+        # device-side time per launch of the timed loop itself: one HIP-event pair on the kernel's stream around the K launches
+        "kernel_us": {"k_calc_nb": nb_k_us, "k_calc_nb_fep": fep_k_us, "how": "HIP events around the timed loop on the kernel's stream / steps"},
         "ms_per_energy_step": ms_energy_step, "ms_per_dhdl_step_11_foreign_lambdas": ms_dhdl_step,
         "ms_per_virial_only_step": ms_virial_only, "ms_per_energy_only_step": ms_energy_only,
         "ms_per_gpu_resident_md_step": ms_md_step, "ms_per_gpu_resident_md_step_unfused_update": ms_md_step_sequence,
         "ms_per_gpu_resident_md_step_with_rolling_prune_8": ms_md_step_prune,
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                     "frac": achieved / HBM_PEAK_GBS,
+                     "traffic": counters.get("hbm_bytes_per_launch_corrected") if counters else None,
+                     "traffic_source": counters["source"] if counters else None,
                      "kernel": "nbnxmKernel<%s,LJcut,F,%s>" % ("EwaldAna" if args.elec == "ewald" else "RF", "fused" if fused else "plain"),
                      "algorithmic_bytes_per_launch": bytes_nb,
                      "fp32_valu_frac_estimate": (pair_evals * 45.0 / (nb_k_us * 1e-6) / 1e12 / FP32_PEAK_TFLOPS)
                      if nb_k_us > 0 else None},
+        "counters": ({"lds_bank_conflict_frac": counters.get("lds_bank_conflict_frac"), "valu_issue_frac": counters.get("valu_issue_frac"),
+                      "active_lanes_per_valu_instruction": counters.get("active_lanes_per_valu_instruction"),
+                      "source": counters["source"]} if counters else None),
         "lambda_windows_batched": batched,
         "host_list_build_s": t_build,
     }
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        # CPU baseline (kind "port") of the same step on the host cores this process may use, bounded to ~10 s: the cluster-pair
-        # part through the SIMD port of the oracle's kernel (oracle/nbnxm_simd.c: 8-wide, rational Ewald correction — the shape
-        # of the reference's CPU kernels), the perturbed pairs through the scalar FEP oracle; the all-scalar oracle where the
-        # CPU has no AVX2 + FMA.
-        import oracle_binding as ob
-        cj_pruned_carved = case.plist.cjPacked.copy()
-        ob.nbnxm_prune(case.plist.sci, cj_pruned_carved, case.grid.xq, case.grid.shift_vec, case.rlist)
-        cstats = list_statistics(type("P", (), {"cjPacked": cj_pruned_carved, "sci": case.plist.sci})())
-        cores = host_cores()
-        g = case.grid
-        ref_p, nbfp_grid, fep_p = tl.oracle_ref_params(case), g.nbat_nbfp(case.sys["nbfp"]), tl.oracle_fep_params(case)
-
-        def cpu_step_simd():
-            f = ob.nbnxm_simd(case.plist.sci, cj_pruned_carved, case.plist.excl, g.xq, g.type, g.num_types, nbfp_grid, ref_p, g.shift_vec,
-                              num_threads=cores)
-            if f is None:
-                return None
-            ob.fep_kernel(case.plist.fep, g.x_wrapped, case.ntype, fep_p, g.shift_vec, case.sys["nbfp"], None, case.sys["qA"], case.sys["qB"],
-                          case.sys["typeA"], case.sys["typeB"], ob.DO_FORCE, case.lambda_coul, case.lambda_vdw, "f32")
-            return f
-
-        def cpu_step_scalar():
-            return tl.run_oracle(case, energy=False, precision="f32", cjPacked=cj_pruned_carved, num_threads=cores)
-
-        simd = cpu_step_simd() is not None      # also the warm-up
-        cpu_step = cpu_step_simd if simd else cpu_step_scalar
-        cpu_step()
-        n_pass, t_cpu = 0, 0.0
-        while t_cpu < 10.0 and n_pass < 1000:
-            t1 = time.perf_counter()
-            cpu_step()
-            t_cpu += time.perf_counter() - t1
-            n_pass += 1
-        cpu_pairs = 64 * cstats["cluster_pairs"] + fep_pairs
-        out["cpu_baseline"] = {"value": cpu_pairs * n_pass / t_cpu, "unit": "pair-interactions/s", "cores": cores,
-                               "kind": "port",
-                               "sample": "%d full passes of the same 96k-atom step (pruned cluster list on %d OpenMP threads, %s; "
-                                         "FEP list scalar), f32, %.1f s"
-                                         % (n_pass, cores, "8-wide SIMD port of the oracle kernel" if simd else "scalar C oracle", t_cpu)}
+        out["cpu_baseline"] = cpu_baseline(case, fep_pairs)
     nb.free()
     if rank == 0:
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
+    return 0
+
+
+def cpu_baseline(case, fep_pairs):
+    """CPU baseline (kind "port") of the same step on the host cores this process may use, bounded to ~10 s: the cluster-pair
+    part through the SIMD port of the oracle's kernel (oracle/nbnxm_simd.c: 8-wide, rational Ewald correction — the shape
+    of the reference's CPU kernels), the perturbed pairs through the scalar FEP oracle; the all-scalar oracle where the
+    CPU has no AVX2 + FMA.  The ONLY leg of this file that loads the oracle (test infrastructure)."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import fep_testlib as tl
+    import oracle_binding as ob
+    cj_pruned_carved = case.plist.cjPacked.copy()
+    ob.nbnxm_prune(case.plist.sci, cj_pruned_carved, case.grid.xq, case.grid.shift_vec, case.rlist)
+    cstats = list_statistics(case.plist.sci, cj_pruned_carved)
+    cores = host_cores()
+    g = case.grid
+    ref_p, nbfp_grid, fep_p = tl.oracle_ref_params(case), g.nbat_nbfp(case.sys["nbfp"]), tl.oracle_fep_params(case)
+
+    def cpu_step_simd():
+        f = ob.nbnxm_simd(case.plist.sci, cj_pruned_carved, case.plist.excl, g.xq, g.type, g.num_types, nbfp_grid, ref_p, g.shift_vec,
+                          num_threads=cores)
+        if f is None:
+            return None
+        ob.fep_kernel(case.plist.fep, g.x_wrapped, case.ntype, fep_p, g.shift_vec, case.sys["nbfp"], None, case.sys["qA"], case.sys["qB"],
+                      case.sys["typeA"], case.sys["typeB"], ob.DO_FORCE, case.lambda_coul, case.lambda_vdw, "f32")
+        return f
+
+    def cpu_step_scalar():
+        return tl.run_oracle(case, energy=False, precision="f32", cjPacked=cj_pruned_carved, num_threads=cores)
+
+    simd = cpu_step_simd() is not None      # also the warm-up
+    cpu_step = cpu_step_simd if simd else cpu_step_scalar
+    cpu_step()
+    n_pass, t_cpu = 0, 0.0
+    while t_cpu < 10.0 and n_pass < 1000:
+        t1 = time.perf_counter()
+        cpu_step()
+        t_cpu += time.perf_counter() - t1
+        n_pass += 1
+    cpu_pairs = 64 * cstats["cluster_pairs"] + fep_pairs
+    return {"value": cpu_pairs * n_pass / t_cpu, "unit": "pair-interactions/s", "cores": cores, "kind": "port",
+            "sample": "%d full passes of the same %d-atom step (pruned cluster list on %d OpenMP threads, %s; FEP list scalar), f32, %.1f s"
+                      % (n_pass, case.natoms, cores, "8-wide SIMD port of the oracle kernel" if simd else "scalar C oracle", t_cpu)}
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

@@ -122,7 +122,8 @@ HOST_SYMBOLS = [
     "nbnxm_host_grid_num_atoms", "nbnxm_host_grid_num_clusters", "nbnxm_host_grid_get",
     "nbnxm_host_grid_update_xq", "nbnxm_host_shift_vectors", "nbnxm_host_pairlist_build",
     "nbnxm_host_pairlist_free", "nbnxm_host_pairlist_sizes", "nbnxm_host_pairlist_get",
-    "nbnxm_host_pairlist_get_fep", "nbnxm_host_abi_version",
+    "nbnxm_host_pairlist_get_fep", "nbnxm_host_abi_version", "nbnxm_host_count_pairs_within",
+    "nbnxm_host_calc_ewaldcoeff_q", "nbnxm_host_calc_ewaldcoeff_lj",
 ]
 
 _hip = None
@@ -264,9 +265,13 @@ class Grid:
                         rlist if rlist_fep is None else rlist_fep)
 
     def __del__(self):
-        if getattr(self, "_h", None):
-            host_lib().nbnxm_host_grid_free(C.c_void_p(self._h))
-            self._h = None
+        # at interpreter shutdown module globals may already be gone: the process is ending, nothing to free
+        try:
+            if getattr(self, "_h", None):
+                host_lib().nbnxm_host_grid_free(C.c_void_p(self._h))
+                self._h = None
+        except Exception:
+            pass
 
 
 class Pairlist:
@@ -528,16 +533,16 @@ class NbnxmGpu:
     def reset_timings(self):
         self._lib.nbnxm_gpu_reset_timings(self.h)
 
-    def stream(self, iloc=LOCAL):
-        return self._lib.nbnxm_gpu_get_stream(self.h, C.c_int(iloc))
-
     def free(self):
         if getattr(self, "_h", None):
             self._lib.nbnxm_gpu_free(self.h)
             self._h = None
 
     def __del__(self):
-        self.free()
+        try:
+            self.free()
+        except Exception:
+            pass
 
 
 def download_cjpacked(nb, ncj, iloc=LOCAL):

@@ -595,8 +595,9 @@ NB_DEVINL bool fepPair(const NBParamGpu& nbp,
             float       f_lr = 0.0F;
             if constexpr (FORCE)
             {
-                if constexpr (ELEC == ELK_EWALD_ANA) { f_lr = -pmeCorrF(beta * beta * r2) * beta * beta * beta; }
-                else { f_lr = interpolateCoulombForceR(nbp, r) * rInv; }
+                /* analytical in the tabulated flavours too: the CPU free-energy kernel this path is checked against has no table
+                 * (nb_free_energy.cpp:1064-1068, pmeForceCorrection); the reference's CUDA kernel interpolates its table here */
+                f_lr = -pmeCorrF(beta * beta * r2) * beta * beta * beta;
             }
             float v_lr = 0.0F;
             if constexpr (ENERGY)

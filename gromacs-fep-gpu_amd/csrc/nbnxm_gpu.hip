@@ -264,6 +264,7 @@ NbnxmGpu* nbnxm_gpu_init(const nbnxm_interaction_params_t* ic, int numTypes, con
         nb->deviceStreams[1].init(nonLocalStream);
         NBNXM_HIP_CHECK(hipEventCreateWithFlags(&nb->nonlocal_done, hipEventDisableTiming));
         NBNXM_HIP_CHECK(hipEventCreateWithFlags(&nb->misc_ops_and_local_H2D_done, hipEventDisableTiming));
+        NBNXM_HIP_CHECK(hipEventCreateWithFlags(&nb->nonlocalKernelDone, hipEventDisableTiming));
     }
     for (auto& t : nb->timers)
     {
@@ -447,6 +448,7 @@ void nbnxm_gpu_free(NbnxmGpu* nb)
     }
     if (nb->nonlocal_done) { (void)hipEventDestroy(nb->nonlocal_done); }
     if (nb->misc_ops_and_local_H2D_done) { (void)hipEventDestroy(nb->misc_ops_and_local_H2D_done); }
+    if (nb->nonlocalKernelDone) { (void)hipEventDestroy(nb->nonlocalKernelDone); }
     for (int i = 0; i < 2; i++)
     {
         if (nb->fepStreams[i].stream) { (void)hipStreamSynchronize(nb->fepStreams[i].stream); }
@@ -652,6 +654,7 @@ void nbnxm_gpu_init_pairlist(NbnxmGpu* nb, int iloc, int na_c, int nsci, const n
     d->workRangesDirty        = true;
     d->slowListDirty          = true;
     d->haveFreshList          = true;
+    d->firstPruneDone         = false;
     d->rollingPruningNumParts = 0;
     d->rollingPruningPart     = 0;
     d->pendingPrunePart       = -1;
@@ -890,8 +893,10 @@ static void updateWorkPartition(NbnxmGpu* nb, int iloc)
     const bool fused     = nb->fusedFep && nb->nbparam->bFEP && nb->atdat->fepBits != nullptr;
     const bool buildSlow = fused && d->slowListDirty;
     if (buildSlow) { clearDeviceBufferAsync(&d->slowCount, 0, 1, s); }
+    /* a list that has been through its first prune: the working masks are inner-pruned, the outer-pruned ones are in d->imask */
+    const unsigned* outerMask = (!d->haveFreshList && d->firstPruneDone) ? d->imask : nullptr;
     hipLaunchKernelGGL(nbnxmWorkWeightKernel, dim3(numBlocks), dim3(c_workBlockSize), 0, s, d->cjPacked, d->ncjPacked, d->sciSorted,
-                       d->nsci, fused ? nb->atdat->fepBits : nullptr, buildSlow ? 1 : 0, d->groupSlowMask, d->slowPairs, d->slowPairSci,
+                       d->nsci, fused ? nb->atdat->fepBits : nullptr, buildSlow ? 1 : 0, outerMask, d->groupSlowMask, d->slowPairs, d->slowPairSci,
                        d->slowPairs_nalloc, d->slowCount, d->groupWeight, d->weightBlockSum);
     hipLaunchKernelGGL(nbnxmWorkScanKernel, dim3(1), dim3(c_workBlockSize), 0, s, d->weightBlockSum, numBlocks);
     NBNXM_HIP_CHECK(hipGetLastError());
@@ -1006,6 +1011,7 @@ void nbnxm_gpu_launch_kernel_pruneonly(NbnxmGpu* nb, int iloc, int numParts)
     if (plist->haveFreshList)
     {
         plist->haveFreshList   = false;
+        plist->firstPruneDone  = true;
         plist->workRangesDirty = true; /* the masks changed: re-balance */
         t.didPrune             = true;
     }
@@ -1174,8 +1180,15 @@ void nbnxm_gpu_launch_kernel(NbnxmGpu* nb, const nbnxm_step_workload_t* stepWork
         plist->pendingPrunePart  = -1;
         /* the force flavour zeroes the spare force buffer for the next step (nbnxm_gpu_clear_outputs swaps) */
         int clearNumFloat4 = 0;
-        if (nb->fDoubleBuffer && !energyFlavour && (3 * adat->numAtoms) % 4 == 0)
+        /* Only the LOCAL launch does it: with two localities both kernels add to the buffer in use, and the buffer being zeroed
+         * is the one the previous step's kernels wrote — the local stream has to be behind the previous NON-LOCAL kernel too,
+         * whatever the caller's copy-back / reduction schedule was (nonlocalKernelDone). */
+        if (nb->fDoubleBuffer && !energyFlavour && (3 * adat->numAtoms) % 4 == 0 && iloc == NBNXM_LOCAL)
         {
+            if (nb->bUseTwoStreams && nb->nonlocalKernelRecorded)
+            {
+                NBNXM_HIP_CHECK(hipStreamWaitEvent(s, nb->nonlocalKernelDone, 0));
+            }
             if (nb->fSpareAlloc < adat->numAtomsAlloc)
             {
                 freeDeviceBuffer(&nb->fSpare);
@@ -1196,6 +1209,11 @@ void nbnxm_gpu_launch_kernel(NbnxmGpu* nb, const nbnxm_step_workload_t* stepWork
                            clearNumFloat4);
         NBNXM_HIP_CHECK(hipGetLastError());
         if (nb->bDoTime) { t.nb_k.closeTimingRegion(s); }
+        if (iloc == NBNXM_NONLOCAL && nb->fDoubleBuffer)
+        {
+            NBNXM_HIP_CHECK(hipEventRecord(nb->nonlocalKernelDone, s));
+            nb->nonlocalKernelRecorded = true;
+        }
     }
     plist->haveFreshList = false;
 

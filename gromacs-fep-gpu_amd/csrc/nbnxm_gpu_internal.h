@@ -70,6 +70,8 @@ struct NbnxmGpu
     bool           fepConcurrentFused          = false; /* fused mode: perturbed-cluster-pair kernel on the FEP stream */
     hipEvent_t     nonlocal_done               = nullptr;
     hipEvent_t     misc_ops_and_local_H2D_done = nullptr;
+    hipEvent_t     nonlocalKernelDone          = nullptr; /* after the last non-local cluster kernel (double-buffered forces) */
+    bool           nonlocalKernelRecorded      = false;
     bool           haveWork[2]                 = { false, false };
 
     bool                bDoTime = false;

@@ -180,6 +180,7 @@ struct gpu_plist
     int                excl_nalloc;
 
     bool haveFreshList;
+    bool firstPruneDone; /* host bookkeeping: the first-pass prune of this list has run, imask[] holds the outer-pruned masks */
     int  rollingPruningNumParts;
     int  rollingPruningPart;
     /* host bookkeeping: a rolling-prune part that waits for the next force-only launch to run in its trailing workgroups */

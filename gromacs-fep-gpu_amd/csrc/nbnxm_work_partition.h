@@ -64,6 +64,7 @@ __launch_bounds__(c_workBlockSize) __global__
                                    const int                             nsci,
                                    const unsigned char* __restrict__     fepBits, /* nullptr: not the fused mode */
                                    const int                             buildSlowList, /* 0: groupSlowMask is up to date */
+                                   const unsigned* __restrict__          outerMask, /* gpu_plist::imask of a list that has been pruned, else nullptr */
                                    unsigned* __restrict__                groupSlowMask,
                                    int* __restrict__                     slowPairs,   /* group * 32 + jm * 8 + i of every listed slow pair ... */
                                    int* __restrict__                     slowPairSci, /* ... and its i-entry: sci * 64 + shift index */
@@ -98,9 +99,10 @@ __launch_bounds__(c_workBlockSize) __global__
                 const unsigned m = (fepBits[cjPacked[g].cj[jm]] != 0) ? 0xFFU : iClusterMask;
                 slow |= m << (jm * c_numClPerSupercl);
             }
-            /* the list masks are those of the fresh, unpruned list here (the launcher builds this before the first prune),
-             * so the pairs are a superset of what any later pruning leaves */
-            unsigned  todo = slow & imask;
+            /* the pairs have to be a superset of what any later pruning leaves: the masks of the fresh list when the
+             * launcher builds this before the first prune; once the list has been pruned (a mode or fepBits change on a live
+             * list), the outer-pruned masks the rolling pass re-adds pairs from — the working mask is checked at run time */
+            unsigned  todo = slow & (outerMask != nullptr ? outerMask[g * NBNXM_GPU_CLUSTERPAIR_SPLIT] : imask);
             const int n    = __popc(todo);
             if (n > 0)
             {

@@ -264,6 +264,118 @@ void nbnxm_host_make_water_box(int nmx, int nmy, int nmz, double spacing, double
     }
 }
 
+/* ---- Ewald splitting parameters ------------------------------------------------------------ */
+
+} // extern "C"
+namespace
+{
+// smallest x >= 0 with tail(x) <= rtol for a tail function that decreases monotonically to 0
+template<typename Tail>
+double solveTail(Tail tail, double rtol)
+{
+    double hi = 1.0;
+    while (tail(hi) > rtol) { hi *= 2.0; }
+    double lo = 0.0;
+    for (int it = 0; it < 200 && hi - lo > 1e-16 * hi; it++)
+    {
+        const double mid = 0.5 * (lo + hi);
+        if (tail(mid) > rtol) { lo = mid; }
+        else { hi = mid; }
+    }
+    return 0.5 * (lo + hi);
+}
+} // namespace
+extern "C" {
+
+double nbnxm_host_calc_ewaldcoeff_q(double rc, double rtol)
+{
+    return solveTail([](double x) { return std::erfc(x); }, rtol) / rc;
+}
+
+double nbnxm_host_calc_ewaldcoeff_lj(double rc, double rtol)
+{
+    return solveTail([](double x) { const double x2 = x * x; return std::exp(-x2) * (1.0 + x2 + 0.5 * x2 * x2); }, rtol) / rc;
+}
+
+/* ---- pair count ----------------------------------------------------------------------------- */
+
+long long nbnxm_host_count_pairs_within(const NbnxmHostGrid* g, float rc, const int* exclIndex, const int* exclAtoms)
+{
+    // uniform cells of edge >= rc over the wrapped coordinates; every pair once (minimum image), excluded pairs taken out
+    const int   n = g->natoms;
+    int         nc[3];
+    float       cs[3];
+    for (int d = 0; d < 3; d++)
+    {
+        nc[d] = std::max(1, static_cast<int>(g->box[d] / rc));
+        cs[d] = g->box[d] / nc[d];
+    }
+    const int              ncell = nc[0] * nc[1] * nc[2];
+    std::vector<int>       cellOf(n), start(ncell + 1, 0), order(n);
+    for (int a = 0; a < n; a++)
+    {
+        int c[3];
+        for (int d = 0; d < 3; d++) { c[d] = std::min(nc[d] - 1, static_cast<int>(g->xw[3 * a + d] / cs[d])); }
+        cellOf[a] = (c[0] * nc[1] + c[1]) * nc[2] + c[2];
+        start[cellOf[a] + 1]++;
+    }
+    for (int c = 0; c < ncell; c++) { start[c + 1] += start[c]; }
+    {
+        std::vector<int> fill(start.begin(), start.end() - 1);
+        for (int a = 0; a < n; a++) { order[fill[cellOf[a]]++] = a; }
+    }
+    const float rc2   = rc * rc;
+    long long   count = 0;
+#pragma omp parallel for schedule(dynamic, 8) reduction(+ : count)
+    for (int c = 0; c < ncell; c++)
+    {
+        const int cx = c / (nc[1] * nc[2]), cy = (c / nc[2]) % nc[1], cz = c % nc[2];
+        // neighbour cells without duplicates (few cells per dimension: the same cell may be reached through several offsets)
+        std::vector<int> nbr;
+        for (int dx = -1; dx <= 1; dx++)
+        {
+            for (int dy = -1; dy <= 1; dy++)
+            {
+                for (int dz = -1; dz <= 1; dz++)
+                {
+                    const int o = (((cx + dx + nc[0]) % nc[0]) * nc[1] + (cy + dy + nc[1]) % nc[1]) * nc[2] + (cz + dz + nc[2]) % nc[2];
+                    if (std::find(nbr.begin(), nbr.end(), o) == nbr.end()) { nbr.push_back(o); }
+                }
+            }
+        }
+        for (int ia = start[c]; ia < start[c + 1]; ia++)
+        {
+            const int    a  = order[ia];
+            const float* xa = &g->xw[3 * a];
+            for (int o : nbr)
+            {
+                for (int ib = start[o]; ib < start[o + 1]; ib++)
+                {
+                    const int b = order[ib];
+                    if (b <= a) { continue; }
+                    float r2 = 0;
+                    for (int d = 0; d < 3; d++)
+                    {
+                        float dd = xa[d] - g->xw[3 * b + d];
+                        dd -= g->box[d] * std::nearbyint(dd / g->box[d]);
+                        r2 += dd * dd;
+                    }
+                    if (r2 < rc2)
+                    {
+                        bool excluded = false;
+                        if (exclIndex != nullptr)
+                        {
+                            for (int k = exclIndex[a]; k < exclIndex[a + 1] && !excluded; k++) { excluded = (exclAtoms[k] == b); }
+                        }
+                        if (!excluded) { count++; }
+                    }
+                }
+            }
+        }
+    }
+    return count;
+}
+
 /* ---- grid ---------------------------------------------------------------------------------- */
 
 NbnxmHostGrid* nbnxm_host_grid_create(int natoms, const float* x, const float* box, const float* qA,

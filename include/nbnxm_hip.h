@@ -71,6 +71,10 @@ enum nbnxm_locality
 };
 
 /* ---- pair-list element types (nbnxm/pairlist.h:198-280) ----------------------------------- */
+/* A translation unit that already sees the reference's own definitions of these four structs (nbnxm/pairlist.h — the
+ * integration shim) defines NBNXM_HIP_USE_REFERENCE_LIST_TYPES before including this header and passes the reference's
+ * objects as they are; integration/nbnxm_hip_shim.cpp static_asserts that their sizes are the ones laid out here. */
+#ifndef NBNXM_HIP_USE_REFERENCE_LIST_TYPES
 typedef struct
 {
     int sci;           /* i-super-cluster */
@@ -96,6 +100,7 @@ typedef struct
     /* word ((j & 3)*8 + i) of half (j >> 2); bit (jm*8 + ci): atom pair interacts */
     unsigned int pair[NBNXM_GPU_EXCL_SIZE];
 } nbnxn_excl_t;
+#endif /* NBNXM_HIP_USE_REFERENCE_LIST_TYPES */
 
 /* ---- parameters ---------------------------------------------------------------------------- */
 typedef struct { float c2, c3, cpot; } nbnxm_shift_consts_t;   /* mdtypes/interaction_const.h shift_consts_t */

@@ -60,6 +60,18 @@ void nbnxm_host_grid_update_xq(const NbnxmHostGrid* g, const float* x, float* xq
 /* 45 shift vectors for the box (pbcutil/pbc.cpp:1218-1233), 135 floats */
 void nbnxm_host_shift_vectors(const float* box, float* shiftVec);
 
+/* Number of interacting atom pairs within rc at the grid's (wrapped) coordinates: every pair once, minimum image, the
+ * topology exclusions (CSR as for the list builder, may be NULL) taken out — the "useful" pairs of the reference's
+ * benchmark (nbnxm/benchmark/bench_setup.cpp: the pair count of the plain-C kernel), next to the pairs a list makes a
+ * kernel evaluate. */
+long long nbnxm_host_count_pairs_within(const NbnxmHostGrid* g, float rc, const int* exclIndex, const int* exclAtoms);
+
+/* ---- Ewald splitting parameters -------------------------------------------------------------- */
+/* beta with erfc(beta rc) = rtol (ewald/ewald_utils.cpp:43-70, calc_ewaldcoeff_q) and the LJ-PME analogue with
+ * exp(-x^2) (1 + x^2 + x^4 / 2) = rtol, x = beta rc (:72-112, calc_ewaldcoeff_lj) */
+double nbnxm_host_calc_ewaldcoeff_q(double rc, double rtol);
+double nbnxm_host_calc_ewaldcoeff_lj(double rc, double rtol);
+
 /* ---- pair lists ---------------------------------------------------------------------------- */
 typedef struct NbnxmHostPairlist NbnxmHostPairlist;
 

@@ -563,6 +563,15 @@ static void eval_pair(const oracle_fep_params_t* p, const consts_t* c, int compu
     o->fscal = computeForces ? fscal : 0;
 }
 
+/* Test scale, not part of the kernel: sums of |V_coul|, |V_vdw|, |dV/dl_coul|, |dV/dl_vdw| over the pairs of the last call —
+ * the magnitude of the terms the energies and dV/dlambda of the perturbed pairs are summed from (what a relative
+ * tolerance on those sums has to be measured against). */
+static double FN(g_absSums)[4];
+void FN(oracle_fep_last_abs_sums)(double* out)
+{
+    for (int i = 0; i < 4; i++) { out[i] = FN(g_absSums)[i]; }
+}
+
 void FN(oracle_nb_free_energy_kernel)(int nri, const int* iinr, const int* jindex, const int* jjnr,
                                       const int* shift, const int* excl_fep, const real* x,
                                       int ntype, const oracle_fep_params_t* p, const real* shiftvec,
@@ -578,6 +587,7 @@ void FN(oracle_nb_free_energy_kernel)(int nri, const int* iinr, const int* jinde
     const int doPotential   = (flags & ORACLE_DO_POTENTIAL) != 0;
 
     real dvdlCoul = 0, dvdlVdw = 0;
+    double absSums[4] = { 0, 0, 0, 0 };
 
     for (int n = 0; n < nri; n++)
     {
@@ -618,6 +628,10 @@ void FN(oracle_nb_free_energy_kernel)(int nri, const int* iinr, const int* jinde
             vVdwTot += o.vVdw;
             dvdlCoul += o.dvdlCoul;
             dvdlVdw += o.dvdlVdw;
+            absSums[0] += fabs((double)o.vCoul);
+            absSums[1] += fabs((double)o.vVdw);
+            absSums[2] += fabs((double)o.dvdlCoul);
+            absSums[3] += fabs((double)o.dvdlVdw);
             if (computeForces && o.fscal != 0)
             {
                 const real tX = o.fscal * dX, tY = o.fscal * dY, tZ = o.fscal * dZ;
@@ -652,6 +666,7 @@ void FN(oracle_nb_free_energy_kernel)(int nri, const int* iinr, const int* jinde
     }
     dvdl[0] += dvdlCoul;
     dvdl[1] += dvdlVdw;
+    for (int i = 0; i < 4; i++) { FN(g_absSums)[i] = absSums[i]; }
 }
 
 /* Energies and dV/dlambda at the current lambda (index 0) and n_lambda foreign lambdas

@@ -72,6 +72,8 @@ double oracle_calc_ewaldcoeff_lj(double rc, double rtol);
                                                const int* typeA, const int* typeB, int flags,        \
                                                double lambdaCoul, double lambdaVdw, REAL* f,         \
                                                REAL* fshift, double* Vc, double* Vv, double* dvdl);  \
+    /* sums of |V_coul|, |V_vdw|, |dV/dl_coul|, |dV/dl_vdw| over the pairs of the last kernel call (test scale) */ \
+    void oracle_fep_last_abs_sums_##SUFFIX(double* out4);                                            \
     void oracle_fep_foreign_##SUFFIX(int nri, const int* iinr, const int* jindex, const int* jjnr,   \
                                      const int* shift, const int* excl_fep, const REAL* x,           \
                                      int ntype, const oracle_fep_params_t* p, const REAL* shiftvec,  \

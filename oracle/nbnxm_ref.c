@@ -63,6 +63,8 @@ void FN(oracle_nbnxm_ref)(int nsci, const nbnxn_sci_t* sci, const nbnxn_cj_packe
 {
     const int  ewald   = is_ewald(p->elecType);
     const int  twin    = (p->elecType == NBNXM_ELEC_EWALD_TAB_TWIN || p->elecType == NBNXM_ELEC_EWALD_ANA_TWIN);
+    const int  tabulated = (p->elecType == NBNXM_ELEC_EWALD_TAB || p->elecType == NBNXM_ELEC_EWALD_TAB_TWIN)
+                          && p->coulomb_tab != NULL;
     const int  ljEwald = (p->vdwType == NBNXM_VDW_EWALD_GEOM || p->vdwType == NBNXM_VDW_EWALD_LB);
     /* EXCLUSION_FORCES, nbnxm_cuda_kernel.cuh:69-78 */
     const int  exclForces = ewald || p->elecType == NBNXM_ELEC_RF || ljEwald
@@ -216,7 +218,20 @@ void FN(oracle_nbnxm_ref)(int nsci, const nbnxn_sci_t* sci, const nbnxn_cj_packe
                             if (ewald)
                             {
                                 const real b2 = beta * beta;
-                                F_invr += qq * (mask * inv_r2 * inv_r + (real)ref_pme_force_correction((double)(b2 * r2)) * b2 * beta);
+                                if (tabulated)
+                                {
+                                    /* kernel_gpu_ref.cpp:265-271: fexcl = (1 - frac) tab[ri] + frac tab[ri + 1] */
+                                    const real rs   = r * (real)p->coulomb_tab_scale;
+                                    int        ri   = (int)rs;
+                                    if (ri > p->coulomb_tab_size - 2) { ri = p->coulomb_tab_size - 2; }
+                                    const real frac = rs - (real)ri;
+                                    const real fexcl = ((real)1 - frac) * (real)p->coulomb_tab[ri] + frac * (real)p->coulomb_tab[ri + 1];
+                                    F_invr += qq * (mask * inv_r2 * inv_r - fexcl * inv_r);
+                                }
+                                else
+                                {
+                                    F_invr += qq * (mask * inv_r2 * inv_r + (real)ref_pme_force_correction((double)(b2 * r2)) * b2 * beta);
+                                }
                                 E_el = qq * (inv_r * (int_bit - (real)erf((double)(r * beta))) - int_bit * (real)p->sh_ewald);
                             }
                             else if (p->elecType == NBNXM_ELEC_RF)

@@ -32,6 +32,11 @@ typedef struct
     double disp_c2, disp_c3, disp_cpot; /* dispersion_shift */
     double rep_c2, rep_c3, rep_cpot;    /* repulsion_shift  */
     double sw_c3, sw_c4, sw_c5;         /* vdw_switch       */
+    /* tabulated Ewald flavours: the force table the GPU kernel is handed (EwaldCorrectionTables::tableF, spacing 1/scale),
+     * interpolated linearly as kernel_gpu_ref.cpp:265-271 / nbnxm_cuda_kernel_utils.cuh:448-459 do; NULL: analytical */
+    double       coulomb_tab_scale;
+    const float* coulomb_tab;
+    int          coulomb_tab_size;
 } nbnxm_ref_params_t;
 
 #define NBNXM_REF_DECL(SUFFIX, REAL)                                                                \

@@ -48,6 +48,7 @@ class RefParams(C.Structure):
         ("disp_c2", C.c_double), ("disp_c3", C.c_double), ("disp_cpot", C.c_double),
         ("rep_c2", C.c_double), ("rep_c3", C.c_double), ("rep_cpot", C.c_double),
         ("sw_c3", C.c_double), ("sw_c4", C.c_double), ("sw_c5", C.c_double),
+        ("coulomb_tab_scale", C.c_double), ("coulomb_tab", C.POINTER(C.c_float)), ("coulomb_tab_size", C.c_int),
     ]
 
 
@@ -116,7 +117,10 @@ def fep_kernel(nbl, x, ntype, p, shiftvec, nbfp, nbfp_grid, qA, qB, typeA, typeB
        C.c_int(ntype), C.byref(p), _ptr(sv), _ptr(nbfp_), _ptr(grid_), _ptr(qA_), _ptr(qB_),
        _ptr(tA), _ptr(tB), C.c_int(flags), C.c_double(lambda_coul), C.c_double(lambda_vdw),
        _ptr(f), _ptr(fshift), C.byref(Vc), C.byref(Vv), dvdl)
-    return dict(f=f, fshift=fshift, Vc=Vc.value, Vv=Vv.value, dvdl_coul=dvdl[0], dvdl_vdw=dvdl[1])
+    sums = (C.c_double * 4)()
+    getattr(lib(), "oracle_fep_last_abs_sums_" + precision)(sums)
+    return dict(f=f, fshift=fshift, Vc=Vc.value, Vv=Vv.value, dvdl_coul=dvdl[0], dvdl_vdw=dvdl[1],
+                abs_sums=dict(e_el=sums[0], e_lj=sums[1], dvdl_coul=sums[2], dvdl_vdw=sums[3]))
 
 
 def fep_foreign(nbl, x, ntype, p, shiftvec, nbfp, nbfp_grid, qA, qB, typeA, typeB, lambda_coul,

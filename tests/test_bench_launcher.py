@@ -1,0 +1,45 @@
+"""`python bench.py --gpus N` has to start its N ranks itself (the driver calls exactly that).  BENCH_DRY_RUN=1 walks through the
+launcher, the torch.distributed rendezvous (gloo here, RCCL on GPUs), the barriers and the one-JSON-line contract without any
+GPU work."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def run_bench(*argv, env_extra=None):
+    env = dict(os.environ, BENCH_DRY_RUN="1")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    env.update(env_extra or {})
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + list(argv), stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                       text=True, env=env, timeout=300)
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    return p, lines
+
+
+@pytest.mark.parametrize("n", [2, 3])
+def test_launcher_starts_n_ranks_and_prints_one_line(n):
+    p, lines = run_bench("--gpus", str(n), "--steps", "4", "--warmup", "1")
+    assert p.returncode == 0, p.stderr[-2000:]
+    assert len(lines) == 1
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == n and rec["rccl_ranks"] == n and rec["steps"] == 4 and rec["warmup"] == 1
+    for key in ("metric", "value", "unit", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config"):
+        assert key in rec
+
+
+def test_single_rank_needs_no_launcher():
+    p, lines = run_bench("--gpus", "1", "--steps", "2", "--warmup", "0")
+    assert p.returncode == 0, p.stderr[-2000:]
+    assert json.loads(lines[0])["n_gpus"] == 1
+
+
+def test_rank_count_mismatch_is_an_error():
+    # a launcher that started 1 rank for --gpus 2 must not produce a line labelled 2
+    p, lines = run_bench("--gpus", "2", env_extra={"RANK": "0", "WORLD_SIZE": "1", "LOCAL_RANK": "0"})
+    assert p.returncode != 0 and not lines
