@@ -170,7 +170,10 @@ __launch_bounds__(c_fepBlockSize) __global__
 
     const FepPairData d = loadFepPair(atdat, nbp, feplist, p);
 
-    __shared__ float red[c_fepBlockSize / c_waveSize][4];
+    /* wave sums of all lambda indices go to LDS, ONE block reduction at the end (dynamic LDS: waves x 4 x (n_lambda + 1) floats;
+     * the reference's kernel does 4 atomics per lambda index and 32-pair chunk, nbnxm_foreign_fep_cuda_kernel.cuh:560-580) */
+    extern __shared__ float red[];
+    const int               numTerms = 4 * (n_lambda + 1);
 
     for (int idx = 0; idx <= n_lambda; idx++)
     {
@@ -187,25 +190,25 @@ __launch_bounds__(c_fepBlockSize) __global__
         E_el    = waveSum(E_el);
         DVDL_lj = waveSum(DVDL_lj);
         DVDL_el = waveSum(DVDL_el);
-        __syncthreads(); /* red[] of the previous lambda has been consumed */
         if (lane == 0U)
         {
-            red[w][0] = E_lj;
-            red[w][1] = E_el;
-            red[w][2] = DVDL_lj;
-            red[w][3] = DVDL_el;
+            /* layout [E_lj | E_el | dV/dl_lj | dV/dl_el][lambda index], as in the accumulator slots */
+            float* r                    = red + w * numTerms + idx;
+            r[0]                        = E_lj;
+            r[n_lambda + 1]             = E_el;
+            r[2 * (n_lambda + 1)]       = DVDL_lj;
+            r[3 * (n_lambda + 1)]       = DVDL_el;
         }
-        __syncthreads();
-        if (threadIdx.x < 4U)
-        {
-            float s = 0.0F;
+    }
+    __syncthreads();
+    for (int t = static_cast<int>(threadIdx.x); t < numTerms; t += c_fepBlockSize)
+    {
+        float s = 0.0F;
 #pragma unroll
-            for (int k = 0; k < c_fepBlockSize / c_waveSize; k++) { s += red[k][threadIdx.x]; }
-            /* foreign-lambda accumulator slots, layout [E_lj | E_el | dV/dl_lj | dV/dl_el][lambda index] as in the fused mode */
-            float* out = atdat.foreignSlots + (blockIdx.x & (c_numForeignSlots - 1)) * atdat.foreignSlotStride
-                         + threadIdx.x * (n_lambda + 1) + idx;
-            if (s != 0.0F) { atomicAdd(out, s); }
-        }
+        for (int k = 0; k < c_fepBlockSize / c_waveSize; k++) { s += red[k * numTerms + t]; }
+        /* foreign-lambda accumulator slots: hundreds of work-groups adding to ONE set of addresses serialise in L2 */
+        float* out = atdat.foreignSlots + (blockIdx.x & (c_numForeignSlots - 1)) * atdat.foreignSlotStride + t;
+        if (s != 0.0F) { atomicAdd(out, s); }
     }
 }
 

@@ -387,7 +387,6 @@ void nbnxm_gpu_free(NbnxmGpu* nb)
     freeDeviceBuffer(&ad->atomTypes);
     freeDeviceBuffer(&ad->ljComb);
     freeDeviceBuffer(&ad->atomTypes4);
-    freeDeviceBuffer(&ad->ljComb4);
     freeDeviceBuffer(&ad->shiftVec);
     freeDeviceBuffer(&ad->fepBits);
     freeDeviceBuffer(&nbp->nbfp);
@@ -534,14 +533,12 @@ void nbnxm_gpu_init_atomdata(NbnxmGpu* nb, int numAtoms, int numAtomsLocal, cons
         freeDeviceBuffer(&ad->ljComb);
         freeDeviceBuffer(&ad->q4);
         freeDeviceBuffer(&ad->atomTypes4);
-        freeDeviceBuffer(&ad->ljComb4);
         allocateDeviceBuffer(&ad->f, nalloc);
         allocateDeviceBuffer(&ad->xq, nalloc);
         allocateDeviceBuffer(&ad->atomTypes, nalloc);
         allocateDeviceBuffer(&ad->ljComb, nalloc);
         allocateDeviceBuffer(&ad->q4, nalloc);
         allocateDeviceBuffer(&ad->atomTypes4, nalloc);
-        allocateDeviceBuffer(&ad->ljComb4, nalloc);
         ad->numAtomsAlloc = nalloc;
         clearDeviceBufferAsync(&ad->f, 0, nalloc, s); /* first use: no stale forces */
         freeDeviceBuffer(&nb->fSpare);
@@ -575,15 +572,11 @@ void nbnxm_gpu_init_atomdata(NbnxmGpu* nb, int numAtoms, int numAtomsLocal, cons
         }
         copyToDeviceBuffer(&ad->q4, nb->h_q4.data, 0, numAtoms, s, true);
         copyToDeviceBuffer(&ad->atomTypes4, nb->h_atomTypes4.data, 0, numAtoms, s, true);
-        if (lj_combA != nullptr && lj_combB != nullptr)
-        {
-            nb->h_ljComb4.resize(numAtoms);
-            for (int i = 0; i < numAtoms; i++)
-            {
-                nb->h_ljComb4.data[i] = make_float4(lj_combA[2 * i], lj_combA[2 * i + 1], lj_combB[2 * i], lj_combB[2 * i + 1]);
-            }
-            copyToDeviceBuffer(&ad->ljComb4, nb->h_ljComb4.data, 0, numAtoms, s, true);
-        }
+        /* lj_combA / lj_combB (NBAtomDataGpu::ljComb4 of the reference, nbnxm_fep_cuda_kernel.cuh:357-375) are not uploaded: the
+         * perturbed pairs of every flavour take c6 / c12 of the A and B state from the type-pair table (nbfp[typeA], nbfp[typeB]),
+         * which holds the numbers the combination rule would produce, so no kernel here reads per-atom A/B LJ parameters */
+        (void)lj_combA;
+        (void)lj_combB;
     }
     for (int i = 0; i < numAtoms; i++)
     {
@@ -1091,7 +1084,8 @@ void nbnxm_gpu_launch_kernel(NbnxmGpu* nb, const nbnxm_step_workload_t* stepWork
             {
                 const FepKernelPtr k = selectFepForeignKernel(nbp->elecType, nbp->vdwType);
                 NBNXM_ASSERT(k != nullptr, "no foreign-lambda kernel for this electrostatics type");
-                hipLaunchKernelGGL(k, dim3(nblock), dim3(256), 0, fs, *adat, *nbp, *feplist, nb->n_lambda);
+                const int foreignLds = (256 / c_waveSize) * 4 * (nb->n_lambda + 1) * static_cast<int>(sizeof(float));
+                hipLaunchKernelGGL(k, dim3(nblock), dim3(256), foreignLds, fs, *adat, *nbp, *feplist, nb->n_lambda);
                 NBNXM_HIP_CHECK(hipGetLastError());
             }
             if (nb->bDoTime) { t.fep_k.closeTimingRegion(fs); }

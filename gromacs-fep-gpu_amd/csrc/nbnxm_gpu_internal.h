@@ -121,7 +121,7 @@ struct NbnxmGpu
 
     /* pinned staging for every asynchronous upload: stays alive until the next upload of the same
      * kind (A.4: the reference frees its temporaries right after queuing the copies) */
-    PinnedBuffer<float4> h_q4, h_ljComb4;
+    PinnedBuffer<float4> h_q4;
     PinnedBuffer<int4>   h_atomTypes4;
     PinnedBuffer<int>    h_atomTypes, h_iinr, h_jjnr, h_shift, h_jindex, h_exclFep, h_pairEntry;
     PinnedBuffer<float2> h_ljComb;

@@ -64,7 +64,7 @@ struct NBAtomDataGpu
     int*    atomTypes;  /* per atom (perturbed atoms: numTypes-1) */
     float2* ljComb;     /* per atom, combination-rule kernels */
     int4*   atomTypes4; /* .x = typeA, .y = typeB (FEP only) */
-    float4* ljComb4;    /* c6A,c12A,c6B,c12B factors (FEP + combination rule) */
+    float4* ljComb4;    /* reference member, kept for the layout; never allocated: A/B LJ parameters come from nbfp[typeA/B] */
 
     float3* shiftVec; /* 45 */
     bool    shiftVecUploaded;

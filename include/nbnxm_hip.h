@@ -209,7 +209,9 @@ void nbnxm_gpu_pme_loadbal_update_param(NbnxmGpu* nb, const nbnxm_interaction_pa
 /* Nbnxm::gpu_init_atomdata — nbnxm/gpu_data_mgmt.h:112-113, nbnxm_gpu_data_mgmt.cpp:873-1045.
  * Arrays are in nbnxm grid order, numAtoms long (nbat->params()):
  *   type / lj_comb(2 per atom)           : "normal" parameters, perturbed atoms zeroed by the caller
- *   qA,qB,typeA,typeB,lj_combA,lj_combB  : A/B-state parameters (FEP only; may be NULL otherwise) */
+ *   qA,qB,typeA,typeB                    : A/B-state parameters (FEP only; may be NULL otherwise)
+ *   lj_combA,lj_combB                    : accepted for the reference's call shape and NOT read: the perturbed pairs take the A/B
+ *                                          c6 / c12 from the type-pair table nbfp[typeA], nbfp[typeB] in every flavour */
 void nbnxm_gpu_init_atomdata(NbnxmGpu* nb, int numAtoms, int numAtomsLocal, const int* type,
                              const float* lj_comb, const float* qA, const float* qB,
                              const int* typeA, const int* typeB, const float* lj_combA,
