@@ -14,7 +14,7 @@ def test_hip_kernel_reproduces_nblib_known_answers(case):
     c = nc.build(DATA, case)
     got = nc.run_gpu(c)
     nc.check(case, got, abs_tol=1e-6, rel_floor=5e-5)
-    # and the oracle on the same float inputs at fp32 round-off
+    # and the float oracle on the same float inputs, everything it produces (forces, energies, virial) at the 1e-4 bar of the path
     ref = nc.run_oracle(c, "f32")
-    nc.check(dict(case, tolerance=2e-5, forces=ref["f"].tolist(), energies=ref["energies"], virial=ref["virial"].tolist()), got,
+    nc.check(dict(case, tolerance=1e-4, forces=ref["f"].tolist(), energies=ref["energies"], virial=ref["virial"].tolist()), got,
              abs_tol=1e-6)
