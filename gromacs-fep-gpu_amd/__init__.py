@@ -100,7 +100,12 @@ HIP_SYMBOLS = [
     "nbnxm_gpu_debug_graph_steps", "nbnxm_gpu_debug_set_work_shares",
     "nbnxm_gpu_init_x_to_nbat_x", "nbnxm_gpu_x_to_nbat_x", "nbnxm_gpu_insert_nonlocal_dependency",
     "nbnxm_gpu_setup_short_range_work", "nbnxm_gpu_force_reduction_reinit", "nbnxm_gpu_force_reduction_execute",
-    "nbnxm_gpu_halo_pack_x", "nbnxm_gpu_halo_unpack_f",
+    "nbnxm_gpu_halo_pack_x", "nbnxm_gpu_halo_unpack_f", "nbnxm_gpu_force_reduction_execute_range",
+]
+HALO_SYMBOLS = [
+    "halo_gpu_get_unique_id", "halo_gpu_create", "halo_gpu_free", "halo_gpu_last_error", "halo_gpu_reinit",
+    "halo_gpu_communicate_coordinates", "halo_gpu_communicate_forces", "halo_gpu_coordinates_ready_event", "halo_gpu_forces_ready_event",
+    "halo_gpu_bytes_per_step", "halo_gpu_pack_shifted",
 ]
 UPDATE_SYMBOLS = [
     "langevin_gpu_create", "langevin_gpu_free", "langevin_gpu_set", "langevin_gpu_integrate",
@@ -123,7 +128,8 @@ HOST_SYMBOLS = [
     "nbnxm_host_grid_update_xq", "nbnxm_host_shift_vectors", "nbnxm_host_pairlist_build",
     "nbnxm_host_pairlist_free", "nbnxm_host_pairlist_sizes", "nbnxm_host_pairlist_get",
     "nbnxm_host_pairlist_get_fep", "nbnxm_host_abi_version", "nbnxm_host_count_pairs_within",
-    "nbnxm_host_calc_ewaldcoeff_q", "nbnxm_host_calc_ewaldcoeff_lj",
+    "nbnxm_host_calc_ewaldcoeff_q", "nbnxm_host_calc_ewaldcoeff_lj", "nbnxm_host_grid_create_dd", "nbnxm_host_grid_num_atoms_home",
+    "nbnxm_host_pairlist_build_dd",
 ]
 
 _hip = None
@@ -214,17 +220,29 @@ def exclusions_from_groups(group_id):
 class Grid:
     """Cluster grid of one system (nbnxm/grid.cpp role)."""
 
-    def __init__(self, x, box, qA, qB, typeA, typeB, ntype, perturbed=None):
+    def __init__(self, x, box, qA, qB, typeA, typeB, ntype, perturbed=None, num_home=None, periodic=(True, True, True)):
+        """num_home: the grid of ONE DOMAIN of a decomposed run — the first num_home atoms are home atoms, the rest halo atoms
+        (two zones); periodic[d] False for a decomposed dimension (nbnxm_host_grid_create_dd)"""
         self.natoms = len(qA)
         self.ntype = int(ntype)
         self.box = _a(box, np.float32)
         x = _a(x, np.float32)
         pert = _a(perturbed, np.uint8)
-        self._h = host_lib().nbnxm_host_grid_create(C.c_int(self.natoms), _p(x), _p(self.box),
+        lib = host_lib()
+        if num_home is None:
+            self._h = lib.nbnxm_host_grid_create(C.c_int(self.natoms), _p(x), _p(self.box),
+                                                 _p(_a(qA, np.float32)), _p(_a(qB, np.float32)),
+                                                 _p(_a(typeA, np.int32)), _p(_a(typeB, np.int32)),
+                                                 C.c_int(self.ntype), _p(pert))
+        else:
+            lib.nbnxm_host_grid_create_dd.restype = C.c_void_p
+            per = _a([1 if p else 0 for p in periodic], np.int32)
+            self._h = lib.nbnxm_host_grid_create_dd(C.c_int(int(num_home)), C.c_int(self.natoms - int(num_home)), _p(x), _p(self.box), _p(per),
                                                     _p(_a(qA, np.float32)), _p(_a(qB, np.float32)),
                                                     _p(_a(typeA, np.int32)), _p(_a(typeB, np.int32)),
                                                     C.c_int(self.ntype), _p(pert))
         h = C.c_void_p(self._h)
+        self.num_atoms_home = lib.nbnxm_host_grid_num_atoms_home(h)      # padded slots of the home zone
         self.num_atoms = host_lib().nbnxm_host_grid_num_atoms(h)
         self.num_clusters = host_lib().nbnxm_host_grid_num_clusters(h)
         np_ = self.num_atoms
@@ -264,6 +282,10 @@ class Grid:
         return Pairlist(self, excl_index, excl_atoms, rlist, max_cjpacked_per_sci, carve_fep,
                         rlist if rlist_fep is None else rlist_fep)
 
+    def build_pairlist_dd(self, non_local, excl_index, excl_atoms, rlist, max_cjpacked_per_sci=0):
+        """one of the two lists of a domain: home x home (non_local False) or home x halo (True); perturbed pairs stay in the list"""
+        return Pairlist(self, excl_index, excl_atoms, rlist, max_cjpacked_per_sci, False, rlist, dd_non_local=bool(non_local))
+
     def __del__(self):
         # at interpreter shutdown module globals may already be gone: the process is ending, nothing to free
         try:
@@ -277,12 +299,17 @@ class Grid:
 class Pairlist:
     """GPU-layout cluster pair list + atom-pair FEP list (NbnxnPairlistGpu + t_nblist)."""
 
-    def __init__(self, grid, excl_index, excl_atoms, rlist, max_cjpacked_per_sci, carve_fep, rlist_fep):
+    def __init__(self, grid, excl_index, excl_atoms, rlist, max_cjpacked_per_sci, carve_fep, rlist_fep, dd_non_local=None):
         ei = _a(excl_index, np.int32)
         ea = _a(excl_atoms, np.int32)
-        h = host_lib().nbnxm_host_pairlist_build(C.c_void_p(grid._h), _p(ei), _p(ea), C.c_float(rlist),
-                                                 C.c_int(max_cjpacked_per_sci), C.c_int(1 if carve_fep else 0),
-                                                 C.c_float(rlist_fep))
+        if dd_non_local is None:
+            h = host_lib().nbnxm_host_pairlist_build(C.c_void_p(grid._h), _p(ei), _p(ea), C.c_float(rlist),
+                                                     C.c_int(max_cjpacked_per_sci), C.c_int(1 if carve_fep else 0),
+                                                     C.c_float(rlist_fep))
+        else:
+            host_lib().nbnxm_host_pairlist_build_dd.restype = C.c_void_p
+            h = host_lib().nbnxm_host_pairlist_build_dd(C.c_void_p(grid._h), C.c_int(1 if dd_non_local else 0), _p(ei), _p(ea),
+                                                        C.c_float(rlist), C.c_int(max_cjpacked_per_sci))
         h = C.c_void_p(h)
         sizes = np.zeros(6, np.int64)
         host_lib().nbnxm_host_pairlist_sizes(h, _p(sizes))
@@ -481,6 +508,10 @@ class NbnxmGpu:
 
     def force_reduction_execute(self, d_base_force, d_rvec_force=None, stream=None):
         self._lib.nbnxm_gpu_force_reduction_execute(self.h, C.c_void_p(d_base_force), C.c_void_p(d_rvec_force), C.c_void_p(stream))
+
+    def force_reduction_execute_range(self, d_base_force, atom_begin, atom_end, accumulate=False, stream=None):
+        self._lib.nbnxm_gpu_force_reduction_execute_range(self.h, C.c_void_p(d_base_force), C.c_int(atom_begin), C.c_int(atom_end),
+                                                          C.c_int(1 if accumulate else 0), C.c_void_p(stream))
 
     def clear_outputs(self, compute_virial=True):
         self._lib.nbnxm_gpu_clear_outputs(self.h, C.c_int(1 if compute_virial else 0))

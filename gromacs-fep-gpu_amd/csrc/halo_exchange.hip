@@ -1,0 +1,366 @@
+/*
+ * GPU halo exchange of a domain-decomposed run over RCCL point-to-point (include/halo_hip.h).
+ *
+ *   domdec/gpuhaloexchange_impl_gpu.cpp:122-246   reinitHalo (index maps, buffers, offsets)
+ *   domdec/gpuhaloexchange_impl_gpu.cpp:263-368   communicateHaloCoordinates / communicateHaloForces
+ *   domdec/gpuhaloexchange_impl_gpu.cpp:370-511   the transfers (MPI on device pointers | peer copies + event handshake)
+ *   domdec/gpuhaloexchange_impl_gpu.cu:62-116     packSendBufKernel / unpackRecvBufKernel
+ *
+ * Everything is queued on ONE stream; RCCL's send / receive are stream-ordered, so there is no host handshake per step
+ * (the reference's peer-copy path exchanges event pointers with MPI_Sendrecv every step, :438-470).
+ */
+#include "halo_hip.h"
+
+#include <dlfcn.h>
+
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include <rccl/rccl.h> /* types and prototypes only: the library is opened with dlopen */
+
+#include "device_utils.h"
+
+using namespace nbnxm_hip;
+
+namespace
+{
+
+std::string g_haloError;
+
+/* the few RCCL entry points used, resolved once */
+struct Rccl
+{
+    void* lib = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId*)                                                        = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int)                                 = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t)                                                           = nullptr;
+    ncclResult_t (*GroupStart)()                                                                      = nullptr;
+    ncclResult_t (*GroupEnd)()                                                                        = nullptr;
+    ncclResult_t (*Send)(const void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t)           = nullptr;
+    ncclResult_t (*Recv)(void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t)                 = nullptr;
+    const char* (*GetErrorString)(ncclResult_t)                                                       = nullptr;
+};
+
+Rccl* rccl()
+{
+    static Rccl r;
+    if (r.lib != nullptr) { return &r; }
+    const char* names[] = { std::getenv("NBNXM_HIP_RCCL_LIB"), "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1" };
+    for (const char* n : names)
+    {
+        if (n == nullptr || n[0] == 0) { continue; }
+        /* RTLD_NOLOAD first: the copy that is already in the process (PyTorch's), so that there is one RCCL, not two */
+        void* lib = dlopen(n, RTLD_NOW | RTLD_NOLOAD);
+        if (lib == nullptr) { lib = dlopen(n, RTLD_NOW | RTLD_LOCAL); }
+        if (lib != nullptr)
+        {
+            r.lib = lib;
+            break;
+        }
+    }
+    if (r.lib == nullptr)
+    {
+        g_haloError = std::string("cannot open librccl (") + dlerror() + ")";
+        return nullptr;
+    }
+#define HALO_SYM(member, name)                                                      \
+    r.member = reinterpret_cast<decltype(r.member)>(dlsym(r.lib, name));            \
+    if (r.member == nullptr)                                                        \
+    {                                                                               \
+        g_haloError = std::string("librccl lacks ") + name;                         \
+        r.lib       = nullptr;                                                      \
+        return nullptr;                                                             \
+    }
+    HALO_SYM(GetUniqueId, "ncclGetUniqueId")
+    HALO_SYM(CommInitRank, "ncclCommInitRank")
+    HALO_SYM(CommDestroy, "ncclCommDestroy")
+    HALO_SYM(GroupStart, "ncclGroupStart")
+    HALO_SYM(GroupEnd, "ncclGroupEnd")
+    HALO_SYM(Send, "ncclSend")
+    HALO_SYM(Recv, "ncclRecv")
+    HALO_SYM(GetErrorString, "ncclGetErrorString")
+#undef HALO_SYM
+    return &r;
+}
+
+#define HALO_RCCL_CHECK(expr)                                                                            \
+    do                                                                                                   \
+    {                                                                                                    \
+        const ncclResult_t res_ = (expr);                                                                \
+        if (res_ != ncclSuccess) { fatal(__FILE__, __LINE__, #expr, rccl()->GetErrorString(res_)); }     \
+    } while (0)
+
+constexpr int c_haloThreadsPerBlock = 256;
+
+/* packed[i] = x[map[i]] + shift[shiftIndex[i]]: all destinations in one launch (the reference launches one
+ * packSendBufKernel<usePbc> per pulse with one shift, gpuhaloexchange_impl_gpu.cu:62-88) */
+__global__ void haloPackShiftedKernel(float3* __restrict__ packed, const float3* __restrict__ x, const int* __restrict__ map,
+                                      const int* __restrict__ shiftIndex, const float3* __restrict__ shiftVectors, const int n)
+{
+    const int i = static_cast<int>(blockIdx.x * blockDim.x + threadIdx.x);
+    if (i >= n) { return; }
+    const float3 v = x[map[i]];
+    const float3 s = shiftVectors[shiftIndex[i]];
+    packed[i]      = make_float3(v.x + s.x, v.y + s.y, v.z + s.z);
+}
+
+/* f[map[i]] (+)= packed[i]; an atom can be sent to several destinations, so it can occur several times in the map:
+ * atomic adds (unpackRecvBufKernel, :90-116, runs once per pulse and needs none) */
+template<bool accumulate>
+__global__ void haloUnpackForcesKernel(float* __restrict__ f, const float3* __restrict__ packed, const int* __restrict__ map, const int n)
+{
+    const int i = static_cast<int>(blockIdx.x * blockDim.x + threadIdx.x);
+    if (i >= n) { return; }
+    const float3 v = packed[i];
+    float*       d = f + 3 * static_cast<size_t>(map[i]);
+    if (accumulate)
+    {
+        atomicAdd(d + 0, v.x);
+        atomicAdd(d + 1, v.y);
+        atomicAdd(d + 2, v.z);
+    }
+    else
+    {
+        d[0] = v.x;
+        d[1] = v.y;
+        d[2] = v.z;
+    }
+}
+
+} // namespace
+
+struct HaloGpu
+{
+    ncclComm_t  comm   = nullptr;
+    int         rank   = 0;
+    int         nranks = 1;
+    hipStream_t stream = nullptr;
+    float3*     d_x    = nullptr;
+    float3*     d_f    = nullptr;
+    int         numHome = 0;
+    /* send side */
+    std::vector<int> sendPeer, sendOffset;
+    int              numSendAtoms = 0;
+    int*             d_sendMap        = nullptr;
+    int*             d_sendShiftIndex = nullptr;
+    float3*          d_shiftVectors   = nullptr;
+    float3*          d_sendBuf        = nullptr; /* packed coordinates out; received forces in */
+    int              sendAlloc = 0, shiftAlloc = 0;
+    /* recv side */
+    std::vector<int> recvPeer, recvAtomOffset, recvCount;
+    hipEvent_t       xReady = nullptr, fReady = nullptr;
+};
+
+extern "C"
+{
+
+const char* halo_gpu_last_error(void)
+{
+    return g_haloError.c_str();
+}
+
+int halo_gpu_get_unique_id(void* uniqueId)
+{
+    Rccl* r = rccl();
+    if (r == nullptr) { return 1; }
+    static_assert(sizeof(ncclUniqueId) == HALO_GPU_UNIQUE_ID_BYTES, "ncclUniqueId size");
+    ncclUniqueId id;
+    if (r->GetUniqueId(&id) != ncclSuccess)
+    {
+        g_haloError = "ncclGetUniqueId failed";
+        return 2;
+    }
+    std::memcpy(uniqueId, &id, sizeof(id));
+    return 0;
+}
+
+HaloGpu* halo_gpu_create(const void* uniqueId, int rank, int nranks, void* stream)
+{
+    Rccl* r = rccl();
+    if (r == nullptr) { return nullptr; }
+    auto* h   = new HaloGpu;
+    h->rank   = rank;
+    h->nranks = nranks;
+    h->stream = static_cast<hipStream_t>(stream);
+    ncclUniqueId id;
+    std::memcpy(&id, uniqueId, sizeof(id));
+    const ncclResult_t res = r->CommInitRank(&h->comm, nranks, id, rank);
+    if (res != ncclSuccess)
+    {
+        g_haloError = std::string("ncclCommInitRank: ") + r->GetErrorString(res);
+        delete h;
+        return nullptr;
+    }
+    NBNXM_HIP_CHECK(hipEventCreateWithFlags(&h->xReady, hipEventDisableTiming));
+    NBNXM_HIP_CHECK(hipEventCreateWithFlags(&h->fReady, hipEventDisableTiming));
+    return h;
+}
+
+void halo_gpu_free(HaloGpu* h)
+{
+    if (h == nullptr) { return; }
+    (void)hipStreamSynchronize(h->stream);
+    if (h->comm != nullptr) { (void)rccl()->CommDestroy(h->comm); }
+    (void)hipFree(h->d_sendMap);
+    (void)hipFree(h->d_sendShiftIndex);
+    (void)hipFree(h->d_shiftVectors);
+    (void)hipFree(h->d_sendBuf);
+    if (h->xReady) { (void)hipEventDestroy(h->xReady); }
+    if (h->fReady) { (void)hipEventDestroy(h->fReady); }
+    delete h;
+}
+
+void halo_gpu_reinit(HaloGpu* h, void* d_x, void* d_f, int numHome, int numSend, const int* sendPeer, const int* sendOffset,
+                     const int* sendMap, const int* sendShiftIndex, int numShiftVectors, const float* shiftVectors, int numRecv,
+                     const int* recvPeer, const int* recvAtomOffset, const int* recvCount)
+{
+    h->d_x     = static_cast<float3*>(d_x);
+    h->d_f     = static_cast<float3*>(d_f);
+    h->numHome = numHome;
+    h->sendPeer.assign(sendPeer, sendPeer + numSend);
+    h->sendOffset.assign(sendOffset, sendOffset + numSend + 1);
+    h->numSendAtoms = h->sendOffset[numSend];
+    for (int k = 0; k < numSend; k++)
+    {
+        NBNXM_ASSERT(sendPeer[k] >= 0 && sendPeer[k] < h->nranks && sendOffset[k] <= sendOffset[k + 1], "bad send link");
+    }
+    for (int i = 0; i < h->numSendAtoms; i++)
+    {
+        NBNXM_ASSERT(sendMap[i] >= 0 && sendMap[i] < numHome, "only home atoms are sent");
+        NBNXM_ASSERT(sendShiftIndex[i] >= 0 && sendShiftIndex[i] < numShiftVectors, "shift index out of range");
+    }
+    h->recvPeer.assign(recvPeer, recvPeer + numRecv);
+    h->recvAtomOffset.assign(recvAtomOffset, recvAtomOffset + numRecv);
+    h->recvCount.assign(recvCount, recvCount + numRecv);
+    for (int k = 0; k < numRecv; k++)
+    {
+        NBNXM_ASSERT(recvPeer[k] >= 0 && recvPeer[k] < h->nranks && recvAtomOffset[k] >= numHome && recvCount[k] >= 0, "bad receive link");
+    }
+    if (h->numSendAtoms > h->sendAlloc)
+    {
+        (void)hipFree(h->d_sendMap);
+        (void)hipFree(h->d_sendShiftIndex);
+        (void)hipFree(h->d_sendBuf);
+        h->sendAlloc = static_cast<int>(h->numSendAtoms * 1.2) + 1024;
+        NBNXM_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&h->d_sendMap), sizeof(int) * h->sendAlloc));
+        NBNXM_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&h->d_sendShiftIndex), sizeof(int) * h->sendAlloc));
+        NBNXM_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&h->d_sendBuf), sizeof(float3) * h->sendAlloc));
+    }
+    if (numShiftVectors > h->shiftAlloc)
+    {
+        (void)hipFree(h->d_shiftVectors);
+        h->shiftAlloc = numShiftVectors + 32;
+        NBNXM_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&h->d_shiftVectors), sizeof(float3) * h->shiftAlloc));
+    }
+    /* search steps are rare: plain synchronous copies */
+    NBNXM_HIP_CHECK(hipStreamSynchronize(h->stream));
+    if (h->numSendAtoms > 0)
+    {
+        NBNXM_HIP_CHECK(hipMemcpy(h->d_sendMap, sendMap, sizeof(int) * h->numSendAtoms, hipMemcpyHostToDevice));
+        NBNXM_HIP_CHECK(hipMemcpy(h->d_sendShiftIndex, sendShiftIndex, sizeof(int) * h->numSendAtoms, hipMemcpyHostToDevice));
+    }
+    if (numShiftVectors > 0)
+    {
+        NBNXM_HIP_CHECK(hipMemcpy(h->d_shiftVectors, shiftVectors, sizeof(float) * 3 * numShiftVectors, hipMemcpyHostToDevice));
+    }
+}
+
+void halo_gpu_communicate_coordinates(HaloGpu* h, void* dependencyEvent)
+{
+    Rccl*       r = rccl();
+    hipStream_t s = h->stream;
+    if (dependencyEvent != nullptr) { NBNXM_HIP_CHECK(hipStreamWaitEvent(s, static_cast<hipEvent_t>(dependencyEvent), 0)); }
+    if (h->numSendAtoms > 0)
+    {
+        hipLaunchKernelGGL(haloPackShiftedKernel, dim3((h->numSendAtoms + c_haloThreadsPerBlock - 1) / c_haloThreadsPerBlock),
+                           dim3(c_haloThreadsPerBlock), 0, s, h->d_sendBuf, h->d_x, h->d_sendMap, h->d_sendShiftIndex, h->d_shiftVectors,
+                           h->numSendAtoms);
+        NBNXM_HIP_CHECK(hipGetLastError());
+    }
+    /* one group: every send and every receive of this rank; coordinates arrive in place (rows of d_x) */
+    HALO_RCCL_CHECK(r->GroupStart());
+    for (size_t k = 0; k < h->recvPeer.size(); k++)
+    {
+        if (h->recvCount[k] > 0)
+        {
+            HALO_RCCL_CHECK(r->Recv(h->d_x + h->recvAtomOffset[k], static_cast<size_t>(3) * h->recvCount[k], ncclFloat, h->recvPeer[k], h->comm, s));
+        }
+    }
+    for (size_t k = 0; k < h->sendPeer.size(); k++)
+    {
+        const int n = h->sendOffset[k + 1] - h->sendOffset[k];
+        if (n > 0) { HALO_RCCL_CHECK(r->Send(h->d_sendBuf + h->sendOffset[k], static_cast<size_t>(3) * n, ncclFloat, h->sendPeer[k], h->comm, s)); }
+    }
+    HALO_RCCL_CHECK(r->GroupEnd());
+    NBNXM_HIP_CHECK(hipEventRecord(h->xReady, s));
+}
+
+void halo_gpu_communicate_forces(HaloGpu* h, int accumulate, void* dependencyEvent)
+{
+    Rccl*       r = rccl();
+    hipStream_t s = h->stream;
+    if (dependencyEvent != nullptr) { NBNXM_HIP_CHECK(hipStreamWaitEvent(s, static_cast<hipEvent_t>(dependencyEvent), 0)); }
+    /* the reverse of the coordinate exchange: the halo rows of d_f go to their owners as they are (contiguous, no pack),
+     * what the others computed on this rank's atoms arrives in the send buffer, in the order of the send map */
+    HALO_RCCL_CHECK(r->GroupStart());
+    for (size_t k = 0; k < h->sendPeer.size(); k++)
+    {
+        const int n = h->sendOffset[k + 1] - h->sendOffset[k];
+        if (n > 0) { HALO_RCCL_CHECK(r->Recv(h->d_sendBuf + h->sendOffset[k], static_cast<size_t>(3) * n, ncclFloat, h->sendPeer[k], h->comm, s)); }
+    }
+    for (size_t k = 0; k < h->recvPeer.size(); k++)
+    {
+        if (h->recvCount[k] > 0)
+        {
+            HALO_RCCL_CHECK(r->Send(h->d_f + h->recvAtomOffset[k], static_cast<size_t>(3) * h->recvCount[k], ncclFloat, h->recvPeer[k], h->comm, s));
+        }
+    }
+    HALO_RCCL_CHECK(r->GroupEnd());
+    if (h->numSendAtoms > 0)
+    {
+        const dim3 grid((h->numSendAtoms + c_haloThreadsPerBlock - 1) / c_haloThreadsPerBlock);
+        if (accumulate)
+        {
+            hipLaunchKernelGGL(haloUnpackForcesKernel<true>, grid, dim3(c_haloThreadsPerBlock), 0, s, reinterpret_cast<float*>(h->d_f),
+                               h->d_sendBuf, h->d_sendMap, h->numSendAtoms);
+        }
+        else
+        {
+            hipLaunchKernelGGL(haloUnpackForcesKernel<false>, grid, dim3(c_haloThreadsPerBlock), 0, s, reinterpret_cast<float*>(h->d_f),
+                               h->d_sendBuf, h->d_sendMap, h->numSendAtoms);
+        }
+        NBNXM_HIP_CHECK(hipGetLastError());
+    }
+    NBNXM_HIP_CHECK(hipEventRecord(h->fReady, s));
+}
+
+void* halo_gpu_coordinates_ready_event(HaloGpu* h)
+{
+    return h->xReady;
+}
+
+void* halo_gpu_forces_ready_event(HaloGpu* h)
+{
+    return h->fReady;
+}
+
+long long halo_gpu_bytes_per_step(const HaloGpu* h)
+{
+    long long n = h->numSendAtoms;
+    for (int c : h->recvCount) { n += c; }
+    return 12LL * n;
+}
+
+void halo_gpu_pack_shifted(void* stream, const void* d_x, const int* d_map, const int* d_shiftIndex, int n, const float* d_shiftVectors,
+                           void* d_packed)
+{
+    if (n <= 0) { return; }
+    hipLaunchKernelGGL(haloPackShiftedKernel, dim3((n + c_haloThreadsPerBlock - 1) / c_haloThreadsPerBlock), dim3(c_haloThreadsPerBlock), 0,
+                       static_cast<hipStream_t>(stream), static_cast<float3*>(d_packed), static_cast<const float3*>(d_x), d_map, d_shiftIndex,
+                       reinterpret_cast<const float3*>(d_shiftVectors), n);
+    NBNXM_HIP_CHECK(hipGetLastError());
+}
+
+} // extern "C"

@@ -171,6 +171,20 @@ void nbnxm_gpu_force_reduction_execute(NbnxmGpu* nb, void* d_baseForce, const vo
     NBNXM_HIP_CHECK(hipGetLastError());
 }
 
+void nbnxm_gpu_force_reduction_execute_range(NbnxmGpu* nb, void* d_baseForce, int atomBegin, int atomEnd, int accumulate, void* stream)
+{
+    NBNXM_ASSERT(nb->reductionAtomStart == 0 && atomBegin >= 0 && atomBegin <= atomEnd && atomEnd <= nb->reductionNumAtoms,
+                 "range outside the cell map of nbnxm_gpu_force_reduction_reinit (atomStart 0)");
+    const int n = atomEnd - atomBegin;
+    if (n == 0) { return; }
+    hipStream_t s    = stream ? static_cast<hipStream_t>(stream) : nb->deviceStreams[0].stream;
+    float3*     base = static_cast<float3*>(d_baseForce) + atomBegin;
+    auto        k    = accumulate ? nbnxmForceReductionKernel<false, true> : nbnxmForceReductionKernel<false, false>;
+    hipLaunchKernelGGL(k, gridFor(n), dim3(c_bufOpsThreadsPerBlock), 0, s, reinterpret_cast<const float3*>(nb->atdat->f), nullptr, base,
+                       nb->cell + atomBegin, n);
+    NBNXM_HIP_CHECK(hipGetLastError());
+}
+
 void nbnxm_gpu_halo_pack_x(void* stream, const void* d_x, const int* d_map, int mapSize, const float* coordinateShift, void* d_sendBuf)
 {
     if (mapSize <= 0) { return; }

@@ -80,14 +80,27 @@ struct Rng
 
 } // namespace
 
+// One gridded set of atoms: columns in x/y over [lo, lo + size), atoms sorted along z inside a column.  A single-domain
+// grid has one zone over the box; a domain of a decomposed run has two: home atoms, then halo atoms (as the reference grids
+// its local and non-local atoms separately, nbnxm/gridset.cpp).
+struct GridZone
+{
+    int              atomBegin = 0, atomEnd = 0; // input atoms [atomBegin, atomEnd)
+    float            lo[2] = { 0, 0 }, size[2] = { 1, 1 };
+    int              ncx = 1, ncy = 1;
+    int              scBegin = 0, scEnd = 0;     // super-clusters of this zone
+    std::vector<int> colScBegin;                 // ncx*ncy+1, absolute super-cluster indices
+};
+
 struct NbnxmHostGrid
 {
     int                natoms = 0; // topology atoms
     int                ntype  = 0; // topology types
     float              box[3] = { 0, 0, 0 };
-    int                ncx = 1, ncy = 1;
-    int                nsc = 0;             // super-clusters
-    std::vector<int>   colScBegin;          // ncx*ncy+1
+    bool               periodic[3] = { true, true, true }; // dims along which coordinates are wrapped and images are searched
+    std::vector<GridZone> zones;
+    int                nsc = 0;             // super-clusters (all zones)
+    int                nscHome() const { return zones.empty() ? 0 : zones[0].scEnd; }
     std::vector<float> xw;                  // wrapped topology-order x (3N)
     std::vector<int>   atomIndices;         // grid -> topo (-1 filler)
     std::vector<int>   gridIndex;           // topo -> grid
@@ -378,50 +391,35 @@ long long nbnxm_host_count_pairs_within(const NbnxmHostGrid* g, float rc, const 
 
 /* ---- grid ---------------------------------------------------------------------------------- */
 
-NbnxmHostGrid* nbnxm_host_grid_create(int natoms, const float* x, const float* box, const float* qA,
-                                      const float* qB, const int* typeA, const int* typeB, int ntype,
-                                      const unsigned char* perturbed)
-{
-    auto* g   = new NbnxmHostGrid;
-    g->natoms = natoms;
-    g->ntype  = ntype;
-    for (int d = 0; d < 3; d++) { g->box[d] = box[d]; }
-    g->xw.resize(static_cast<size_t>(natoms) * 3);
-    for (int a = 0; a < natoms; a++)
-    {
-        for (int d = 0; d < 3; d++)
-        {
-            float v = x[3 * a + d];
-            v -= box[d] * std::floor(v / box[d]);
-            if (v >= box[d]) { v = 0; }
-            g->xw[3 * a + d] = v;
-        }
-    }
-    const double volume  = static_cast<double>(box[0]) * box[1] * box[2];
-    const double density = natoms / volume;
-    const double colSize = std::cbrt(SC / density);
-    g->ncx               = std::max(1, static_cast<int>(box[0] / colSize));
-    g->ncy               = std::max(1, static_cast<int>(box[1] / colSize));
-    const int ncol       = g->ncx * g->ncy;
+} // extern "C"
 
+namespace
+{
+// Grids the atoms [zone.atomBegin, zone.atomEnd) of g->xw: fills zone.colScBegin, g->atomIndices, g->gridIndex for its slots.
+void gridZone(NbnxmHostGrid* g, GridZone& zone, double density)
+{
+    const std::vector<float>& xw   = g->xw;
+    const int                 n    = zone.atomEnd - zone.atomBegin;
+    const double              colSize = std::cbrt(SC / density);
+    zone.ncx                       = std::max(1, static_cast<int>(zone.size[0] / colSize));
+    zone.ncy                       = std::max(1, static_cast<int>(zone.size[1] / colSize));
+    const int ncol                 = zone.ncx * zone.ncy;
     std::vector<std::vector<int>> colAtoms(ncol);
-    for (int a = 0; a < natoms; a++)
+    for (int a = zone.atomBegin; a < zone.atomEnd; a++)
     {
-        const int cx = std::min(g->ncx - 1, static_cast<int>(g->xw[3 * a + 0] / box[0] * g->ncx));
-        const int cy = std::min(g->ncy - 1, static_cast<int>(g->xw[3 * a + 1] / box[1] * g->ncy));
-        colAtoms[cx * g->ncy + cy].push_back(a);
+        const int cx = std::min(zone.ncx - 1, std::max(0, static_cast<int>((xw[3 * a + 0] - zone.lo[0]) / zone.size[0] * zone.ncx)));
+        const int cy = std::min(zone.ncy - 1, std::max(0, static_cast<int>((xw[3 * a + 1] - zone.lo[1]) / zone.size[1] * zone.ncy)));
+        colAtoms[cx * zone.ncy + cy].push_back(a);
     }
-    g->colScBegin.assign(ncol + 1, 0);
+    zone.colScBegin.assign(ncol + 1, zone.scBegin);
     for (int c = 0; c < ncol; c++)
     {
-        g->colScBegin[c + 1] = g->colScBegin[c] + static_cast<int>((colAtoms[c].size() + SC - 1) / SC);
+        zone.colScBegin[c + 1] = zone.colScBegin[c] + static_cast<int>((colAtoms[c].size() + SC - 1) / SC);
     }
-    g->nsc       = g->colScBegin[ncol];
-    const int np = g->numAtomsPadded();
-    g->atomIndices.assign(np, -1);
-    g->gridIndex.assign(natoms, -1);
+    zone.scEnd = zone.colScBegin[ncol];
+    g->atomIndices.resize(static_cast<size_t>(zone.scEnd) * SC, -1);
+    (void)n;
 
-    const std::vector<float>& xw = g->xw;
     auto sortBy = [&xw](int* begin, int* end, int dim) {
         std::stable_sort(begin, end, [&xw, dim](int a, int b) { return xw[3 * a + dim] < xw[3 * b + dim]; });
     };
@@ -430,7 +428,7 @@ NbnxmHostGrid* nbnxm_host_grid_create(int natoms, const float* x, const float* b
     {
         std::vector<int>& atoms = colAtoms[c];
         sortBy(atoms.data(), atoms.data() + atoms.size(), 2);
-        const int nscCol = g->colScBegin[c + 1] - g->colScBegin[c];
+        const int nscCol = zone.colScBegin[c + 1] - zone.colScBegin[c];
         for (int s = 0; s < nscCol; s++)
         {
             int*      first = atoms.data() + static_cast<size_t>(s) * SC;
@@ -440,7 +438,7 @@ NbnxmHostGrid* nbnxm_host_grid_create(int natoms, const float* x, const float* b
             // still has compact clusters.
             const int nz[2] = { (n + 1) / 2, n / 2 };
             int       off   = 0;
-            int       slot  = (g->colScBegin[c] + s) * SC;
+            int       slot  = (zone.colScBegin[c] + s) * SC;
             for (int iz = 0; iz < 2; iz++)
             {
                 int* zb = first + off;
@@ -470,6 +468,82 @@ NbnxmHostGrid* nbnxm_host_grid_create(int natoms, const float* x, const float* b
             }
         }
     }
+}
+
+// natomsHome atoms of the domain, then the halo atoms; periodic[d]: wrap coordinates into the box along d and let the list
+// builder search the images along d (a decomposed dimension has neither: its halo arrives already shifted)
+NbnxmHostGrid* gridCreate(int natoms, int natomsHome, const float* x, const float* box, const int* periodic, const float* qA,
+                          const float* qB, const int* typeA, const int* typeB, int ntype, const unsigned char* perturbed)
+{
+    auto* g   = new NbnxmHostGrid;
+    g->natoms = natoms;
+    g->ntype  = ntype;
+    for (int d = 0; d < 3; d++)
+    {
+        g->box[d]      = box[d];
+        g->periodic[d] = (periodic == nullptr) || (periodic[d] != 0);
+    }
+    g->xw.resize(static_cast<size_t>(natoms) * 3);
+    for (int a = 0; a < natoms; a++)
+    {
+        for (int d = 0; d < 3; d++)
+        {
+            float v = x[3 * a + d];
+            if (g->periodic[d])
+            {
+                v -= box[d] * std::floor(v / box[d]);
+                if (v >= box[d]) { v = 0; }
+            }
+            g->xw[3 * a + d] = v;
+        }
+    }
+    g->gridIndex.assign(natoms, -1);
+    const int numZones = (natomsHome < natoms) ? 2 : 1;
+    g->zones.resize(numZones);
+    double density = 0;
+    for (int z = 0; z < numZones; z++)
+    {
+        GridZone& zone = g->zones[z];
+        zone.atomBegin = (z == 0) ? 0 : natomsHome;
+        zone.atomEnd   = (z == 0) ? natomsHome : natoms;
+        zone.scBegin   = (z == 0) ? 0 : g->zones[0].scEnd;
+        float lo[3], hi[3];
+        for (int d = 0; d < 3; d++)
+        {
+            lo[d] = g->periodic[d] ? 0.0F : 1e30F;
+            hi[d] = g->periodic[d] ? box[d] : -1e30F;
+        }
+        for (int a = zone.atomBegin; a < zone.atomEnd; a++)
+        {
+            for (int d = 0; d < 3; d++)
+            {
+                if (!g->periodic[d])
+                {
+                    lo[d] = std::min(lo[d], g->xw[3 * a + d]);
+                    hi[d] = std::max(hi[d], g->xw[3 * a + d]);
+                }
+            }
+        }
+        for (int d = 0; d < 3; d++)
+        {
+            if (hi[d] <= lo[d]) { hi[d] = lo[d] + 1e-3F; }
+        }
+        for (int d = 0; d < 2; d++)
+        {
+            zone.lo[d]   = lo[d];
+            zone.size[d] = (hi[d] - lo[d]) * (g->periodic[d] ? 1.0F : 1.0001F);
+        }
+        if (z == 0)
+        {
+            // number density of the home atoms; the halo (a shell around them) is gridded with columns of the same size
+            density = std::max(1, zone.atomEnd - zone.atomBegin)
+                      / (static_cast<double>(hi[0] - lo[0]) * (hi[1] - lo[1]) * (hi[2] - lo[2]));
+        }
+        gridZone(g, zone, density);
+    }
+    g->nsc       = g->zones.back().scEnd;
+    const int np = g->numAtomsPadded();
+    g->atomIndices.resize(np, -1);
 
     g->xq.assign(static_cast<size_t>(np) * 4, 0.0F);
     g->qA.assign(np, 0.0F);
@@ -504,6 +578,28 @@ NbnxmHostGrid* nbnxm_host_grid_create(int natoms, const float* x, const float* b
         }
     }
     return g;
+}
+} // namespace
+
+extern "C" {
+
+NbnxmHostGrid* nbnxm_host_grid_create(int natoms, const float* x, const float* box, const float* qA,
+                                      const float* qB, const int* typeA, const int* typeB, int ntype,
+                                      const unsigned char* perturbed)
+{
+    return gridCreate(natoms, natoms, x, box, nullptr, qA, qB, typeA, typeB, ntype, perturbed);
+}
+
+NbnxmHostGrid* nbnxm_host_grid_create_dd(int natomsHome, int natomsHalo, const float* x, const float* box, const int* periodic,
+                                         const float* qA, const float* qB, const int* typeA, const int* typeB, int ntype,
+                                         const unsigned char* perturbed)
+{
+    return gridCreate(natomsHome + natomsHalo, natomsHome, x, box, periodic, qA, qB, typeA, typeB, ntype, perturbed);
+}
+
+int nbnxm_host_grid_num_atoms_home(const NbnxmHostGrid* g)
+{
+    return g->nscHome() * SC;
 }
 
 void nbnxm_host_grid_free(NbnxmHostGrid* g)
@@ -587,49 +683,69 @@ inline nbnxn_excl_t& exclusionMask(SciWork& w, int group, int half)
 
 } // namespace
 
-NbnxmHostPairlist* nbnxm_host_pairlist_build(const NbnxmHostGrid* g, const int* exclIndex,
-                                             const int* exclAtoms, float rlist,
-                                             int maxCjPackedPerSci, int carveFep, float rlistFep)
+} // extern "C"
+
+namespace
+{
+// jZone: which zone the j-clusters come from.  0: the home zone, every pair once (half of the shift vectors, and on the
+// central image only j super-clusters >= i); 1: the halo zone — its clusters never act as i-clusters, so every image is searched.
+NbnxmHostPairlist* pairlistBuild(const NbnxmHostGrid* g, const int jZone, const int* exclIndex, const int* exclAtoms, float rlist,
+                                 int maxCjPackedPerSci, int carveFep, float rlistFep)
 {
     const float rl2    = rlist * rlist;
     const float rlFep2 = rlistFep * rlistFep;
     float       shiftVec[3 * NBNXM_NUM_SHIFT_VECTORS];
     nbnxm_host_shift_vectors(g->box, shiftVec);
 
-    std::vector<SciWork> work(g->nsc);
+    const int       nscI  = g->nscHome(); // only home super-clusters act as i
+    const GridZone& zoneJ = g->zones[jZone];
+    const bool      halfList = (jZone == 0);
+    // extent of the j zone's atoms (to skip images that cannot reach it)
+    BB bbZone = emptyBB();
+    for (int scj = zoneJ.scBegin; scj < zoneJ.scEnd; scj++)
+    {
+        if (!g->bbSc[scj].empty())
+        {
+            extend(bbZone, g->bbSc[scj].lo);
+            extend(bbZone, g->bbSc[scj].hi);
+        }
+    }
+
+    std::vector<SciWork> work(nscI);
 
 #pragma omp parallel for schedule(dynamic, 4)
-    for (int sci = 0; sci < g->nsc; sci++)
+    for (int sci = 0; sci < nscI; sci++)
     {
         SciWork&  w   = work[sci];
         const BB& bbI = g->bbSc[sci];
-        if (bbI.empty()) { continue; }
+        if (bbI.empty() || bbZone.empty()) { continue; }
         std::vector<int> cand;
         std::vector<int> entryCj; // cj of the open entry, ascending
-        for (int s = NBNXM_CENTRAL_SHIFT_INDEX; s < NBNXM_NUM_SHIFT_VECTORS; s++)
+        for (int s = (halfList ? NBNXM_CENTRAL_SHIFT_INDEX : 0); s < NBNXM_NUM_SHIFT_VECTORS; s++)
         {
             const float* S       = &shiftVec[3 * s];
             const bool   central = (s == NBNXM_CENTRAL_SHIFT_INDEX);
-            // shifted i box must come within rlist of the unit cell
+            // images only along the periodic dimensions; the shifted i box must come within rlist of the j zone's atoms
             bool reach = true;
             for (int d = 0; d < 3; d++)
             {
-                if (bbI.lo[d] + S[d] - rlist > g->box[d] || bbI.hi[d] + S[d] + rlist < 0) { reach = false; }
+                if (!g->periodic[d] && S[d] != 0.0F) { reach = false; }
+                if (bbI.lo[d] + S[d] - rlist > bbZone.hi[d] || bbI.hi[d] + S[d] + rlist < bbZone.lo[d]) { reach = false; }
             }
             if (!reach) { continue; }
-            const int cx0 = std::max(0, static_cast<int>(std::floor((bbI.lo[0] + S[0] - rlist) / g->box[0] * g->ncx)));
-            const int cx1 = std::min(g->ncx - 1, static_cast<int>(std::floor((bbI.hi[0] + S[0] + rlist) / g->box[0] * g->ncx)));
-            const int cy0 = std::max(0, static_cast<int>(std::floor((bbI.lo[1] + S[1] - rlist) / g->box[1] * g->ncy)));
-            const int cy1 = std::min(g->ncy - 1, static_cast<int>(std::floor((bbI.hi[1] + S[1] + rlist) / g->box[1] * g->ncy)));
+            const int cx0 = std::max(0, static_cast<int>(std::floor((bbI.lo[0] + S[0] - rlist - zoneJ.lo[0]) / zoneJ.size[0] * zoneJ.ncx)));
+            const int cx1 = std::min(zoneJ.ncx - 1, static_cast<int>(std::floor((bbI.hi[0] + S[0] + rlist - zoneJ.lo[0]) / zoneJ.size[0] * zoneJ.ncx)));
+            const int cy0 = std::max(0, static_cast<int>(std::floor((bbI.lo[1] + S[1] - rlist - zoneJ.lo[1]) / zoneJ.size[1] * zoneJ.ncy)));
+            const int cy1 = std::min(zoneJ.ncy - 1, static_cast<int>(std::floor((bbI.hi[1] + S[1] + rlist - zoneJ.lo[1]) / zoneJ.size[1] * zoneJ.ncy)));
             cand.clear();
             for (int cx = cx0; cx <= cx1; cx++)
             {
                 for (int cy = cy0; cy <= cy1; cy++)
                 {
-                    const int col = cx * g->ncy + cy;
-                    for (int scj = g->colScBegin[col]; scj < g->colScBegin[col + 1]; scj++)
+                    const int col = cx * zoneJ.ncy + cy;
+                    for (int scj = zoneJ.colScBegin[col]; scj < zoneJ.colScBegin[col + 1]; scj++)
                     {
-                        if (central && scj < sci) { continue; }
+                        if (halfList && central && scj < sci) { continue; }
                         if (bbDist2(bbI, S, g->bbSc[scj]) < rl2) { cand.push_back(scj); }
                     }
                 }
@@ -648,7 +764,7 @@ NbnxmHostPairlist* nbnxm_host_pairlist_build(const NbnxmHostGrid* g, const int* 
                     unsigned int mask = 0;
                     for (int cil = 0; cil < NCL; cil++)
                     {
-                        if (central && scj == sci && cjl < cil) { continue; }
+                        if (halfList && central && scj == sci && cjl < cil) { continue; }
                         const int ci = sci * NCL + cil;
                         if (g->bbCluster[ci].empty()) { continue; }
                         if (bbDist2(g->bbCluster[ci], S, g->bbCluster[cj]) < rl2) { mask |= (1U << cil); }
@@ -685,7 +801,7 @@ NbnxmHostPairlist* nbnxm_host_pairlist_build(const NbnxmHostGrid* g, const int* 
             };
 
             // diagonal: on the central image a cluster paired with itself keeps only j > i
-            if (central)
+            if (central && halfList)
             {
                 for (int cil = 0; cil < NCL; cil++)
                 {
@@ -723,10 +839,10 @@ NbnxmHostPairlist* nbnxm_host_pairlist_build(const NbnxmHostGrid* g, const int* 
                         for (int d = 0; d < 3; d++)
                         {
                             const float dd = g->xq[4 * static_cast<size_t>(gi) + d] + S[d] - g->xq[4 * static_cast<size_t>(gj) + d];
-                            if (std::fabs(dd) > 0.5F * g->box[d]) { minImage = false; }
+                            if (g->periodic[d] && std::fabs(dd) > 0.5F * g->box[d]) { minImage = false; }
                         }
                         if (!minImage) { continue; }
-                        if (central && cj == sci * NCL + cil && jc <= ic) { continue; } // already cleared
+                        if (halfList && central && cj == sci * NCL + cil && jc <= ic) { continue; } // already cleared
                         clearPair(pos, cil, ic, jc);
                     }
                 }
@@ -754,7 +870,7 @@ NbnxmHostPairlist* nbnxm_host_pairlist_build(const NbnxmHostGrid* g, const int* 
                             const int aj = g->atomIndices[gj];
                             if (aj < 0) { continue; }
                             if (!(fepI || ((g->fepBits[cj] >> jc) & 1U))) { continue; }
-                            if (central && gj < gi) { continue; }
+                            if (halfList && central && gj < gi) { continue; }
                             float d2 = 0;
                             for (int d = 0; d < 3; d++)
                             {
@@ -804,7 +920,7 @@ NbnxmHostPairlist* nbnxm_host_pairlist_build(const NbnxmHostGrid* g, const int* 
     for (unsigned int& p : allOnes.pair) { p = 0xffffffffU; }
     pl->excl.push_back(allOnes);
     pl->jindex.push_back(0);
-    for (int sci = 0; sci < g->nsc; sci++)
+    for (int sci = 0; sci < nscI; sci++)
     {
         SciWork&  w       = work[sci];
         const int cjBase  = static_cast<int>(pl->cjPacked.size());
@@ -859,6 +975,32 @@ NbnxmHostPairlist* nbnxm_host_pairlist_build(const NbnxmHostGrid* g, const int* 
     };
     std::stable_sort(pl->sci.begin(), pl->sci.end(), [&](const nbnxn_sci_t& a, const nbnxn_sci_t& b) { return cost(a) > cost(b); });
     return pl;
+}
+} // namespace
+
+extern "C" {
+
+NbnxmHostPairlist* nbnxm_host_pairlist_build(const NbnxmHostGrid* g, const int* exclIndex,
+                                             const int* exclAtoms, float rlist,
+                                             int maxCjPackedPerSci, int carveFep, float rlistFep)
+{
+    return pairlistBuild(g, 0, exclIndex, exclAtoms, rlist, maxCjPackedPerSci, carveFep, rlistFep);
+}
+
+NbnxmHostPairlist* nbnxm_host_pairlist_build_dd(const NbnxmHostGrid* g, int nonLocal, const int* exclIndex, const int* exclAtoms,
+                                                float rlist, int maxCjPackedPerSci)
+{
+    if (nonLocal && g->zones.size() < 2)
+    {
+        auto*        pl = new NbnxmHostPairlist; // no halo: an empty list (with the shared all-ones exclusion entry)
+        nbnxn_excl_t allOnes;
+        for (unsigned int& p : allOnes.pair) { p = 0xffffffffU; }
+        pl->excl.push_back(allOnes);
+        pl->jindex.push_back(0);
+        return pl;
+    }
+    return pairlistBuild(g, nonLocal ? 1 : 0, nonLocal ? nullptr : exclIndex, nonLocal ? nullptr : exclAtoms, rlist, maxCjPackedPerSci, 0,
+                         rlist);
 }
 
 void nbnxm_host_pairlist_free(NbnxmHostPairlist* pl)

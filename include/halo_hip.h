@@ -1,0 +1,75 @@
+/*
+ * halo_hip.h — C ABI of the GPU halo exchange of a domain-decomposed run on MI355X: coordinates out to the ranks that need
+ * them and forces back, over RCCL point-to-point (ncclSend / ncclRecv groups, xGMI inside a node), stream-ordered on the
+ * caller's non-local stream so that it overlaps the local non-bonded kernel.
+ *
+ * Replaces gmx::GpuHaloExchange (domdec/gpuhaloexchange.h:75-160; implementation domdec/gpuhaloexchange_impl_gpu.cpp:122-511,
+ * kernels domdec/gpuhaloexchange_impl_gpu.cu:62-183):
+ *     reinitHalo(d_x, d_f)                               -> halo_gpu_reinit
+ *     communicateHaloCoordinates(box, dependencyEvent)   -> halo_gpu_communicate_coordinates
+ *     communicateHaloForces(accumulate, dependencyEvents)-> halo_gpu_communicate_forces
+ *     getForcesReadyOnDeviceEvent()                      -> halo_gpu_forces_ready_event
+ * MI355X-first differences: the reference has one object per (dimension, pulse) and forwards halo atoms dimension by dimension
+ * (MPI_Sendrecv of device pointers, or peer copies plus an MPI handshake of events per pulse).  xGMI links every GPU of a node to
+ * every other, so ONE object per rank talks to all its neighbours directly: one pack kernel for all destinations, one
+ * ncclGroup of sends and receives (coordinates land in place in the receiver's coordinate array, no unpack), one unpack-and-add
+ * kernel for the forces.  A "link" is one (peer, periodic image) pair; the coordinate shift of the image is applied while
+ * packing (packSendBufKernel's usePbc path).
+ *
+ * librccl is opened at run time (dlopen: the copy already in the process — PyTorch brings one — or /opt/rocm/lib/librccl.so.1);
+ * this library has no link-time dependency on it, and single-GPU users never load it.
+ */
+#ifndef HALO_HIP_H
+#define HALO_HIP_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct HaloGpu HaloGpu;
+
+#define HALO_GPU_UNIQUE_ID_BYTES 128
+
+/* ncclGetUniqueId: call on ONE rank and hand the 128 bytes to all ranks (any out-of-band channel).  Returns 0 on success. */
+int halo_gpu_get_unique_id(void* uniqueId);
+
+/* ncclCommInitRank (collective over the nranks).  stream: the hipStream_t the exchanges are queued on (the non-local stream of
+ * the non-bonded module).  Returns NULL on failure (halo_gpu_last_error() has the text). */
+HaloGpu* halo_gpu_create(const void* uniqueId, int rank, int nranks, void* stream);
+void     halo_gpu_free(HaloGpu* h);
+const char* halo_gpu_last_error(void);
+
+/* reinitHalo — after every domain repartitioning / search.
+ *  d_x, d_f        float3 arrays in the rank's atom order: home atoms [0, numHome), then the halo blocks
+ *  send side: numSend destinations; destination k gets the home atoms sendMap[sendOffset[k] .. sendOffset[k+1]) in that order;
+ *             entry i is shifted by shiftVectors[3 * sendShiftIndex[i] ..] while packing (the periodic image the receiver sees)
+ *  recv side: numRecv sources; source k's atoms occupy x/f rows [recvAtomOffset[k], recvAtomOffset[k] + recvCount[k])
+ * Host arrays are copied; the maps go to the device. */
+void halo_gpu_reinit(HaloGpu* h, void* d_x, void* d_f, int numHome, int numSend, const int* sendPeer, const int* sendOffset,
+                     const int* sendMap, const int* sendShiftIndex, int numShiftVectors, const float* shiftVectors, int numRecv,
+                     const int* recvPeer, const int* recvAtomOffset, const int* recvCount);
+
+/* communicateHaloCoordinates: [wait dependencyEvent (hipEvent_t or NULL: coordinates updated)] pack -> group(send, recv) on the
+ * object's stream.  The halo rows of d_x are valid for work queued on that stream afterwards. */
+void halo_gpu_communicate_coordinates(HaloGpu* h, void* dependencyEvent);
+
+/* communicateHaloForces: [wait dependencyEvent] group(send the halo rows of d_f to their owners, receive what the others
+ * computed on this rank's atoms) -> f[sendMap[i]] += received (accumulate != 0) or = received. */
+void halo_gpu_communicate_forces(HaloGpu* h, int accumulate, void* dependencyEvent);
+
+/* recorded on the object's stream after the last communicate_* call (hipEvent_t) */
+void* halo_gpu_coordinates_ready_event(HaloGpu* h);
+void* halo_gpu_forces_ready_event(HaloGpu* h);
+
+/* bytes this rank sends per step (coordinates out + forces back), for reporting */
+long long halo_gpu_bytes_per_step(const HaloGpu* h);
+
+/* The pack and unpack-add kernels alone, on caller-provided buffers (tests, and transports other than RCCL):
+ *   packed[i] = x[map[i]] + shiftVectors[shiftIndex[i]]            f[map[i]] (+)= packed[i] */
+void halo_gpu_pack_shifted(void* stream, const void* d_x, const int* d_map, const int* d_shiftIndex, int n, const float* d_shiftVectors,
+                           void* d_packed);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -329,12 +329,16 @@ void nbnxm_gpu_setup_short_range_work(NbnxmGpu* nb, int haveListedForcesGpuInter
  * cell = atom index -> grid slot (gridSet.cells()).  stream NULL: the local non-bonded stream. */
 void nbnxm_gpu_force_reduction_reinit(NbnxmGpu* nb, int numAtoms, const int* cell, int atomStart, int accumulate);
 void nbnxm_gpu_force_reduction_execute(NbnxmGpu* nb, void* d_baseForce, const void* d_rvecForceToAdd, void* stream);
+/* A part of the atoms only — the reference keeps one GpuForceReduction object per locality (mdrun/runner.cpp: local atoms
+ * [0, numHome), non-local atoms behind them) with its own atomStart / accumulate; here both use the one cell map uploaded
+ * with nbnxm_gpu_force_reduction_reinit(nb, numAtomsAll, cell, 0, .):  f[i] = (accumulate ? f[i] : 0) + nbnxmForce[cell[i]]
+ * for i in [atomBegin, atomEnd), on `stream` (NULL: the local non-bonded stream). */
+void nbnxm_gpu_force_reduction_execute_range(NbnxmGpu* nb, void* d_baseForce, int atomBegin, int atomEnd, int accumulate, void* stream);
 
 /* Pack / unpack kernels of gmx::GpuHaloExchange — domdec/gpuhaloexchange_impl_gpu.cu:62-116,118-183:
  *   pack:    sendBuf[i] = x[map[i]] (+ coordinateShift when not NULL)
  *   unpack:  f[map[i]] (+)= recvBuf[i]
- * Device pointers; stream is a hipStream_t.  The exchange itself (RCCL send/recv over xGMI) is driven by the caller
- * (gromacs-fep-gpu_amd/halo.py for the tests and the bench). */
+ * Device pointers; stream is a hipStream_t.  The exchange itself: include/halo_hip.h (RCCL send / receive groups). */
 void nbnxm_gpu_halo_pack_x(void* stream, const void* d_x, const int* d_map, int mapSize, const float* coordinateShift,
                            void* d_sendBuf);
 void nbnxm_gpu_halo_unpack_f(void* stream, void* d_f, const int* d_map, int mapSize, const void* d_recvBuf, int accumulate);

@@ -42,6 +42,14 @@ typedef struct NbnxmHostGrid NbnxmHostGrid;
 NbnxmHostGrid* nbnxm_host_grid_create(int natoms, const float* x, const float* box, const float* qA,
                                       const float* qB, const int* typeA, const int* typeB, int ntype,
                                       const unsigned char* perturbed);
+/* The grid of ONE DOMAIN of a decomposed run (nbnxm/gridset.cpp: local grid + non-local grid): natomsHome home atoms followed
+ * by natomsHalo halo atoms, gridded as two zones (home slots first).  periodic[d] != 0: coordinates are wrapped into the box along
+ * d and the list builder searches the images along d; 0 for a decomposed dimension, where the halo coordinates arrive already
+ * shifted into the domain's own frame (domdec/gpuhaloexchange_impl_gpu.cu:62-88) and nothing is wrapped. */
+NbnxmHostGrid* nbnxm_host_grid_create_dd(int natomsHome, int natomsHalo, const float* x, const float* box, const int* periodic,
+                                         const float* qA, const float* qB, const int* typeA, const int* typeB, int ntype,
+                                         const unsigned char* perturbed);
+int  nbnxm_host_grid_num_atoms_home(const NbnxmHostGrid* g); /* padded slots of the home zone (= numAtomsLocal of the GPU module) */
 void nbnxm_host_grid_free(NbnxmHostGrid* g);
 int  nbnxm_host_grid_num_atoms(const NbnxmHostGrid* g);    /* padded: 64 * numSuperClusters */
 int  nbnxm_host_grid_num_clusters(const NbnxmHostGrid* g); /* 8 * numSuperClusters */
@@ -87,6 +95,12 @@ typedef struct NbnxmHostPairlist NbnxmHostPairlist;
 NbnxmHostPairlist* nbnxm_host_pairlist_build(const NbnxmHostGrid* g, const int* exclIndex,
                                              const int* exclAtoms, float rlist,
                                              int maxCjPackedPerSci, int carveFep, float rlistFep);
+/* The two lists of a domain (InteractionLocality::Local / NonLocal, nbnxm/pairlist.cpp:3960-4100): nonLocal == 0: home i-clusters x
+ * home j-clusters, every pair once; nonLocal != 0: home i-clusters x halo j-clusters, all images (a halo cluster never is an
+ * i-cluster).  Perturbed pairs stay in the cluster list (fused mode).  Exclusions: CSR over the grid's own atom numbering; with
+ * whole molecules per domain no exclusion reaches into the halo, so the non-local list takes none. */
+NbnxmHostPairlist* nbnxm_host_pairlist_build_dd(const NbnxmHostGrid* g, int nonLocal, const int* exclIndex, const int* exclAtoms,
+                                                float rlist, int maxCjPackedPerSci);
 void nbnxm_host_pairlist_free(NbnxmHostPairlist* pl);
 /* sizes[0..5] = nsci, ncjPacked, nexcl, fep nri, fep nrj, number of set imask bits (cluster pairs) */
 void nbnxm_host_pairlist_sizes(const NbnxmHostPairlist* pl, long long* sizes);

@@ -46,6 +46,15 @@ def test_hip_library_exports_every_update_symbol():
     assert sorted(names) == sorted(pkg.UPDATE_SYMBOLS)
 
 
+def test_hip_library_exports_every_halo_exchange_symbol():
+    lib = pkg.hip_lib()
+    names = declared_functions("halo_hip.h", "halo_gpu_")
+    assert len(names) == 11
+    for n in names:
+        assert hasattr(lib, n), "libnbnxm_hip.so does not export %s" % n
+    assert sorted(names) == sorted(pkg.HALO_SYMBOLS)
+
+
 def test_host_library_exports_every_declared_symbol():
     lib = pkg.host_lib()
     names = declared_functions("nbnxm_host.h", "nbnxm_host_")

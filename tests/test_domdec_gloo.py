@@ -1,8 +1,9 @@
-"""Domain decomposition + halo exchange on CPU: the decomposition plan and the exchange schedule of
-gromacs-fep-gpu_amd/domdec.py, with two gloo ranks.  The HIP pack / unpack kernels and the cluster kernel need a GPU;
-here index-copy stand-ins and the CPU oracle take their place (test doubles injected from this file), so what is under
-test is: which entries a rank evaluates, which atoms travel in which direction, and that owners end up with the same
-forces as a single-domain evaluation."""
+"""Domain decomposition + halo exchange on CPU (SURVEY §8 rows e / f2): the decomposition plan, the per-rank grids and pair
+lists of gromacs-fep-gpu_amd/domdec.py, and the exchange schedule with gloo ranks.  The HIP kernels and the RCCL transport need
+GPUs; here the CPU oracle evaluates each rank's two lists and a tensor-index test double (domdec.TensorHalo, constructed by the
+tests only) moves the halo, so what is under test is: every pair is evaluated on exactly one rank, which atoms travel where
+with which image shift, and that the owners end up with the forces of a single-domain evaluation."""
+import importlib
 import os
 import socket
 import sys
@@ -26,119 +27,157 @@ def _free_port():
     return port
 
 
-def _case():
+def _case(nm=(10, 10, 10)):
     import fep_testlib as tl
-    return tl, tl.make_case(nm=(12, 8, 8), num_perturbed_molecules=0, elec="rf", seed=77)
+    return tl, tl.make_case(nm=nm, num_perturbed_molecules=0, elec="rf", seed=77)
 
 
 def _domdec():
     from __graft_entry__ import load_package
     load_package()
-    import importlib
     return importlib.import_module("gromacs_fep_gpu_amd.domdec")
 
 
-def _pack(stream, data, imap, out):
-    out.copy_(data[imap.long()])
-
-
-def _unpack(stream, data, imap, buf, accumulate):
-    if accumulate:
-        data.index_add_(0, imap.long(), buf)
-    else:
-        data[imap.long()] = buf
-
-
-def _rank_forces(tl, case, plan):
-    """Grid-order forces of one rank's share of the list (CPU oracle on the rank's entries)."""
+def _single_domain(tl, c):
     import oracle_binding as ob
-    g = case.grid
-    p = tl.oracle_ref_params(case)
-    res = ob.nbnxm_ref(plan.sci, plan.cjPacked, case.plist_fused.excl, g.xq, g.type, g.num_types, g.nbat_nbfp(case.sys["nbfp"]),
-                       p, g.shift_vec, compute_energy=False, compute_fshift=False, precision="f64")
-    return res["f"]
+    g, full = c.grid, c.plist_fused
+    r = ob.nbnxm_ref(full.sci, full.cjPacked, full.excl, g.xq, g.type, g.num_types, g.nbat_nbfp(c.sys["nbfp"]), tl.oracle_ref_params(c),
+                     g.shift_vec)
+    real = g.atomIndices >= 0
+    f = np.zeros((c.natoms, 3))
+    f[g.atomIndices[real]] = r["f"][real]
+    return f, r
 
 
-@pytest.mark.parametrize("num_ranks", [2, 3, 4])
-def test_plan_covers_the_list_once_and_maps_are_symmetric(num_ranks):
-    tl, case = _case()
-    dd = _domdec().SlabDecomposition(case.grid, case.plist_fused, num_ranks)
-    plans = [dd.plan(r) for r in range(num_ranks)]
-    full = case.plist_fused
-    assert sum(len(p.sci) for p in plans) == len(full.sci)
-    assert sum(len(p.cjPacked) for p in plans) == int((full.sci["cjPackedEnd"] - full.sci["cjPackedBegin"]).sum())
-    # every entry's groups survive unchanged
-    key = lambda sci, cj: sorted((int(e["sci"]), int(e["shift"]), cj[e["cjPackedBegin"]:e["cjPackedEnd"]].tobytes()) for e in sci)
-    merged = []
+def _rank_system(tl, domdec, c, plan):
+    return domdec.RankSystem(tl.pkg, plan, c.sys["box"], c.sys["qA"], c.sys["qB"], c.sys["typeA"], c.sys["typeB"], c.ntype, c.sys["molId"],
+                             c.rlist, perturbed=c.perturbed)
+
+
+def _rank_oracle(tl, c, system, xq=None):
+    """forces of a rank's local + non-local list in rank atom order (home, then halo), energies, pairs within the cut-off"""
+    import oracle_binding as ob
+    g = system.grid
+    f = np.zeros((g.num_atoms, 3))
+    vc = vv = 0.0
+    npairs = 0
+    for pl in (system.local, system.nonlocal_):
+        res = ob.nbnxm_ref(pl.sci, pl.cjPacked, pl.excl, g.xq if xq is None else xq, g.type, g.num_types, g.nbat_nbfp(c.sys["nbfp"]),
+                           tl.oracle_ref_params(c), g.shift_vec)
+        f += res["f"]
+        vc, vv, npairs = vc + res["Vc"], vv + res["Vv"], npairs + res["npairs"]
+    return f[system.cell], vc, vv, npairs
+
+
+@pytest.mark.parametrize("nm,ncells,self_links", [
+    ((10, 10, 10), (2, 1, 1), (False, False, False)),
+    ((10, 10, 10), (2, 2, 1), (False, False, False)),
+    ((10, 10, 10), (2, 2, 2), (False, False, False)),      # BASELINE configs[4]
+    ((14, 8, 8), (3, 1, 1), (False, False, False)),
+    ((10, 10, 10), (1, 1, 1), (True, False, False)),        # a rank that is its own neighbour
+    ((10, 10, 10), (1, 1, 1), (True, True, True)),
+])
+def test_every_pair_is_evaluated_on_exactly_one_rank(nm, ncells, self_links):
+    tl, c = _case(nm)
+    domdec = _domdec()
+    f0, r0 = _single_domain(tl, c)
+    dd = domdec.DomainDecomposition(c.sys["x"], c.sys["box"], c.sys["molId"], ncells, c.rlist, self_links=self_links)
+    f = np.zeros((c.natoms, 3))
+    vc = vv = 0.0
+    npairs = 0
+    homes = []
+    for r in range(dd.num_ranks):
+        plan = dd.plan(r)
+        homes.append(plan.home)
+        system = _rank_system(tl, domdec, c, plan)
+        fr, a, b, n = _rank_oracle(tl, c, system)
+        np.add.at(f, plan.global_ids, fr)       # what the force halo does: halo rows go back to their owners
+        vc, vv, npairs = vc + a, vv + b, npairs + n
+        # molecules are whole on their home rank
+        mol = c.sys["molId"]
+        assert np.isin(mol[plan.home], mol[np.setdiff1d(np.arange(c.natoms), plan.home)]).sum() == 0
+    assert np.array_equal(np.sort(np.concatenate(homes)), np.arange(c.natoms))      # one owner per atom
+    assert npairs == r0["npairs"]                # atom pairs within the cut-off: the same count, so none twice and none missing
+    rms = np.sqrt((f0 ** 2).sum(axis=1).mean())
+    assert np.abs(f - f0).max() <= 5e-5 * rms    # float32 coordinates in shifted frames (x + box rounds differently)
+    assert abs(vc - r0["Vc"]) <= 1e-6 * abs(r0["Vc"]) and abs(vv - r0["Vv"]) <= 1e-6 * abs(r0["Vv"])
+
+
+def test_plans_agree_on_both_sides_of_every_link():
+    tl, c = _case()
+    domdec = _domdec()
+    dd = domdec.DomainDecomposition(c.sys["x"], c.sys["box"], c.sys["molId"], (2, 2, 2), c.rlist)
+    plans = [dd.plan(r) for r in range(8)]
+    assert len(dd.directions) == 13
     for p in plans:
-        merged += key(p.sci, p.cjPacked)
-    assert sorted(merged) == key(full.sci, full.cjPacked)
-    ai = case.grid.atomIndices
-    homes = np.concatenate([p.home_atoms for p in plans])
-    assert np.array_equal(np.sort(homes), np.arange(case.natoms))           # every atom has exactly one owner
-    for r, p in enumerate(plans):
-        for q, atoms in p.recv_atoms.items():
-            assert q != r and np.array_equal(atoms, plans[q].send_atoms[r])  # same map on both sides
-            assert np.isin(atoms, plans[q].home_atoms).all()
-        # every j atom a rank touches is home or in its halo
-        jcl = np.unique(p.cjPacked["cj"])
-        jat = ai.reshape(-1, 8)[jcl].reshape(-1)
-        jat = jat[jat >= 0]
-        known = np.concatenate([p.home_atoms] + list(p.recv_atoms.values()))
-        assert np.isin(jat, known).all()
+        a = p.halo_arrays()
+        assert len(a["recv_peer"]) == len(set(a["recv_peer"])) and len(a["send_peer"]) == len(set(a["send_peer"]))   # one message per peer
+        for k, src in enumerate(a["recv_peer"]):
+            b = plans[src].halo_arrays()
+            j = list(b["send_peer"]).index(p.rank)
+            n = b["send_offset"][j + 1] - b["send_offset"][j]
+            assert n == a["recv_count"][k]
+            # the same atoms in the same order, and the image the sender packs is the one the receiver gridded
+            sent_ids = plans[src].home[b["send_map"][b["send_offset"][j]:b["send_offset"][j + 1]]]
+            recv_ids = p.global_ids[a["recv_offset"][k]:a["recv_offset"][k] + n]
+            assert np.array_equal(sent_ids, recv_ids)
+            sent_x = plans[src].x_rank[b["send_map"][b["send_offset"][j]:b["send_offset"][j + 1]]] \
+                + b["shift_vectors"][b["send_shift_index"][b["send_offset"][j]:b["send_offset"][j + 1]]]
+            assert np.abs(sent_x - p.x_rank[a["recv_offset"][k]:a["recv_offset"][k] + n]).max() < 2e-6
+    st = dd.halo_statistics()
+    assert st["links_per_rank"] == 13 and st["halo_atoms_max"] > 0
 
 
-def _worker(rank, world, port, out_dir):
+def test_default_grid():
+    domdec = _domdec()
+    assert domdec.default_grid(8) == (2, 2, 2) and domdec.default_grid(4) == (2, 2, 1) and domdec.default_grid(2) == (2, 1, 1)
+    assert domdec.default_grid(1) == (1, 1, 1) and domdec.default_grid(6) == (3, 2, 1)
+
+
+def _worker(rank, world, port, out_dir, ncells):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
+    torch.set_num_threads(1)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    tl, case = _case()
+    tl, c = _case()
     domdec = _domdec()
-    dd = domdec.SlabDecomposition(case.grid, case.plist_fused, world)
+    dd = domdec.DomainDecomposition(c.sys["x"], c.sys["box"], c.sys["molId"], ncells, c.rlist)
     plan = dd.plan(rank)
-    halo = domdec.HaloExchange(plan, "cpu", pack_fn=_pack, unpack_fn=_unpack)
-    comm = domdec.TorchDistComm(dist)
-    g = case.grid
-    ai = g.atomIndices
-    real = ai >= 0
-    # coordinates: this rank only knows its home atoms; the halo brings the rest it needs
-    x_true = np.zeros((case.natoms, 3), np.float32)
-    x_true[ai[real]] = g.xq.reshape(-1, 4)[real, :3]
-    x = torch.full((case.natoms, 3), 1.0e6)
-    x[plan.home_atoms.astype(np.int64)] = torch.from_numpy(x_true[plan.home_atoms])
-    halo.pack_x(x)
-    comm.exchange_x(halo)
-    halo.unpack_x(x)
-    needed = np.concatenate([plan.home_atoms] + list(plan.recv_atoms.values()))
-    assert np.array_equal(x.numpy()[needed], x_true[needed])
-    # forces of this rank's entries, grid order -> atom order
-    f_grid = _rank_forces(tl, case, plan)
-    f = torch.zeros((case.natoms, 3), dtype=torch.float32)
-    f[torch.from_numpy(ai[real].astype(np.int64))] = torch.from_numpy(f_grid[real].astype(np.float32))
-    halo.pack_f(f)
-    comm.exchange_f(halo)
-    halo.unpack_f(f)
-    np.save(os.path.join(out_dir, "f_home_%d.npy" % rank), f.numpy()[plan.home_atoms])
-    np.save(os.path.join(out_dir, "home_%d.npy" % rank), plan.home_atoms)
+    system = _rank_system(tl, domdec, c, plan)
+    # this rank knows the coordinates of its home atoms only; the halo brings the rest
+    x = torch.from_numpy(plan.x_rank.copy())
+    x[plan.num_home:] = 1.0e6
+    f = torch.zeros((plan.num_home + plan.num_halo, 3), dtype=torch.float32)
+    halo = domdec.TensorHalo(dist)
+    halo.reinit(plan, x, f)
+    halo.communicate_coordinates()
+    assert np.abs(x.numpy() - plan.x_rank).max() < 2e-6
+    # the rank's two lists on the coordinates that arrived
+    g = system.grid
+    xq = g.xq.reshape(-1, 4).copy()
+    real = g.atomIndices >= 0
+    xq[real, :3] = x.numpy()[g.atomIndices[real]]
+    fr, vc, vv, npairs = _rank_oracle(tl, c, system, xq=xq)
+    f.copy_(torch.from_numpy(fr.astype(np.float32)))
+    halo.communicate_forces(True)
+    np.save(os.path.join(out_dir, "f_home_%d.npy" % rank), f.numpy()[:plan.num_home])
+    np.save(os.path.join(out_dir, "home_%d.npy" % rank), plan.home)
+    np.save(os.path.join(out_dir, "npairs_%d.npy" % rank), np.array([npairs]))
     dist.barrier()
     dist.destroy_process_group()
 
 
-def test_two_rank_halo_exchange_matches_single_domain(tmp_path):
-    world = 2
-    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
-    tl, case = _case()
-    import oracle_binding as ob
-    g = case.grid
-    full = case.plist_fused
-    ref = ob.nbnxm_ref(full.sci, full.cjPacked, full.excl, g.xq, g.type, g.num_types, g.nbat_nbfp(case.sys["nbfp"]),
-                       tl.oracle_ref_params(case), g.shift_vec, compute_energy=False, compute_fshift=False, precision="f64")["f"]
-    ai = g.atomIndices
-    real = ai >= 0
-    f_ref = np.zeros((case.natoms, 3))
-    f_ref[ai[real]] = ref[real]
-    f_dd = np.zeros((case.natoms, 3))
+@pytest.mark.parametrize("ncells", [(2, 1, 1), (2, 2, 2)])
+def test_gloo_ranks_with_halo_exchange_match_single_domain(tmp_path, ncells):
+    world = int(np.prod(ncells))
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path), ncells), nprocs=world, join=True)
+    tl, c = _case()
+    f_ref, r0 = _single_domain(tl, c)
+    f_dd = np.zeros((c.natoms, 3))
+    npairs = 0
     for r in range(world):
         f_dd[np.load(os.path.join(str(tmp_path), "home_%d.npy" % r))] = np.load(os.path.join(str(tmp_path), "f_home_%d.npy" % r))
+        npairs += int(np.load(os.path.join(str(tmp_path), "npairs_%d.npy" % r))[0])
+    assert npairs == r0["npairs"]
     rms = np.sqrt((f_ref ** 2).sum(axis=1).mean())
-    assert np.abs(f_dd - f_ref).max() <= 1e-5 * rms      # float32 transport of double forces, different summation order
+    assert np.abs(f_dd - f_ref).max() <= 5e-5 * rms      # float32 transport, shifted frames, different summation order

@@ -463,65 +463,88 @@ def test_halo_pack_unpack_kernels():
     pkg.halo_pack_x(s, d_x.data_ptr(), d_map.data_ptr(), 0, d_send.data_ptr(), None)
 
 
-def _check_virtual_rank_decomposition(c, num_ranks, oracle_threads=1):
-    """All ranks of a slab decomposition in one process on one GPU (LoopbackComm): HIP pack / unpack, x -> xq, the fused
-    cluster kernel on each rank's share of the list, force reduction, force halo.  Owners must end up with the forces of
-    the single-domain evaluation (and of the CPU oracle)."""
+def _check_virtual_rank_decomposition(c, ncells, oracle_threads=1, self_links=(False, False, False), rccl=False):
+    """All ranks of a decomposition in one process on one GPU: per rank its own grid over home + halo atoms, local and non-local
+    list, two streams, x -> xq per locality, fused cluster kernels, force reduction per locality; the halo moves through the
+    in-process test double (or, rccl=True with ONE rank that is its own neighbour, through the real RCCL transport of
+    include/halo_hip.h).  Owners must end up with the forces of the single-domain oracle; energies and dV/dlambda summed over
+    the ranks must equal the single-domain ones."""
     import importlib
     import torch
     domdec = importlib.import_module("gromacs_fep_gpu_amd.domdec")
-    g = c.grid
-    full = c.plist_fused
-    dd = domdec.SlabDecomposition(g, full, num_ranks)
-    plans = [dd.plan(r) for r in range(num_ranks)]
-    ai = g.atomIndices
-    real = ai >= 0
-    x_true = np.zeros((c.natoms, 3), np.float32)
-    x_true[ai[real]] = g.xq.reshape(-1, 4)[real, :3]
-    sw = pkg.step_workload(energy=False, virial=False, dhdl=False)
-    steps = []
-    for p in plans:
-        nb = tl.setup_gpu(c, fused=True, list_override=(p.sci, p.cjPacked, full.excl))
-        # start from garbage coordinates everywhere but at home: the halo and x -> xq must supply the rest
-        xq_bad = g.xq.reshape(-1, 4).copy()
-        xq_bad[real, :3] = 1.0e5
-        nb.copy_xq_to_gpu(xq_bad)
-        st = domdec.DomainStep(nb, g, p, domdec.HaloExchange(p, "cuda"))
-        x0 = np.full((c.natoms, 3), 1.0e5, np.float32)
-        x0[p.home_atoms] = x_true[p.home_atoms]
-        st.d_x.copy_(torch.from_numpy(x0))
+    wl = importlib.import_module("gromacs_fep_gpu_amd.workload")
+    dd = domdec.DomainDecomposition(c.sys["x"], c.sys["box"], c.sys["molId"], ncells, c.rlist, self_links=self_links)
+    sw = pkg.step_workload(energy=True, virial=False, dhdl=False)
+    steps, halos = [], []
+    for r in range(dd.num_ranks):
+        plan = dd.plan(r)
+        system = domdec.RankSystem(pkg, plan, c.sys["box"], c.sys["qA"], c.sys["qB"], c.sys["typeA"], c.sys["typeB"], c.ntype,
+                                   c.sys["molId"], c.rlist, perturbed=c.perturbed)
+        nb = domdec.make_rank_gpu(pkg, wl, c, system, use_dynamic_pruning=True)
+        # garbage in the xq buffer and in the halo rows of x: x -> xq and the halo exchange must supply everything
+        nb.copy_xq_to_gpu(np.full((system.grid.num_atoms, 4), 1.0e5, np.float32) * np.array([1, 1, 1, 0], np.float32)
+                          + system.grid.xq.reshape(-1, 4) * np.array([0, 0, 0, 1], np.float32), pkg.LOCAL)
+        nb.copy_xq_to_gpu(np.full((system.grid.num_atoms, 4), 1.0e5, np.float32) * np.array([1, 1, 1, 0], np.float32)
+                          + system.grid.xq.reshape(-1, 4) * np.array([0, 0, 0, 1], np.float32), pkg.NONLOCAL)
+        halo = domdec.RcclHalo(pkg, None, 0, 1, nb.stream(pkg.NONLOCAL)) if rccl else domdec.TensorHalo(peers={})
+        st = domdec.DomainStep(pkg, nb, system, halo)
+        st.d_x[plan.num_home:] = 1.0e5
         steps.append(st)
+        halos.append(halo)
     torch.cuda.synchronize()
-    comm = domdec.LoopbackComm([s.halo for s in steps])
-    for s in steps:
-        s.pack_x()
-    torch.cuda.synchronize()
-    comm.exchange_all_x()
-    torch.cuda.synchronize()
-    for s in steps:
-        s.compute(sw)
-    torch.cuda.synchronize()
-    comm.exchange_all_f()
-    torch.cuda.synchronize()
-    for s in steps:
-        s.unpack_f()
-    torch.cuda.synchronize()
+    for repeat in range(2):                 # the second pass runs on the pruned lists and the swapped force buffers
+        if rccl:
+            steps[0].step(sw)
+        else:
+            domdec.loopback_exchange_coordinates(halos)
+            torch.cuda.synchronize()
+            for s in steps:
+                s.launch(sw)
+                s.reduce_halo_forces()
+            torch.cuda.synchronize()
+            domdec.loopback_exchange_forces(halos)
+            torch.cuda.synchronize()
+            for s in steps:
+                s.reduce_home_forces()
+        torch.cuda.synchronize()
     f_dd = np.zeros((c.natoms, 3), np.float32)
-    for s, p in zip(steps, plans):
-        f_dd[p.home_atoms] = s.d_f.cpu().numpy()[p.home_atoms]
-    want = tl.run_oracle(c, energy=False, num_threads=oracle_threads)
-    f_ref = np.zeros((c.natoms, 3))
-    f_ref[ai[real]] = want["f"][real]
-    rms = np.sqrt((f_ref ** 2).sum(axis=1).mean())
-    err = np.abs(f_dd - f_ref)
-    assert (err <= 1e-4 * np.maximum(np.linalg.norm(f_ref, axis=1, keepdims=True), rms)).all()
+    e_lj = e_el = dvdl_c = dvdl_v = 0.0
     for s in steps:
+        f_dd[s.sys.plan.home] = s.home_forces()
+        fbuf = np.zeros((s.sys.grid.num_atoms, 3), np.float32)
+        s.nb.launch_cpyback(fbuf, sw, pkg.NONLOCAL)
+        s.nb.launch_cpyback(fbuf, sw, pkg.LOCAL)
+        s.nb.wait_finish_task(sw, c.have_soft_core, pkg.NONLOCAL)
+        res = s.nb.wait_finish_task(sw, c.have_soft_core, pkg.LOCAL)
+        e_lj, e_el = e_lj + res["e_lj"], e_el + res["e_el"]
+        dv = res["dvdl_nonlin"] if c.have_soft_core else res["dvdl_lin"]
+        dvdl_c, dvdl_v = dvdl_c + dv[0], dvdl_v + dv[1]
+    want = tl.run_oracle(c, energy=True, num_threads=oracle_threads)
+    g = c.grid
+    real = g.atomIndices >= 0
+    f_ref = np.zeros((c.natoms, 3))
+    f_ref[g.atomIndices[real]] = want["f"][real]
+    got = dict(f=f_dd.astype(np.float64), fshift=want["fshift"], e_lj=e_lj, e_el=e_el, dvdl_coul=dvdl_c, dvdl_vdw=dvdl_v)
+    tl.assert_parity(got, dict(want, f=f_ref), rel=1e-4, label="decomposition %s" % (ncells,))
+    for s, h in zip(steps, halos):
+        h.free()
         s.nb.free()
 
 
-@pytest.mark.parametrize("num_ranks", [2, 3])
-def test_domain_decomposition_virtual_ranks(num_ranks):
-    _check_virtual_rank_decomposition(tl.make_case(nm=(12, 8, 8), num_perturbed_molecules=3, elec="ewald", seed=78), num_ranks)
+@pytest.mark.parametrize("ncells", [(2, 1, 1), (3, 1, 1), (2, 2, 1), (2, 2, 2)])
+def test_domain_decomposition_virtual_ranks(ncells):
+    nm = (14, 8, 8) if ncells[0] == 3 else (10, 10, 10)
+    _check_virtual_rank_decomposition(tl.make_case(nm=nm, num_perturbed_molecules=3, elec="ewald", seed=78), ncells)
+
+
+@pytest.mark.parametrize("self_links", [(True, False, False), (True, True, True)])
+def test_halo_exchange_over_rccl_with_a_rank_that_is_its_own_neighbour(self_links):
+    """The RCCL transport of include/halo_hip.h on ONE GPU: a single rank whose periodic images are its halo (ncclSend / ncclRecv
+    to itself inside a group), through the whole two-locality step.  More than one rank per GPU is refused by RCCL, so this is
+    the only way to run that code path on a one-GPU box; the multi-rank schedule is covered by the gloo tests and the
+    virtual-rank test above."""
+    _check_virtual_rank_decomposition(tl.make_case(nm=(10, 10, 10), num_perturbed_molecules=3, elec="ewald", seed=79), (1, 1, 1),
+                                      self_links=self_links, rccl=True)
 
 
 def test_full_size_properties_1m():
@@ -536,7 +559,7 @@ def test_full_size_properties_1m():
     want = tl.run_oracle(c, energy=True, num_threads=8)
     tl.assert_parity(fused, want, rel=1e-4, label="1M fused")
     tl.assert_parity(split, want, rel=1e-4, label="1M split")
-    _check_virtual_rank_decomposition(c, 8, oracle_threads=8)
+    _check_virtual_rank_decomposition(c, (2, 2, 2), oracle_threads=8)
 
 
 def test_work_partition_with_unequal_shares_covers_the_list_once():

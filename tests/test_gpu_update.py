@@ -714,16 +714,18 @@ def test_md_loop_with_listed_forces_on_the_nonbonded_buffers():
     assert np.max(np.abs(traj[True][1] - traj[False][1])) <= 2e-3
 
 
-@pytest.mark.parametrize("num_ranks", [2, 3])
-def test_domain_decomposed_md_steps_with_whole_molecules(num_ranks):
-    """Config 5 end to end on one GPU (all ranks in this process, LoopbackComm): per step halo x, kernels on the rank's share of
-    the list, halo f, then leap-frog + SETTLE on the molecules the rank owns.  Molecules are kept whole by the decomposition
-    (update groups); the trajectory of every atom, taken from its owner, equals the single-domain GPU-resident loop."""
+@pytest.mark.parametrize("ncells", [(2, 1, 1), (2, 2, 2)])
+def test_domain_decomposed_md_steps_with_whole_molecules(ncells):
+    """Config 5 end to end on one GPU (all ranks in this process, in-process halo double): per step halo x, local and non-local
+    kernels on the rank's own lists, halo f, then leap-frog + SETTLE on the rank's home molecules — rows [0, num_home) of the
+    rank's own arrays.  The trajectory of every atom, taken from its owner, equals the single-domain GPU-resident loop (positions
+    modulo the box: a rank keeps its molecules whole and unwrapped along the decomposed dimensions)."""
     import importlib
     import torch
     domdec = importlib.import_module("gromacs_fep_gpu_amd.domdec")
     mdloop = importlib.import_module("gromacs_fep_gpu_amd.mdloop")
-    c = tl.make_case(nm=(12, 8, 8), num_perturbed_molecules=3, elec="ewald", seed=52)
+    wl = importlib.import_module("gromacs_fep_gpu_amd.workload")
+    c = tl.make_case(nm=(10, 10, 10), num_perturbed_molecules=3, elec="ewald", seed=52)
     g = c.grid
     n = c.natoms
     mO, mH = 15.9994, 1.008
@@ -743,40 +745,39 @@ def test_domain_decomposed_md_steps_with_whole_molecules(num_ranks):
     ref.free()
     nb0.free()
     # decomposed
-    dd = domdec.SlabDecomposition(g, c.plist_fused, num_ranks, molecule_ids=c.sys["molId"])
-    plans = [dd.plan(r) for r in range(num_ranks)]
-    owners = np.full(n, -1)
-    for p in plans:
-        assert (owners[p.home_atoms] == -1).all()
-        owners[p.home_atoms] = p.rank
-    assert (owners >= 0).all() and (owners.reshape(-1, 3) == owners.reshape(-1, 3)[:, :1]).all()      # whole waters
-    steps = []
-    for p in plans:
-        nb = tl.setup_gpu(c, fused=True, list_override=(p.sci, p.cjPacked, c.plist_fused.excl))
-        steps.append(domdec.DomainMdStep(nb, g, p, domdec.HaloExchange(p, "cuda"), g.x_wrapped, v0, im, dt, bx, settles=settles,
-                                         settle_params=(mO, mH, 0.1, 0.16330)))
-    comm = domdec.LoopbackComm([s.halo for s in steps])
+    dd = domdec.DomainDecomposition(c.sys["x"], c.sys["box"], c.sys["molId"], ncells, c.rlist)
+    steps, halos = [], []
+    for r in range(dd.num_ranks):
+        plan = dd.plan(r)
+        system = domdec.RankSystem(pkg, plan, c.sys["box"], c.sys["qA"], c.sys["qB"], c.sys["typeA"], c.sys["typeB"], c.ntype,
+                                   c.sys["molId"], c.rlist, perturbed=c.perturbed)
+        nb = domdec.make_rank_gpu(pkg, wl, c, system, use_dynamic_pruning=False)
+        halo = domdec.TensorHalo(peers={})
+        steps.append(domdec.DomainMdStep(pkg, nb, system, halo, v0, im, dt, bx, settles=settles, settle_params=(mO, mH, 0.1, 0.16330)))
+        halos.append(halo)
     for step in range(3):
-        for s in steps:
-            s.pack_x()
         torch.cuda.synchronize()
-        comm.exchange_all_x()
+        domdec.loopback_exchange_coordinates(halos)
         torch.cuda.synchronize()
         for s in steps:
-            s.compute(sw)
+            s.launch(sw)
+            s.reduce_halo_forces()
         torch.cuda.synchronize()
-        comm.exchange_all_f()
+        domdec.loopback_exchange_forces(halos)
         torch.cuda.synchronize()
         for s in steps:
-            s.unpack_f()
+            s.reduce_home_forces()
             s.integrate(step)
-        torch.cuda.synchronize()
+    torch.cuda.synchronize()
     x_dd, v_dd = np.zeros((n, 3), np.float32), np.zeros((n, 3), np.float32)
-    for s, p in zip(steps, plans):
-        x_dd[p.home_atoms] = s.d_x.cpu().numpy()[p.home_atoms]
-        v_dd[p.home_atoms] = s.d_v.cpu().numpy()[p.home_atoms]
-    assert np.max(np.abs(x_dd - x_ref)) <= 3e-6
-    assert np.max(np.abs(v_dd - v_ref)) <= 3e-3
+    for s in steps:
+        home = s.sys.plan.home
+        x_dd[home] = s.d_x.cpu().numpy()[:len(home)]
+        v_dd[home] = s.d_v.cpu().numpy()
+    dx = (x_dd - x_ref).astype(np.float64)
+    dx -= g.box.astype(np.float64) * np.rint(dx / g.box.astype(np.float64))
+    assert np.max(np.abs(dx)) <= 5e-6
+    assert np.max(np.abs(v_dd - v_ref)) <= 5e-3
     for s in steps:
         s.update.free()
         s.nb.free()
