@@ -47,20 +47,31 @@ def positive_half_directions(decomposed):
     return out
 
 
-def default_grid(num_ranks):
-    """2 x 2 x 2 for 8 ranks (BASELINE configs[4]); otherwise the most cubic factorisation, longest side first"""
-    best = None
+def default_grid(num_ranks, box=None, rcomm=1.2):
+    """The domain grid with the smallest halo for this box: halo volume of the positive half shell of an a x b x c cell is
+    ((a + 2r)(b + 2r)(c + 2r) - abc) / 2 over the decomposed dimensions.  Without a box: the most cubic factorisation
+    (2 x 2 x 2 for 8 ranks, the grid BASELINE configs[4] names); ties go to the more cubic grid."""
+    cands = set()
     for nx in range(1, num_ranks + 1):
         if num_ranks % nx:
             continue
         for ny in range(1, num_ranks // nx + 1):
-            if (num_ranks // nx) % ny:
-                continue
-            nz = num_ranks // nx // ny
-            cand = tuple(sorted((nx, ny, nz), reverse=True))
-            score = max(cand) - min(cand)
-            if best is None or score < best[0]:
-                best = (score, cand)
+            if (num_ranks // nx) % ny == 0:
+                cands.add((nx, ny, num_ranks // nx // ny))
+    if box is None:
+        cubic = min({tuple(sorted(c, reverse=True)) for c in cands}, key=lambda c: (c[0] - c[2], c))
+        return cubic
+    best = None
+    for c in sorted(cands):
+        cell = [float(box[k]) / c[k] for k in range(3)]
+        if any(c[k] > 1 and cell[k] < rcomm + 0.2 for k in range(3)):
+            continue
+        grown = [cell[k] + (2 * rcomm if c[k] > 1 else 0.0) for k in range(3)]
+        halo = 0.5 * (grown[0] * grown[1] * grown[2] - cell[0] * cell[1] * cell[2])
+        key = (round(halo, 6), max(c) - min(c))
+        if best is None or key < best[0]:
+            best = (key, c)
+    assert best is not None, "the box is too small for %d domains" % num_ranks
     return best[1]
 
 

@@ -41,7 +41,7 @@ def make_case(nm=(8, 8, 8), num_perturbed_molecules=3, elec="rf", vdw="cut", see
               rlist_fep=None, sc_alpha=0.5, sc_power=1, sc_sigma=0.3, sc_coul=True, lambda_coul=0.5,
               lambda_vdw=0.5, n_lambda=0, max_cjpacked_per_sci=0, identical_states=False, rvdw_switch=0.8,
               spacing=0.310736, jitter=0.03, num_extra_types=0, rvdw=None, softcore="beutler",
-              gapsys=(0.85, 0.3, 0.3)):
+              gapsys=(0.85, 0.3, 0.3), build_lists=True):
     """elec: 'rf' | 'cut' | 'ewald' | 'ewald_tab';  vdw: 'cut' | 'pswitch' | 'fswitch' | 'comb_geom' | 'comb_lb' |
     'ewald_geom' | 'ewald_lb' (LJ-PME real-space part; perturbed pairs as in the CPU kernel, with the grid correction)."""
     sysd = pkg.make_water_box(nm[0], nm[1], nm[2], spacing=spacing, jitter=jitter, seed=seed,
@@ -55,15 +55,17 @@ def make_case(nm=(8, 8, 8), num_perturbed_molecules=3, elec="rf", vdw="cut", see
     if num_extra_types > 0:
         add_oxygen_type_variants(sysd, num_extra_types, seed)
     ntype = sysd["ntype"]
-    grid = pkg.Grid(sysd["x"], sysd["box"], sysd["qA"], sysd["qB"], sysd["typeA"], sysd["typeB"], ntype,
-                    perturbed=perturbed.astype(np.uint8))
-    excl_index, excl_atoms = pkg.exclusions_from_groups(sysd["molId"])
     if rlist_fep is None:
         rlist_fep = rlist + 0.0886  # rlist_fep 1.1886 for rlist 1.1
-    plist = grid.build_pairlist(excl_index, excl_atoms, rlist, max_cjpacked_per_sci, carve_fep=True,
-                                rlist_fep=rlist_fep)
-    plist_fused = grid.build_pairlist(excl_index, excl_atoms, rlist, max_cjpacked_per_sci, carve_fep=False,
-                                      rlist_fep=rlist_fep)
+    grid = plist = plist_fused = excl_index = excl_atoms = None
+    if build_lists:     # (a domain-decomposed run builds grids and lists per rank instead: domdec.RankSystem)
+        grid = pkg.Grid(sysd["x"], sysd["box"], sysd["qA"], sysd["qB"], sysd["typeA"], sysd["typeB"], ntype,
+                        perturbed=perturbed.astype(np.uint8))
+        excl_index, excl_atoms = pkg.exclusions_from_groups(sysd["molId"])
+        plist = grid.build_pairlist(excl_index, excl_atoms, rlist, max_cjpacked_per_sci, carve_fep=True,
+                                    rlist_fep=rlist_fep)
+        plist_fused = grid.build_pairlist(excl_index, excl_atoms, rlist, max_cjpacked_per_sci, carve_fep=False,
+                                          rlist_fep=rlist_fep)
 
     c = SimpleNamespace()
     c.sys, c.grid, c.plist, c.plist_fused = sysd, grid, plist, plist_fused
