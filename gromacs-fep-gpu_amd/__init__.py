@@ -148,10 +148,11 @@ def hip_lib():
     """Loads lib/libnbnxm_hip.so.  Raises if it has not been built — there is no fallback."""
     global _hip
     if _hip is None:
-        if not os.path.exists(HIP_LIB_PATH):
+        path = os.environ.get("NBNXM_HIP_LIB", HIP_LIB_PATH)     # (kernel experiments: another build of the same library)
+        if not os.path.exists(path):
             raise RuntimeError("HIP extension missing: %s (run __graft_entry__.build() / make -C %s)"
-                               % (HIP_LIB_PATH, PKG_DIR))
-        lib = C.CDLL(HIP_LIB_PATH)
+                               % (path, PKG_DIR))
+        lib = C.CDLL(path)
         lib.nbnxm_gpu_init.restype = C.c_void_p
         lib.nbnxm_gpu_get_xq.restype = C.c_void_p
         lib.nbnxm_gpu_get_f.restype = C.c_void_p

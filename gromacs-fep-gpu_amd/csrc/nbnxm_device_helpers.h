@@ -178,6 +178,28 @@ NB_DEVINL void nbPair(const NBParamGpu& nbp,
     auto masked = [intMask](float v) { return __builtin_bit_cast(float, __builtin_bit_cast(int, v) & intMask); };
     [[maybe_unused]] const float int_bit = HAS_EXCL ? masked(1.0F) : 1.0F;
     constexpr bool MASK_FORCES = EXCL_FORCES && HAS_EXCL;
+    if constexpr (!ENERGY && VDW == VDK_CUT && !TWIN && MASK_FORCES && (ELEC == ELK_RF || (ELEC == ELK_EWALD_ANA && CORR_TABLE)))
+    {
+        /* The force-only flavours of the headline configurations: ONE mask for everything an exclusion removes,
+         *   F/r = mask((q q / r + (c12 r^-6 - c6) r^-6) / r^2) + q q corr,
+         * instead of masking r^-6 and r^-3 separately.  The AND is written as asm: left to the compiler, a single masked value
+         * becomes v_and + v_cmp + v_cndmask (three instructions, two of them half rate, plus the VCC hazard). */
+        [[maybe_unused]] float2 t = make_float2(0.0F, 0.0F);
+        [[maybe_unused]] float  xs = 0.0F;
+        if constexpr (ELEC != ELK_RF)
+        {
+            /* the table read is issued first: its LDS round trip overlaps the reciprocal square root and the LJ part */
+            xs                 = r2 * nbp.ewaldCorrTabScale;
+            const unsigned idx = static_cast<unsigned>(xs);
+            t                  = ewaldCorrLds[idx];
+        }
+        const float lj = fmaf(c12, inv_r6, -c6) * inv_r6;
+        float       nm = fmaf(qq, inv_r, lj) * inv_r2;
+        asm("v_and_b32 %0, %1, %2" : "=v"(nm) : "v"(intMask), "v"(nm));
+        if constexpr (ELEC == ELK_RF) { F_invr = fmaf(qq, -nbp.two_k_rf, nm); }
+        else { F_invr = fmaf(qq, fmaf(__builtin_amdgcn_fractf(xs), t.y, t.x), nm); }
+        return;
+    }
     if constexpr (MASK_FORCES) { inv_r6 = masked(inv_r6); }
     const float inv_r3m = MASK_FORCES ? masked(inv_r2 * inv_r) : inv_r2 * inv_r; /* masked 1/r^3 */
 

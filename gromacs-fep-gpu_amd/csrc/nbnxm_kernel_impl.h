@@ -223,7 +223,7 @@ NB_DEVINL void pruneEntry(const NBAtomDataGpu& atdat, const NBParamGpu& nbp, con
                                 float c6, c12; \
                                 if constexpr (USE_TABLE) \
                                 { \
-                                    const float2 c6c12 = *reinterpret_cast<const float2*>(nbLds + trow[i] + typejBytes); \
+                                    const float2 c6c12 = *reinterpret_cast<const float2*>(nbLds + c_ewaldTabBytes + trow[i] + typejBytes); \
                                     c6                 = c6c12.x; \
                                     c12                = c6c12.y; \
                                 } \
@@ -303,7 +303,11 @@ __launch_bounds__(c_nbBlockSize) __attribute__((amdgpu_waves_per_eu(c_nbWavesPer
      * group loop) */
     extern __shared__ __align__(16) unsigned char nbLds[];
     const int numTypes   = atdat.numTypes;
-    float2*   nbfpLds    = reinterpret_cast<float2*>(nbLds);
+    /* LDS layout: the Ewald correction table (fixed size) first, then the LJ table: both bases are compile-time offsets, so a
+     * table read needs no base-address add (the offset sits in the ds_read's immediate field) */
+    constexpr bool EWALD_CORR_TABLE = (ELEC == ELK_EWALD_ANA);
+    constexpr int  c_ewaldTabBytes  = EWALD_CORR_TABLE ? c_ewaldCorrTabSize * static_cast<int>(sizeof(float2)) : 0;
+    float2*   nbfpLds    = reinterpret_cast<float2*>(nbLds + c_ewaldTabBytes);
     if constexpr (!ENERGY)
     {
         /* Trailing workgroups, behind the ones of the ranges.  The dispatcher hands workgroups out in order, so their waves start
@@ -357,12 +361,11 @@ __launch_bounds__(c_nbBlockSize) __attribute__((amdgpu_waves_per_eu(c_nbWavesPer
             return;
         }
     }
-    constexpr bool EWALD_CORR_TABLE = (ELEC == ELK_EWALD_ANA);
     /* LJ-PME: the per-type grid parameters (nbfp_comb) follow the pair table */
     const int      nbfpEntries = numTypes * numTypes + (LJ_EWALD ? numTypes : 0);
     const int      nbfpBytes   = USE_TABLE ? ((nbfpEntries * static_cast<int>(sizeof(float2)) + 15) & ~15) : 0;
-    const int      tableBytes = nbfpBytes + (EWALD_CORR_TABLE ? c_ewaldCorrTabSize * static_cast<int>(sizeof(float2)) : 0);
-    [[maybe_unused]] const float2* ewaldCorrLds = reinterpret_cast<const float2*>(nbLds + nbfpBytes);
+    const int      tableBytes = nbfpBytes + c_ewaldTabBytes;
+    [[maybe_unused]] const float2* ewaldCorrLds = reinterpret_cast<const float2*>(nbLds);
     unsigned char* jStage = nbLds + tableBytes + wave * (2 * c_jStageBytes + c_jRingBytes);
     if constexpr (USE_TABLE)
     {
@@ -375,7 +378,7 @@ __launch_bounds__(c_nbBlockSize) __attribute__((amdgpu_waves_per_eu(c_nbWavesPer
     if constexpr (EWALD_CORR_TABLE)
     {
         const float4* __restrict__ src = reinterpret_cast<const float4*>(nbp.ewaldCorrTab);
-        float4*                    dst = reinterpret_cast<float4*>(nbLds + nbfpBytes);
+        float4*                    dst = reinterpret_cast<float4*>(nbLds);
         for (int t = threadIdx.x; t < c_ewaldCorrTabSize / 2; t += blockSize) { dst[t] = src[t]; }
     }
 

@@ -17,7 +17,7 @@ for _ in range(5):
     nb.clear_outputs(False); nb.launch_kernel(sw)
 torch.cuda.synchronize()
 lib = pkg.hip_lib()
-n = 5120
+n = 5120 if len(sys.argv) < 4 else int(sys.argv[3])
 buf = (ctypes.c_ulonglong * (4 * n))()
 lib.nbnxm_gpu_debug_timeline.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]
 lib.nbnxm_gpu_debug_timeline(ctypes.c_void_p(nb._h), buf, n)
