@@ -191,7 +191,12 @@ NB_DEVINL void nbPair(const NBParamGpu& nbp,
             /* the table read is issued first: its LDS round trip overlaps the reciprocal square root and the LJ part */
             xs                 = r2 * nbp.ewaldCorrTabScale;
             const unsigned idx = static_cast<unsigned>(xs);
-            t                  = ewaldCorrLds[idx];
+            /* the table sits at LDS address 0 (nbnxmKernel checks it): the address is idx * 8, no base to add */
+            typedef __attribute__((address_space(3))) const float LdsFloat;
+            LdsFloat* tab = reinterpret_cast<LdsFloat*>(static_cast<uintptr_t>(idx * 8U));
+            t.x           = tab[0];
+            t.y           = tab[1];
+            (void)ewaldCorrLds;
         }
         const float lj = fmaf(c12, inv_r6, -c6) * inv_r6;
         float       nm = fmaf(qq, inv_r, lj) * inv_r2;

@@ -210,7 +210,7 @@ NB_DEVINL void pruneEntry(const NBAtomDataGpu& atdat, const NBParamGpu& nbp, con
                                 intMask = __builtin_amdgcn_sbfe(static_cast<int>(wexclJ), i, 1); \
                                 if constexpr (EXCL_FORCES) \
                                 { \
-                                    if (diagI == i) \
+                                    if (diagBits & (1U << i)) \
                                     { \
                                         asm volatile("" ::: "memory"); \
                                         active = active && (tidxj > tidxi); \
@@ -381,6 +381,9 @@ __launch_bounds__(c_nbBlockSize) __attribute__((amdgpu_waves_per_eu(c_nbWavesPer
         float4*                    dst = reinterpret_cast<float4*>(nbLds);
         for (int t = threadIdx.x; t < c_ewaldCorrTabSize / 2; t += blockSize) { dst[t] = src[t]; }
     }
+
+    /* nbPair addresses the Ewald table with absolute LDS addresses from 0: the kernel has no static LDS, so the dynamic block starts there */
+    if (EWALD_CORR_TABLE && reinterpret_cast<uintptr_t>((__attribute__((address_space(3))) unsigned char*)nbLds) != 0) { __builtin_trap(); }
 
     __syncthreads(); /* the table is in place; from here on the waves of the workgroup are independent */
 
@@ -628,7 +631,8 @@ __launch_bounds__(c_nbBlockSize) __attribute__((amdgpu_waves_per_eu(c_nbWavesPer
 
                 const unsigned fastMask = imaskJ;
                 /* which i-cluster (if any) is this j-cluster itself on the central image */
-                [[maybe_unused]] const int diagI = (central && (cj >> 3) == sci) ? (cj & 7) : -1;
+                /* as one bit per i-cluster: a single scalar bit test per pair block */
+                [[maybe_unused]] const unsigned diagBits = (central && (cj >> 3) == sci) ? (1U << (cj & 7)) : 0U;
 
                 float3    fcj_buf    = make_float3(0.0F, 0.0F, 0.0F);
                 const int typejBytes = typej * static_cast<int>(sizeof(float2));
