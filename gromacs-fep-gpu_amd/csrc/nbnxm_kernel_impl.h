@@ -602,7 +602,7 @@ __launch_bounds__(c_nbBlockSize) __attribute__((amdgpu_waves_per_eu(c_nbWavesPer
         {
             const unsigned laneG = laneIdNow(); /* see NBNXM_STAGE_GROUP */
             const unsigned wexcl = *reinterpret_cast<const unsigned*>(jData + c_jStageExclOffset + laneG * 4U);
-#pragma unroll 1
+#pragma unroll
             for (int jm = 0; jm < c_jGroupSize; jm++)
             {
                 /* every slot ends in exactly one VMEM atomic: a skipped slot sends nothing (all lanes out of range) */
