@@ -433,9 +433,10 @@ __launch_bounds__(c_nbBlockSize) __attribute__((amdgpu_waves_per_eu(c_nbWavesPer
 /* W(g): list words of group g -> ring record g & 3 (lanes 0-7: the 8 dwords of nbnxn_cj_packed_t; FUSED: lane 8 adds
  * groupSlowMask[g] behind them).  The lane id is recomputed in place on purpose: hoisted out of the loops it would be
  * spilled, and a scratch reload in this loop is a VMEM load that drains the pipeline. */
-#define NBNXM_STAGE_WORDS(g)                                                                                    \
+#define NBNXM_STAGE_WORDS(g) NBNXM_STAGE_WORDS_L(g, laneIdNow())
+#define NBNXM_STAGE_WORDS_L(g, laneExpr)                                                                        \
     {                                                                                                          \
-        const unsigned lane = laneIdNow();                                                                     \
+        const unsigned lane = (laneExpr);                                                                      \
         const unsigned gw   = static_cast<unsigned>(min((g), lastGroup));                                      \
         const unsigned rec  = ringLds + (static_cast<unsigned>(g) & 3U) * c_ringRecordBytes;                   \
         if (lane < 8U) { ldsDirectLoad4(rec, gw * 32U + lane * 4U, cjPackedList); }                            \
@@ -445,9 +446,10 @@ __launch_bounds__(c_nbBlockSize) __attribute__((amdgpu_waves_per_eu(c_nbWavesPer
         }                                                                                                      \
     }
 /* J(g): the three staging loads of group g into buffer buf; each lane reads the list words it needs from the ring */
-#define NBNXM_STAGE_GROUP(g, buf)                                                                               \
+#define NBNXM_STAGE_GROUP(g, buf) NBNXM_STAGE_GROUP_L(g, buf, laneIdNow())
+#define NBNXM_STAGE_GROUP_L(g, buf, laneExpr)                                                                   \
     {                                                                                                          \
-        const unsigned lane  = laneIdNow();                                                                    \
+        const unsigned lane  = (laneExpr);                                                                     \
         const unsigned half  = lane >> 5;                                                                      \
         const unsigned char* rec = ring + (static_cast<unsigned>(g) & 3U) * c_ringRecordBytes;                 \
         const int      cjl   = *reinterpret_cast<const int*>(rec + ((lane >> 3) & 3U) * 4U);                   \
@@ -484,6 +486,7 @@ __launch_bounds__(c_nbBlockSize) __attribute__((amdgpu_waves_per_eu(c_nbWavesPer
     const int prioStep2 = rangeBegin + (((rangeEnd - rangeBegin) * NBNXM_PRIO_T2) >> 4);
     const int prioStep3 = rangeBegin + (((rangeEnd - rangeBegin) * NBNXM_PRIO_T3) >> 4);
     __builtin_amdgcn_s_setprio(3);
+    int nextPrioStep = prioStep1;
 
     int curBuf      = 0;  /* staging buffer that holds (or receives) the j-side of group stagedGroup */
     int stagedGroup = -1;
@@ -578,13 +581,27 @@ __launch_bounds__(c_nbBlockSize) __attribute__((amdgpu_waves_per_eu(c_nbWavesPer
          * other and the last one runs alone, latency-bound, for the last ~10 % of the kernel (measured with a
          * per-wave timeline).  Each wave therefore lowers its own priority as it advances through its range, so
          * that the waves that are behind get the issue slots and all of them finish together. */
-        if (jPacked == prioStep1) { __builtin_amdgcn_s_setprio(2); }
-        else if (jPacked == prioStep2) { __builtin_amdgcn_s_setprio(1); }
-        else if (jPacked == prioStep3) { __builtin_amdgcn_s_setprio(0); }
+        /* (one compare per group: the next threshold; the three-way chain cost three compares and branches per group) */
+        if (__builtin_expect(jPacked == nextPrioStep, 0))
+        {
+            if (jPacked == prioStep3) { __builtin_amdgcn_s_setprio(0); }
+            else if (jPacked == prioStep2)
+            {
+                __builtin_amdgcn_s_setprio(1);
+                nextPrioStep = prioStep3;
+            }
+            else
+            {
+                __builtin_amdgcn_s_setprio(2);
+                nextPrioStep = (prioStep2 > prioStep1) ? prioStep2 : prioStep3;
+            }
+        }
 
-        /* pipeline step (see above): W(g+3); J(g+1); wait for J(g) */
-        NBNXM_STAGE_WORDS(jPacked + 3)
-        NBNXM_STAGE_GROUP(jPacked + 1, curBuf ^ 1)
+        /* pipeline step (see above): W(g+3); J(g+1); wait for J(g).  One lane-id computation per iteration serves the two
+         * staging steps and the slot loop (it is recomputed per iteration on purpose, see NBNXM_STAGE_WORDS) */
+        const unsigned laneIter = laneIdNow();
+        NBNXM_STAGE_WORDS_L(jPacked + 3, laneIter)
+        NBNXM_STAGE_GROUP_L(jPacked + 1, curBuf ^ 1, laneIter)
         NBNXM_WAIT_VMEM(c_vmOpsPerGroup);
 
 #ifdef NBNXM_WAVE_TIMELINE
@@ -600,7 +617,7 @@ __launch_bounds__(c_nbBlockSize) __attribute__((amdgpu_waves_per_eu(c_nbWavesPer
         if constexpr (FUSED) { imask &= ~__builtin_amdgcn_readfirstlane(*reinterpret_cast<const unsigned*>(rec + 32U)); }
         const unsigned char* jData = jStage + curBuf * c_jStageBytes;
         {
-            const unsigned laneG = laneIdNow(); /* see NBNXM_STAGE_GROUP */
+            const unsigned laneG = laneIter;
             const unsigned wexcl = *reinterpret_cast<const unsigned*>(jData + c_jStageExclOffset + laneG * 4U);
 #pragma unroll
             for (int jm = 0; jm < c_jGroupSize; jm++)
@@ -710,6 +727,8 @@ __launch_bounds__(c_nbBlockSize) __attribute__((amdgpu_waves_per_eu(c_nbWavesPer
     } /* pieces */
 #undef NBNXM_STAGE_GROUP
 #undef NBNXM_STAGE_WORDS
+#undef NBNXM_STAGE_GROUP_L
+#undef NBNXM_STAGE_WORDS_L
 #undef NBNXM_WAIT_VMEM
 #undef NBNXM_DUMMY_ATOMIC
 
