@@ -58,6 +58,24 @@ NB_DEVINL float reduceOver8Lanes(float v)
     return v;
 }
 
+/* x, y and z summed over the 8 consecutive lanes that share a j atom, delivered where the j-force atomic wants them: lane
+ * (l & 7) == 0 gets sum x, 1 gets sum y, 2 gets sum z (the other lanes hold partial sums).  Transposing while reducing takes
+ * 4 DPP adds + 4 selects; three separate reductions take 9 DPP adds and a select chain. */
+NB_DEVINL float reduceXyzOver8Lanes(const float3 v, const unsigned lane)
+{
+    const bool odd  = (lane & 1U) != 0U;
+    const bool high = (lane & 2U) != 0U;
+    float      keep = odd ? v.y : v.x;
+    const float give = odd ? v.x : v.y;
+    keep += dppMove<0xB1>(give); /* lane ^ 1: even lanes x + x', odd lanes y + y' */
+    const float zz    = v.z + dppMove<0xB1>(v.z);
+    const float give2 = high ? keep : zz;
+    float       keep2 = high ? zz : keep;
+    keep2 += dppMove<0x4E>(give2);  /* lane ^ 2: lanes 0, 1 of a quad: x, y over the quad; lanes 2, 3: z over the quad */
+    keep2 += dppMove<0x104>(keep2); /* row_shl:4: lane l += lane l + 4 (zero beyond the row) */
+    return keep2;
+}
+
 /* Sum over the 8 lanes with the same (lane & 7), i.e. over tidxj; every lane gets the sum. */
 NB_DEVINL float reduceOverTidxj(float v)
 {

@@ -659,10 +659,7 @@ __launch_bounds__(c_nbBlockSize) __attribute__((amdgpu_waves_per_eu(c_nbWavesPer
                 NBNXM_PAIR_LOOP(true)
 
                 /* j-force: sum over the 8 lanes of a j atom; lanes tidxi 0..2 carry x,y,z (96 contiguous bytes) */
-                const float fjx = reduceOver8Lanes(fcj_buf.x);
-                const float fjy = reduceOver8Lanes(fcj_buf.y);
-                const float fjz = reduceOver8Lanes(fcj_buf.z);
-                fjv   = (tidxi == 0U) ? fjx : ((tidxi == 1U) ? fjy : fjz);
+                fjv   = reduceXyzOver8Lanes(fcj_buf, laneG);
                 fjOff = (tidxi < 3U) ? (3 * aj + static_cast<int>(tidxi)) * static_cast<int>(sizeof(float)) : c_dropLane;
                 }
                 __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(fjv, fRsrc, fjOff, 0, 0);
