@@ -85,6 +85,40 @@ NB_DEVINL float reduceOverTidxj(float v)
     return v;
 }
 
+/* gfx950 lane-swap instructions (no selects, no LDS crossbar): v_permlane32_swap exchanges lanes 32-63 of the first register
+ * with lanes 0-31 of the second; v_permlane16_swap exchanges the odd 16-lane rows of the first with the even rows of the second.
+ * After the swap, a + b holds the first register's sum over the swapped lane bit in the lanes where that bit is 0 and the second
+ * register's in the lanes where it is 1.  Inline asm (operands read and written); the s_nop keep the neighbouring VALU writes at
+ * a safe distance, which the compiler's hazard recogniser cannot do for asm. */
+NB_DEVINL float sumPairOverLaneBit5(float a, float b)
+{
+    asm("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
+    return a + b;
+}
+NB_DEVINL float sumPairOverLaneBit4(float a, float b)
+{
+    asm("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
+    return a + b;
+}
+
+/* The 8 per-i-cluster accumulators of one force component, summed over tidxj (lane bits 3-5): lane (tidxj, tidxi) gets the sum
+ * of cluster tidxj.  A transposing reduction: 8 -> 4 -> 2 -> 1 registers with 6 lane swaps, 7 adds and 2 selects; reducing each
+ * accumulator by itself takes 8 x (1 DPP + 2 LDS-crossbar shuffles) and a select chain. */
+NB_DEVINL float reduceOverTidxjTransposed(float a0, float a1, float a2, float a3, float a4, float a5, float a6, float a7, const unsigned lane)
+{
+    const float r0 = sumPairOverLaneBit5(a0, a4); /* lanes 0-31: cluster 0, lanes 32-63: cluster 4 */
+    const float r1 = sumPairOverLaneBit5(a1, a5);
+    const float r2 = sumPairOverLaneBit5(a2, a6);
+    const float r3 = sumPairOverLaneBit5(a3, a7);
+    const float t0 = sumPairOverLaneBit4(r0, r2); /* lane bit 4 = 0: clusters 0 | 4, = 1: clusters 2 | 6 */
+    const float t1 = sumPairOverLaneBit4(r1, r3);
+    const bool  b3   = (lane & 8U) != 0U;
+    float       keep = b3 ? t1 : t0;
+    const float give = b3 ? t0 : t1;
+    keep += dppMove<0x128>(give); /* lane ^ 8 */
+    return keep;
+}
+
 NB_DEVINL float waveSum(float v)
 {
     v += dppMove<0xB1>(v);

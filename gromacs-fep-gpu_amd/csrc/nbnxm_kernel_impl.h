@@ -673,15 +673,13 @@ __launch_bounds__(c_nbBlockSize) __attribute__((amdgpu_waves_per_eu(c_nbWavesPer
 #endif
 
     /* i-forces: reduce over tidxj; lane (tidxj, tidxi) keeps the sum of cluster tidxj, atom tidxi */
-    float3 mine = make_float3(0.0F, 0.0F, 0.0F);
-#pragma unroll
-    for (int i = 0; i < c_numClPerSupercl; i++)
-    {
-        const float sx = reduceOverTidxj(fci_buf[i].x);
-        const float sy = reduceOverTidxj(fci_buf[i].y);
-        const float sz = reduceOverTidxj(fci_buf[i].z);
-        if (tidxj == static_cast<unsigned>(i)) { mine = make_float3(sx, sy, sz); }
-    }
+    float3 mine;
+    mine.x = reduceOverTidxjTransposed(fci_buf[0].x, fci_buf[1].x, fci_buf[2].x, fci_buf[3].x, fci_buf[4].x, fci_buf[5].x, fci_buf[6].x,
+                                       fci_buf[7].x, lane);
+    mine.y = reduceOverTidxjTransposed(fci_buf[0].y, fci_buf[1].y, fci_buf[2].y, fci_buf[3].y, fci_buf[4].y, fci_buf[5].y, fci_buf[6].y,
+                                       fci_buf[7].y, lane);
+    mine.z = reduceOverTidxjTransposed(fci_buf[0].z, fci_buf[1].z, fci_buf[2].z, fci_buf[3].z, fci_buf[4].z, fci_buf[5].z, fci_buf[6].z,
+                                       fci_buf[7].z, lane);
     {
         const int ai = sci * c_superClSize + static_cast<int>(lane);
         atomicAdd(&f[3 * ai + 0], mine.x);
