@@ -20,10 +20,17 @@
 #include "nbnxm_hip_types.h"
 
 constexpr int c_workBlockSize = 256;
+#ifndef NBNXM_WEIGHT_GROUP
+#define NBNXM_WEIGHT_SLOT 0
+#define NBNXM_WEIGHT_GROUP 34
+#define NBNXM_WEIGHT_ENTRY 60
+#endif
+/* refitted in round 2 (tools/calibrate_weights.py on the kernel of profiles/r02): the i-entry start got cheaper (lane-swap reduction of the
+ * i-forces), the group relatively dearer; a non-empty slot no longer shows (round 1: 2 / 30 / 76; the fit says 0 / 38 / 41, measured best between the two: 0 / 34 / 60) */
 constexpr int c_weightPair    = 8;
-constexpr int c_weightSlot    = 2;
-constexpr int c_weightGroup   = 30;
-constexpr int c_weightEntry   = 76;
+constexpr int c_weightSlot    = NBNXM_WEIGHT_SLOT;
+constexpr int c_weightGroup   = NBNXM_WEIGHT_GROUP;
+constexpr int c_weightEntry   = NBNXM_WEIGHT_ENTRY;
 
 /* largest k with sciSorted[k].cjPackedBegin <= group (entries ordered by (cjPackedBegin, cjPackedEnd)); -1 if none */
 __device__ __forceinline__ int findSciOfGroup(const nbnxn_sci_t* __restrict__ sciSorted, int nsci, int group)
