@@ -234,8 +234,8 @@ def main(argv=None):
     npert = {"24k": 3, "96k": 16, "768k": 16}[args.atoms]
     if args.perturbed_molecules >= 0:
         npert = args.perturbed_molecules
-    if args.dd and world > 1:
-        # --dd: the decomposed box IS the measurement (strong scaling)
+    if args.dd:
+        # --dd: the decomposed box IS the measurement (strong scaling; one rank: a 1 x 1 x 1 grid without a halo, a rehearsal of the leg)
         bench_dd = importlib.import_module("gromacs_fep_gpu_amd.bench_dd")
         rec = bench_dd.measure(args, rank, world, dist, torch, nm, npert, reduce_device, args.steps, args.warmup)
         if rank == 0:
@@ -247,7 +247,8 @@ def main(argv=None):
                            "mode": "fused", "atoms": rec["atoms"], "parallelism": "dd " + rec["domain_grid"]},
                 "ns_per_day_kernel_bound": 86400.0 / (rec["ms_per_step"] * 1e-3) * DT_FS * 1e-6, "roofline": None,
                 "domain_decomposition": rec}), flush=True)
-        dist.destroy_process_group()
+        if world > 1:
+            dist.destroy_process_group()
         return 0
     lam = replica.replica_lambda(rank, world)   # 0.5 on one GPU; window rank mod 11 in the replica set (config 4)
     t0 = time.time()

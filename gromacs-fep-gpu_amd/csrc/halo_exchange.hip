@@ -21,6 +21,7 @@
 #include <rccl/rccl.h> /* types and prototypes only: the library is opened with dlopen */
 
 #include "device_utils.h"
+#include "nbnxm_hip.h"
 
 using namespace nbnxm_hip;
 
@@ -351,6 +352,32 @@ long long halo_gpu_bytes_per_step(const HaloGpu* h)
     long long n = h->numSendAtoms;
     for (int c : h->recvCount) { n += c; }
     return 12LL * n;
+}
+
+/* One domain's force step with the two-locality schedule of mdlib/sim_util.cpp:1783-1924 (do_force with GPU halo exchange and GPU
+ * buffer ops), host side in C++ as in the reference:
+ *   non-local stream: halo x -> x to xq (halo slots) -> non-local kernel -> halo rows of f to atom order -> halo f (added to home rows)
+ *   local stream:     clear -> x to xq (home slots) -> local kernel [beside all of the above] -> wait for the non-local stream
+ *                     -> home rows of f += nbnxm forces
+ * The object's stream must be the non-local stream of nb. */
+void halo_gpu_domain_force_step(HaloGpu* h, NbnxmGpu* nb, const nbnxm_step_workload_t* stepWork, int numHomeSlots, int numSlots, int numAtoms)
+{
+    hipStream_t sLocal    = static_cast<hipStream_t>(nbnxm_gpu_get_stream(nb, NBNXM_LOCAL));
+    hipStream_t sNonLocal = static_cast<hipStream_t>(nbnxm_gpu_get_stream(nb, NBNXM_NONLOCAL));
+    NBNXM_ASSERT(sNonLocal == h->stream, "the halo object must have been created on the non-local stream of the non-bonded object");
+    halo_gpu_communicate_coordinates(h, nullptr);
+    nbnxm_gpu_clear_outputs(nb, stepWork->computeVirial);
+    nbnxm_gpu_x_to_nbat_x(nb, h->d_x, nullptr, NBNXM_LOCAL, 0, numHomeSlots, 1);
+    nbnxm_gpu_launch_kernel(nb, stepWork, NBNXM_LOCAL);
+    nbnxm_gpu_x_to_nbat_x(nb, h->d_x, nullptr, NBNXM_NONLOCAL, numHomeSlots, numSlots, 1);
+    nbnxm_gpu_launch_kernel(nb, stepWork, NBNXM_NONLOCAL);
+    /* the home rows are zeroed on the non-local stream, so that the forces arriving from the other ranks can be added while the
+     * local kernel is still running; the halo rows come from the non-local kernel alone */
+    NBNXM_HIP_CHECK(hipMemsetAsync(h->d_f, 0, sizeof(float3) * static_cast<size_t>(h->numHome), sNonLocal));
+    nbnxm_gpu_force_reduction_execute_range(nb, h->d_f, h->numHome, numAtoms, 0, sNonLocal);
+    halo_gpu_communicate_forces(h, 1, nullptr);
+    NBNXM_HIP_CHECK(hipStreamWaitEvent(sLocal, h->fReady, 0));
+    nbnxm_gpu_force_reduction_execute_range(nb, h->d_f, 0, h->numHome, 1, sLocal);
 }
 
 void halo_gpu_pack_shifted(void* stream, const void* d_x, const int* d_map, const int* d_shiftIndex, int n, const float* d_shiftVectors,

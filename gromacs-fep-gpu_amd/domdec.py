@@ -312,6 +312,12 @@ class RcclHalo:
     def bytes_per_step(self):
         return int(self._lib.halo_gpu_bytes_per_step(self._C.c_void_p(self._h)))
 
+    def domain_force_step(self, nb, step_work, num_home_slots, num_slots, num_atoms):
+        """halo_gpu_domain_force_step: the whole two-locality force step of the domain, host side in C++"""
+        C = self._C
+        self._lib.halo_gpu_domain_force_step(C.c_void_p(self._h), nb.h, C.byref(step_work), C.c_int(num_home_slots), C.c_int(num_slots),
+                                             C.c_int(num_atoms))
+
     def free(self):
         if getattr(self, "_h", None):
             self._lib.halo_gpu_free(self._C.c_void_p(self._h))
@@ -471,7 +477,11 @@ class DomainStep:
         self.ev_local_done.record(self.ts_local)
 
     def step(self, step_work):
-        """the whole step of a rank that has its own process"""
+        """the whole step of a rank that has its own process: one call into the library when the transport is the RCCL one
+        (halo_gpu_domain_force_step, host side in C++), else the same schedule spelled out"""
+        if hasattr(self.halo, "domain_force_step"):
+            self.halo.domain_force_step(self.nb, step_work, self.home_slots, self.all_slots, self.num_all)
+            return
         self.halo.communicate_coordinates()
         self.launch(step_work)
         self.reduce_halo_forces()

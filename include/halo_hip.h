@@ -22,6 +22,8 @@
 #ifndef HALO_HIP_H
 #define HALO_HIP_H
 
+#include "nbnxm_hip.h"
+
 #ifdef __cplusplus
 extern "C" {
 #endif
@@ -60,6 +62,15 @@ void halo_gpu_communicate_forces(HaloGpu* h, int accumulate, void* dependencyEve
 /* recorded on the object's stream after the last communicate_* call (hipEvent_t) */
 void* halo_gpu_coordinates_ready_event(HaloGpu* h);
 void* halo_gpu_forces_ready_event(HaloGpu* h);
+
+/* The whole force step of one domain in one call (host side in C++, as in the reference's do_force): halo x beside the local kernel,
+ * x -> xq per locality, local and non-local non-bonded kernels on their two streams, forces to atom order per locality, halo f added
+ * to the home rows (mdlib/sim_util.cpp:1783-1924).  nb: the domain's non-bonded object (include/nbnxm_hip.h) with both localities, its
+ * cell map uploaded with nbnxm_gpu_force_reduction_reinit(nb, numAtoms, cell, 0, .) and its atom indices with
+ * nbnxm_gpu_init_x_to_nbat_x; numHomeSlots / numSlots: grid slots of the home zone / of both zones; numAtoms: home + halo atoms.
+ * h must have been created on nb's non-local stream.  On return everything is queued; the home rows of d_f are final on nb's local
+ * stream. */
+void halo_gpu_domain_force_step(HaloGpu* h, NbnxmGpu* nb, const nbnxm_step_workload_t* stepWork, int numHomeSlots, int numSlots, int numAtoms);
 
 /* bytes this rank sends per step (coordinates out + forces back), for reporting */
 long long halo_gpu_bytes_per_step(const HaloGpu* h);
