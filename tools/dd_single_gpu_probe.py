@@ -40,7 +40,8 @@ t1 = time.perf_counter()
 n = 200
 for _ in range(n):
     st.step(sw)
+ms_enqueue = 1e3 * (time.perf_counter() - t1) / n      # host time to queue a step (if it equals ms_per_step, the step is launch-bound)
 torch.cuda.synchronize()
 ms = 1e3 * (time.perf_counter() - t1) / n
-print(json.dumps({"atoms": case.natoms, "self_links": links, "home": plan.num_home, "halo": plan.num_halo, "ms_per_step": ms,
+print(json.dumps({"atoms": case.natoms, "self_links": links, "home": plan.num_home, "halo": plan.num_halo, "ms_per_step": ms, "ms_host_enqueue_per_step": ms_enqueue,
                   "host_plan_s": t_plan, "host_rank_lists_s": t_lists, "halo_bytes": halo.bytes_per_step()}))
