@@ -61,7 +61,7 @@ def parse_args(argv=None):
                     help="box of the domain-decomposition leg that follows the replica measurement when N > 1 (configs[4] size)")
     ap.add_argument("--dd-steps", type=int, default=200)
     ap.add_argument("--no-dd-leg", action="store_true", help="N > 1: replicas only, skip the domain-decomposition leg")
-    ap.add_argument("--dd-timeout", type=float, default=240.0, help="seconds after which the domain-decomposition leg is given up")
+    ap.add_argument("--dd-timeout", type=float, default=150.0, help="seconds after which the domain-decomposition leg is given up")
     return ap.parse_args(argv)
 
 

@@ -250,8 +250,11 @@ NB_DEVINL void pruneEntry(const NBAtomDataGpu& atdat, const NBParamGpu& nbp, con
 
 /* 5 waves per SIMD (<= 96 VGPRs) for the flavours that fit without scratch; the energy, combination-rule and
  * switch flavours carry more live values and run at 4 waves (<= 128 VGPRs) instead of spilling. */
+#ifndef NBNXM_FORCE_WAVES_PER_EU
+#define NBNXM_FORCE_WAVES_PER_EU 5
+#endif
 template<int VDW, bool ENERGY>
-constexpr int c_nbWavesPerEu = (VDW == VDK_CUT && !ENERGY) ? 5 : 4;
+constexpr int c_nbWavesPerEu = (VDW == VDK_CUT && !ENERGY) ? NBNXM_FORCE_WAVES_PER_EU : 4;
 
 /* FUSED: the cluster pairs that touch a perturbed atom are masked out of the list words (gpu_plist::groupSlowMask) and
  * left to nbnxmFepClusterKernel; otherwise the kernel is the plain one */
