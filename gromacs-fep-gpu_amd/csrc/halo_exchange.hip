@@ -360,7 +360,8 @@ long long halo_gpu_bytes_per_step(const HaloGpu* h)
  *   local stream:     clear -> x to xq (home slots) -> local kernel [beside all of the above] -> wait for the non-local stream
  *                     -> home rows of f += nbnxm forces
  * The object's stream must be the non-local stream of nb. */
-void halo_gpu_domain_force_step(HaloGpu* h, NbnxmGpu* nb, const nbnxm_step_workload_t* stepWork, int numHomeSlots, int numSlots, int numAtoms)
+void halo_gpu_domain_force_step(HaloGpu* h, NbnxmGpu* nb, const nbnxm_step_workload_t* stepWork, int numHomeSlots, int numSlots, int numAtoms,
+                                void* coordinatesReadyEvent)
 {
     hipStream_t sLocal    = static_cast<hipStream_t>(nbnxm_gpu_get_stream(nb, NBNXM_LOCAL));
     hipStream_t sNonLocal = static_cast<hipStream_t>(nbnxm_gpu_get_stream(nb, NBNXM_NONLOCAL));
@@ -368,9 +369,9 @@ void halo_gpu_domain_force_step(HaloGpu* h, NbnxmGpu* nb, const nbnxm_step_workl
     /* the local work is queued FIRST: the host needs tens of microseconds to queue an RCCL group, and the local kernel depends on
      * nothing that travels */
     nbnxm_gpu_clear_outputs(nb, stepWork->computeVirial);
-    nbnxm_gpu_x_to_nbat_x(nb, h->d_x, nullptr, NBNXM_LOCAL, 0, numHomeSlots, 1);
+    nbnxm_gpu_x_to_nbat_x(nb, h->d_x, coordinatesReadyEvent, NBNXM_LOCAL, 0, numHomeSlots, 1);
     nbnxm_gpu_launch_kernel(nb, stepWork, NBNXM_LOCAL);
-    halo_gpu_communicate_coordinates(h, nullptr);
+    halo_gpu_communicate_coordinates(h, coordinatesReadyEvent);
     nbnxm_gpu_x_to_nbat_x(nb, h->d_x, nullptr, NBNXM_NONLOCAL, numHomeSlots, numSlots, 1);
     nbnxm_gpu_launch_kernel(nb, stepWork, NBNXM_NONLOCAL);
     /* the home rows are zeroed on the non-local stream, so that the forces arriving from the other ranks can be added while the

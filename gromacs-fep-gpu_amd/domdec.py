@@ -312,11 +312,11 @@ class RcclHalo:
     def bytes_per_step(self):
         return int(self._lib.halo_gpu_bytes_per_step(self._C.c_void_p(self._h)))
 
-    def domain_force_step(self, nb, step_work, num_home_slots, num_slots, num_atoms):
+    def domain_force_step(self, nb, step_work, num_home_slots, num_slots, num_atoms, coordinates_ready_event=None):
         """halo_gpu_domain_force_step: the whole two-locality force step of the domain, host side in C++"""
         C = self._C
         self._lib.halo_gpu_domain_force_step(C.c_void_p(self._h), nb.h, C.byref(step_work), C.c_int(num_home_slots), C.c_int(num_slots),
-                                             C.c_int(num_atoms))
+                                             C.c_int(num_atoms), C.c_void_p(coordinates_ready_event))
 
     def free(self):
         if getattr(self, "_h", None):
@@ -476,11 +476,11 @@ class DomainStep:
         self.nb.force_reduction_execute_range(self.d_f.data_ptr(), 0, self.num_home, True, self.s_local)
         self.ev_local_done.record(self.ts_local)
 
-    def step(self, step_work):
+    def step(self, step_work, coordinates_ready_event=None):
         """the whole step of a rank that has its own process: one call into the library when the transport is the RCCL one
         (halo_gpu_domain_force_step, host side in C++), else the same schedule spelled out"""
         if hasattr(self.halo, "domain_force_step"):
-            self.halo.domain_force_step(self.nb, step_work, self.home_slots, self.all_slots, self.num_all)
+            self.halo.domain_force_step(self.nb, step_work, self.home_slots, self.all_slots, self.num_all, coordinates_ready_event)
             return
         self.halo.communicate_coordinates()
         self.launch(step_work)
@@ -530,12 +530,21 @@ class DomainMdStep(DomainStep):
         if not ok:
             raise ValueError("a group of coupled constraints is too large for the GPU LINCS")
         self.update.set_pbc(3, box)
+        self._x_ready = None
+        self.update.x_updated_event()       # a consumer exists: the update records the event from its first step on
         torch.cuda.synchronize()
         del local_of
 
     def integrate(self, step_index=0, seed=0, tc_lambdas=None):
         """on the local stream, behind reduce_home_forces"""
         return self.update.integrate(self.dt, update_velocities=True, tc_lambdas=tc_lambdas, seed=seed, step=step_index)
+
+    def md_step(self, step_work, step_index=0):
+        """force step + update of a rank with its own process: the next step's coordinate reads (x -> xq on the local stream, the
+        halo pack on the non-local one) wait for this step's update through the update's x-updated event"""
+        self.step(step_work, self._x_ready)
+        self.integrate(step_index)
+        self._x_ready = self.update.x_updated_event()
 
 
 def make_rank_gpu(pkg, wl, case, system, use_dynamic_pruning=True):

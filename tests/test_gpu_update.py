@@ -714,7 +714,7 @@ def test_md_loop_with_listed_forces_on_the_nonbonded_buffers():
     assert np.max(np.abs(traj[True][1] - traj[False][1])) <= 2e-3
 
 
-@pytest.mark.parametrize("ncells", [(2, 1, 1), (2, 2, 2)])
+@pytest.mark.parametrize("ncells", [(2, 1, 1), (2, 2, 2), "rccl-self"])
 def test_domain_decomposed_md_steps_with_whole_molecules(ncells):
     """Config 5 end to end on one GPU (all ranks in this process, in-process halo double): per step halo x, local and non-local
     kernels on the rank's own lists, halo f, then leap-frog + SETTLE on the rank's home molecules — rows [0, num_home) of the
@@ -745,17 +745,24 @@ def test_domain_decomposed_md_steps_with_whole_molecules(ncells):
     ref.free()
     nb0.free()
     # decomposed
-    dd = domdec.DomainDecomposition(c.sys["x"], c.sys["box"], c.sys["molId"], ncells, c.rlist)
+    # "rccl-self": ONE rank that is its own neighbour in every dimension, the real RCCL transport and the one-call C++ force step
+    # (halo_gpu_domain_force_step) with the update's x-updated event as the dependency of the next step's coordinate reads
+    rccl = ncells == "rccl-self"
+    dd = domdec.DomainDecomposition(c.sys["x"], c.sys["box"], c.sys["molId"], (1, 1, 1) if rccl else ncells, c.rlist,
+                                    self_links=(True, True, True) if rccl else (False, False, False))
     steps, halos = [], []
     for r in range(dd.num_ranks):
         plan = dd.plan(r)
         system = domdec.RankSystem(pkg, plan, c.sys["box"], c.sys["qA"], c.sys["qB"], c.sys["typeA"], c.sys["typeB"], c.ntype,
                                    c.sys["molId"], c.rlist, perturbed=c.perturbed)
         nb = domdec.make_rank_gpu(pkg, wl, c, system, use_dynamic_pruning=False)
-        halo = domdec.TensorHalo(peers={})
+        halo = domdec.RcclHalo(pkg, None, 0, 1, nb.stream(pkg.NONLOCAL)) if rccl else domdec.TensorHalo(peers={})
         steps.append(domdec.DomainMdStep(pkg, nb, system, halo, v0, im, dt, bx, settles=settles, settle_params=(mO, mH, 0.1, 0.16330)))
         halos.append(halo)
     for step in range(3):
+        if rccl:
+            steps[0].md_step(sw, step)       # no host synchronisation between the steps
+            continue
         torch.cuda.synchronize()
         domdec.loopback_exchange_coordinates(halos)
         torch.cuda.synchronize()
@@ -778,6 +785,7 @@ def test_domain_decomposed_md_steps_with_whole_molecules(ncells):
     dx -= g.box.astype(np.float64) * np.rint(dx / g.box.astype(np.float64))
     assert np.max(np.abs(dx)) <= 5e-6
     assert np.max(np.abs(v_dd - v_ref)) <= 5e-3
-    for s in steps:
+    for s, h in zip(steps, halos):
         s.update.free()
+        h.free()
         s.nb.free()
