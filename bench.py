@@ -35,6 +35,8 @@ HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8 TB/s
 FP32_PEAK_TFLOPS = 157.3   # vector fp32
 DT_FS = 2.0                # MD time step for the kernel-bound ns/day figure
 METRIC = "ns/day + pair-interactions/s, 100k-atom FEP box @ λ=0.5, 1/2/4/8 MI355X"
+# molecules per box edge of the synthetic water boxes (3 atoms each): configs[1], configs[2], 8 x configs[2], configs[4]'s 1.02 M atoms
+BOXES = {"24k": (20, 20, 20), "96k": (40, 40, 20), "768k": (80, 80, 40), "1m": (88, 88, 44)}
 COUNTERS_FILE = os.path.join("profiles", "r02", "counters_fused_force_kernel.json")   # written by tools/summarize_counters.py
 
 
@@ -44,7 +46,7 @@ def parse_args(argv=None):
     ap.add_argument("--steps", type=int, default=500)
     ap.add_argument("--warmup", type=int, default=50)
     ap.add_argument("--mode", choices=["fused", "split"], default="fused")
-    ap.add_argument("--atoms", choices=["24k", "96k", "768k"], default="96k")
+    ap.add_argument("--atoms", choices=["24k", "96k", "768k", "1m"], default="96k")
     ap.add_argument("--elec", choices=["ewald", "rf"], default="ewald", help="rf: BASELINE configs[1] (with --atoms 24k)")
     ap.add_argument("--max-cjpacked-per-sci", type=int, default=16)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -57,8 +59,8 @@ def parse_args(argv=None):
                     help="N > 1: one box decomposed over the ranks with a halo exchange (config 5, strong scaling) "
                          "instead of the default independent lambda replicas (config 4, weak scaling)")
     ap.add_argument("--dd-grid", default="", help="domain grid as AxBxC (default: 2x2x2 for 8 ranks, else the most cubic factorisation)")
-    ap.add_argument("--dd-atoms", choices=["24k", "96k", "768k"], default="768k",
-                    help="box of the domain-decomposition leg that follows the replica measurement when N > 1 (configs[4] size)")
+    ap.add_argument("--dd-atoms", choices=["24k", "96k", "768k", "1m"], default="1m",
+                    help="box of the domain-decomposition leg that follows the replica measurement when N > 1 (configs[4]: 1M atoms)")
     ap.add_argument("--dd-steps", type=int, default=200)
     ap.add_argument("--no-dd-leg", action="store_true", help="N > 1: replicas only, skip the domain-decomposition leg")
     ap.add_argument("--dd-timeout", type=float, default=150.0, help="seconds after which the domain-decomposition leg is given up")
@@ -230,8 +232,8 @@ def main(argv=None):
     wl = importlib.import_module("gromacs_fep_gpu_amd.workload")
     replica = importlib.import_module("gromacs_fep_gpu_amd.replica")
 
-    nm = {"24k": (20, 20, 20), "96k": (40, 40, 20), "768k": (80, 80, 40)}[args.atoms]
-    npert = {"24k": 3, "96k": 16, "768k": 16}[args.atoms]
+    nm = BOXES[args.atoms]
+    npert = 3 if args.atoms == "24k" else 16
     if args.perturbed_molecules >= 0:
         npert = args.perturbed_molecules
     if args.dd:
@@ -354,7 +356,7 @@ def main(argv=None):
     # lambda windows batched into one object (secondary figure; BASELINE configs[3]: 11 windows — more than the GPUs of a node):
     # one list over 11 x N slots, per-window lambdas in the perturbed-pair kernel (nbnxm_gpu_set_window_lambdas)
     batched = None
-    if fused and world == 1 and not args.primary_only and args.atoms != "768k":
+    if fused and world == 1 and not args.primary_only and args.atoms in ("24k", "96k"):
         R = 11
         b = replica.batch_windows(case.grid, pl, R)
         nbw = pkg.NbnxmGpu(wl.gpu_interaction_params(case, not args.no_prune), case.grid.num_types, case.grid.nbat_nbfp(case.sys["nbfp"]),
@@ -467,8 +469,8 @@ def guarded_dd_leg(args, rank, world, dist, torch, out, reduce_device):
     timer = threading.Timer(args.dd_timeout, give_up)
     timer.daemon = True
     timer.start()
-    nm = {"24k": (20, 20, 20), "96k": (40, 40, 20), "768k": (80, 80, 40)}[args.dd_atoms]
-    npert = {"24k": 3, "96k": 16, "768k": 16}[args.dd_atoms]
+    nm = BOXES[args.dd_atoms]
+    npert = 3 if args.dd_atoms == "24k" else 16
     try:
         bench_dd = importlib.import_module("gromacs_fep_gpu_amd.bench_dd")
         rec = bench_dd.measure(args, rank, world, dist, torch, nm, npert, reduce_device, args.dd_steps, 10)
