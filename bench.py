@@ -387,6 +387,21 @@ def main(argv=None):
                    "pair_interactions_per_s": R * 64 * stats["cluster_pairs"] / (ms_batched * 1e-3),
                    "speedup_over_one_window_at_a_time": R * (elapsed / args.steps) / (ms_batched * 1e-3)}
 
+    # the same step for a caller that keeps the device pointer of the forces (gpu_get_f: GPU update, GPU force reduction glue): the
+    # buffer is pinned from then on, nbnxm_gpu_clear_outputs launches its clear kernel again instead of swapping (secondary figure;
+    # measured last, because the pin lasts for the life of the object)
+    ms_pinned = None
+    if fused and not args.primary_only:
+        nb.f_device_pointer()
+        for _ in range(10):
+            one_step()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(100):
+            one_step()
+        torch.cuda.synchronize()
+        ms_pinned = 1e3 * (time.perf_counter() - t1) / 100
+
     ms_per_step = 1e3 * elapsed / args.steps
     pair_evals = 64 * stats["cluster_pairs"]          # atom pairs in the (pruned) list, SURVEY §8d
     fep_pairs = len(case.plist.fep["jjnr"])
@@ -418,6 +433,7 @@ def main(argv=None):
         "kernel_us": {"k_calc_nb": nb_k_us, "k_calc_nb_fep": fep_k_us, "how": "HIP events around the timed loop on the kernel's stream / steps"},
         "ms_per_energy_step": ms_energy_step, "ms_per_dhdl_step_11_foreign_lambdas": ms_dhdl_step,
         "ms_per_virial_only_step": ms_virial_only, "ms_per_energy_only_step": ms_energy_only,
+        "ms_per_step_with_pinned_force_buffer": ms_pinned,
         "ms_per_gpu_resident_md_step": ms_md_step, "ms_per_gpu_resident_md_step_unfused_update": ms_md_step_sequence,
         "ms_per_gpu_resident_md_step_with_rolling_prune_8": ms_md_step_prune,
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
