@@ -21,6 +21,7 @@
 #include <rccl/rccl.h> /* types and prototypes only: the library is opened with dlopen */
 
 #include "device_utils.h"
+#include "nbnxm_gpu_internal.h"
 #include "nbnxm_hip.h"
 
 using namespace nbnxm_hip;
@@ -128,6 +129,42 @@ __global__ void haloUnpackForcesKernel(float* __restrict__ f, const float3* __re
         d[1] = v.y;
         d[2] = v.z;
     }
+}
+
+/* the two force-buffer passes of a domain step, each fused into one launch (every launch on a stream costs its duration plus a
+ * gap of a few microseconds):
+ *   A (non-local stream, behind the non-local kernel): home rows of f = 0, halo rows of f = nbnxm forces of the halo slots
+ *   B (local stream, behind the local kernel and the force halo): home rows += nbnxm forces of the home slots, and
+ *     f[sendMap[j]] += what the other ranks computed on this rank's atoms — all with atomic adds, the rows are shared */
+__global__ void domainHaloRowsKernel(float3* __restrict__ f, const float3* __restrict__ nbnxmForce, const int* __restrict__ cell,
+                                     const int numHome, const int numAtoms)
+{
+    const int i = static_cast<int>(blockIdx.x * blockDim.x + threadIdx.x);
+    if (i >= numAtoms) { return; }
+    f[i] = (i < numHome) ? make_float3(0.0F, 0.0F, 0.0F) : nbnxmForce[cell[i]];
+}
+
+__global__ void domainHomeRowsKernel(float* __restrict__ f, const float3* __restrict__ nbnxmForce, const int* __restrict__ cell,
+                                     const int numHome, const float3* __restrict__ received, const int* __restrict__ sendMap,
+                                     const int numReceived)
+{
+    const int i = static_cast<int>(blockIdx.x * blockDim.x + threadIdx.x);
+    float3    v;
+    float*    d;
+    if (i < numHome)
+    {
+        v = nbnxmForce[cell[i]];
+        d = f + 3 * static_cast<size_t>(i);
+    }
+    else if (i < numHome + numReceived)
+    {
+        v = received[i - numHome];
+        d = f + 3 * static_cast<size_t>(sendMap[i - numHome]);
+    }
+    else { return; }
+    atomicAdd(d + 0, v.x);
+    atomicAdd(d + 1, v.y);
+    atomicAdd(d + 2, v.z);
 }
 
 } // namespace
@@ -298,11 +335,11 @@ void halo_gpu_communicate_coordinates(HaloGpu* h, void* dependencyEvent)
     NBNXM_HIP_CHECK(hipEventRecord(h->xReady, s));
 }
 
-void halo_gpu_communicate_forces(HaloGpu* h, int accumulate, void* dependencyEvent)
+/* the transfers of the force halo alone: halo rows out, what the others computed on this rank's atoms into the send buffer */
+static void exchangeForces(HaloGpu* h)
 {
     Rccl*       r = rccl();
     hipStream_t s = h->stream;
-    if (dependencyEvent != nullptr) { NBNXM_HIP_CHECK(hipStreamWaitEvent(s, static_cast<hipEvent_t>(dependencyEvent), 0)); }
     /* the reverse of the coordinate exchange: the halo rows of d_f go to their owners as they are (contiguous, no pack),
      * what the others computed on this rank's atoms arrives in the send buffer, in the order of the send map */
     HALO_RCCL_CHECK(r->GroupStart());
@@ -319,6 +356,13 @@ void halo_gpu_communicate_forces(HaloGpu* h, int accumulate, void* dependencyEve
         }
     }
     HALO_RCCL_CHECK(r->GroupEnd());
+}
+
+void halo_gpu_communicate_forces(HaloGpu* h, int accumulate, void* dependencyEvent)
+{
+    hipStream_t s = h->stream;
+    if (dependencyEvent != nullptr) { NBNXM_HIP_CHECK(hipStreamWaitEvent(s, static_cast<hipEvent_t>(dependencyEvent), 0)); }
+    exchangeForces(h);
     if (h->numSendAtoms > 0)
     {
         const dim3 grid((h->numSendAtoms + c_haloThreadsPerBlock - 1) / c_haloThreadsPerBlock);
@@ -374,13 +418,20 @@ void halo_gpu_domain_force_step(HaloGpu* h, NbnxmGpu* nb, const nbnxm_step_workl
     halo_gpu_communicate_coordinates(h, coordinatesReadyEvent);
     nbnxm_gpu_x_to_nbat_x(nb, h->d_x, nullptr, NBNXM_NONLOCAL, numHomeSlots, numSlots, 1);
     nbnxm_gpu_launch_kernel(nb, stepWork, NBNXM_NONLOCAL);
-    /* the home rows are zeroed on the non-local stream, so that the forces arriving from the other ranks can be added while the
-     * local kernel is still running; the halo rows come from the non-local kernel alone */
-    NBNXM_HIP_CHECK(hipMemsetAsync(h->d_f, 0, sizeof(float3) * static_cast<size_t>(h->numHome), sNonLocal));
-    nbnxm_gpu_force_reduction_execute_range(nb, h->d_f, h->numHome, numAtoms, 0, sNonLocal);
-    halo_gpu_communicate_forces(h, 1, nullptr);
+    NBNXM_ASSERT(nb->reductionAtomStart == 0 && nb->reductionNumAtoms >= numAtoms, "the cell map must cover home and halo atoms");
+    /* pass A: home rows zeroed, halo rows from the non-local kernel (one launch on the non-local stream) */
+    hipLaunchKernelGGL(domainHaloRowsKernel, dim3((numAtoms + c_haloThreadsPerBlock - 1) / c_haloThreadsPerBlock), dim3(c_haloThreadsPerBlock), 0,
+                       sNonLocal, h->d_f, reinterpret_cast<const float3*>(nb->atdat->f), nb->cell, h->numHome, numAtoms);
+    NBNXM_HIP_CHECK(hipGetLastError());
+    exchangeForces(h);
+    NBNXM_HIP_CHECK(hipEventRecord(h->fReady, sNonLocal));
+    /* pass B: behind the local kernel (stream order) and the arrival of the force halo (event) */
     NBNXM_HIP_CHECK(hipStreamWaitEvent(sLocal, h->fReady, 0));
-    nbnxm_gpu_force_reduction_execute_range(nb, h->d_f, 0, h->numHome, 1, sLocal);
+    const int n = h->numHome + h->numSendAtoms;
+    hipLaunchKernelGGL(domainHomeRowsKernel, dim3((n + c_haloThreadsPerBlock - 1) / c_haloThreadsPerBlock), dim3(c_haloThreadsPerBlock), 0, sLocal,
+                       reinterpret_cast<float*>(h->d_f), reinterpret_cast<const float3*>(nb->atdat->f), nb->cell, h->numHome, h->d_sendBuf,
+                       h->d_sendMap, h->numSendAtoms);
+    NBNXM_HIP_CHECK(hipGetLastError());
 }
 
 void halo_gpu_pack_shifted(void* stream, const void* d_x, const int* d_map, const int* d_shiftIndex, int n, const float* d_shiftVectors,
