@@ -3,7 +3,6 @@ as inputs of the cluster-pair path: grid + GPU-layout list from libnbnxm_host, p
 createInteractionConst() sets them (api/nblib/nbnxmsetuphelpers.cpp:232-292).  Shared by the oracle test (CPU) and
 the HIP test (GPU)."""
 import json
-import math
 import os
 from types import SimpleNamespace
 
