@@ -55,6 +55,8 @@ def parse_args(argv=None):
                     help="skip the secondary figures (energy / dH/dl / virial steps, MD loops): the profile of such a run holds "
                          "the force-only kernels of the timed loop and nothing else")
     ap.add_argument("--perturbed-molecules", type=int, default=-1, help="override the ligand size (diagnostics)")
+    ap.add_argument("--extra-types", type=int, default=0,
+                    help="diagnostics: give the water oxygens this many extra atom types (the LJ table in LDS grows as ntype^2)")
     ap.add_argument("--dd", action="store_true",
                     help="N > 1: one box decomposed over the ranks with a halo exchange (config 5, strong scaling) "
                          "instead of the default independent lambda replicas (config 4, weak scaling)")
@@ -157,7 +159,7 @@ def committed_counters(fused, args):
     command, tools/gpu_pmc.sh + tools/gpu_traffic.sh -> tools/summarize_counters.py).  NOT measured in this run: the record
     says so (`source`, with the commit the profile was taken at)."""
     path = os.path.join(ROOT, COUNTERS_FILE)
-    if not (fused and args.atoms == "96k" and args.elec == "ewald" and args.perturbed_molecules < 0 and os.path.exists(path)):
+    if not (fused and args.atoms == "96k" and args.elec == "ewald" and args.perturbed_molecules < 0 and args.extra_types == 0 and os.path.exists(path)):
         return None
     try:
         rec = json.load(open(path))
@@ -255,7 +257,7 @@ def main(argv=None):
     lam = replica.replica_lambda(rank, world)   # 0.5 on one GPU; window rank mod 11 in the replica set (config 4)
     t0 = time.time()
     case = wl.make_case(nm=nm, num_perturbed_molecules=npert, elec=args.elec, seed=2026, n_lambda=11,
-                        lambda_coul=lam, lambda_vdw=lam, max_cjpacked_per_sci=args.max_cjpacked_per_sci)
+                        lambda_coul=lam, lambda_vdw=lam, max_cjpacked_per_sci=args.max_cjpacked_per_sci, num_extra_types=args.extra_types)
     t_build = time.time() - t0
     fused = args.mode == "fused"
     nb = wl.setup_gpu(case, fused=fused, use_dynamic_pruning=not args.no_prune)
@@ -421,7 +423,7 @@ def main(argv=None):
         "rccl_ranks": rccl_ranks,
         "config": {"workload": "configs[2]: 96k-atom water + 48 perturbed atoms, Ewald(analytical) + LJ cut, rc 1.0, rlist 1.1, lambda 0.5"
                    if (args.atoms == "96k" and args.elec == "ewald") else "%s-atom box, %s" % (args.atoms, args.elec),
-                   "mode": args.mode, "atoms": int(case.natoms), "perturbed_atoms": int(case.perturbed.sum()),
+                   "mode": args.mode, "atoms": int(case.natoms), "atom_types": int(case.ntype), "perturbed_atoms": int(case.perturbed.sum()),
                    "nsci": stats["nsci"], "cj_slots": stats["cj_slots"], "cluster_pairs": stats["cluster_pairs"],
                    "fep_pairs": fep_pairs, "max_cjpacked_per_sci": args.max_cjpacked_per_sci,
                    "parallelism": "1 lambda replica per GPU" if world > 1 else "single GPU"},

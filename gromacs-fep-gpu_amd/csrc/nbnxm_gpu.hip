@@ -1154,18 +1154,33 @@ void nbnxm_gpu_launch_kernel(NbnxmGpu* nb, const nbnxm_step_workload_t* stepWork
         const bool ljEwald  = (nbp->vdwType == NBNXM_VDW_EWALD_GEOM || nbp->vdwType == NBNXM_VDW_EWALD_LB);
         const bool useTable = (nbp->vdwType == NBNXM_VDW_CUT || nbp->vdwType == NBNXM_VDW_FSWITCH || nbp->vdwType == NBNXM_VDW_PSWITCH || ljEwald);
         NBNXM_ASSERT(!ljEwald || nbp->nbfp_comb != nullptr, "LJ-PME kernel selected without the grid parameters (nbfp_comb)");
-        int        wavesPerBlock = nb->nbWavesPerBlock;
-        const int  tableBytes    = useTable ? adat->numTypes * adat->numTypes * 8 : 0;
-        if (tableBytes > 8 * 1024) { wavesPerBlock = c_nbWavesPerBlock; } /* one table copy per 4 waves */
         const bool ewaldCorrTable = (nbp->elecType == NBNXM_ELEC_EWALD_ANA || nbp->elecType == NBNXM_ELEC_EWALD_ANA_TWIN);
-        const int  ldsBytes       = nbLdsBytes(adat->numTypes, useTable, ljEwald, ewaldCorrTable, fused, wavesPerBlock);
-        NBNXM_ASSERT(ldsBytes <= 160 * 1024, "too many atom types: the LJ parameter table does not fit the 160 KB LDS");
+        /* Workgroup shape.  Every workgroup holds its own copy of the tables in LDS.  The default is one workgroup of 4 waves (one
+         * per SIMD) per wave slot; the LJ table of a force field with many atom types (8 numTypes^2 bytes: 32 KB at 64 types) makes
+         * that many copies overflow the CU's 160 KB, and the dispatcher would silently keep fewer waves resident.  Then fewer,
+         * larger workgroups share a copy — 8 waves (two workgroups per CU) or 16 (one) — at 4 waves per SIMD: measured on MI355X the
+         * force kernel loses 4 % from 5 to 4 waves per SIMD, but 2x from 5 to 2. */
+        const int compiledWavesPerSimd = nbKernelWavesPerEu(nbp->vdwType, energyFlavour, fused);
+        int       wavesPerBlock = 0, wavesPerSimd = 0;
+        for (const int w : { nb->nbWavesPerBlock, 2 * c_nbWavesPerBlock, 4 * c_nbWavesPerBlock })
+        {
+            const int lds      = (nbLdsBytes(adat->numTypes, useTable, ljEwald, ewaldCorrTable, fused, w) + c_ldsAllocGranularity - 1)
+                            / c_ldsAllocGranularity * c_ldsAllocGranularity;
+            const int resident = std::min(c_simdsPerCu * compiledWavesPerSimd / w, c_ldsBytesPerCu / lds) * w / c_simdsPerCu;
+            if (resident > wavesPerSimd)
+            {
+                wavesPerBlock = w;
+                wavesPerSimd  = resident;
+            }
+        }
+        NBNXM_ASSERT(wavesPerSimd >= 4, "too many atom types: the LJ parameter table does not fit the 160 KB LDS");
+        const int ldsBytes = nbLdsBytes(adat->numTypes, useTable, ljEwald, ewaldCorrTable, fused, wavesPerBlock);
         if (ldsBytes > 64 * 1024)
         {
             NBNXM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, ldsBytes));
         }
-        /* one wave per resident wave slot, each with an equal share of the list (see updateWorkPartition) */
-        const int p         = nbKernelWavesPerEu(nbp->vdwType, energyFlavour, fused) - 4;
+        /* one wave per resident wave slot, each with its share of the list (see updateWorkPartition) */
+        const int p         = wavesPerSimd - 4;
         const int numRanges = plist->numWorkRanges[p];
         NBNXM_ASSERT(numRanges > 0, "work partition missing");
         const int mergedFepItems = mergeFep ? plist->numSlowPairs : 0;

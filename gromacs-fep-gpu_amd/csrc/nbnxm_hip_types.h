@@ -24,6 +24,12 @@ constexpr int c_waveSize          = 64;
 /* launch geometry of the cluster-pair kernel: one wavefront per i-entry, 4 wavefronts per workgroup */
 constexpr int c_nbWavesPerBlock   = 4;
 constexpr int c_nbBlockSize       = c_nbWavesPerBlock * c_waveSize;
+/* the launch may use workgroups of 8 or 16 waves that share one copy of the LDS tables (many atom types, see nbnxm_gpu_launch_kernel);
+ * the bound changes nothing in the generated code (the register budget comes from amdgpu_waves_per_eu) */
+constexpr int c_nbMaxBlockSize    = 1024;
+constexpr int c_simdsPerCu        = 4;
+constexpr int c_ldsBytesPerCu     = 160 * 1024;
+constexpr int c_ldsAllocGranularity = 1024; /* rounding used when counting resident workgroups (conservative) */
 /* nbnxm/pairlist.h:166: keeps r^-12 finite in fp32 */
 constexpr float c_nbnxnMinDistanceSquared = 3.82e-07F;
 /* nb_free_energy.cpp:107: cap on r^-6 in the perturbed-pair math */

@@ -259,7 +259,7 @@ constexpr int c_nbWavesPerEu = (VDW == VDK_CUT && !ENERGY) ? NBNXM_FORCE_WAVES_P
 /* FUSED: the cluster pairs that touch a perturbed atom are masked out of the list words (gpu_plist::groupSlowMask) and
  * left to nbnxmFepClusterKernel; otherwise the kernel is the plain one */
 template<int ELEC, bool TWIN, int VDW, bool ENERGY, bool FUSED>
-__launch_bounds__(c_nbBlockSize) __attribute__((amdgpu_waves_per_eu(c_nbWavesPerEu<VDW, ENERGY>))) __global__
+__launch_bounds__(c_nbMaxBlockSize) __attribute__((amdgpu_waves_per_eu(c_nbWavesPerEu<VDW, ENERGY>))) __global__
         void nbnxmKernel(const NBAtomDataGpu atdat,
                          const NBParamGpu    nbp,
                          const gpu_plist     plist,

@@ -314,6 +314,21 @@ def test_many_atom_types_table_in_lds(extra):
         tl.assert_parity(got, want, rel=1e-4, label="types %d" % extra)
 
 
+@pytest.mark.parametrize("extra", [26, 60, 96])
+@pytest.mark.parametrize("elec", ["ewald", "rf"])
+def test_many_atom_types_larger_workgroups(extra, elec):
+    """30 / 64 / 100 atom types: the LJ table (8 ntype^2 bytes) no longer fits the LDS once per 4-wave workgroup at full occupancy, so
+    the launch switches to the 4-waves-per-SIMD partition and to workgroups of 8 or 16 waves that share one copy
+    (nbnxm_gpu_launch_kernel).  Force-only (the 5-waves-per-SIMD flavour) and energy steps, both modes."""
+    c = tl.make_case(elec=elec, seed=44, num_extra_types=extra, **SMALL)
+    assert c.grid.num_types == 4 + extra
+    for fused in (False, True):
+        for energy in (False, True):
+            got = tl.run_gpu(c, energy=energy, fused=fused)
+            want = tl.run_oracle(c, energy=energy)
+            tl.assert_parity(got, want, rel=1e-4, energy=energy, label="types %d %s fused %d energy %d" % (4 + extra, elec, fused, energy))
+
+
 def test_local_and_nonlocal_streams():
     """Two localities as with domain decomposition: the sci entries are dealt to a Local and a NonLocal list,
     both kernels accumulate into the same force buffer, copy-back order NonLocal then Local (sim_util.cpp:1914-1924)."""
