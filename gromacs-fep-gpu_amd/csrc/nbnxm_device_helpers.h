@@ -230,7 +230,8 @@ NB_DEVINL void nbPair(const NBParamGpu& nbp,
     auto masked = [intMask](float v) { return __builtin_bit_cast(float, __builtin_bit_cast(int, v) & intMask); };
     [[maybe_unused]] const float int_bit = HAS_EXCL ? masked(1.0F) : 1.0F;
     constexpr bool MASK_FORCES = EXCL_FORCES && HAS_EXCL;
-    if constexpr (!ENERGY && VDW == VDK_CUT && !TWIN && MASK_FORCES && (ELEC == ELK_RF || (ELEC == ELK_EWALD_ANA && CORR_TABLE)))
+    if constexpr (!ENERGY && (VDW == VDK_CUT || VDW == VDK_COMB_GEOM || VDW == VDK_COMB_LB || VDW == VDK_FSWITCH || VDW == VDK_PSWITCH) && MASK_FORCES
+                  && (ELEC == ELK_RF || (ELEC == ELK_EWALD_ANA && CORR_TABLE)))
     {
         /* The force-only flavours of the headline configurations: ONE mask for everything an exclusion removes,
          *   F/r = mask((q q / r + (c12 r^-6 - c6) r^-6) / r^2) + q q corr,
@@ -250,8 +251,38 @@ NB_DEVINL void nbPair(const NBParamGpu& nbp,
             t.y           = tab[1];
             (void)ewaldCorrLds;
         }
-        const float lj = fmaf(c12, inv_r6, -c6) * inv_r6;
-        float       nm = fmaf(qq, inv_r, lj) * inv_r2;
+        float lj = fmaf(c12, inv_r6, -c6) * inv_r6; /* r^2 times the plain LJ F/r */
+        /* The switch flavours: every instruction below takes at most ONE scalar (kernel argument) operand.  An FMA with two of them
+         * needs a copy of one in a VGPR, which the compiler hoists out of the loops: that is what pushed these flavours over the
+         * 96 VGPRs of 5 waves per SIMD. */
+        if constexpr (VDW == VDK_FSWITCH)
+        {
+            /* force switch (nbnxm_cuda_kernel_utils.cuh:180-216), times r^2 like lj (the term's 1/r becomes r):
+             * c12 (r2 + r3 rs) - c6 (d2 + d3 rs) = (c12 r2 - c6 d2) + (c12 r3 - c6 d3) rs */
+            const float r  = r2 * inv_r;
+            const float rs = fmaxf(r - nbp.rvdw_switch, 0.0F);
+            const float a  = fmaf(-c6, nbp.dispersion_shift.c2, c12 * nbp.repulsion_shift.c2);
+            const float b  = fmaf(-c6, nbp.dispersion_shift.c3, c12 * nbp.repulsion_shift.c3);
+            lj             = fmaf(fmaf(b, rs, a) * (rs * rs), r, lj);
+        }
+        if constexpr (VDW == VDK_PSWITCH)
+        {
+            /* potential switch (:247-271): F/r = F_lj/r sw - E_lj dsw / r, times r^2; the exclusion mask below covers E_lj too.
+             * sw = 1 + (c3 + (c4 + c5 rs) rs) rs^3,  dsw = (3 c3 + (4 c4 + 5 c5 rs) rs) rs^2 with 4 c4 + 5 c5 rs = 4 (c4 + c5 rs) + c5 rs */
+            const float r   = r2 * inv_r;
+            const float rs  = fmaxf(r - nbp.rvdw_switch, 0.0F);
+            const float ea  = fmaf(inv_r6, inv_r6, nbp.repulsion_shift.cpot) * c12;
+            const float eb  = (inv_r6 + nbp.dispersion_shift.cpot) * c6;
+            const float e   = fmaf(eb, -c_oneSixth, ea * c_oneTwelfth);
+            const float rs2 = rs * rs;
+            const float u   = rs * nbp.vdw_switch.c5;
+            const float v   = u + nbp.vdw_switch.c4;
+            const float sw  = fmaf(fmaf(v, rs, nbp.vdw_switch.c3), rs2 * rs, 1.0F);
+            const float dsw = fmaf(fmaf(v, 4.0F, u), rs, nbp.vdwSwitch3c3) * rs2;
+            lj              = fmaf(-r * e, dsw, lj * sw);
+        }
+        if constexpr (TWIN) { lj = (r2 < nbp.rvdw_sq) ? lj : 0.0F; } /* rvdw < rcoulomb (what PME tuning leaves) */
+        float nm = fmaf(qq, inv_r, lj) * inv_r2;
         asm("v_and_b32 %0, %1, %2" : "=v"(nm) : "v"(intMask), "v"(nm));
         if constexpr (ELEC == ELK_RF) { F_invr = fmaf(qq, -nbp.two_k_rf, nm); }
         else { F_invr = fmaf(qq, fmaf(__builtin_amdgcn_fractf(xs), t.y, t.x), nm); }

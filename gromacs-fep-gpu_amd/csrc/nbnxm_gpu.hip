@@ -74,6 +74,7 @@ void setCutoffParameters(NBParamGpu* nbp, const nbnxm_interaction_params_t* ic)
     nbp->dispersion_shift  = ic->dispersion_shift;
     nbp->repulsion_shift   = ic->repulsion_shift;
     nbp->vdw_switch        = ic->vdw_switch;
+    nbp->vdwSwitch3c3      = 3.0F * ic->vdw_switch.c3;
 }
 
 void uploadCoulombTable(NbnxmGpu* nb, const nbnxm_interaction_params_t* ic)

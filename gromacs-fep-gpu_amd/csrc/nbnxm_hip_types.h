@@ -159,6 +159,8 @@ struct NBParamGpu
      * the class of the rational fit (pme_corr_coeffs.h).  ewaldCorrTabScale = intervals per unit of r^2. */
     float2* ewaldCorrTab;
     float   ewaldCorrTabScale;
+    /* MI355X extension: 3 vdw_switch.c3, so that the potential-switch derivative needs no scalar product in the kernel */
+    float   vdwSwitch3c3;
 };
 
 constexpr int c_ewaldCorrTabSize = 2048;

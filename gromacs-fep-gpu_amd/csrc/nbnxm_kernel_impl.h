@@ -253,8 +253,18 @@ NB_DEVINL void pruneEntry(const NBAtomDataGpu& atdat, const NBParamGpu& nbp, con
 #ifndef NBNXM_FORCE_WAVES_PER_EU
 #define NBNXM_FORCE_WAVES_PER_EU 5
 #endif
+#ifndef NBNXM_COMB_WAVES_PER_EU
+#define NBNXM_COMB_WAVES_PER_EU 4
+#endif
+#ifndef NBNXM_PSWITCH_WAVES_PER_EU
+#define NBNXM_PSWITCH_WAVES_PER_EU 5
+#endif
 template<int VDW, bool ENERGY>
-constexpr int c_nbWavesPerEu = (VDW == VDK_CUT && !ENERGY) ? NBNXM_FORCE_WAVES_PER_EU : 4;
+constexpr int c_nbWavesPerEu = ENERGY ? 4
+                               : (VDW == VDK_CUT || VDW == VDK_FSWITCH) ? NBNXM_FORCE_WAVES_PER_EU
+                               : (VDW == VDK_PSWITCH)                   ? NBNXM_PSWITCH_WAVES_PER_EU
+                               : (VDW == VDK_COMB_GEOM || VDW == VDK_COMB_LB) ? NBNXM_COMB_WAVES_PER_EU
+                                                                        : 4;
 
 /* FUSED: the cluster pairs that touch a perturbed atom are masked out of the list words (gpu_plist::groupSlowMask) and
  * left to nbnxmFepClusterKernel; otherwise the kernel is the plain one */

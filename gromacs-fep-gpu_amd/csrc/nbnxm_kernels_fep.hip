@@ -95,7 +95,16 @@ FepKernelPtr selectFepForeignKernel(int elecType, int vdwType)
 int nbKernelWavesPerEu(int vdwType, bool energy, bool fused)
 {
     (void)fused;
-    return (vdwKindOf(vdwType) == VDK_CUT && !energy) ? c_nbWavesPerEu<VDK_CUT, false> : c_nbWavesPerEu<VDK_PSWITCH, true>;
+    if (energy) { return c_nbWavesPerEu<VDK_CUT, true>; }
+    switch (vdwKindOf(vdwType))
+    {
+        case VDK_CUT: return c_nbWavesPerEu<VDK_CUT, false>;
+        case VDK_FSWITCH: return c_nbWavesPerEu<VDK_FSWITCH, false>;
+        case VDK_PSWITCH: return c_nbWavesPerEu<VDK_PSWITCH, false>;
+        case VDK_COMB_GEOM:
+        case VDK_COMB_LB: return c_nbWavesPerEu<VDK_COMB_GEOM, false>;
+        default: return c_nbWavesPerEu<VDK_EWALD_LB, false>;
+    }
 }
 
 PruneKernelPtr selectPruneKernel(bool haveFreshList)
