@@ -231,7 +231,7 @@ NB_DEVINL void nbPair(const NBParamGpu& nbp,
     [[maybe_unused]] const float int_bit = HAS_EXCL ? masked(1.0F) : 1.0F;
     constexpr bool MASK_FORCES = EXCL_FORCES && HAS_EXCL;
     if constexpr (!ENERGY && (VDW == VDK_CUT || VDW == VDK_COMB_GEOM || VDW == VDK_COMB_LB || VDW == VDK_FSWITCH || VDW == VDK_PSWITCH) && MASK_FORCES
-                  && (ELEC == ELK_RF || (ELEC == ELK_EWALD_ANA && CORR_TABLE)))
+                  && (ELEC == ELK_RF || ((ELEC == ELK_EWALD_ANA || ELEC == ELK_EWALD_TAB) && CORR_TABLE)))
     {
         /* The force-only flavours of the headline configurations: ONE mask for everything an exclusion removes,
          *   F/r = mask((q q / r + (c12 r^-6 - c6) r^-6) / r^2) + q q corr,
@@ -239,16 +239,26 @@ NB_DEVINL void nbPair(const NBParamGpu& nbp,
          * becomes v_and + v_cmp + v_cndmask (three instructions, two of them half rate, plus the VCC hazard). */
         [[maybe_unused]] float2 t = make_float2(0.0F, 0.0F);
         [[maybe_unused]] float  xs = 0.0F;
-        if constexpr (ELEC != ELK_RF)
+        typedef __attribute__((address_space(3))) const float LdsFloat;
+        if constexpr (ELEC == ELK_EWALD_ANA)
         {
             /* the table read is issued first: its LDS round trip overlaps the reciprocal square root and the LJ part */
             xs                 = r2 * nbp.ewaldCorrTabScale;
             const unsigned idx = static_cast<unsigned>(xs);
             /* the table sits at LDS address 0 (nbnxmKernel checks it): the address is idx * 8, no base to add */
-            typedef __attribute__((address_space(3))) const float LdsFloat;
             LdsFloat* tab = reinterpret_cast<LdsFloat*>(static_cast<uintptr_t>(idx * 8U));
             t.x           = tab[0];
             t.y           = tab[1];
+            (void)ewaldCorrLds;
+        }
+        if constexpr (ELEC == ELK_EWALD_TAB)
+        {
+            /* the reference's table, indexed by r (nbnxm_cuda_kernel_utils.cuh:448-459), staged into LDS from address 0 by the kernel */
+            xs                 = (r2 * inv_r) * nbp.coulomb_tab_scale;
+            const unsigned idx = static_cast<unsigned>(xs);
+            LdsFloat*      tab = reinterpret_cast<LdsFloat*>(static_cast<uintptr_t>(idx * 4U));
+            t.x                = tab[0];
+            t.y                = tab[1];
             (void)ewaldCorrLds;
         }
         float lj = fmaf(c12, inv_r6, -c6) * inv_r6; /* r^2 times the plain LJ F/r */
@@ -285,7 +295,12 @@ NB_DEVINL void nbPair(const NBParamGpu& nbp,
         float nm = fmaf(qq, inv_r, lj) * inv_r2;
         asm("v_and_b32 %0, %1, %2" : "=v"(nm) : "v"(intMask), "v"(nm));
         if constexpr (ELEC == ELK_RF) { F_invr = fmaf(qq, -nbp.two_k_rf, nm); }
-        else { F_invr = fmaf(qq, fmaf(__builtin_amdgcn_fractf(xs), t.y, t.x), nm); }
+        else if constexpr (ELEC == ELK_EWALD_ANA) { F_invr = fmaf(qq, fmaf(__builtin_amdgcn_fractf(xs), t.y, t.x), nm); }
+        else
+        {
+            const float fr = __builtin_amdgcn_fractf(xs);
+            F_invr         = fmaf(-qq * inv_r, fmaf(fr, t.y, fmaf(-fr, t.x, t.x)), nm);
+        }
         return;
     }
     if constexpr (MASK_FORCES) { inv_r6 = masked(inv_r6); }
@@ -381,7 +396,16 @@ NB_DEVINL void nbPair(const NBParamGpu& nbp,
         }
         else
         {
-            F_invr += qq * (inv_r3m - interpolateCoulombForceR(nbp, r2 * inv_r) * inv_r);
+            if constexpr (CORR_TABLE)
+            {
+                const float    xs  = (r2 * inv_r) * nbp.coulomb_tab_scale;
+                const unsigned idx = static_cast<unsigned>(xs);
+                const float*   tab = reinterpret_cast<const float*>(ewaldCorrLds);
+                const float    fr  = __builtin_amdgcn_fractf(xs);
+                const float    d0  = tab[idx];
+                F_invr += qq * (inv_r3m - fmaf(fr, tab[idx + 1], fmaf(-fr, d0, d0)) * inv_r);
+            }
+            else { F_invr += qq * (inv_r3m - interpolateCoulombForceR(nbp, r2 * inv_r) * inv_r); }
         }
         if constexpr (ENERGY && ELEC == ELK_EWALD_ANA)
         {

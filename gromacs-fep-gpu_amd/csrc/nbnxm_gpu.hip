@@ -90,6 +90,7 @@ void uploadCoulombTable(NbnxmGpu* nb, const nbnxm_interaction_params_t* ic)
         }
         copyToDeviceBuffer(&nbp->coulomb_tab, ic->coulomb_tab, 0, ic->coulomb_tab_size, nb->deviceStreams[0].stream, false);
         nbp->coulomb_tab_scale = ic->coulomb_tab_scale;
+        nbp->coulombTabSize    = ic->coulomb_tab_size;
     }
     const bool tabulated = (nbp->elecType == NBNXM_ELEC_EWALD_TAB || nbp->elecType == NBNXM_ELEC_EWALD_TAB_TWIN);
     NBNXM_ASSERT(!tabulated || nbp->coulomb_tab != nullptr, "tabulated Ewald kernel selected without a force table");
@@ -1156,6 +1157,10 @@ void nbnxm_gpu_launch_kernel(NbnxmGpu* nb, const nbnxm_step_workload_t* stepWork
         const bool useTable = (nbp->vdwType == NBNXM_VDW_CUT || nbp->vdwType == NBNXM_VDW_FSWITCH || nbp->vdwType == NBNXM_VDW_PSWITCH || ljEwald);
         NBNXM_ASSERT(!ljEwald || nbp->nbfp_comb != nullptr, "LJ-PME kernel selected without the grid parameters (nbfp_comb)");
         const bool ewaldCorrTable = (nbp->elecType == NBNXM_ELEC_EWALD_ANA || nbp->elecType == NBNXM_ELEC_EWALD_ANA_TWIN);
+        const bool ewaldRTable    = (nbp->elecType == NBNXM_ELEC_EWALD_TAB || nbp->elecType == NBNXM_ELEC_EWALD_TAB_TWIN);
+        NBNXM_ASSERT(!ewaldRTable || nbp->coulombTabSize <= c_coulombTabMaxLds, "the Ewald force table is too large for the LDS (16384 entries)");
+        const int ewaldTableBytes = ewaldCorrTable ? c_ewaldCorrTabSize * static_cast<int>(sizeof(float2))
+                                                   : (ewaldRTable ? coulombTabLdsBytes(nbp->coulombTabSize) : 0);
         /* Workgroup shape.  Every workgroup holds its own copy of the tables in LDS.  The default is one workgroup of 4 waves (one
          * per SIMD) per wave slot; the LJ table of a force field with many atom types (8 numTypes^2 bytes: 32 KB at 64 types) makes
          * that many copies overflow the CU's 160 KB, and the dispatcher would silently keep fewer waves resident.  Then fewer,
@@ -1165,7 +1170,7 @@ void nbnxm_gpu_launch_kernel(NbnxmGpu* nb, const nbnxm_step_workload_t* stepWork
         int       wavesPerBlock = 0, wavesPerSimd = 0;
         for (const int w : { nb->nbWavesPerBlock, 2 * c_nbWavesPerBlock, 4 * c_nbWavesPerBlock })
         {
-            const int lds      = (nbLdsBytes(adat->numTypes, useTable, ljEwald, ewaldCorrTable, fused, w) + c_ldsAllocGranularity - 1)
+            const int lds      = (nbLdsBytes(adat->numTypes, useTable, ljEwald, ewaldTableBytes, w) + c_ldsAllocGranularity - 1)
                             / c_ldsAllocGranularity * c_ldsAllocGranularity;
             const int resident = std::min(c_simdsPerCu * compiledWavesPerSimd / w, c_ldsBytesPerCu / lds) * w / c_simdsPerCu;
             if (resident > wavesPerSimd)
@@ -1175,7 +1180,7 @@ void nbnxm_gpu_launch_kernel(NbnxmGpu* nb, const nbnxm_step_workload_t* stepWork
             }
         }
         NBNXM_ASSERT(wavesPerSimd >= 4, "too many atom types: the LJ parameter table does not fit the 160 KB LDS");
-        const int ldsBytes = nbLdsBytes(adat->numTypes, useTable, ljEwald, ewaldCorrTable, fused, wavesPerBlock);
+        const int ldsBytes = nbLdsBytes(adat->numTypes, useTable, ljEwald, ewaldTableBytes, wavesPerBlock);
         if (ldsBytes > 64 * 1024)
         {
             NBNXM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, ldsBytes));

@@ -161,9 +161,12 @@ struct NBParamGpu
     float   ewaldCorrTabScale;
     /* MI355X extension: 3 vdw_switch.c3, so that the potential-switch derivative needs no scalar product in the kernel */
     float   vdwSwitch3c3;
+    /* MI355X extension, tabulated Ewald flavours: entries of coulomb_tab; the cluster kernel stages the table into LDS */
+    int     coulombTabSize;
 };
 
 constexpr int c_ewaldCorrTabSize = 2048;
+constexpr int c_coulombTabMaxLds = 16384; /* entries of the r-indexed table that the tabulated flavours stage into LDS (64 KB) */
 /* waves per workgroup of nbnxmFepClusterKernel */
 constexpr int c_fepClusterWavesPerBlockDef = 4;
 constexpr unsigned c_clearFloat4PerThread = 4; /* trailing clear workgroups of the cluster kernel: float4 stores per thread */
@@ -262,11 +265,16 @@ constexpr int c_ringRecordBytes  = 64;
 constexpr int c_jRingBytes       = 4 * c_ringRecordBytes;
 
 /* Dynamic LDS bytes of one workgroup of the cluster-pair kernel (must match the carve-up in the kernel). */
-inline int nbLdsBytes(int numTypes, bool useTable, bool ljEwald, bool ewaldCorrTable, bool fused, int wavesPerBlock)
+/* LDS bytes of the reference's r-indexed Ewald force table (tabulated flavours) */
+__host__ __device__ inline int coulombTabLdsBytes(int coulombTabSize)
+{
+    return (coulombTabSize * static_cast<int>(sizeof(float)) + 15) & ~15;
+}
+/* ewaldTableBytes: the correction table of the analytical flavours (c_ewaldCorrTabSize float2) or coulombTabLdsBytes() or 0 */
+inline int nbLdsBytes(int numTypes, bool useTable, bool ljEwald, int ewaldTableBytes, int wavesPerBlock)
 {
     const int tableBytes = (useTable ? (((numTypes * numTypes + (ljEwald ? numTypes : 0)) * static_cast<int>(sizeof(float2)) + 15) & ~15) : 0)
-                           + (ewaldCorrTable ? c_ewaldCorrTabSize * static_cast<int>(sizeof(float2)) : 0);
-    (void)fused;
+                           + ewaldTableBytes;
     return tableBytes + wavesPerBlock * (2 * c_jStageBytes + c_jRingBytes);
 }
 

@@ -320,7 +320,11 @@ __launch_bounds__(c_nbMaxBlockSize) __attribute__((amdgpu_waves_per_eu(c_nbWaves
      * table read needs no base-address add (the offset sits in the ds_read's immediate field) */
     constexpr bool EWALD_CORR_TABLE = (ELEC == ELK_EWALD_ANA);
     constexpr int  c_ewaldTabBytes  = EWALD_CORR_TABLE ? c_ewaldCorrTabSize * static_cast<int>(sizeof(float2)) : 0;
-    float2*   nbfpLds    = reinterpret_cast<float2*>(nbLds + c_ewaldTabBytes);
+    /* tabulated Ewald: the reference's r-indexed force table (run-time size) takes the same place; the LJ table's row offsets
+     * (trow) carry its size, so that a table read still needs no base-address add */
+    constexpr bool EWALD_R_TABLE = (ELEC == ELK_EWALD_TAB);
+    const int      rTabBytes     = EWALD_R_TABLE ? __builtin_amdgcn_readfirstlane(coulombTabLdsBytes(nbp.coulombTabSize)) : 0;
+    float2*   nbfpLds    = reinterpret_cast<float2*>(nbLds + c_ewaldTabBytes + rTabBytes);
     if constexpr (!ENERGY)
     {
         /* Trailing workgroups, behind the ones of the ranges.  The dispatcher hands workgroups out in order, so their waves start
@@ -377,7 +381,7 @@ __launch_bounds__(c_nbMaxBlockSize) __attribute__((amdgpu_waves_per_eu(c_nbWaves
     /* LJ-PME: the per-type grid parameters (nbfp_comb) follow the pair table */
     const int      nbfpEntries = numTypes * numTypes + (LJ_EWALD ? numTypes : 0);
     const int      nbfpBytes   = USE_TABLE ? ((nbfpEntries * static_cast<int>(sizeof(float2)) + 15) & ~15) : 0;
-    const int      tableBytes = nbfpBytes + c_ewaldTabBytes;
+    const int      tableBytes = nbfpBytes + c_ewaldTabBytes + rTabBytes;
     [[maybe_unused]] const float2* ewaldCorrLds = reinterpret_cast<const float2*>(nbLds);
     unsigned char* jStage = nbLds + tableBytes + wave * (2 * c_jStageBytes + c_jRingBytes);
     if constexpr (USE_TABLE)
@@ -395,8 +399,14 @@ __launch_bounds__(c_nbMaxBlockSize) __attribute__((amdgpu_waves_per_eu(c_nbWaves
         for (int t = threadIdx.x; t < c_ewaldCorrTabSize / 2; t += blockSize) { dst[t] = src[t]; }
     }
 
+    if constexpr (EWALD_R_TABLE)
+    {
+        float* dst = reinterpret_cast<float*>(nbLds);
+        for (int t = threadIdx.x; t < nbp.coulombTabSize; t += blockSize) { dst[t] = nbp.coulomb_tab[t]; }
+    }
+
     /* nbPair addresses the Ewald table with absolute LDS addresses from 0: the kernel has no static LDS, so the dynamic block starts there */
-    if (EWALD_CORR_TABLE && reinterpret_cast<uintptr_t>((__attribute__((address_space(3))) unsigned char*)nbLds) != 0) { __builtin_trap(); }
+    if ((EWALD_CORR_TABLE || EWALD_R_TABLE) && reinterpret_cast<uintptr_t>((__attribute__((address_space(3))) unsigned char*)nbLds) != 0) { __builtin_trap(); }
 
     __syncthreads(); /* the table is in place; from here on the waves of the workgroup are independent */
 
@@ -555,7 +565,7 @@ __launch_bounds__(c_nbMaxBlockSize) __attribute__((amdgpu_waves_per_eu(c_nbWaves
             if constexpr (USE_TABLE)
             {
                 const int ti = atomTypes[ai];
-                trow[i]      = numTypes * ti * static_cast<int>(sizeof(float2));
+                trow[i]      = numTypes * ti * static_cast<int>(sizeof(float2)) + rTabBytes;
                 if constexpr (LJ_EWALD) { ljcpi[i] = nbfpLds[numTypes * numTypes + ti]; }
             }
             else { ljcpi[i] = ljComb[ai]; }
