@@ -230,6 +230,51 @@ NB_DEVINL void nbPair(const NBParamGpu& nbp,
     auto masked = [intMask](float v) { return __builtin_bit_cast(float, __builtin_bit_cast(int, v) & intMask); };
     [[maybe_unused]] const float int_bit = HAS_EXCL ? masked(1.0F) : 1.0F;
     constexpr bool MASK_FORCES = EXCL_FORCES && HAS_EXCL;
+    if constexpr (ENERGY && (VDW == VDK_CUT || VDW == VDK_COMB_GEOM || VDW == VDK_COMB_LB) && !TWIN && HAS_EXCL
+                  && (ELEC == ELK_RF || (ELEC == ELK_EWALD_ANA && CORR_TABLE)))
+    {
+        /* Energy steps of the headline flavours: the force as in the block below, and each energy with ONE mask,
+         *   E_lj = mask(c12 (r^-12 + cpot12) / 12 - c6 (r^-6 + cpot6) / 6),   E_el = q q (mask(1/r - shift) - beta V((beta r)^2)),
+         * with the potential correction from the same table entry as the force correction (one ds_read_b128). */
+        [[maybe_unused]] float4 t  = make_float4(0.0F, 0.0F, 0.0F, 0.0F);
+        [[maybe_unused]] float  xs = 0.0F;
+        if constexpr (ELEC == ELK_EWALD_ANA)
+        {
+            xs                 = r2 * nbp.ewaldCorrTabScale;
+            const unsigned idx = static_cast<unsigned>(xs);
+            typedef __attribute__((address_space(3))) const float LdsFloat;
+            LdsFloat* tab = reinterpret_cast<LdsFloat*>(static_cast<uintptr_t>(idx * 16U));
+            t.x           = tab[0];
+            t.y           = tab[1];
+            t.z           = tab[2];
+            t.w           = tab[3];
+            (void)ewaldCorrLds;
+        }
+        const float lj = fmaf(c12, inv_r6, -c6) * inv_r6;
+        float       nm = fmaf(qq, inv_r, lj) * inv_r2;
+        asm("v_and_b32 %0, %1, %2" : "=v"(nm) : "v"(intMask), "v"(nm));
+        const float e12 = fmaf(inv_r6, inv_r6, nbp.repulsion_shift.cpot) * c12;
+        const float e6  = (inv_r6 + nbp.dispersion_shift.cpot) * c6;
+        float       elj = fmaf(e6, -c_oneSixth, e12 * c_oneTwelfth);
+        asm("v_and_b32 %0, %1, %2" : "=v"(elj) : "v"(intMask), "v"(elj));
+        E_lj = elj;
+        if constexpr (ELEC == ELK_RF)
+        {
+            F_invr    = fmaf(qq, -nbp.two_k_rf, nm);
+            float eel = inv_r;
+            asm("v_and_b32 %0, %1, %2" : "=v"(eel) : "v"(intMask), "v"(eel));
+            E_el = qq * (eel + fmaf(0.5F * nbp.two_k_rf, r2, -nbp.c_rf));
+        }
+        else
+        {
+            const float fr = __builtin_amdgcn_fractf(xs);
+            F_invr         = fmaf(qq, fmaf(fr, t.y, t.x), nm);
+            float eel      = inv_r - nbp.sh_ewald;
+            asm("v_and_b32 %0, %1, %2" : "=v"(eel) : "v"(intMask), "v"(eel));
+            E_el = qq * (eel - fmaf(fr, t.w, t.z));
+        }
+        return;
+    }
     if constexpr (!ENERGY && (VDW == VDK_CUT || VDW == VDK_COMB_GEOM || VDW == VDK_COMB_LB || VDW == VDK_FSWITCH || VDW == VDK_PSWITCH) && MASK_FORCES
                   && (ELEC == ELK_RF || ((ELEC == ELK_EWALD_ANA || ELEC == ELK_EWALD_TAB) && CORR_TABLE)))
     {
@@ -375,7 +420,8 @@ NB_DEVINL void nbPair(const NBParamGpu& nbp,
     }
     else
     {
-        const float beta = nbp.ewald_beta;
+        const float            beta  = nbp.ewald_beta;
+        [[maybe_unused]] float corrV = 0.0F; /* beta V((beta r)^2) from the table (energy flavours of the cluster kernel) */
         if constexpr (ELEC == ELK_EWALD_ANA)
         {
             if constexpr (CORR_TABLE)
@@ -384,8 +430,19 @@ NB_DEVINL void nbPair(const NBParamGpu& nbp,
                  * which is what bounds the index */
                 const float    xs  = r2 * nbp.ewaldCorrTabScale;
                 const unsigned idx = static_cast<unsigned>(xs);
-                const float2   t   = ewaldCorrLds[idx];
-                F_invr += qq * (inv_r3m + fmaf(__builtin_amdgcn_fractf(xs), t.y, t.x));
+                if constexpr (ENERGY)
+                {
+                    /* the energy flavours' table carries the potential correction too */
+                    const float4 t  = reinterpret_cast<const float4*>(ewaldCorrLds)[idx];
+                    const float  fr = __builtin_amdgcn_fractf(xs);
+                    F_invr += qq * (inv_r3m + fmaf(fr, t.y, t.x));
+                    corrV = fmaf(fr, t.w, t.z);
+                }
+                else
+                {
+                    const float2 t = ewaldCorrLds[idx];
+                    F_invr += qq * (inv_r3m + fmaf(__builtin_amdgcn_fractf(xs), t.y, t.x));
+                }
             }
             else
             {
@@ -411,7 +468,8 @@ NB_DEVINL void nbPair(const NBParamGpu& nbp,
         {
             /* erf(beta r)/r = beta V(beta^2 r^2): branch-free, shares z^2 with the force correction (the libm
              * erff costs two divergent branches per pair) */
-            E_el = qq * (int_bit * (inv_r - nbp.sh_ewald) - beta * pmeCorrV(beta * beta * r2));
+            if constexpr (CORR_TABLE) { E_el = qq * (int_bit * (inv_r - nbp.sh_ewald) - corrV); }
+            else { E_el = qq * (int_bit * (inv_r - nbp.sh_ewald) - beta * pmeCorrV(beta * beta * r2)); }
         }
         else if constexpr (ENERGY)
         {

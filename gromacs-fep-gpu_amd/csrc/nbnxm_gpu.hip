@@ -122,15 +122,41 @@ void uploadEwaldCorrectionTable(NbnxmGpu* nb)
         const double z = std::sqrt(x);
         return (2.0 / std::sqrt(M_PI) * z * std::exp(-x) - std::erf(z)) / (x * z);
     };
+    /* V(x) = erf(z) / z */
+    auto V = [](double x) {
+        if (x < 1.0e-2)
+        {
+            /* series: 2/sqrt(pi) sum_k (-1)^k x^k / ((2k+1) k!) */
+            double s = 0, xp = 1, kf = 1;
+            for (int k = 0; k < 10; k++)
+            {
+                if (k > 0) { kf *= k; }
+                const double term = xp / ((2.0 * k + 1.0) * kf);
+                s += (k & 1) ? -term : term;
+                xp *= x;
+            }
+            return 2.0 / std::sqrt(M_PI) * s;
+        }
+        const double z = std::sqrt(x);
+        return std::erf(z) / z;
+    };
     nb->h_ewaldCorrTab.resize(n);
+    nb->h_ewaldCorrTabFV.resize(n);
     const double b3 = beta * beta * beta;
     for (int k = 0; k < n; k++)
     {
         const double t0 = b3 * F(xMax * k / n), t1 = b3 * F(xMax * (k + 1) / n);
-        nb->h_ewaldCorrTab.data[k] = make_float2(static_cast<float>(t0), static_cast<float>(t1 - t0));
+        const double v0 = beta * V(xMax * k / n), v1 = beta * V(xMax * (k + 1) / n);
+        nb->h_ewaldCorrTab.data[k]   = make_float2(static_cast<float>(t0), static_cast<float>(t1 - t0));
+        nb->h_ewaldCorrTabFV.data[k] = make_float4(static_cast<float>(t0), static_cast<float>(t1 - t0), static_cast<float>(v0), static_cast<float>(v1 - v0));
     }
-    if (nbp->ewaldCorrTab == nullptr) { allocateDeviceBuffer(&nbp->ewaldCorrTab, n); }
+    if (nbp->ewaldCorrTab == nullptr)
+    {
+        allocateDeviceBuffer(&nbp->ewaldCorrTab, n);
+        allocateDeviceBuffer(&nbp->ewaldCorrTabFV, n);
+    }
     copyToDeviceBuffer(&nbp->ewaldCorrTab, nb->h_ewaldCorrTab.data, 0, n, nb->deviceStreams[0].stream, true);
+    copyToDeviceBuffer(&nbp->ewaldCorrTabFV, nb->h_ewaldCorrTabFV.data, 0, n, nb->deviceStreams[0].stream, true);
     nbp->ewaldCorrTabScale = static_cast<float>(beta * beta * n / xMax);
 }
 
@@ -395,6 +421,7 @@ void nbnxm_gpu_free(NbnxmGpu* nb)
     freeDeviceBuffer(&nbp->nbfp_comb);
     freeDeviceBuffer(&nbp->coulomb_tab);
     freeDeviceBuffer(&nbp->ewaldCorrTab);
+    freeDeviceBuffer(&nbp->ewaldCorrTabFV);
     freeDeviceBuffer(&nb->atomIndices);
     freeDeviceBuffer(&nb->cell);
     freeDeviceBuffer(&nbp->allLambdaCoul);
@@ -1159,7 +1186,7 @@ void nbnxm_gpu_launch_kernel(NbnxmGpu* nb, const nbnxm_step_workload_t* stepWork
         const bool ewaldCorrTable = (nbp->elecType == NBNXM_ELEC_EWALD_ANA || nbp->elecType == NBNXM_ELEC_EWALD_ANA_TWIN);
         const bool ewaldRTable    = (nbp->elecType == NBNXM_ELEC_EWALD_TAB || nbp->elecType == NBNXM_ELEC_EWALD_TAB_TWIN);
         NBNXM_ASSERT(!ewaldRTable || nbp->coulombTabSize <= c_coulombTabMaxLds, "the Ewald force table is too large for the LDS (16384 entries)");
-        const int ewaldTableBytes = ewaldCorrTable ? c_ewaldCorrTabSize * static_cast<int>(sizeof(float2))
+        const int ewaldTableBytes = ewaldCorrTable ? c_ewaldCorrTabSize * static_cast<int>(energyFlavour ? sizeof(float4) : sizeof(float2))
                                                    : (ewaldRTable ? coulombTabLdsBytes(nbp->coulombTabSize) : 0);
         /* Workgroup shape.  Every workgroup holds its own copy of the tables in LDS.  The default is one workgroup of 4 waves (one
          * per SIMD) per wave slot; the LJ table of a force field with many atom types (8 numTypes^2 bytes: 32 KB at 64 types) makes

@@ -102,6 +102,7 @@ struct NbnxmGpu
     bool reductionAccumulate = false;
     PinnedBuffer<int> h_atomIndices, h_cell;
     PinnedBuffer<float2>      h_ewaldCorrTab;
+    PinnedBuffer<float4>      h_ewaldCorrTabFV;
 
     float* scalarOutputs    = nullptr; /* device block behind atdat->eLJ ... dvdlElecForeign, energySlots */
     /* batched lambda windows: device accumulators (atdat->windowSlots), pinned mirror, per-window sums of the last energy step */

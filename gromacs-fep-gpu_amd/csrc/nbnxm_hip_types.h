@@ -159,6 +159,10 @@ struct NBParamGpu
      * the class of the rational fit (pme_corr_coeffs.h).  ewaldCorrTabScale = intervals per unit of r^2. */
     float2* ewaldCorrTab;
     float   ewaldCorrTabScale;
+    /* the same grid with the potential correction beside the force correction, for the energy flavours: {beta^3 F, step, beta V, step}
+     * with V(x) = erf(z)/z, x = z^2 (gmx::pmePotentialCorrection, simd/simd_math.h:1660-1760): one ds_read_b128 and two FMAs per pair
+     * instead of two [5/4] rationals with a reciprocal each */
+    float4* ewaldCorrTabFV;
     /* MI355X extension: 3 vdw_switch.c3, so that the potential-switch derivative needs no scalar product in the kernel */
     float   vdwSwitch3c3;
     /* MI355X extension, tabulated Ewald flavours: entries of coulomb_tab; the cluster kernel stages the table into LDS */

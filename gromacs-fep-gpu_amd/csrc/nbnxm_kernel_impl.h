@@ -319,7 +319,7 @@ __launch_bounds__(c_nbMaxBlockSize) __attribute__((amdgpu_waves_per_eu(c_nbWaves
     /* LDS layout: the Ewald correction table (fixed size) first, then the LJ table: both bases are compile-time offsets, so a
      * table read needs no base-address add (the offset sits in the ds_read's immediate field) */
     constexpr bool EWALD_CORR_TABLE = (ELEC == ELK_EWALD_ANA);
-    constexpr int  c_ewaldTabBytes  = EWALD_CORR_TABLE ? c_ewaldCorrTabSize * static_cast<int>(sizeof(float2)) : 0;
+    constexpr int  c_ewaldTabBytes  = EWALD_CORR_TABLE ? c_ewaldCorrTabSize * static_cast<int>(ENERGY ? sizeof(float4) : sizeof(float2)) : 0;
     /* tabulated Ewald: the reference's r-indexed force table (run-time size) takes the same place; the LJ table's row offsets
      * (trow) carry its size, so that a table read still needs no base-address add */
     constexpr bool EWALD_R_TABLE = (ELEC == ELK_EWALD_TAB);
@@ -394,9 +394,10 @@ __launch_bounds__(c_nbMaxBlockSize) __attribute__((amdgpu_waves_per_eu(c_nbWaves
     }
     if constexpr (EWALD_CORR_TABLE)
     {
-        const float4* __restrict__ src = reinterpret_cast<const float4*>(nbp.ewaldCorrTab);
+        /* force flavours: {F, step} (16 KB); energy flavours: {F, step, V, step} (32 KB, they run at 4 waves per SIMD) */
+        const float4* __restrict__ src = ENERGY ? nbp.ewaldCorrTabFV : reinterpret_cast<const float4*>(nbp.ewaldCorrTab);
         float4*                    dst = reinterpret_cast<float4*>(nbLds);
-        for (int t = threadIdx.x; t < c_ewaldCorrTabSize / 2; t += blockSize) { dst[t] = src[t]; }
+        for (int t = threadIdx.x; t < c_ewaldTabBytes / static_cast<int>(sizeof(float4)); t += blockSize) { dst[t] = src[t]; }
     }
 
     if constexpr (EWALD_R_TABLE)
