@@ -223,6 +223,19 @@ def test_full_size_properties_100k():
     tl.assert_parity(fused, want, rel=1e-4, label="96k fused")
 
 
+@pytest.mark.parametrize("elec", ["rf", "ewald", "ewald_tab", "cut"])
+@pytest.mark.parametrize("vdw", ["cut", "fswitch", "pswitch", "comb_geom", "comb_lb", "ewald_geom"])
+def test_force_only_flavours(elec, vdw):
+    """The force-only instances are code of their own (one-mask pair block, 5 waves per SIMD for cut-off and switch flavours, the Ewald
+    tables read first): every electrostatics x VdW combination as a force-only step, both modes, against the forces of the oracle's
+    energy pass."""
+    c = tl.make_case(elec=elec, vdw=vdw, seed=57, **SMALL)
+    want = tl.run_oracle(c, energy=True)
+    for fused in (False, True):
+        got = tl.run_gpu(c, energy=False, fused=fused)
+        tl.assert_parity(got, want, rel=1e-4, energy=False, label="F %s %s fused %d" % (elec, vdw, fused))
+
+
 @pytest.mark.parametrize("elec", ["ewald", "ewald_tab"])
 @pytest.mark.parametrize("vdw", ["cut", "pswitch", "fswitch", "comb_lb"])
 @pytest.mark.parametrize("fused", [False, True])
