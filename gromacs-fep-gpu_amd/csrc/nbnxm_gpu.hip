@@ -312,6 +312,8 @@ NbnxmGpu* nbnxm_gpu_init(const nbnxm_interaction_params_t* ic, int numTypes, con
         nb->nbWavesPerBlock = w;
     }
 
+    if (const char* env = std::getenv("NBNXM_HIP_KEEP_COMB_KERNELS")) { nb->keepCombinationKernels = (std::atoi(env) != 0); }
+
     /* pinned staging (gpu_init :573-583) */
     auto pinned = [](float** p, size_t n) {
         NBNXM_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(p), n * sizeof(float), hipHostMallocDefault));
@@ -1132,7 +1134,17 @@ void nbnxm_gpu_launch_kernel(NbnxmGpu* nb, const nbnxm_step_workload_t* stepWork
     if (plist->nsci > 0)
     {
         const bool        energyFlavour = stepWork->computeEnergy != 0;
-        const NbKernelPtr kernel        = selectNbKernel(nbp->elecType, nbp->vdwType, energyFlavour, fused);
+        /* Combination-rule flavours: the reference has them to save the table lookup.  Here the lookup is one LDS read and the
+         * combination kernels pay for their 16 per-atom parameter registers with the fifth wave per SIMD, so while five table copies
+         * fit the LDS (up to 28 types) the force-only step takes the table kernel: 0.0655 / 0.0695 -> 0.062 ms.  The table holds what
+         * the rule gives (nbnxn_atomdata_t builds both from the same per-type parameters). */
+        int vdwTypeKernel = nbp->vdwType;
+        if ((nbp->vdwType == NBNXM_VDW_CUT_COMB_GEOM || nbp->vdwType == NBNXM_VDW_CUT_COMB_LB) && !energyFlavour && !nb->keepCombinationKernels
+            && adat->numTypes <= c_maxTypesAtFullOccupancy)
+        {
+            vdwTypeKernel = NBNXM_VDW_CUT;
+        }
+        const NbKernelPtr kernel        = selectNbKernel(nbp->elecType, vdwTypeKernel, energyFlavour, fused);
         if (kernel == nullptr)
         {
             fatal(__FILE__, __LINE__, "nbnxm_gpu_launch_kernel", "no kernel for this electrostatics / VdW combination");
@@ -1181,7 +1193,7 @@ void nbnxm_gpu_launch_kernel(NbnxmGpu* nb, const nbnxm_step_workload_t* stepWork
         if (nb->bDoTime) { t.nb_k.openTimingRegion(s); }
         /* The LJ table lives in LDS (up to ~140 types in the 160 KB; large tables cost occupancy) */
         const bool ljEwald  = (nbp->vdwType == NBNXM_VDW_EWALD_GEOM || nbp->vdwType == NBNXM_VDW_EWALD_LB);
-        const bool useTable = (nbp->vdwType == NBNXM_VDW_CUT || nbp->vdwType == NBNXM_VDW_FSWITCH || nbp->vdwType == NBNXM_VDW_PSWITCH || ljEwald);
+        const bool useTable = (vdwTypeKernel == NBNXM_VDW_CUT || nbp->vdwType == NBNXM_VDW_FSWITCH || nbp->vdwType == NBNXM_VDW_PSWITCH || ljEwald);
         NBNXM_ASSERT(!ljEwald || nbp->nbfp_comb != nullptr, "LJ-PME kernel selected without the grid parameters (nbfp_comb)");
         const bool ewaldCorrTable = (nbp->elecType == NBNXM_ELEC_EWALD_ANA || nbp->elecType == NBNXM_ELEC_EWALD_ANA_TWIN);
         const bool ewaldRTable    = (nbp->elecType == NBNXM_ELEC_EWALD_TAB || nbp->elecType == NBNXM_ELEC_EWALD_TAB_TWIN);
@@ -1193,7 +1205,7 @@ void nbnxm_gpu_launch_kernel(NbnxmGpu* nb, const nbnxm_step_workload_t* stepWork
          * that many copies overflow the CU's 160 KB, and the dispatcher would silently keep fewer waves resident.  Then fewer,
          * larger workgroups share a copy — 8 waves (two workgroups per CU) or 16 (one) — at 4 waves per SIMD: measured on MI355X the
          * force kernel loses 4 % from 5 to 4 waves per SIMD, but 2x from 5 to 2. */
-        const int compiledWavesPerSimd = nbKernelWavesPerEu(nbp->vdwType, energyFlavour, fused);
+        const int compiledWavesPerSimd = nbKernelWavesPerEu(vdwTypeKernel, energyFlavour, fused);
         int       wavesPerBlock = 0, wavesPerSimd = 0;
         for (const int w : { nb->nbWavesPerBlock, 2 * c_nbWavesPerBlock, 4 * c_nbWavesPerBlock })
         {

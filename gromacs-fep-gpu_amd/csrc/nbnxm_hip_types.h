@@ -29,6 +29,7 @@ constexpr int c_nbBlockSize       = c_nbWavesPerBlock * c_waveSize;
 constexpr int c_nbMaxBlockSize    = 1024;
 constexpr int c_simdsPerCu        = 4;
 constexpr int c_ldsBytesPerCu     = 160 * 1024;
+constexpr int c_maxTypesAtFullOccupancy = 28; /* 8 ntype^2 bytes + 16 KB Ewald table + 9 KB staging, five times in 160 KB */
 constexpr int c_ldsAllocGranularity = 1024; /* rounding used when counting resident workgroups (conservative) */
 /* nbnxm/pairlist.h:166: keeps r^-12 finite in fp32 */
 constexpr float c_nbnxnMinDistanceSquared = 3.82e-07F;

@@ -225,15 +225,19 @@ def test_full_size_properties_100k():
 
 @pytest.mark.parametrize("elec", ["rf", "ewald", "ewald_tab", "cut"])
 @pytest.mark.parametrize("vdw", ["cut", "fswitch", "pswitch", "comb_geom", "comb_lb", "ewald_geom"])
-def test_force_only_flavours(elec, vdw):
+def test_force_only_flavours(elec, vdw, monkeypatch):
     """The force-only instances are code of their own (one-mask pair block, 5 waves per SIMD for cut-off and switch flavours, the Ewald
     tables read first): every electrostatics x VdW combination as a force-only step, both modes, against the forces of the oracle's
-    energy pass."""
+    energy pass.  With few atom types the combination-rule flavours run the table kernel (nbnxm_gpu_launch_kernel); their own force
+    instances, which systems with more than 28 types get, are switched back on for a second pass."""
     c = tl.make_case(elec=elec, vdw=vdw, seed=57, **SMALL)
     want = tl.run_oracle(c, energy=True)
-    for fused in (False, True):
-        got = tl.run_gpu(c, energy=False, fused=fused)
-        tl.assert_parity(got, want, rel=1e-4, energy=False, label="F %s %s fused %d" % (elec, vdw, fused))
+    for keep_comb in ((False, True) if vdw.startswith("comb") else (False,)):
+        if keep_comb:
+            monkeypatch.setenv("NBNXM_HIP_KEEP_COMB_KERNELS", "1")
+        for fused in (False, True):
+            got = tl.run_gpu(c, energy=False, fused=fused)
+            tl.assert_parity(got, want, rel=1e-4, energy=False, label="F %s %s fused %d own comb kernel %d" % (elec, vdw, fused, keep_comb))
 
 
 @pytest.mark.parametrize("elec", ["ewald", "ewald_tab"])
