@@ -100,7 +100,7 @@ HIP_SYMBOLS = [
     "nbnxm_gpu_debug_graph_steps", "nbnxm_gpu_debug_set_work_shares",
     "nbnxm_gpu_init_x_to_nbat_x", "nbnxm_gpu_x_to_nbat_x", "nbnxm_gpu_insert_nonlocal_dependency",
     "nbnxm_gpu_setup_short_range_work", "nbnxm_gpu_force_reduction_reinit", "nbnxm_gpu_force_reduction_execute",
-    "nbnxm_gpu_halo_pack_x", "nbnxm_gpu_halo_unpack_f", "nbnxm_gpu_force_reduction_execute_range",
+    "nbnxm_gpu_halo_pack_x", "nbnxm_gpu_halo_unpack_f", "nbnxm_gpu_force_reduction_execute_range", "nbnxm_hip_query_launch_shape",
 ]
 HALO_SYMBOLS = [
     "halo_gpu_get_unique_id", "halo_gpu_create", "halo_gpu_free", "halo_gpu_last_error", "halo_gpu_reinit",

@@ -186,9 +186,47 @@ void accumulateTimings(NbnxmGpu* nb, int iloc)
     nb->timings.prune_k_count = nb->timers[0].prune_k.count + nb->timers[1].prune_k.count;
 }
 
+/* Workgroup shape of the cluster-pair kernel (host arithmetic only).  Every workgroup holds its own copy of the tables in LDS.  The
+ * default is one workgroup of 4 waves (one per SIMD) per wave slot; the LJ table of a force field with many atom types (8 numTypes^2
+ * bytes: 32 KB at 64 types) makes that many copies overflow the CU's 160 KB, and the dispatcher would silently keep fewer waves resident.
+ * Then fewer, larger workgroups share a copy — 8 waves (two workgroups per CU) or 16 (one) — at 4 waves per SIMD: measured on MI355X
+ * the force kernel loses 4 % from 5 to 4 waves per SIMD, but 2x from 5 to 2. */
+struct NbLaunchShape
+{
+    int wavesPerBlock, wavesPerSimd, ldsBytes;
+};
+static NbLaunchShape chooseNbLaunchShape(int elecType, int vdwType, bool energy, int numTypes, int coulombTabSize, int defaultWavesPerBlock)
+{
+    const bool ljEwald        = (vdwType == NBNXM_VDW_EWALD_GEOM || vdwType == NBNXM_VDW_EWALD_LB);
+    const bool useTable       = (vdwType == NBNXM_VDW_CUT || vdwType == NBNXM_VDW_FSWITCH || vdwType == NBNXM_VDW_PSWITCH || ljEwald);
+    const bool ewaldCorrTable = (elecType == NBNXM_ELEC_EWALD_ANA || elecType == NBNXM_ELEC_EWALD_ANA_TWIN);
+    const bool ewaldRTable    = (elecType == NBNXM_ELEC_EWALD_TAB || elecType == NBNXM_ELEC_EWALD_TAB_TWIN);
+    const int  ewaldTableBytes = ewaldCorrTable ? c_ewaldCorrTabSize * static_cast<int>(energy ? sizeof(float4) : sizeof(float2))
+                                                : (ewaldRTable ? coulombTabLdsBytes(coulombTabSize) : 0);
+    const int  compiledWavesPerSimd = nbKernelWavesPerEu(vdwType, energy, false);
+    NbLaunchShape shape{ 0, 0, 0 };
+    for (const int w : { defaultWavesPerBlock, 2 * c_nbWavesPerBlock, 4 * c_nbWavesPerBlock })
+    {
+        const int bytes    = nbLdsBytes(numTypes, useTable, ljEwald, ewaldTableBytes, w);
+        const int lds      = (bytes + c_ldsAllocGranularity - 1) / c_ldsAllocGranularity * c_ldsAllocGranularity;
+        const int resident = std::min(c_simdsPerCu * compiledWavesPerSimd / w, c_ldsBytesPerCu / lds) * w / c_simdsPerCu;
+        if (resident > shape.wavesPerSimd) { shape = NbLaunchShape{ w, resident, bytes }; }
+    }
+    return shape;
+}
+
 } // namespace
 
 extern "C" {
+
+void nbnxm_hip_query_launch_shape(int elecType, int vdwType, int computeEnergy, int numTypes, int coulombTabSize, int* wavesPerWorkgroup,
+                                  int* wavesPerSimd, int* ldsBytesPerWorkgroup)
+{
+    const NbLaunchShape shape = chooseNbLaunchShape(elecType, vdwType, computeEnergy != 0, numTypes, coulombTabSize, c_nbWavesPerBlock);
+    *wavesPerWorkgroup    = shape.wavesPerBlock;
+    *wavesPerSimd         = shape.wavesPerSimd;
+    *ldsBytesPerWorkgroup = shape.ldsBytes;
+}
 
 int nbnxm_hip_abi_version(void)
 {
@@ -313,6 +351,7 @@ NbnxmGpu* nbnxm_gpu_init(const nbnxm_interaction_params_t* ic, int numTypes, con
     }
 
     if (const char* env = std::getenv("NBNXM_HIP_KEEP_COMB_KERNELS")) { nb->keepCombinationKernels = (std::atoi(env) != 0); }
+    nb->debugLaunchShape = (std::getenv("NBNXM_HIP_DEBUG_LAUNCH_SHAPE") != nullptr);
 
     /* pinned staging (gpu_init :573-583) */
     auto pinned = [](float** p, size_t n) {
@@ -1192,40 +1231,27 @@ void nbnxm_gpu_launch_kernel(NbnxmGpu* nb, const nbnxm_step_workload_t* stepWork
         }
         if (nb->bDoTime) { t.nb_k.openTimingRegion(s); }
         /* The LJ table lives in LDS (up to ~140 types in the 160 KB; large tables cost occupancy) */
-        const bool ljEwald  = (nbp->vdwType == NBNXM_VDW_EWALD_GEOM || nbp->vdwType == NBNXM_VDW_EWALD_LB);
-        const bool useTable = (vdwTypeKernel == NBNXM_VDW_CUT || nbp->vdwType == NBNXM_VDW_FSWITCH || nbp->vdwType == NBNXM_VDW_PSWITCH || ljEwald);
+        const bool ljEwald = (nbp->vdwType == NBNXM_VDW_EWALD_GEOM || nbp->vdwType == NBNXM_VDW_EWALD_LB);
         NBNXM_ASSERT(!ljEwald || nbp->nbfp_comb != nullptr, "LJ-PME kernel selected without the grid parameters (nbfp_comb)");
-        const bool ewaldCorrTable = (nbp->elecType == NBNXM_ELEC_EWALD_ANA || nbp->elecType == NBNXM_ELEC_EWALD_ANA_TWIN);
-        const bool ewaldRTable    = (nbp->elecType == NBNXM_ELEC_EWALD_TAB || nbp->elecType == NBNXM_ELEC_EWALD_TAB_TWIN);
+        const bool ewaldRTable = (nbp->elecType == NBNXM_ELEC_EWALD_TAB || nbp->elecType == NBNXM_ELEC_EWALD_TAB_TWIN);
         NBNXM_ASSERT(!ewaldRTable || nbp->coulombTabSize <= c_coulombTabMaxLds, "the Ewald force table is too large for the LDS (16384 entries)");
-        const int ewaldTableBytes = ewaldCorrTable ? c_ewaldCorrTabSize * static_cast<int>(energyFlavour ? sizeof(float4) : sizeof(float2))
-                                                   : (ewaldRTable ? coulombTabLdsBytes(nbp->coulombTabSize) : 0);
-        /* Workgroup shape.  Every workgroup holds its own copy of the tables in LDS.  The default is one workgroup of 4 waves (one
-         * per SIMD) per wave slot; the LJ table of a force field with many atom types (8 numTypes^2 bytes: 32 KB at 64 types) makes
-         * that many copies overflow the CU's 160 KB, and the dispatcher would silently keep fewer waves resident.  Then fewer,
-         * larger workgroups share a copy — 8 waves (two workgroups per CU) or 16 (one) — at 4 waves per SIMD: measured on MI355X the
-         * force kernel loses 4 % from 5 to 4 waves per SIMD, but 2x from 5 to 2. */
-        const int compiledWavesPerSimd = nbKernelWavesPerEu(vdwTypeKernel, energyFlavour, fused);
-        int       wavesPerBlock = 0, wavesPerSimd = 0;
-        for (const int w : { nb->nbWavesPerBlock, 2 * c_nbWavesPerBlock, 4 * c_nbWavesPerBlock })
+        const NbLaunchShape shape = chooseNbLaunchShape(nbp->elecType, vdwTypeKernel, energyFlavour, adat->numTypes, nbp->coulombTabSize,
+                                                        nb->nbWavesPerBlock);
+        NBNXM_ASSERT(shape.wavesPerSimd >= 1, "too many atom types: the LJ parameter table does not fit the 160 KB LDS");
+        const int wavesPerBlock = shape.wavesPerBlock, wavesPerSimd = shape.wavesPerSimd, ldsBytes = shape.ldsBytes;
+        if (nb->debugLaunchShape)
         {
-            const int lds      = (nbLdsBytes(adat->numTypes, useTable, ljEwald, ewaldTableBytes, w) + c_ldsAllocGranularity - 1)
-                            / c_ldsAllocGranularity * c_ldsAllocGranularity;
-            const int resident = std::min(c_simdsPerCu * compiledWavesPerSimd / w, c_ldsBytesPerCu / lds) * w / c_simdsPerCu;
-            if (resident > wavesPerSimd)
-            {
-                wavesPerBlock = w;
-                wavesPerSimd  = resident;
-            }
+            std::fprintf(stderr, "nbnxm_hip: cluster kernel launch shape: %d types, %d waves per workgroup, %d waves per SIMD, %d LDS bytes per workgroup\n",
+                         adat->numTypes, wavesPerBlock, wavesPerSimd, ldsBytes);
+            nb->debugLaunchShape = false;
         }
-        NBNXM_ASSERT(wavesPerSimd >= 4, "too many atom types: the LJ parameter table does not fit the 160 KB LDS");
-        const int ldsBytes = nbLdsBytes(adat->numTypes, useTable, ljEwald, ewaldTableBytes, wavesPerBlock);
         if (ldsBytes > 64 * 1024)
         {
             NBNXM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, ldsBytes));
         }
         /* one wave per resident wave slot, each with its share of the list (see updateWorkPartition) */
-        const int p         = wavesPerSimd - 4;
+        /* (fewer than 4 resident waves per SIMD — 118 to 131 types — run the 4-wave partition in rounds) */
+        const int p         = std::max(0, wavesPerSimd - 4);
         const int numRanges = plist->numWorkRanges[p];
         NBNXM_ASSERT(numRanges > 0, "work partition missing");
         const int mergedFepItems = mergeFep ? plist->numSlowPairs : 0;

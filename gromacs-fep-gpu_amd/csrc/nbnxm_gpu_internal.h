@@ -84,6 +84,7 @@ struct NbnxmGpu
 
     int nbWavesPerBlock = c_nbWavesPerBlock; /* tunable: NBNXM_HIP_WAVES_PER_BLOCK = 1..4 */
     bool keepCombinationKernels = false;     /* diagnostics: NBNXM_HIP_KEEP_COMB_KERNELS=1 */
+    bool debugLaunchShape       = false;     /* diagnostics: NBNXM_HIP_DEBUG_LAUNCH_SHAPE prints the first launch's workgroup shape */
     /* work partition (gpu_plist::work*): SIMDs of the device, smallest range worth a wave (NBNXM_HIP_MIN_GROUPS_PER_WAVE) */
     int numSimds          = 1024;
     int minGroupsPerWave  = 2;

@@ -30,7 +30,7 @@ constexpr int c_nbMaxBlockSize    = 1024;
 constexpr int c_simdsPerCu        = 4;
 constexpr int c_ldsBytesPerCu     = 160 * 1024;
 constexpr int c_maxTypesAtFullOccupancy = 28; /* 8 ntype^2 bytes + 16 KB Ewald table + 9 KB staging, five times in 160 KB */
-constexpr int c_ldsAllocGranularity = 1024; /* rounding used when counting resident workgroups (conservative) */
+constexpr int c_ldsAllocGranularity = 1280; /* LDS allocation granule of gfx950, bytes (measured: five workgroups of 31,872 B are resident per CU, five of 32,336 B are not) */
 /* nbnxm/pairlist.h:166: keeps r^-12 finite in fp32 */
 constexpr float c_nbnxnMinDistanceSquared = 3.82e-07F;
 /* nb_free_energy.cpp:107: cap on r^-6 in the perturbed-pair math */

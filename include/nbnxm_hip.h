@@ -374,6 +374,13 @@ void  nbnxm_gpu_debug_set_work_shares(NbnxmGpu* nb, int iloc, int p, const float
  * a hipGraph and replayed numSteps times; on MI355X this was slower than the plain launches */
 void  nbnxm_gpu_debug_graph_steps(NbnxmGpu* nb, const nbnxm_step_workload_t* stepWork, int numSteps);
 
+/* Host arithmetic only (no device call): the workgroup shape nbnxm_gpu_launch_kernel gives the cluster-pair kernel of a flavour —
+ * waves per workgroup (4, 8 or 16: larger workgroups share one copy of the LDS tables when the LJ table of numTypes types is large),
+ * resident waves per SIMD (5 or 4; < 4: the tables do not fit the 160 KB LDS and the launch aborts) and the LDS bytes per workgroup.
+ * coulombTabSize: entries of the tabulated flavours' force table, else ignored. */
+void nbnxm_hip_query_launch_shape(int elecType, int vdwType, int computeEnergy, int numTypes, int coulombTabSize, int* wavesPerWorkgroup,
+                                  int* wavesPerSimd, int* ldsBytesPerWorkgroup);
+
 /* Library/ABI version and a last-error string for diagnostics (never needed on the success path). */
 int         nbnxm_hip_abi_version(void);
 const char* nbnxm_hip_last_error(void);

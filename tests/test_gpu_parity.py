@@ -331,12 +331,13 @@ def test_many_atom_types_table_in_lds(extra):
         tl.assert_parity(got, want, rel=1e-4, label="types %d" % extra)
 
 
-@pytest.mark.parametrize("extra", [26, 60, 96])
+@pytest.mark.parametrize("extra", [26, 60, 96, 119])
 @pytest.mark.parametrize("elec", ["ewald", "rf"])
 def test_many_atom_types_larger_workgroups(extra, elec):
-    """30 / 64 / 100 atom types: the LJ table (8 ntype^2 bytes) no longer fits the LDS once per 4-wave workgroup at full occupancy, so
-    the launch switches to the 4-waves-per-SIMD partition and to workgroups of 8 or 16 waves that share one copy
-    (nbnxm_gpu_launch_kernel).  Force-only (the 5-waves-per-SIMD flavour) and energy steps, both modes."""
+    """30 / 64 / 100 / 123 atom types: the LJ table (8 ntype^2 bytes) no longer fits the LDS once per 4-wave workgroup at full occupancy,
+    so the launch switches to the 4-waves-per-SIMD partition and to workgroups of 8 or 16 waves that share one copy; at 123 types only
+    one 8-wave workgroup fits a CU and the partition runs in rounds (nbnxm_gpu_launch_kernel, tests/test_launch_shape.py).  Force-only
+    (the 5-waves-per-SIMD flavour) and energy steps, both modes."""
     c = tl.make_case(elec=elec, seed=44, num_extra_types=extra, **SMALL)
     assert c.grid.num_types == 4 + extra
     for fused in (False, True):
