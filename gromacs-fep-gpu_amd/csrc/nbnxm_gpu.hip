@@ -711,7 +711,24 @@ void nbnxm_gpu_init_pairlist(NbnxmGpu* nb, int iloc, int na_c, int nsci, const n
             NBNXM_ASSERT(nb->h_sciSorted.data[i].cjPackedBegin >= nb->h_sciSorted.data[i - 1].cjPackedEnd,
                          "the j-group ranges of two sci entries overlap");
         }
-        copyToDeviceBuffer(&d->sciSorted, nb->h_sciSorted.data, 0, nsci, s, true);
+        /* A list builder that balances for GPUs by i-entry count (pairlist.cpp:2283-2400) cuts the j-list of one (super-cluster,
+         * shift) into consecutive entries.  The cluster kernel balances by wave-slot ranges that cut through entries, and every
+         * entry start costs it an i-side staging and a force reduction (19,551 instead of 2,637 entries on the 96k box: 83.6 vs
+         * 61.6 us), so its own entry list joins such pieces again; list pruning keeps working on the caller's entries (d->sci). */
+        int nWork = 0;
+        for (int i = 0; i < nsci; i++)
+        {
+            nbnxn_sci_t*       w = nb->h_sciSorted.data;
+            const nbnxn_sci_t& e = w[i];
+            if (e.cjPackedBegin == e.cjPackedEnd) { continue; }
+            if (nWork > 0 && w[nWork - 1].sci == e.sci && w[nWork - 1].shift == e.shift && w[nWork - 1].cjPackedEnd == e.cjPackedBegin)
+            {
+                w[nWork - 1].cjPackedEnd = e.cjPackedEnd;
+            }
+            else { w[nWork++] = e; }
+        }
+        d->nsciWork = nWork;
+        copyToDeviceBuffer(&d->sciSorted, nb->h_sciSorted.data, 0, nWork, s, true);
     }
     NBNXM_HIP_CHECK(hipStreamSynchronize(s));
     d->workRangesDirty        = true;
@@ -959,7 +976,7 @@ static void updateWorkPartition(NbnxmGpu* nb, int iloc)
     /* a list that has been through its first prune: the working masks are inner-pruned, the outer-pruned ones are in d->imask */
     const unsigned* outerMask = (!d->haveFreshList && d->firstPruneDone) ? d->imask : nullptr;
     hipLaunchKernelGGL(nbnxmWorkWeightKernel, dim3(numBlocks), dim3(c_workBlockSize), 0, s, d->cjPacked, d->ncjPacked, d->sciSorted,
-                       d->nsci, fused ? nb->atdat->fepBits : nullptr, buildSlow ? 1 : 0, outerMask, d->groupSlowMask, d->slowPairs, d->slowPairSci,
+                       d->nsciWork, fused ? nb->atdat->fepBits : nullptr, buildSlow ? 1 : 0, outerMask, d->groupSlowMask, d->slowPairs, d->slowPairSci,
                        d->slowPairs_nalloc, d->slowCount, d->groupWeight, d->weightBlockSum);
     hipLaunchKernelGGL(nbnxmWorkScanKernel, dim3(1), dim3(c_workBlockSize), 0, s, d->weightBlockSum, numBlocks);
     NBNXM_HIP_CHECK(hipGetLastError());
@@ -1014,7 +1031,7 @@ static void updateWorkPartition(NbnxmGpu* nb, int iloc)
         out[p].firstSci   = d->workFirstSci[p];
     }
     hipLaunchKernelGGL(nbnxmWorkRangesKernel, dim3(numBlocks), dim3(c_workBlockSize), 0, s, d->groupWeight, d->weightBlockSum,
-                       d->ncjPacked, numBlocks, d->sciSorted, d->nsci, out[0], out[1]);
+                       d->ncjPacked, numBlocks, d->sciSorted, d->nsciWork, out[0], out[1]);
     NBNXM_HIP_CHECK(hipGetLastError());
 }
 

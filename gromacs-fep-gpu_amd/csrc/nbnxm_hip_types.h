@@ -183,6 +183,8 @@ struct gpu_plist
 
     int          nsci;
     int          sci_nalloc;
+    /* MI355X extension: entries of sciSorted, the cluster kernel's own i-entry list (see nbnxm_gpu_init_pairlist) */
+    int          nsciWork;
     nbnxn_sci_t* sci;
 
     int                ncjPacked;

@@ -519,7 +519,7 @@ __launch_bounds__(c_nbMaxBlockSize) __attribute__((amdgpu_waves_per_eu(c_nbWaves
 
     /* ---- the pieces of this wave's range: one per i-entry it touches ---------------------------------- */
 #pragma unroll 1
-    for (; rangeBegin < rangeEnd && sciIdx < plist.nsci; sciIdx++)
+    for (; rangeBegin < rangeEnd && sciIdx < plist.nsciWork; sciIdx++)
     {
     const nbnxn_sci_t nb_sci        = sciList[sciIdx];
     const int         cjPackedBegin = max(rangeBegin, nb_sci.cjPackedBegin);
