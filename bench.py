@@ -36,7 +36,7 @@ FP32_PEAK_TFLOPS = 157.3   # vector fp32
 DT_FS = 2.0                # MD time step for the kernel-bound ns/day figure
 METRIC = "ns/day + pair-interactions/s, 100k-atom FEP box @ λ=0.5, 1/2/4/8 MI355X"
 # molecules per box edge of the synthetic water boxes (3 atoms each): configs[1], configs[2], 8 x configs[2], configs[4]'s 1.02 M atoms
-BOXES = {"24k": (20, 20, 20), "96k": (40, 40, 20), "768k": (80, 80, 40), "1m": (88, 88, 44)}
+BOXES = {"3k": (10, 10, 10), "24k": (20, 20, 20), "96k": (40, 40, 20), "768k": (80, 80, 40), "1m": (88, 88, 44)}
 COUNTERS_FILE = os.path.join("profiles", "r02", "counters_fused_force_kernel.json")   # written by tools/summarize_counters.py
 
 
@@ -46,7 +46,7 @@ def parse_args(argv=None):
     ap.add_argument("--steps", type=int, default=500)
     ap.add_argument("--warmup", type=int, default=50)
     ap.add_argument("--mode", choices=["fused", "split"], default="fused")
-    ap.add_argument("--atoms", choices=["24k", "96k", "768k", "1m"], default="96k")
+    ap.add_argument("--atoms", choices=["3k", "24k", "96k", "768k", "1m"], default="96k")
     ap.add_argument("--elec", choices=["ewald", "rf"], default="ewald", help="rf: BASELINE configs[1] (with --atoms 24k)")
     ap.add_argument("--max-cjpacked-per-sci", type=int, default=16)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -358,7 +358,7 @@ def main(argv=None):
     # lambda windows batched into one object (secondary figure; BASELINE configs[3]: 11 windows — more than the GPUs of a node):
     # one list over 11 x N slots, per-window lambdas in the perturbed-pair kernel (nbnxm_gpu_set_window_lambdas)
     batched = None
-    if fused and world == 1 and not args.primary_only and args.atoms in ("24k", "96k"):
+    if fused and world == 1 and not args.primary_only and args.atoms in ("3k", "24k", "96k"):
         R = 11
         b = replica.batch_windows(case.grid, pl, R)
         nbw = pkg.NbnxmGpu(wl.gpu_interaction_params(case, not args.no_prune), case.grid.num_types, case.grid.nbat_nbfp(case.sys["nbfp"]),

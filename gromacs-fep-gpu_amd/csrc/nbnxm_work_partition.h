@@ -30,6 +30,10 @@ constexpr int c_workBlockSize = 256;
 constexpr int c_weightPair    = 8;
 constexpr int c_weightSlot    = NBNXM_WEIGHT_SLOT;
 constexpr int c_weightGroup   = NBNXM_WEIGHT_GROUP;
+#ifndef NBNXM_WEIGHT_EMPTY_GROUP
+#define NBNXM_WEIGHT_EMPTY_GROUP NBNXM_WEIGHT_GROUP
+#endif
+constexpr int c_weightEmptyGroup = NBNXM_WEIGHT_EMPTY_GROUP;
 constexpr int c_weightEntry   = NBNXM_WEIGHT_ENTRY;
 
 /* largest k with sciSorted[k].cjPackedBegin <= group (entries ordered by (cjPackedBegin, cjPackedEnd)); -1 if none */
@@ -131,7 +135,9 @@ __launch_bounds__(c_workBlockSize) __global__
         const unsigned fast  = imask & ~slow;
         int            slots = 0;
         for (int jm = 0; jm < c_jGroupSize; jm++) { slots += ((fast >> (jm * c_numClPerSupercl)) & 0xFFU) != 0U ? 1 : 0; }
-        w = c_weightPair * __popc(fast) + c_weightSlot * slots + (fast != 0U ? c_weightGroup : 0);
+        /* a group with nothing left for this kernel (pruned away, or all of it perturbed) still costs the wave its pipeline step: a run of
+         * them at weight 0 ends up in ONE range (3k-atom box with 48 perturbed atoms: 47 groups in one range, kernel 23.6 instead of 12 us) */
+        w = c_weightPair * __popc(fast) + c_weightSlot * slots + (fast != 0U ? c_weightGroup : c_weightEmptyGroup);
         if (owned && sciSorted[k].cjPackedBegin == g) { w += c_weightEntry; }
         groupWeight[g] = w;
     }
