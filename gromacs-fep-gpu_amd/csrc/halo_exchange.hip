@@ -13,7 +13,9 @@
 
 #include <dlfcn.h>
 
+#include <chrono>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -189,6 +191,10 @@ struct HaloGpu
     /* recv side */
     std::vector<int> recvPeer, recvAtomOffset, recvCount;
     hipEvent_t       xReady = nullptr, fReady = nullptr;
+    /* HALO_GPU_HOST_TIMING: host microseconds spent queueing the parts of halo_gpu_domain_force_step */
+    double                                hostTimingUs[9] = { 0, 0, 0, 0, 0, 0, 0, 0, 0 };
+    long                                  hostTimingSteps = 0;
+    std::chrono::steady_clock::time_point hostTimingLast;
 };
 
 extern "C"
@@ -240,6 +246,13 @@ void halo_gpu_free(HaloGpu* h)
 {
     if (h == nullptr) { return; }
     (void)hipStreamSynchronize(h->stream);
+    if (h->hostTimingSteps > 0)
+    {
+        static const char* names[9] = { "halo x (pack, send/recv group)", "clear outputs", "x -> xq local", "local kernel", "x -> xq non-local",
+                                        "non-local kernel", "halo rows kernel", "halo f (send/recv group)", "event, wait, home rows kernel" };
+        std::fprintf(stderr, "halo_gpu: host microseconds per step spent queueing (%ld steps):\n", h->hostTimingSteps);
+        for (int i = 0; i < 9; i++) { std::fprintf(stderr, "  %-34s %7.2f\n", names[i], h->hostTimingUs[i] / h->hostTimingSteps); }
+    }
     if (h->comm != nullptr) { (void)rccl()->CommDestroy(h->comm); }
     (void)hipFree(h->d_sendMap);
     (void)hipFree(h->d_sendShiftIndex);
@@ -413,18 +426,41 @@ void halo_gpu_domain_force_step(HaloGpu* h, NbnxmGpu* nb, const nbnxm_step_workl
     /* the halo coordinates leave first: the pack and the RCCL kernel find the device idle at the start of a step; queued behind the
      * local kernel — which fills every wave slot — the RCCL kernel would wait for slots, and the peers with it (on one GPU the order
      * makes no difference: 0.141 ms either way) */
+    /* diagnostics (HALO_GPU_HOST_TIMING=1): host time spent queueing each part, printed by halo_gpu_free */
+    static const bool s_hostTiming = (std::getenv("HALO_GPU_HOST_TIMING") != nullptr);
+    auto              tick         = [&](int part) {
+        if (s_hostTiming)
+        {
+            const auto now = std::chrono::steady_clock::now();
+            h->hostTimingUs[part] += std::chrono::duration<double, std::micro>(now - h->hostTimingLast).count();
+            h->hostTimingLast = now;
+        }
+    };
+    if (s_hostTiming)
+    {
+        h->hostTimingLast = std::chrono::steady_clock::now();
+        h->hostTimingSteps++;
+    }
     halo_gpu_communicate_coordinates(h, coordinatesReadyEvent);
+    tick(0);
     nbnxm_gpu_clear_outputs(nb, stepWork->computeVirial);
+    tick(1);
     nbnxm_gpu_x_to_nbat_x(nb, h->d_x, coordinatesReadyEvent, NBNXM_LOCAL, 0, numHomeSlots, 1);
+    tick(2);
     nbnxm_gpu_launch_kernel(nb, stepWork, NBNXM_LOCAL);
+    tick(3);
     nbnxm_gpu_x_to_nbat_x(nb, h->d_x, nullptr, NBNXM_NONLOCAL, numHomeSlots, numSlots, 1);
+    tick(4);
     nbnxm_gpu_launch_kernel(nb, stepWork, NBNXM_NONLOCAL);
+    tick(5);
     NBNXM_ASSERT(nb->reductionAtomStart == 0 && nb->reductionNumAtoms >= numAtoms, "the cell map must cover home and halo atoms");
     /* pass A: home rows zeroed, halo rows from the non-local kernel (one launch on the non-local stream) */
     hipLaunchKernelGGL(domainHaloRowsKernel, dim3((numAtoms + c_haloThreadsPerBlock - 1) / c_haloThreadsPerBlock), dim3(c_haloThreadsPerBlock), 0,
                        sNonLocal, h->d_f, reinterpret_cast<const float3*>(nb->atdat->f), nb->cell, h->numHome, numAtoms);
     NBNXM_HIP_CHECK(hipGetLastError());
+    tick(6);
     exchangeForces(h);
+    tick(7);
     NBNXM_HIP_CHECK(hipEventRecord(h->fReady, sNonLocal));
     /* pass B: behind the local kernel (stream order) and the arrival of the force halo (event) */
     NBNXM_HIP_CHECK(hipStreamWaitEvent(sLocal, h->fReady, 0));
@@ -433,6 +469,7 @@ void halo_gpu_domain_force_step(HaloGpu* h, NbnxmGpu* nb, const nbnxm_step_workl
                        reinterpret_cast<float*>(h->d_f), reinterpret_cast<const float3*>(nb->atdat->f), nb->cell, h->numHome, h->d_sendBuf,
                        h->d_sendMap, h->numSendAtoms);
     NBNXM_HIP_CHECK(hipGetLastError());
+    tick(8);
 }
 
 void halo_gpu_pack_shifted(void* stream, const void* d_x, const int* d_map, const int* d_shiftIndex, int n, const float* d_shiftVectors,

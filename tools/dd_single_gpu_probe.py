@@ -45,3 +45,5 @@ torch.cuda.synchronize()
 ms = 1e3 * (time.perf_counter() - t1) / n
 print(json.dumps({"atoms": case.natoms, "self_links": links, "home": plan.num_home, "halo": plan.num_halo, "ms_per_step": ms, "ms_host_enqueue_per_step": ms_enqueue,
                   "host_plan_s": t_plan, "host_rank_lists_s": t_lists, "halo_bytes": halo.bytes_per_step()}))
+halo.free()     # (HALO_GPU_HOST_TIMING=1: prints the host time spent queueing each part of the step)
+nb.free()
