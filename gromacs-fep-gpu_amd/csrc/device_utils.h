@@ -136,12 +136,20 @@ struct DeviceStream
 {
     hipStream_t stream = nullptr;
     bool        owned  = false;
-    void        init(void* external)
+    /* highPriority: the non-local stream, as DeviceStreamManager creates it (gpu_utils/device_stream_manager.cpp:107-108: NonBondedNonLocal is
+     * DeviceStreamPriority::High), so that the work the force halo waits for is dispatched ahead of whatever else is queued */
+    void        init(void* external, bool highPriority = false)
     {
         if (external) { stream = static_cast<hipStream_t>(external); }
         else
         {
-            NBNXM_HIP_CHECK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+            if (highPriority)
+            {
+                int lo = 0, hi = 0;
+                NBNXM_HIP_CHECK(hipDeviceGetStreamPriorityRange(&lo, &hi));
+                NBNXM_HIP_CHECK(hipStreamCreateWithPriority(&stream, hipStreamNonBlocking, hi));
+            }
+            else { NBNXM_HIP_CHECK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking)); }
             owned = true;
         }
     }

@@ -327,7 +327,7 @@ NbnxmGpu* nbnxm_gpu_init(const nbnxm_interaction_params_t* ic, int numTypes, con
     }
     if (nb->bUseTwoStreams)
     {
-        nb->deviceStreams[1].init(nonLocalStream);
+        nb->deviceStreams[1].init(nonLocalStream, true);
         NBNXM_HIP_CHECK(hipEventCreateWithFlags(&nb->nonlocal_done, hipEventDisableTiming));
         NBNXM_HIP_CHECK(hipEventCreateWithFlags(&nb->misc_ops_and_local_H2D_done, hipEventDisableTiming));
         NBNXM_HIP_CHECK(hipEventCreateWithFlags(&nb->nonlocalKernelDone, hipEventDisableTiming));
