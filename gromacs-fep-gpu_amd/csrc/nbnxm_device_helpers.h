@@ -473,7 +473,16 @@ NB_DEVINL void nbPair(const NBParamGpu& nbp,
         }
         else if constexpr (ENERGY)
         {
-            E_el = qq * (inv_r * (int_bit - erff(r2 * inv_r * beta)) - int_bit * nbp.sh_ewald);
+            if constexpr (CORR_TABLE)
+            {
+                /* cluster kernel, tabulated flavours: erf(beta r)/r = beta V((beta r)^2) from the potential table at LDS address 0 */
+                typedef __attribute__((address_space(3))) const float LdsFloat;
+                const float    xs2  = r2 * nbp.ewaldCorrTabScale;
+                const unsigned idx2 = static_cast<unsigned>(xs2);
+                LdsFloat*      tabV = reinterpret_cast<LdsFloat*>(static_cast<uintptr_t>(idx2 * 8U));
+                E_el = qq * (int_bit * (inv_r - nbp.sh_ewald) - fmaf(__builtin_amdgcn_fractf(xs2), tabV[1], tabV[0]));
+            }
+            else { E_el = qq * (inv_r * (int_bit - erff(r2 * inv_r * beta)) - int_bit * nbp.sh_ewald); }
         }
     }
 }

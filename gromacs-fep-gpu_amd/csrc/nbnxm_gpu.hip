@@ -101,7 +101,12 @@ void uploadCoulombTable(NbnxmGpu* nb, const nbnxm_interaction_params_t* ic)
 void uploadEwaldCorrectionTable(NbnxmGpu* nb)
 {
     NBParamGpu* nbp = nb->nbparam;
-    if (nbp->elecType != NBNXM_ELEC_EWALD_ANA && nbp->elecType != NBNXM_ELEC_EWALD_ANA_TWIN) { return; }
+    /* (the tabulated flavours use the potential part on energy steps) */
+    if (nbp->elecType != NBNXM_ELEC_EWALD_ANA && nbp->elecType != NBNXM_ELEC_EWALD_ANA_TWIN && nbp->elecType != NBNXM_ELEC_EWALD_TAB
+        && nbp->elecType != NBNXM_ELEC_EWALD_TAB_TWIN)
+    {
+        return;
+    }
     const double beta = nbp->ewald_beta;
     const double xMax = beta * beta * nbp->rcoulomb_sq * (1.0 + 1.0e-5);
     const int    n    = c_ewaldCorrTabSize;
@@ -201,8 +206,12 @@ static NbLaunchShape chooseNbLaunchShape(int elecType, int vdwType, bool energy,
     const bool useTable       = (vdwType == NBNXM_VDW_CUT || vdwType == NBNXM_VDW_FSWITCH || vdwType == NBNXM_VDW_PSWITCH || ljEwald);
     const bool ewaldCorrTable = (elecType == NBNXM_ELEC_EWALD_ANA || elecType == NBNXM_ELEC_EWALD_ANA_TWIN);
     const bool ewaldRTable    = (elecType == NBNXM_ELEC_EWALD_TAB || elecType == NBNXM_ELEC_EWALD_TAB_TWIN);
+    /* analytical: {F, step} or, on energy steps, {F, step, V, step}; tabulated: the caller's r-indexed force table, on energy steps behind
+     * the {V, step} part of the correction table */
     const int  ewaldTableBytes = ewaldCorrTable ? c_ewaldCorrTabSize * static_cast<int>(energy ? sizeof(float4) : sizeof(float2))
-                                                : (ewaldRTable ? coulombTabLdsBytes(coulombTabSize) : 0);
+                                                : (ewaldRTable ? coulombTabLdsBytes(coulombTabSize)
+                                                                         + (energy ? c_ewaldCorrTabSize * static_cast<int>(sizeof(float2)) : 0)
+                                                               : 0);
     const int  compiledWavesPerSimd = nbKernelWavesPerEu(vdwType, energy, false);
     NbLaunchShape shape{ 0, 0, 0 };
     for (const int w : { defaultWavesPerBlock, 2 * c_nbWavesPerBlock, 4 * c_nbWavesPerBlock })

@@ -319,7 +319,11 @@ __launch_bounds__(c_nbMaxBlockSize) __attribute__((amdgpu_waves_per_eu(c_nbWaves
     /* LDS layout: the Ewald correction table (fixed size) first, then the LJ table: both bases are compile-time offsets, so a
      * table read needs no base-address add (the offset sits in the ds_read's immediate field) */
     constexpr bool EWALD_CORR_TABLE = (ELEC == ELK_EWALD_ANA);
-    constexpr int  c_ewaldTabBytes  = EWALD_CORR_TABLE ? c_ewaldCorrTabSize * static_cast<int>(ENERGY ? sizeof(float4) : sizeof(float2)) : 0;
+    /* tabulated Ewald, energy steps: the potential correction {beta V, step} of the analytical flavours' table in front of the r-indexed
+     * force table (the reference calls erff there, two divergent branches per pair) */
+    constexpr bool EWALD_V_TABLE    = (ELEC == ELK_EWALD_TAB) && ENERGY;
+    constexpr int  c_ewaldTabBytes  = EWALD_CORR_TABLE ? c_ewaldCorrTabSize * static_cast<int>(ENERGY ? sizeof(float4) : sizeof(float2))
+                                                       : (EWALD_V_TABLE ? c_ewaldCorrTabSize * static_cast<int>(sizeof(float2)) : 0);
     /* tabulated Ewald: the reference's r-indexed force table (run-time size) takes the same place; the LJ table's row offsets
      * (trow) carry its size, so that a table read still needs no base-address add */
     constexpr bool EWALD_R_TABLE = (ELEC == ELK_EWALD_TAB);
@@ -382,7 +386,8 @@ __launch_bounds__(c_nbMaxBlockSize) __attribute__((amdgpu_waves_per_eu(c_nbWaves
     const int      nbfpEntries = numTypes * numTypes + (LJ_EWALD ? numTypes : 0);
     const int      nbfpBytes   = USE_TABLE ? ((nbfpEntries * static_cast<int>(sizeof(float2)) + 15) & ~15) : 0;
     const int      tableBytes = nbfpBytes + c_ewaldTabBytes + rTabBytes;
-    [[maybe_unused]] const float2* ewaldCorrLds = reinterpret_cast<const float2*>(nbLds);
+    /* (tabulated Ewald on energy steps: the r-indexed table sits behind the potential table) */
+    [[maybe_unused]] const float2* ewaldCorrLds = reinterpret_cast<const float2*>(nbLds + (EWALD_V_TABLE ? c_ewaldTabBytes : 0));
     unsigned char* jStage = nbLds + tableBytes + wave * (2 * c_jStageBytes + c_jRingBytes);
     if constexpr (USE_TABLE)
     {
@@ -402,8 +407,17 @@ __launch_bounds__(c_nbMaxBlockSize) __attribute__((amdgpu_waves_per_eu(c_nbWaves
 
     if constexpr (EWALD_R_TABLE)
     {
-        float* dst = reinterpret_cast<float*>(nbLds);
+        float* dst = reinterpret_cast<float*>(nbLds + (EWALD_V_TABLE ? c_ewaldTabBytes : 0));
         for (int t = threadIdx.x; t < nbp.coulombTabSize; t += blockSize) { dst[t] = nbp.coulomb_tab[t]; }
+    }
+    if constexpr (EWALD_V_TABLE)
+    {
+        float2* dst = reinterpret_cast<float2*>(nbLds);
+        for (int t = threadIdx.x; t < c_ewaldCorrTabSize; t += blockSize)
+        {
+            const float4 fv = nbp.ewaldCorrTabFV[t];
+            dst[t]          = make_float2(fv.z, fv.w);
+        }
     }
 
     /* nbPair addresses the Ewald table with absolute LDS addresses from 0: the kernel has no static LDS, so the dynamic block starts there */
