@@ -136,16 +136,19 @@ def test_prune_kernel_matches_oracle_and_keeps_forces():
     nb.free()
 
 
+@pytest.mark.parametrize("split", [0, 3])
 @pytest.mark.parametrize("fused", [False, True])
 @pytest.mark.parametrize("merged", [True, False])
-def test_rolling_prune_with_moving_atoms(fused, merged, monkeypatch):
+def test_rolling_prune_with_moving_atoms(fused, merged, split, monkeypatch):
     """Dynamic pruning as mdrun drives it: the first launch prunes the fresh list to the outer radius (kept in gpu_plist::imask) and
     to the inner radius (the working masks); afterwards every step re-checks one of numParts parts of the list for cluster pairs that
     have come inside the inner radius (nbnxm_cuda_kernel_pruneonly.cuh:100-316).  merged: the part runs in trailing workgroups of the
-    force-only cluster kernel; otherwise in the prune kernel, at once.  Masks against the oracle's pruning, forces against the oracle."""
+    force-only cluster kernel; otherwise in the prune kernel, at once.  Masks against the oracle's pruning, forces against the oracle.
+    split 3: the i-entries arrive cut into pieces of at most 3 groups (a list builder balancing for GPUs); the cluster kernel walks them
+    joined again (gpu_plist::sciSorted) while the pruning works on the caller's entries."""
     import oracle_binding as ob
     monkeypatch.setenv("NBNXM_HIP_PRUNE_MERGED", "1" if merged else "0")
-    c = tl.make_case(elec="ewald", seed=33, **SMALL)
+    c = tl.make_case(elec="ewald", seed=33, max_cjpacked_per_sci=split, **SMALL)
     c.rlist_inner = 1.03
     g = c.grid
     pl = c.plist_fused if fused else c.plist
