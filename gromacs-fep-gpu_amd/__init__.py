@@ -101,6 +101,7 @@ HIP_SYMBOLS = [
     "nbnxm_gpu_init_x_to_nbat_x", "nbnxm_gpu_x_to_nbat_x", "nbnxm_gpu_insert_nonlocal_dependency",
     "nbnxm_gpu_setup_short_range_work", "nbnxm_gpu_force_reduction_reinit", "nbnxm_gpu_force_reduction_execute",
     "nbnxm_gpu_halo_pack_x", "nbnxm_gpu_halo_unpack_f", "nbnxm_gpu_force_reduction_execute_range", "nbnxm_hip_query_launch_shape",
+    "nbnxm_gpu_set_local_launch_parts", "nbnxm_gpu_launch_kernel_part",
 ]
 HALO_SYMBOLS = [
     "halo_gpu_get_unique_id", "halo_gpu_create", "halo_gpu_free", "halo_gpu_last_error", "halo_gpu_reinit",
@@ -519,6 +520,13 @@ class NbnxmGpu:
 
     def launch_kernel(self, step_work, iloc=LOCAL):
         self._lib.nbnxm_gpu_launch_kernel(self.h, C.byref(step_work), C.c_int(iloc))
+
+    def set_local_launch_parts(self, num_parts, first_part_fraction=0.65):
+        """nbnxm_gpu_set_local_launch_parts: the local list partitioned for a launch in two parts (domain decomposition)"""
+        self._lib.nbnxm_gpu_set_local_launch_parts(self.h, C.c_int(num_parts), C.c_float(first_part_fraction))
+
+    def launch_kernel_part(self, step_work, part, iloc=LOCAL):
+        self._lib.nbnxm_gpu_launch_kernel_part(self.h, C.byref(step_work), C.c_int(iloc), C.c_int(part))
 
     def launch_kernel_pruneonly(self, iloc=LOCAL, num_parts=1):
         self._lib.nbnxm_gpu_launch_kernel_pruneonly(self.h, C.c_int(iloc), C.c_int(num_parts))

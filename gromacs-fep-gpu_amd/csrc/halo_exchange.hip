@@ -97,6 +97,8 @@ Rccl* rccl()
     } while (0)
 
 constexpr int c_haloThreadsPerBlock = 256;
+/* the local launch of a domain step in two parts (halo_gpu_domain_force_step) */
+constexpr float c_defaultLocalPartFraction = 0.65F;
 
 /* packed[i] = x[map[i]] + shift[shiftIndex[i]]: all destinations in one launch (the reference launches one
  * packSendBufKernel<usePbc> per pulse with one shift, gpuhaloexchange_impl_gpu.cu:62-88) */
@@ -194,6 +196,9 @@ struct HaloGpu
     /* HALO_GPU_HOST_TIMING: host microseconds spent queueing the parts of halo_gpu_domain_force_step */
     double                                hostTimingUs[9] = { 0, 0, 0, 0, 0, 0, 0, 0, 0 };
     long                                  hostTimingSteps = 0;
+    /* the local launch of halo_gpu_domain_force_step in one or two parts */
+    int   localParts        = 1;
+    float localPartFraction = c_defaultLocalPartFraction;
     std::chrono::steady_clock::time_point hostTimingLast;
 };
 
@@ -239,6 +244,14 @@ HaloGpu* halo_gpu_create(const void* uniqueId, int rank, int nranks, void* strea
     }
     NBNXM_HIP_CHECK(hipEventCreateWithFlags(&h->xReady, hipEventDisableTiming));
     NBNXM_HIP_CHECK(hipEventCreateWithFlags(&h->fReady, hipEventDisableTiming));
+    /* the local launch of a domain step in two parts: on by default where the exchanges leave the device (see halo_gpu_domain_force_step) */
+    h->localParts = (nranks > 1) ? 2 : 1;
+    if (const char* env = std::getenv("HALO_GPU_LOCAL_PARTS")) { h->localParts = (std::atoi(env) == 2) ? 2 : 1; }
+    if (const char* env = std::getenv("HALO_GPU_LOCAL_PART_FRACTION"))
+    {
+        const float v = static_cast<float>(std::atof(env));
+        if (v > 0.05F && v < 0.95F) { h->localPartFraction = v; }
+    }
     return h;
 }
 
@@ -441,13 +454,22 @@ void halo_gpu_domain_force_step(HaloGpu* h, NbnxmGpu* nb, const nbnxm_step_workl
         h->hostTimingLast = std::chrono::steady_clock::now();
         h->hostTimingSteps++;
     }
+    /* The local kernel takes every wave slot until its balanced ranges retire together, so the non-local kernel runs behind it and
+     * the force halo is exposed.  In two parts — most of the local list beside the coordinate halo, the rest behind the non-local
+     * kernel (high-priority stream) beside the force halo — the step is max(L1, halo x) + non-local + max(L2, halo f)
+     * (read at halo_gpu_create: HALO_GPU_LOCAL_PARTS=1 / 2 switches it off / on — the default is on with more than one rank, where the
+     * exchanges cross xGMI —, HALO_GPU_LOCAL_PART_FRACTION sets L1's share of the local work).  Lists too short for two sets of
+     * one range per wave slot run as one launch. */
+    const bool twoParts = (h->localParts == 2 && (h->numSendAtoms > 0 || !h->recvPeer.empty()));
+    nbnxm_gpu_set_local_launch_parts(nb, twoParts ? 2 : 1, h->localPartFraction);
     halo_gpu_communicate_coordinates(h, coordinatesReadyEvent);
     tick(0);
     nbnxm_gpu_clear_outputs(nb, stepWork->computeVirial);
     tick(1);
     nbnxm_gpu_x_to_nbat_x(nb, h->d_x, coordinatesReadyEvent, NBNXM_LOCAL, 0, numHomeSlots, 1);
     tick(2);
-    nbnxm_gpu_launch_kernel(nb, stepWork, NBNXM_LOCAL);
+    if (twoParts) { nbnxm_gpu_launch_kernel_part(nb, stepWork, NBNXM_LOCAL, 1); }
+    else { nbnxm_gpu_launch_kernel(nb, stepWork, NBNXM_LOCAL); }
     tick(3);
     nbnxm_gpu_x_to_nbat_x(nb, h->d_x, nullptr, NBNXM_NONLOCAL, numHomeSlots, numSlots, 1);
     tick(4);
@@ -462,6 +484,7 @@ void halo_gpu_domain_force_step(HaloGpu* h, NbnxmGpu* nb, const nbnxm_step_workl
     exchangeForces(h);
     tick(7);
     NBNXM_HIP_CHECK(hipEventRecord(h->fReady, sNonLocal));
+    if (twoParts) { nbnxm_gpu_launch_kernel_part(nb, stepWork, NBNXM_LOCAL, 2); }
     /* pass B: behind the local kernel (stream order) and the arrival of the force halo (event) */
     NBNXM_HIP_CHECK(hipStreamWaitEvent(sLocal, h->fReady, 0));
     const int n = h->numHome + h->numSendAtoms;

@@ -1007,25 +1007,34 @@ static void updateWorkPartition(NbnxmGpu* nb, int iloc)
     for (int p = 0; p < 2; p++)
     {
         const int slots = nb->numSimds * (4 + p);
-        d->numWorkRanges[p] = std::max(1, std::min(slots, d->ncjPacked / nb->minGroupsPerWave));
+        /* a launch in two parts (the local list of a decomposed run, force flavour): two sets of one range per wave slot, the first
+         * set holding localPartFraction of the weight */
+        const bool twoParts = (iloc == NBNXM_LOCAL && nb->localLaunchParts == 2 && nb->numWorkRangesOverride <= 0
+                               && d->ncjPacked / nb->minGroupsPerWave >= 2 * slots);
+        const int  want     = twoParts ? 2 * slots : slots;
+        d->workParts[p]     = twoParts ? 2 : 1;
+        d->numWorkRanges[p] = std::max(1, std::min(want, d->ncjPacked / nb->minGroupsPerWave));
         if (nb->numWorkRangesOverride > 0) { d->numWorkRanges[p] = std::min(nb->numWorkRangesOverride, d->ncjPacked); }
         reallocateDeviceBuffer(&d->workRangeStart[p], d->numWorkRanges[p] + 1, &dummy, &d->work_nalloc[p]);
         out[p].numRanges = d->numWorkRanges[p];
         /* shares: only for the launch they are meant for, one wave per slot of every SIMD; they start from the age classes
          * (the waves of a SIMD are dispatched numRanges / classes apart) and survive new lists of the same size */
-        if (d->numWorkRanges[p] == slots && d->workShareCount[p] != slots)
+        const float fraction = twoParts ? nb->localPartFraction : 1.0F;
+        if (d->numWorkRanges[p] == want && (d->workShareCount[p] != want || d->workPartFraction[p] != fraction))
         {
             const int          classes = 4 + p, perClass = slots / classes;
-            std::vector<float> share(slots);
+            std::vector<float> share(want);
             /* the age-class shares were measured for the fused mode; with the atom-pair kernels running beside the cluster
              * kernel (split mode) equal shares are the better start (0.1037 vs 0.1055 ms per step) */
-            for (int r = 0; r < slots; r++)
+            for (int r = 0; r < want; r++)
             {
-                share[r] = nb->fusedFep ? nb->waveClassShare[p][std::min(classes - 1, r / perClass)] / 1024.0F : 1.0F;
+                const float ofClass = nb->fusedFep ? nb->waveClassShare[p][std::min(classes - 1, (r % slots) / perClass)] / 1024.0F : 1.0F;
+                share[r]            = ofClass * (twoParts ? (r < slots ? fraction : 1.0F - fraction) : 1.0F);
             }
-            setWorkShares(d, p, share.data(), slots, s);
+            setWorkShares(d, p, share.data(), want, s);
+            d->workPartFraction[p] = fraction;
         }
-        out[p].shareCum = (d->numWorkRanges[p] == slots) ? d->workShareCum[p] : nullptr;
+        out[p].shareCum = (d->numWorkRanges[p] == want) ? d->workShareCum[p] : nullptr;
     }
     /* workFirstSci shares work_nalloc with workRangeStart: reallocate when that one grew */
     for (int p = 0; p < 2; p++)
@@ -1042,6 +1051,7 @@ static void updateWorkPartition(NbnxmGpu* nb, int iloc)
     hipLaunchKernelGGL(nbnxmWorkRangesKernel, dim3(numBlocks), dim3(c_workBlockSize), 0, s, d->groupWeight, d->weightBlockSum,
                        d->ncjPacked, numBlocks, d->sciSorted, d->nsciWork, out[0], out[1]);
     NBNXM_HIP_CHECK(hipGetLastError());
+    d->workRangesDirty = false; /* (setWorkShares above marks the ranges dirty: they have just been computed with the new shares) */
 }
 
 /* a deferred rolling-prune part in its own kernel, now */
@@ -1130,6 +1140,10 @@ void nbnxm_gpu_launch_kernel(NbnxmGpu* nb, const nbnxm_step_workload_t* stepWork
     InteractionTimers& t     = nb->timers[iloc];
     NBNXM_ASSERT(adat->shiftVecUploaded, "shift vectors have not been uploaded");
     if (stepWork->computeEnergy || stepWork->computeDhdl) { nb->scalarsDirty = true; } /* see nbnxm_gpu_clear_outputs */
+    /* nbnxm_gpu_launch_kernel_part: 1 = everything up to and including the first set of ranges (or the whole launch when the list is
+     * not partitioned in two), 2 = the second set of ranges with the trailing workgroups (or nothing) */
+    const int launchPart = nb->launchPartNow;
+    NBNXM_ASSERT(launchPart != 2 || !plist->workRangesDirty, "the second part of a launch needs the partition its first part ran on");
 
     if (canSkipNonbondedWork(*nb, iloc))
     {
@@ -1141,6 +1155,7 @@ void nbnxm_gpu_launch_kernel(NbnxmGpu* nb, const nbnxm_step_workload_t* stepWork
         /* the non-local kernel must see the local H2D and the output clearing (nbnxm_cuda.cu:625-641) */
         NBNXM_HIP_CHECK(hipStreamWaitEvent(s, nb->misc_ops_and_local_H2D_done, 0));
     }
+    const bool secondPartOnly = (launchPart == 2); /* the perturbed-pair kernels, pruning and the partition belong to the first part */
     /* A.4: the reference returns before the FEP launch when the normal list is empty; here the
      * perturbed pairs are evaluated regardless.
      * The atom-pair kernels are few, latency-bound waves: they go first, on the locality's FEP stream, and
@@ -1152,7 +1167,7 @@ void nbnxm_gpu_launch_kernel(NbnxmGpu* nb, const nbnxm_step_workload_t* stepWork
                              && ((nbp->softcoreType == NBNXM_SOFTCORE_GAPSYS) ? (nbp->gapsysLinpointCoul != 0.0F || nbp->gapsysLinpointVdw != 0.0F)
                                                                                : (nbp->alpha_coul != 0.0F || nbp->alpha_vdw != 0.0F));
     bool       fepForked = false;
-    if (nbp->bFEP && !fused)
+    if (nbp->bFEP && !fused && !secondPartOnly)
     {
         gpu_feplist* feplist   = nb->feplist[iloc];
         const bool   doForce   = true;
@@ -1219,7 +1234,7 @@ void nbnxm_gpu_launch_kernel(NbnxmGpu* nb, const nbnxm_step_workload_t* stepWork
 
         /* force-only steps: the perturbed cluster pairs ride in trailing workgroups of the cluster kernel (nbnxm_kernel_impl.h) */
         const bool mergeFep = fused && plist->numSlowPairs > 0 && nb->fepMergedFused && !energyFlavour && !wantForeign;
-        if (fused && plist->numSlowPairs > 0 && !mergeFep)
+        if (fused && plist->numSlowPairs > 0 && !mergeFep && !secondPartOnly)
         {
             /* (energy / dH/dl steps, or NBNXM_HIP_FEP_MERGED=0; force-only steps: trailing workgroups of the cluster kernel, below)
              * the cluster pairs that touch a perturbed atom: a few thousand short latency-bound waves, ~10 us on the 96k
@@ -1280,16 +1295,23 @@ void nbnxm_gpu_launch_kernel(NbnxmGpu* nb, const nbnxm_step_workload_t* stepWork
         const int p         = std::max(0, wavesPerSimd - 4);
         const int numRanges = plist->numWorkRanges[p];
         NBNXM_ASSERT(numRanges > 0, "work partition missing");
-        const int mergedFepItems = mergeFep ? plist->numSlowPairs : 0;
-        const int pruneEntries   = (plist->pendingPrunePart >= 0) ? plist->pendingPruneEntries : 0;
+        /* two sets of ranges (workParts 2): one launch per set; the trailing workgroups ride with the second.  A caller that does
+         * not ask for a part gets both launches back to back. */
+        const bool twoSets   = (plist->workParts[p] == 2 && numRanges % 2 == 0);
+        const int  firstSet  = (twoSets && launchPart == 2) ? 1 : 0;
+        const int  lastSet   = (twoSets && launchPart != 1) ? 1 : 0;
+        const bool withTail  = !twoSets || lastSet == 1;
+        const int  setRanges = twoSets ? numRanges / 2 : numRanges;
+        const int mergedFepItems = (mergeFep && withTail) ? plist->numSlowPairs : 0;
+        const int pruneEntries   = (plist->pendingPrunePart >= 0 && withTail) ? plist->pendingPruneEntries : 0;
         const int prunePart      = std::max(plist->pendingPrunePart, 0);
-        plist->pendingPrunePart  = -1;
+        if (withTail) { plist->pendingPrunePart = -1; }
         /* the force flavour zeroes the spare force buffer for the next step (nbnxm_gpu_clear_outputs swaps) */
         int clearNumFloat4 = 0;
         /* Only the LOCAL launch does it: with two localities both kernels add to the buffer in use, and the buffer being zeroed
          * is the one the previous step's kernels wrote — the local stream has to be behind the previous NON-LOCAL kernel too,
          * whatever the caller's copy-back / reduction schedule was (nonlocalKernelDone). */
-        if (nb->fDoubleBuffer && !energyFlavour && (3 * adat->numAtoms) % 4 == 0 && iloc == NBNXM_LOCAL)
+        if (nb->fDoubleBuffer && !energyFlavour && (3 * adat->numAtoms) % 4 == 0 && iloc == NBNXM_LOCAL && withTail)
         {
             if (nb->bUseTwoStreams && nb->nonlocalKernelRecorded)
             {
@@ -1305,15 +1327,22 @@ void nbnxm_gpu_launch_kernel(NbnxmGpu* nb, const nbnxm_step_workload_t* stepWork
             nb->fSpareCleared = true;
         }
         const int clearChunk     = wavesPerBlock * c_waveSize * static_cast<int>(c_clearFloat4PerThread);
-        const int numBlocks      = (numRanges + wavesPerBlock - 1) / wavesPerBlock + (mergedFepItems + wavesPerBlock - 1) / wavesPerBlock
-                              + (pruneEntries + wavesPerBlock - 1) / wavesPerBlock + (clearNumFloat4 + clearChunk - 1) / clearChunk;
-        hipLaunchKernelGGL(kernel, dim3(numBlocks), dim3(wavesPerBlock * c_waveSize), ldsBytes, s,
-                           *adat, *nbp, *plist, stepWork->computeVirial, plist->sciSorted, plist->cjPacked, plist->excl, adat->xq,
-                           adat->atomTypes, adat->ljComb, reinterpret_cast<const unsigned*>(adat->fepBits),
-                           plist->workRangeStart[p], plist->workFirstSci[p], numRanges, plist->groupSlowMask, mergedFepItems,
-                           std::max(plist->rollingPruningNumParts, 1), prunePart, pruneEntries, reinterpret_cast<float4*>(nb->fSpare),
-                           clearNumFloat4);
-        NBNXM_HIP_CHECK(hipGetLastError());
+        /* (a list that is not partitioned in two ran completely with the first part) */
+        for (int set = firstSet; set <= lastSet && !(secondPartOnly && !twoSets); set++)
+        {
+            const bool tail      = withTail && set == lastSet;
+            const int  numBlocks = (setRanges + wavesPerBlock - 1) / wavesPerBlock
+                                  + (tail ? (mergedFepItems + wavesPerBlock - 1) / wavesPerBlock + (pruneEntries + wavesPerBlock - 1) / wavesPerBlock
+                                                    + (clearNumFloat4 + clearChunk - 1) / clearChunk
+                                          : 0);
+            hipLaunchKernelGGL(kernel, dim3(numBlocks), dim3(wavesPerBlock * c_waveSize), ldsBytes, s,
+                               *adat, *nbp, *plist, stepWork->computeVirial, plist->sciSorted, plist->cjPacked, plist->excl, adat->xq,
+                               adat->atomTypes, adat->ljComb, reinterpret_cast<const unsigned*>(adat->fepBits),
+                               plist->workRangeStart[p] + set * setRanges, plist->workFirstSci[p] + set * setRanges, setRanges, plist->groupSlowMask,
+                               tail ? mergedFepItems : 0, std::max(plist->rollingPruningNumParts, 1), prunePart, tail ? pruneEntries : 0,
+                               reinterpret_cast<float4*>(nb->fSpare), tail ? clearNumFloat4 : 0);
+            NBNXM_HIP_CHECK(hipGetLastError());
+        }
         if (nb->bDoTime) { t.nb_k.closeTimingRegion(s); }
         if (iloc == NBNXM_NONLOCAL && nb->fDoubleBuffer)
         {
@@ -1324,6 +1353,23 @@ void nbnxm_gpu_launch_kernel(NbnxmGpu* nb, const nbnxm_step_workload_t* stepWork
     plist->haveFreshList = false;
 
     if (fepForked) { NBNXM_HIP_CHECK(hipStreamWaitEvent(s, nb->fepJoin[iloc], 0)); }
+}
+
+void nbnxm_gpu_set_local_launch_parts(NbnxmGpu* nb, int numParts, float firstPartFraction)
+{
+    NBNXM_ASSERT((numParts == 1 || numParts == 2) && firstPartFraction > 0.0F && firstPartFraction < 1.0F, "one or two parts, the first one a fraction of the work");
+    if (nb->localLaunchParts == numParts && nb->localPartFraction == firstPartFraction) { return; }
+    nb->localLaunchParts  = numParts;
+    nb->localPartFraction = firstPartFraction;
+    if (nb->plist[NBNXM_LOCAL] != nullptr) { nb->plist[NBNXM_LOCAL]->workRangesDirty = true; }
+}
+
+void nbnxm_gpu_launch_kernel_part(NbnxmGpu* nb, const nbnxm_step_workload_t* stepWork, int iloc, int part)
+{
+    NBNXM_ASSERT(part == 1 || part == 2, "part 1 or 2");
+    nb->launchPartNow = part;
+    nbnxm_gpu_launch_kernel(nb, stepWork, iloc);
+    nb->launchPartNow = 0;
 }
 
 void nbnxm_gpu_launch_cpyback(NbnxmGpu* nb, float* f_out, const nbnxm_step_workload_t* stepWork,

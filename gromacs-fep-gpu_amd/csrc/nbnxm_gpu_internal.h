@@ -84,6 +84,11 @@ struct NbnxmGpu
 
     int nbWavesPerBlock = c_nbWavesPerBlock; /* tunable: NBNXM_HIP_WAVES_PER_BLOCK = 1..4 */
     bool keepCombinationKernels = false;     /* diagnostics: NBNXM_HIP_KEEP_COMB_KERNELS=1 */
+    /* domain decomposition: the local force-only launch in two parts (nbnxm_gpu_set_local_launch_parts), the second one behind the
+     * non-local kernel so that it runs beside the force halo */
+    int   localLaunchParts    = 1;
+    float localPartFraction   = 0.65F;
+    int   launchPartNow       = 0; /* 0: whole launch; 1 / 2: the part nbnxm_gpu_launch_kernel_part asked for */
     bool debugLaunchShape       = false;     /* diagnostics: NBNXM_HIP_DEBUG_LAUNCH_SHAPE prints the first launch's workgroup shape */
     /* work partition (gpu_plist::work*): SIMDs of the device, smallest range worth a wave (NBNXM_HIP_MIN_GROUPS_PER_WAVE) */
     int numSimds          = 1024;

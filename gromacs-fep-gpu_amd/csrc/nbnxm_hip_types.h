@@ -233,6 +233,8 @@ struct gpu_plist
     float*       workShare[2];      /* numWorkRanges: share of the total weight of each range, mean 1 (see WorkPartitionOut) */
     float*       workShareCum[2];   /* numWorkRanges + 1: its running sum, normalised to 1 */
     int          workShareCount[2]; /* the number of ranges the shares were set up for */
+    int          workParts[2];      /* 2: the ranges are two sets of one-per-wave-slot, for a launch in two parts (nbnxm_gpu_launch_kernel_part) */
+    float        workPartFraction[2]; /* ... and the first set's share of the weight the shares were set up for */
     bool         workRangesDirty;
     unsigned long long* debugTimeline; /* diagnostics builds (NBNXM_WAVE_TIMELINE) only, else nullptr */
 };

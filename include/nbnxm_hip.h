@@ -374,6 +374,16 @@ void  nbnxm_gpu_debug_set_work_shares(NbnxmGpu* nb, int iloc, int p, const float
  * a hipGraph and replayed numSteps times; on MI355X this was slower than the plain launches */
 void  nbnxm_gpu_debug_graph_steps(NbnxmGpu* nb, const nbnxm_step_workload_t* stepWork, int numSteps);
 
+/* MI355X extension for domain decomposition.  The cluster kernel takes every wave slot of the device until its balanced ranges retire
+ * together, so a non-local kernel queued beside the local one only starts behind it and the force halo is exposed.  With two parts the
+ * local list is partitioned into two sets of ranges (the first holding firstPartFraction of the work):
+ *   nbnxm_gpu_launch_kernel_part(nb, stepWork, NBNXM_LOCAL, 1)   beside the coordinate halo
+ *   nbnxm_gpu_launch_kernel(nb, stepWork, NBNXM_NONLOCAL)        on the (high-priority) non-local stream
+ *   nbnxm_gpu_launch_kernel_part(nb, stepWork, NBNXM_LOCAL, 2)   behind it, beside the force halo
+ * Lists too short for two sets, and callers that use nbnxm_gpu_launch_kernel, run as before (part 2 is then empty). */
+void nbnxm_gpu_set_local_launch_parts(NbnxmGpu* nb, int numParts, float firstPartFraction);
+void nbnxm_gpu_launch_kernel_part(NbnxmGpu* nb, const nbnxm_step_workload_t* stepWork, int iloc, int part);
+
 /* Host arithmetic only (no device call): the workgroup shape nbnxm_gpu_launch_kernel gives the cluster-pair kernel of a flavour —
  * waves per workgroup (4, 8 or 16: larger workgroups share one copy of the LDS tables when the LJ table of numTypes types is large),
  * resident waves per SIMD (5 or 4; < 4: the tables do not fit the 160 KB LDS and the launch aborts) and the LDS bytes per workgroup.

@@ -7,6 +7,8 @@ compared against the RMS force, sums that cancel against the magnitude of their 
 """
 import ctypes as C
 
+import math
+
 import numpy as np
 import pytest
 
@@ -187,6 +189,47 @@ def test_rolling_prune_with_moving_atoms(fused, merged, split, monkeypatch):
         tl.assert_parity(got, want, rel=1e-4, energy=False, label="rolling prune")
     dev = pkg.download_cjpacked(nb, len(outer))
     assert np.array_equal(dev["imei"]["imask"], want_mask)
+    nb.free()
+
+
+@pytest.mark.parametrize("fused", [False, True])
+def test_local_launch_in_two_parts(fused):
+    """nbnxm_gpu_set_local_launch_parts / nbnxm_gpu_launch_kernel_part (the schedule of a decomposed step: most of the local list beside
+    the coordinate halo, the rest behind the non-local kernel): on the 96k box the list is long enough for two sets of ranges.  Part 1 +
+    part 2 must give what one launch gives — forces against the oracle —, a caller that does not ask for parts gets both sets from
+    nbnxm_gpu_launch_kernel, energy steps work on the two-set partition too, and the first part alone must NOT be the whole result."""
+    c = tl.make_case(elec="ewald", seed=2026, nm=(40, 40, 20), num_perturbed_molecules=16, max_cjpacked_per_sci=16)
+    want = tl.run_oracle(c, energy=True, num_threads=8)
+    nb = tl.setup_gpu(c, fused=fused, use_dynamic_pruning=True)
+    nb.set_local_launch_parts(2, 0.65)
+    f = np.zeros((c.grid.num_atoms, 3), np.float32)
+    frms = math.sqrt(float(np.mean(np.sum(np.asarray(want["f"]) ** 2, axis=1))))
+
+    def forces(launch):
+        sw = pkg.step_workload(energy=False, virial=True)
+        nb.clear_outputs(True)
+        launch(sw)
+        nb.launch_cpyback(f, sw)
+        res = nb.wait_finish_task(sw, c.have_soft_core)
+        return dict(f=f.astype(np.float64).copy(), fshift=res["fshift"].astype(np.float64))
+
+    def both_parts(sw):
+        nb.launch_kernel_part(sw, 1)
+        nb.launch_kernel_part(sw, 2)
+
+    for step in range(3):       # fresh list (first prune inside part 1), then steady state with swapped force buffers
+        got = forces(both_parts)
+        tl.assert_parity(got, want, rel=1e-4, energy=False, label="two parts, step %d" % step)
+    first_only = forces(lambda sw: nb.launch_kernel_part(sw, 1))
+    assert np.max(np.abs(first_only["f"] - want["f"])) > frms              # the second set is real work
+    nb.clear_outputs(True)
+    got = forces(lambda sw: nb.launch_kernel(sw))                            # no parts asked for: both sets, back to back
+    tl.assert_parity(got, want, rel=1e-4, energy=False, label="two sets, one call")
+    got = tl.run_gpu(c, energy=True, fused=fused, nb=nb)                     # energy flavour on its own two-set partition
+    tl.assert_parity(got, want, rel=1e-4, label="two sets, energy step")
+    nb.set_local_launch_parts(1)
+    got = forces(lambda sw: nb.launch_kernel(sw))
+    tl.assert_parity(got, want, rel=1e-4, energy=False, label="back to one set")
     nb.free()
 
 
@@ -499,7 +542,7 @@ def test_halo_pack_unpack_kernels():
     pkg.halo_pack_x(s, d_x.data_ptr(), d_map.data_ptr(), 0, d_send.data_ptr(), None)
 
 
-def _check_virtual_rank_decomposition(c, ncells, oracle_threads=1, self_links=(False, False, False), rccl=False):
+def _check_virtual_rank_decomposition(c, ncells, oracle_threads=1, self_links=(False, False, False), rccl=False, energy=True):
     """All ranks of a decomposition in one process on one GPU: per rank its own grid over home + halo atoms, local and non-local
     list, two streams, x -> xq per locality, fused cluster kernels, force reduction per locality; the halo moves through the
     in-process test double (or, rccl=True with ONE rank that is its own neighbour, through the real RCCL transport of
@@ -510,7 +553,7 @@ def _check_virtual_rank_decomposition(c, ncells, oracle_threads=1, self_links=(F
     domdec = importlib.import_module("gromacs_fep_gpu_amd.domdec")
     wl = importlib.import_module("gromacs_fep_gpu_amd.workload")
     dd = domdec.DomainDecomposition(c.sys["x"], c.sys["box"], c.sys["molId"], ncells, c.rlist, self_links=self_links)
-    sw = pkg.step_workload(energy=True, virial=False, dhdl=False)
+    sw = pkg.step_workload(energy=energy, virial=False, dhdl=False)
     steps, halos = [], []
     for r in range(dd.num_ranks):
         plan = dd.plan(r)
@@ -561,7 +604,7 @@ def _check_virtual_rank_decomposition(c, ncells, oracle_threads=1, self_links=(F
     f_ref = np.zeros((c.natoms, 3))
     f_ref[g.atomIndices[real]] = want["f"][real]
     got = dict(f=f_dd.astype(np.float64), fshift=want["fshift"], e_lj=e_lj, e_el=e_el, dvdl_coul=dvdl_c, dvdl_vdw=dvdl_v)
-    tl.assert_parity(got, dict(want, f=f_ref), rel=1e-4, label="decomposition %s" % (ncells,))
+    tl.assert_parity(got, dict(want, f=f_ref), rel=1e-4, energy=energy, label="decomposition %s" % (ncells,))
     for s, h in zip(steps, halos):
         h.free()
         s.nb.free()
@@ -581,6 +624,16 @@ def test_halo_exchange_over_rccl_with_a_rank_that_is_its_own_neighbour(self_link
     virtual-rank test above."""
     _check_virtual_rank_decomposition(tl.make_case(nm=(10, 10, 10), num_perturbed_molecules=3, elec="ewald", seed=79), (1, 1, 1),
                                       self_links=self_links, rccl=True)
+
+
+@pytest.mark.parametrize("energy", [False, True])
+def test_domain_step_over_rccl_with_the_local_launch_in_two_parts(energy, monkeypatch):
+    """halo_gpu_domain_force_step with the local launch in two parts (the default with more than one rank: part 1 beside the coordinate
+    halo, the non-local kernel, part 2 beside the force halo).  The 96k box is long enough for two sets of ranges; one rank that is its
+    own neighbour along x, y and z runs the real RCCL groups.  Force-only steps (trailing workgroups ride with part 2) and energy steps."""
+    monkeypatch.setenv("HALO_GPU_LOCAL_PARTS", "2")
+    c = tl.make_case(nm=(40, 40, 20), num_perturbed_molecules=16, elec="ewald", seed=2026, max_cjpacked_per_sci=16)
+    _check_virtual_rank_decomposition(c, (1, 1, 1), oracle_threads=8, self_links=(True, True, True), rccl=True, energy=energy)
 
 
 def test_full_size_properties_1m():
