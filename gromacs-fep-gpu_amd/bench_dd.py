@@ -2,6 +2,7 @@
 (gromacs-fep-gpu_amd/domdec.py), halo exchange over RCCL (include/halo_hip.h); kept out of bench.py so that the contract file
 stays short."""
 import importlib
+import os
 import time
 
 import numpy as np
@@ -67,6 +68,8 @@ def measure(args, rank, world, dist, torch, nm, npert, reduce_device, steps, war
                "domain_grid": "%dx%dx%d" % ncells, "atoms": int(case.natoms), "cluster_pairs_all_ranks": int(tot[0].item()),
                "halo_atoms_per_rank_mean": float(tot[1].item()) / world, "home_atoms_per_rank_mean": float(tot[2].item()) / world,
                "halo_bytes_sent_and_received_rank0_per_step": halo.bytes_per_step(), "transport": "RCCL ncclSend/ncclRecv groups (halo_hip.h)",
+               "local_launch": ("two parts, the second behind the non-local kernel (HALO_GPU_LOCAL_PARTS)" if world > 1 and os.environ.get("HALO_GPU_LOCAL_PARTS", "2") == "2"
+                                else "one launch"),
                "host_plan_s": t_plan, "host_rank_lists_s": t_lists}
     halo.free()
     nb.free()
