@@ -39,7 +39,13 @@ groups = (imask != 0).astype(np.int64)
 excl_ind = cj["imei"][:, 0]["excl_ind"]
 xpairs = np.where(excl_ind != 0, popc, 0).astype(np.int64)      # cluster pairs of the groups that carry an exclusion mask
 starts = np.zeros(len(imask), np.int64)
-starts[pl.sci["cjPackedBegin"][pl.sci["cjPackedEnd"] > pl.sci["cjPackedBegin"]]] = 1
+# the kernel walks the caller's entries joined again where they are pieces of one (super-cluster, shift) j-list (nbnxm_gpu_init_pairlist)
+sci_sorted = np.sort(pl.sci[pl.sci["cjPackedEnd"] > pl.sci["cjPackedBegin"]], order="cjPackedBegin")
+joined = np.ones(len(sci_sorted), bool)
+joined[1:] = ~((sci_sorted["sci"][1:] == sci_sorted["sci"][:-1]) & (sci_sorted["shift"][1:] == sci_sorted["shift"][:-1])
+               & (sci_sorted["cjPackedBegin"][1:] == sci_sorted["cjPackedEnd"][:-1]))
+starts[sci_sorted["cjPackedBegin"][joined]] = 1
+empty = (imask == 0).astype(np.int64)
 cs = lambda a: np.concatenate([[0], np.cumsum(a)])
 feat = np.stack([cs(popc)[ranges[1:]] - cs(popc)[ranges[:-1]], cs(slots)[ranges[1:]] - cs(slots)[ranges[:-1]],
                  cs(groups)[ranges[1:]] - cs(groups)[ranges[:-1]], cs(starts)[ranges[1:]] - cs(starts)[ranges[:-1]] + 1,
@@ -62,12 +68,23 @@ print("SIMDs %d; per-SIMD finish: mean %.1f std %.2f us; features per SIMD mean 
 print("fit: us per cluster pair %.5f, per slot %.5f, per group %.5f, per piece %.5f, per cluster pair with exclusion mask %.5f, const %.2f; "
       "residual std %.2f us" % (*coef, (y - pred).std()))
 w = coef[:5] / coef[0] * 8
-print("weights relative to 8 per cluster pair: slot %.1f group %.1f piece %.1f excl-pair %.1f (current 2 / 30 / 76 / 0)" % (w[1], w[2], w[3], w[4]))
+print("weights relative to 8 per cluster pair: slot %.1f group %.1f piece %.1f excl-pair %.1f (current 0 / 34 / 60 / 0)" % (w[1], w[2], w[3], w[4]))
 A4 = np.concatenate([X[:, :4], np.ones((len(uk), 1))], axis=1)
 c4 = np.linalg.lstsq(A4, y, rcond=None)[0]
 print("without the exclusion feature: residual std %.2f us" % (y - A4 @ c4).std())
 print("per-SIMD features: std/mean %s" % (X.std(axis=0) / X.mean(axis=0)).round(3))
-cur = feat[:, :4] @ np.array([8, 2, 30, 76.0])
+start_t = (a[:, 0] - t0).astype(np.float64) / 100.0
+dur = end - start_t
+nempty = cs(empty)[ranges[1:]] - cs(empty)[ranges[:-1]]
+print("slowest waves (work item: end us, duration us | cluster pairs, slots, non-empty groups, pieces, empty groups | waves' mean):")
+for w_ in np.argsort(end)[-12:][::-1]:
+    print("  %5d: %.1f %.1f | %d %d %d %d %d" % (w_, end[w_], dur[w_], feat[w_, 0], feat[w_, 1], feat[w_, 2], feat[w_, 3], nempty[w_]))
+print("  mean : %.1f %.1f | %.0f %.0f %.0f %.1f %.1f" % (end.mean(), dur.mean(), feat[:, 0].mean(), feat[:, 1].mean(), feat[:, 2].mean(), feat[:, 3].mean(), nempty.mean()))
+order = np.argsort(end)[-200:]
+print("the 200 last waves: mean cluster pairs %.0f slots %.0f groups %.1f pieces %.2f empty %.2f; SIMD-mates' mean end %.1f" % (
+    feat[order, 0].mean(), feat[order, 1].mean(), feat[order, 2].mean(), feat[order, 3].mean(), nempty[order].mean(),
+    np.mean([end[(key == key[w_])].mean() for w_ in order])))
+cur = feat[:, :4] @ np.array([8, 0, 34, 60.0])
 print("current weight per wave: mean %.0f std %.1f (%.2f %%)" % (cur.mean(), cur.std(), 100 * cur.std() / cur.mean()))
 # a second launch of the same work: is a slow SIMD slow again?
 nb.clear_outputs(False); nb.launch_kernel(sw)

@@ -9,7 +9,7 @@ import torch
 import fep_testlib as tl
 pkg = tl.pkg
 mode = sys.argv[1] if len(sys.argv) > 1 else "split"
-nm = {"24k": (20, 20, 20), "96k": (40, 40, 20)}[sys.argv[2] if len(sys.argv) > 2 else "96k"]
+nm = {"3k": (10, 10, 10), "24k": (20, 20, 20), "96k": (40, 40, 20)}[sys.argv[2] if len(sys.argv) > 2 else "96k"]
 case = tl.make_case(nm=nm, num_perturbed_molecules=16, elec="ewald", seed=2026, n_lambda=11, max_cjpacked_per_sci=16)
 nb = tl.setup_gpu(case, fused=(mode == "fused"))
 sw = pkg.step_workload(energy=False, virial=False, dhdl=False)
