@@ -1300,7 +1300,8 @@ void nbnxm_gpu_launch_kernel(NbnxmGpu* nb, const nbnxm_step_workload_t* stepWork
         const bool twoSets   = (plist->workParts[p] == 2 && numRanges % 2 == 0);
         const int  firstSet  = (twoSets && launchPart == 2) ? 1 : 0;
         const int  lastSet   = (twoSets && launchPart != 1) ? 1 : 0;
-        const bool withTail  = !twoSets || lastSet == 1;
+        const bool nothingLeft = secondPartOnly && !twoSets; /* a list that is not partitioned in two ran completely with the first part */
+        const bool withTail    = (!twoSets || lastSet == 1) && !nothingLeft;
         const int  setRanges = twoSets ? numRanges / 2 : numRanges;
         const int mergedFepItems = (mergeFep && withTail) ? plist->numSlowPairs : 0;
         const int pruneEntries   = (plist->pendingPrunePart >= 0 && withTail) ? plist->pendingPruneEntries : 0;
@@ -1327,8 +1328,7 @@ void nbnxm_gpu_launch_kernel(NbnxmGpu* nb, const nbnxm_step_workload_t* stepWork
             nb->fSpareCleared = true;
         }
         const int clearChunk     = wavesPerBlock * c_waveSize * static_cast<int>(c_clearFloat4PerThread);
-        /* (a list that is not partitioned in two ran completely with the first part) */
-        for (int set = firstSet; set <= lastSet && !(secondPartOnly && !twoSets); set++)
+        for (int set = firstSet; set <= lastSet && !nothingLeft; set++)
         {
             const bool tail      = withTail && set == lastSet;
             const int  numBlocks = (setRanges + wavesPerBlock - 1) / wavesPerBlock
