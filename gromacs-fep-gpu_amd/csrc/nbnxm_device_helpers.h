@@ -275,7 +275,10 @@ NB_DEVINL void nbPair(const NBParamGpu& nbp,
         }
         return;
     }
-    if constexpr (!ENERGY && (VDW == VDK_CUT || VDW == VDK_COMB_GEOM || VDW == VDK_COMB_LB || VDW == VDK_FSWITCH || VDW == VDK_PSWITCH) && MASK_FORCES
+    if constexpr (!ENERGY
+                  && (VDW == VDK_CUT || VDW == VDK_COMB_GEOM || VDW == VDK_COMB_LB || VDW == VDK_FSWITCH || VDW == VDK_PSWITCH || VDW == VDK_EWALD_GEOM
+                      || VDW == VDK_EWALD_LB)
+                  && MASK_FORCES
                   && (ELEC == ELK_RF || ((ELEC == ELK_EWALD_ANA || ELEC == ELK_EWALD_TAB) && CORR_TABLE)))
     {
         /* The force-only flavours of the headline configurations: ONE mask for everything an exclusion removes,
@@ -345,6 +348,17 @@ NB_DEVINL void nbPair(const NBParamGpu& nbp,
         {
             const float fr = __builtin_amdgcn_fractf(xs);
             F_invr         = fmaf(-qq * inv_r, fmaf(fr, t.y, fmaf(-fr, t.x, t.x)), nm);
+        }
+        if constexpr (VDW == VDK_EWALD_GEOM || VDW == VDK_EWALD_LB)
+        {
+            /* real-space part of the LJ-PME grid term (nbnxm_cuda_kernel_utils.cuh:231-330): outside the exclusion mask — an excluded
+             * pair within the cut-off keeps the correction for what the grid adds */
+            const float cr2     = nbp.ljEwaldCoeff2 * r2;
+            const float expmcr2 = __expf(-cr2);
+            const float poly    = fmaf(fmaf(0.5F, cr2, 1.0F), cr2, 1.0F);
+            float       grid    = c6grid * (inv_r6 - expmcr2 * fmaf(inv_r6, poly, nbp.ljEwaldCoeff6_6));
+            if constexpr (TWIN) { grid = (r2 < nbp.rvdw_sq) ? grid : 0.0F; }
+            F_invr = fmaf(grid, inv_r2, F_invr);
         }
         return;
     }

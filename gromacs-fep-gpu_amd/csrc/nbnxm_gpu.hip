@@ -75,6 +75,11 @@ void setCutoffParameters(NBParamGpu* nbp, const nbnxm_interaction_params_t* ic)
     nbp->repulsion_shift   = ic->repulsion_shift;
     nbp->vdw_switch        = ic->vdw_switch;
     nbp->vdwSwitch3c3      = 3.0F * ic->vdw_switch.c3;
+    {
+        const double c2      = static_cast<double>(ic->ewaldcoeff_lj) * ic->ewaldcoeff_lj;
+        nbp->ljEwaldCoeff2   = static_cast<float>(c2);
+        nbp->ljEwaldCoeff6_6 = static_cast<float>(c2 * c2 * c2 / 6.0);
+    }
 }
 
 void uploadCoulombTable(NbnxmGpu* nb, const nbnxm_interaction_params_t* ic)

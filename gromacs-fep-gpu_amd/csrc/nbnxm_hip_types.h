@@ -166,6 +166,9 @@ struct NBParamGpu
     float4* ewaldCorrTabFV;
     /* MI355X extension: 3 vdw_switch.c3, so that the potential-switch derivative needs no scalar product in the kernel */
     float   vdwSwitch3c3;
+    /* MI355X extension, LJ-PME flavours: ewaldcoeff_lj^2 and ewaldcoeff_lj^6 / 6 (the kernel would compute them per launch in VGPRs) */
+    float   ljEwaldCoeff2;
+    float   ljEwaldCoeff6_6;
     /* MI355X extension, tabulated Ewald flavours: entries of coulomb_tab; the cluster kernel stages the table into LDS */
     int     coulombTabSize;
 };

@@ -355,6 +355,8 @@ def test_lj_pme_twin_range_kernel():
     for fused in (False, True):
         got = tl.run_gpu(c, energy=True, fused=fused)
         tl.assert_parity(got, want, rel=1e-4, label="LJ-PME twin")
+        got = tl.run_gpu(c, energy=False, fused=fused)          # the force-only instance: grid term cut at rvdw too
+        tl.assert_parity(got, want, rel=1e-4, energy=False, label="LJ-PME twin F")
 
 
 @pytest.mark.parametrize("vdw", ["comb_geom", "comb_lb"])
