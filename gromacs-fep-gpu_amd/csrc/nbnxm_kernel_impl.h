@@ -461,7 +461,11 @@ __launch_bounds__(c_nbMaxBlockSize) __attribute__((amdgpu_waves_per_eu(c_nbWaves
      * VMEM operations (W + 3 J loads + 4 j-force atomics, dummies for skipped slots): the one wait of an iteration,
      * for J(g), is a counted vmcnt(c_vmOpsPerGroup) and never waits for an atomic.  The pipeline runs across
      * piece borders (the groups of a range are contiguous). */
+#ifdef NBNXM_TIMING_NO_J_INSTR /* timing-only diagnostics build (tools/gpu_atomics.sh): results are wrong by construction */
+    constexpr int  c_vmOpsPerGroup = (FUSED ? 2 : 1) + 3;
+#else
     constexpr int  c_vmOpsPerGroup = (FUSED ? 2 : 1) + 3 + 4;
+#endif
     const unsigned jStageLds = __builtin_amdgcn_readfirstlane(static_cast<unsigned>(reinterpret_cast<size_t>(jStage)));
     const unsigned ringLds   = jStageLds + 2U * c_jStageBytes;
     const unsigned char* ring = jStage + 2 * c_jStageBytes;
@@ -510,7 +514,11 @@ __launch_bounds__(c_nbMaxBlockSize) __attribute__((amdgpu_waves_per_eu(c_nbWaves
         }                                                                                                      \
         ldsDirectLoad4(base + c_jStageExclOffset, static_cast<unsigned>(exl) * 128U + (lane & 31U) * 4U, exclList); \
     }
+#ifdef NBNXM_TIMING_NO_J_INSTR
+#define NBNXM_DUMMY_ATOMIC()
+#else
 #define NBNXM_DUMMY_ATOMIC() __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(0.0F, fRsrc, c_dropLane, 0, 0)
+#endif
 #define NBNXM_WAIT_VMEM(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory")
 
     /* progress thresholds of the wave priority in 1/16 of the range (see the group loop): late ones, because only the end
@@ -712,8 +720,16 @@ __launch_bounds__(c_nbMaxBlockSize) __attribute__((amdgpu_waves_per_eu(c_nbWaves
                 /* j-force: sum over the 8 lanes of a j atom; lanes tidxi 0..2 carry x,y,z (96 contiguous bytes) */
                 fjv   = reduceXyzOver8Lanes(fcj_buf, laneG);
                 fjOff = (tidxi < 3U) ? (3 * aj + static_cast<int>(tidxi)) * static_cast<int>(sizeof(float)) : c_dropLane;
+#if defined(NBNXM_TIMING_NO_J_ATOMIC) /* timing-only: the add keeps its instruction and its operands, every lane is dropped */
+                asm volatile("" : "+v"(fjv), "+v"(fjOff));
+                fjOff = c_dropLane;
+#endif
                 }
+#ifdef NBNXM_TIMING_NO_J_INSTR
+                asm volatile("" ::"v"(fjv), "v"(fjOff));
+#else
                 __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(fjv, fRsrc, fjOff, 0, 0);
+#endif
             }
         }
         curBuf ^= 1;
@@ -732,10 +748,35 @@ __launch_bounds__(c_nbMaxBlockSize) __attribute__((amdgpu_waves_per_eu(c_nbWaves
     mine.z = reduceOverTidxjTransposed(fci_buf[0].z, fci_buf[1].z, fci_buf[2].z, fci_buf[3].z, fci_buf[4].z, fci_buf[5].z, fci_buf[6].z,
                                        fci_buf[7].z, lane);
     {
-        const int ai = sci * c_superClSize + static_cast<int>(lane);
+        [[maybe_unused]] const int ai = sci * c_superClSize + static_cast<int>(lane);
+#ifdef NBNXM_TIMING_NO_I_ATOMIC /* timing-only diagnostics build */
+        asm volatile("" ::"v"(mine.x), "v"(mine.y), "v"(mine.z), "v"(ai));
+#elif defined(NBNXM_I_FORCE_STRIDED) /* round 2's form, kept for A/B runs: three 64-lane adds at a 12-byte stride */
         atomicAdd(&f[3 * ai + 0], mine.x);
         atomicAdd(&f[3 * ai + 1], mine.y);
         atomicAdd(&f[3 * ai + 2], mine.z);
+#else
+        /* The super-cluster's 192 force floats are contiguous (768 bytes).  A float atomic leaves L2 as one memory-side request
+         * per 64-byte line it touches (tools/ubench/atomic_shapes.hip: 13-14 ns per line and CU whatever the shape), and an add
+         * at a 12-byte stride touches all twelve lines: 36 requests per piece.  Transposed through the staging buffer that the
+         * group loop has just left (the other one may be receiving the next group), lane l adds floats l, l + 64 and l + 128:
+         * three adds of 256 contiguous bytes, 12 requests.  DS operations of one wave execute in order: no wait between the
+         * stores and the loads, the compiler barrier only keeps their program order. */
+        const unsigned laneT = laneIdNow(); /* in place: an address hoisted out of the loops would cost the group loop a register */
+        float*         tr    = reinterpret_cast<float*>(jStage + (curBuf ^ 1) * c_jStageBytes);
+        tr[3U * laneT + 0U]  = mine.x;
+        tr[3U * laneT + 1U]  = mine.y;
+        tr[3U * laneT + 2U]  = mine.z;
+        __builtin_amdgcn_wave_barrier();
+        asm volatile("" ::: "memory");
+        const float o0 = tr[laneT];
+        const float o1 = tr[laneT + 64U];
+        const float o2 = tr[laneT + 128U];
+        float*      fs = f + 3 * (sci * c_superClSize) + static_cast<int>(laneT);
+        atomicAdd(fs, o0);
+        atomicAdd(fs + 64, o1);
+        atomicAdd(fs + 128, o2);
+#endif
     }
     float3 fshiftAcc = mine; /* per-lane share of this entry's total i-force */
 
