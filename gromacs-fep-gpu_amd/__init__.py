@@ -101,7 +101,7 @@ HIP_SYMBOLS = [
     "nbnxm_gpu_init_x_to_nbat_x", "nbnxm_gpu_x_to_nbat_x", "nbnxm_gpu_insert_nonlocal_dependency",
     "nbnxm_gpu_setup_short_range_work", "nbnxm_gpu_force_reduction_reinit", "nbnxm_gpu_force_reduction_execute",
     "nbnxm_gpu_halo_pack_x", "nbnxm_gpu_halo_unpack_f", "nbnxm_gpu_force_reduction_execute_range", "nbnxm_hip_query_launch_shape",
-    "nbnxm_gpu_set_local_launch_parts", "nbnxm_gpu_launch_kernel_part",
+    "nbnxm_gpu_set_local_launch_parts", "nbnxm_gpu_launch_kernel_part", "nbnxm_hip_query_launch_plan",
 ]
 HALO_SYMBOLS = [
     "halo_gpu_get_unique_id", "halo_gpu_create", "halo_gpu_free", "halo_gpu_last_error", "halo_gpu_reinit",

@@ -231,6 +231,47 @@ static NbLaunchShape chooseNbLaunchShape(int elecType, int vdwType, bool energy,
 
 } // namespace
 
+/* Which sets of work ranges one call launches and whether the trailing workgroups (perturbed cluster pairs, a pending rolling-prune
+ * part, the clear of the spare force buffer) ride with it.  Host arithmetic only, so that the C ABI can expose it and the CPU tests
+ * can walk through every case (tests/test_launch_plan.py).
+ *   launchPart 0: a plain nbnxm_gpu_launch_kernel: everything, both sets back to back when the list is partitioned in two;
+ *              1: nbnxm_gpu_launch_kernel_part(.., 1): the first set only; the whole launch, tail included, when there is one set;
+ *              2: nbnxm_gpu_launch_kernel_part(.., 2): the second set with the tail; NOTHING when there is one set.
+ * A plan that launches nothing has withTail == false: no state of the step (pending prune part, spare-buffer flag) may be consumed
+ * by a call that queues no kernel (that was the bug fixed in c622397). */
+struct NbLaunchPlan
+{
+    int  firstSet;  /* sets firstSet .. firstSet + numSets - 1 are launched, one kernel each */
+    int  numSets;   /* 0: nothing to launch */
+    int  setRanges; /* ranges (= waves of the main part) per set; offset of set k in the range arrays: k * setRanges */
+    bool withTail;  /* the trailing workgroups ride with the LAST launched set */
+};
+static NbLaunchPlan planNbLaunch(int launchPart, int workParts, int numRanges)
+{
+    NbLaunchPlan plan;
+    /* two sets exist only when the partition made them (workParts 2 always yields an even count; the test is a guard) */
+    const bool twoSets = (workParts == 2 && numRanges >= 2 && numRanges % 2 == 0);
+    plan.setRanges     = twoSets ? numRanges / 2 : numRanges;
+    if (numRanges <= 0)
+    {
+        plan.firstSet = 0;
+        plan.numSets  = 0;
+    }
+    else if (!twoSets)
+    {
+        plan.firstSet = 0;
+        plan.numSets  = (launchPart == 2) ? 0 : 1; /* a list that is not partitioned in two ran completely with the first part */
+    }
+    else
+    {
+        plan.firstSet = (launchPart == 2) ? 1 : 0;
+        plan.numSets  = (launchPart == 0) ? 2 : 1;
+    }
+    const int lastSet = plan.firstSet + plan.numSets - 1;
+    plan.withTail     = plan.numSets > 0 && (!twoSets || lastSet == 1);
+    return plan;
+}
+
 extern "C" {
 
 void nbnxm_hip_query_launch_shape(int elecType, int vdwType, int computeEnergy, int numTypes, int coulombTabSize, int* wavesPerWorkgroup,
@@ -240,6 +281,15 @@ void nbnxm_hip_query_launch_shape(int elecType, int vdwType, int computeEnergy, 
     *wavesPerWorkgroup    = shape.wavesPerBlock;
     *wavesPerSimd         = shape.wavesPerSimd;
     *ldsBytesPerWorkgroup = shape.ldsBytes;
+}
+
+void nbnxm_hip_query_launch_plan(int launchPart, int workParts, int numRanges, int* firstSet, int* numSets, int* setRanges, int* withTail)
+{
+    const NbLaunchPlan plan = planNbLaunch(launchPart, workParts, numRanges);
+    *firstSet               = plan.firstSet;
+    *numSets                = plan.numSets;
+    *setRanges              = plan.setRanges;
+    *withTail               = plan.withTail ? 1 : 0;
 }
 
 int nbnxm_hip_abi_version(void)
@@ -1302,12 +1352,10 @@ void nbnxm_gpu_launch_kernel(NbnxmGpu* nb, const nbnxm_step_workload_t* stepWork
         NBNXM_ASSERT(numRanges > 0, "work partition missing");
         /* two sets of ranges (workParts 2): one launch per set; the trailing workgroups ride with the second.  A caller that does
          * not ask for a part gets both launches back to back. */
-        const bool twoSets   = (plist->workParts[p] == 2 && numRanges % 2 == 0);
-        const int  firstSet  = (twoSets && launchPart == 2) ? 1 : 0;
-        const int  lastSet   = (twoSets && launchPart != 1) ? 1 : 0;
-        const bool nothingLeft = secondPartOnly && !twoSets; /* a list that is not partitioned in two ran completely with the first part */
-        const bool withTail    = (!twoSets || lastSet == 1) && !nothingLeft;
-        const int  setRanges = twoSets ? numRanges / 2 : numRanges;
+        const NbLaunchPlan plan     = planNbLaunch(launchPart, plist->workParts[p], numRanges);
+        const int          firstSet = plan.firstSet, lastSet = plan.firstSet + plan.numSets - 1, setRanges = plan.setRanges;
+        const bool         withTail = plan.withTail; /* false whenever nothing is launched: no state is consumed then */
+        NBNXM_ASSERT(plan.numSets == 0 || (firstSet + plan.numSets) * setRanges <= numRanges, "launch plan beyond the range arrays");
         const int mergedFepItems = (mergeFep && withTail) ? plist->numSlowPairs : 0;
         const int pruneEntries   = (plist->pendingPrunePart >= 0 && withTail) ? plist->pendingPruneEntries : 0;
         const int prunePart      = std::max(plist->pendingPrunePart, 0);
@@ -1333,13 +1381,14 @@ void nbnxm_gpu_launch_kernel(NbnxmGpu* nb, const nbnxm_step_workload_t* stepWork
             nb->fSpareCleared = true;
         }
         const int clearChunk     = wavesPerBlock * c_waveSize * static_cast<int>(c_clearFloat4PerThread);
-        for (int set = firstSet; set <= lastSet && !nothingLeft; set++)
+        for (int set = firstSet; set <= lastSet; set++)
         {
             const bool tail      = withTail && set == lastSet;
             const int  numBlocks = (setRanges + wavesPerBlock - 1) / wavesPerBlock
                                   + (tail ? (mergedFepItems + wavesPerBlock - 1) / wavesPerBlock + (pruneEntries + wavesPerBlock - 1) / wavesPerBlock
                                                     + (clearNumFloat4 + clearChunk - 1) / clearChunk
                                           : 0);
+            NBNXM_ASSERT(numBlocks > 0, "empty cluster-kernel launch");
             hipLaunchKernelGGL(kernel, dim3(numBlocks), dim3(wavesPerBlock * c_waveSize), ldsBytes, s,
                                *adat, *nbp, *plist, stepWork->computeVirial, plist->sciSorted, plist->cjPacked, plist->excl, adat->xq,
                                adat->atomTypes, adat->ljComb, reinterpret_cast<const unsigned*>(adat->fepBits),

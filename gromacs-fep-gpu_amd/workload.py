@@ -250,13 +250,18 @@ def setup_gpu(c, fused=False, use_dynamic_pruning=False, list_override=None):
     nb.copy_xq_to_gpu(g.xq)
     return nb
 
-def run_gpu(c, energy=True, fused=False, dhdl=False, nb=None, prune=False):
+def run_gpu(c, energy=True, fused=False, dhdl=False, nb=None, prune=False, launch=None):
+    """One step through the C ABI: clear, launch, copy back, finish.  launch(nb, sw) replaces the plain nbnxm_gpu_launch_kernel call
+    (e.g. the two calls of nbnxm_gpu_launch_kernel_part)."""
     own = nb is None
     if own:
         nb = setup_gpu(c, fused=fused, use_dynamic_pruning=prune)
     sw = pkg.step_workload(energy=energy, virial=True, dhdl=dhdl)
     nb.clear_outputs(True)
-    nb.launch_kernel(sw)
+    if launch is None:
+        nb.launch_kernel(sw)
+    else:
+        launch(nb, sw)
     f = np.zeros((c.grid.num_atoms, 3), np.float32)
     nb.launch_cpyback(f, sw)
     res = nb.wait_finish_task(sw, c.have_soft_core)

@@ -391,6 +391,14 @@ void nbnxm_gpu_launch_kernel_part(NbnxmGpu* nb, const nbnxm_step_workload_t* ste
 void nbnxm_hip_query_launch_shape(int elecType, int vdwType, int computeEnergy, int numTypes, int coulombTabSize, int* wavesPerWorkgroup,
                                   int* wavesPerSimd, int* ldsBytesPerWorkgroup);
 
+/* Host arithmetic only (no device call): which sets of work ranges one call of nbnxm_gpu_launch_kernel (launchPart 0) or
+ * nbnxm_gpu_launch_kernel_part (launchPart 1 / 2) launches for a list whose partition has workParts (1 or 2) sets and numRanges
+ * ranges in all: sets firstSet .. firstSet + numSets - 1 of setRanges ranges each (numSets 0: the call queues no kernel), and whether
+ * the trailing workgroups — perturbed cluster pairs, a pending rolling-prune part, the clear of the spare force buffer — ride with
+ * the last of them.  A call that queues nothing consumes no state of the step (withTail 0).  Replaces nothing in the reference
+ * (its launch is always whole, nbnxm_cuda.cu:642-760); it is what makes the two-part schedule testable on a CPU. */
+void nbnxm_hip_query_launch_plan(int launchPart, int workParts, int numRanges, int* firstSet, int* numSets, int* setRanges, int* withTail);
+
 /* Library/ABI version and a last-error string for diagnostics (never needed on the success path). */
 int         nbnxm_hip_abi_version(void);
 const char* nbnxm_hip_last_error(void);

@@ -12,6 +12,11 @@ for p in (HERE, ROOT):
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # pytest captures file descriptor 2, so the message of a fatal error of the library (which aborts the process) would be lost
+    # with the capture file: the library appends it to this file too (csrc/device_utils.h: fatal()).
+    out = os.path.join(ROOT, "gpurun_out")
+    if os.path.isdir(out) and os.access(out, os.W_OK):
+        os.environ.setdefault("NBNXM_HIP_FATAL_LOG", os.path.join(out, "nbnxm_hip_fatal.log"))
 
 
 def have_gpu():

@@ -233,6 +233,68 @@ def test_local_launch_in_two_parts(fused):
     nb.free()
 
 
+@pytest.mark.parametrize("fused", [False, True])
+def test_two_part_launch_on_a_list_too_short_for_two_sets(fused):
+    """The two-part local launch is the default of a decomposed run (csrc/halo_exchange.hip), and a small domain's local list is too
+    short for two sets of ranges: part 1 is then the whole launch and part 2 must queue nothing AND take nothing.  Before commit
+    c622397 the empty part 2 dropped a pending rolling-prune part and marked the spare force buffer as zeroed, so the next
+    nbnxm_gpu_clear_outputs swapped in a buffer nobody had cleared (forces doubled).  Steps F, F, VF, F with a rolling-prune part
+    pending before each: forces (and energies on the VF step) against the oracle EVERY step, and the pruning masks must have
+    advanced exactly as in a run without parts."""
+    import ctypes as C
+    import oracle_binding as ob
+    c = tl.make_case(elec="ewald", seed=33, **SMALL)
+    c.rlist_inner = 1.03
+    g = c.grid
+    pl = c.plist_fused if fused else c.plist
+    nb = tl.setup_gpu(c, fused=fused, use_dynamic_pruning=True)
+    nb.set_local_launch_parts(2, 0.65)
+
+    def both_parts(nb_, sw):
+        nb_.launch_kernel_part(sw, 1)
+        nb_.launch_kernel_part(sw, 2)
+
+    want0 = tl.run_oracle(c, energy=True)
+    got = tl.run_gpu(c, energy=False, fused=fused, nb=nb, launch=both_parts)        # fresh list: first prune inside part 1
+    tl.assert_parity(got, want0, rel=1e-4, energy=False, label="short list, fresh")
+    # the list really is too short for two sets: one set of ranges in both partitions
+    lib = pkg.hip_lib()
+    lib.nbnxm_gpu_debug_get_work_ranges.restype = C.c_void_p
+    for p in (0, 1):
+        n = C.c_int()
+        lib.nbnxm_gpu_debug_get_work_ranges(nb.h, C.c_int(pkg.LOCAL), C.c_int(p), C.byref(n))
+        assert 0 < n.value <= 1024 * (4 + p), "the 3k box must not be partitioned in two sets"
+    outer = pl.cjPacked.copy()
+    ob.nbnxm_prune(pl.sci, outer, g.xq, g.shift_vec, c.rlist)
+    inner = outer.copy()
+    ob.nbnxm_prune(pl.sci, inner, g.xq, g.shift_vec, c.rlist_inner)
+    # the atoms move (the list stays valid), so that the rolling passes have cluster pairs to bring back
+    rng = np.random.default_rng(5)
+    xq_new = g.xq.reshape(-1, 4).copy()
+    xq_new[:, :3] += rng.normal(0.0, 0.012, size=(len(xq_new), 3)).astype(np.float32) * (g.atomIndices >= 0)[:, None]
+    nb.copy_xq_to_gpu(xq_new)
+    came_in = outer.copy()
+    ob.nbnxm_prune(pl.sci, came_in, xq_new, g.shift_vec, c.rlist_inner)
+    want_mask = inner["imei"]["imask"] | came_in["imei"]["imask"]
+    assert (want_mask != inner["imei"]["imask"]).any()
+    xq_old, xw_old = g.xq, g.x_wrapped
+    xw = g.x_wrapped.copy()
+    real = g.atomIndices >= 0
+    xw[g.atomIndices[real]] = xq_new[real, :3]
+    g.xq, g.x_wrapped = xq_new, xw
+    try:
+        want = tl.run_oracle(c, energy=True)
+    finally:
+        g.xq, g.x_wrapped = xq_old, xw_old
+    for step, energy in enumerate((False, False, True, False)):
+        nb.launch_kernel_pruneonly(num_parts=4)                                   # a rolling-prune part is pending at every launch
+        got = tl.run_gpu(c, energy=energy, fused=fused, nb=nb, launch=both_parts)
+        tl.assert_parity(got, want, rel=1e-4, energy=energy, label="short list in two parts, step %d" % step)
+    dev = pkg.download_cjpacked(nb, len(outer))
+    assert np.array_equal(dev["imei"]["imask"], want_mask), "a rolling-prune part was dropped"
+    nb.free()
+
+
 def test_force_buffer_swap_and_pinning():
     """nbnxm_gpu_clear_outputs swaps to the force buffer that the last force-only kernel zeroed in its tail; an energy-step kernel has
     no tail (the next clear is a kernel again); nbnxm_gpu_get_f pins the buffer.  Every step of a mixed sequence must give the
