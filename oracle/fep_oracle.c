@@ -571,6 +571,14 @@ void FN(oracle_fep_last_abs_sums)(double* out)
 {
     for (int i = 0; i < 4; i++) { out[i] = FN(g_absSums)[i]; }
 }
+/* the same for the shift forces of the last call: per shift vector and component the sum of |f_i| of the i-entries booked to it
+ * (at most ORACLE_MAX_SHIFT shift vectors are tracked) */
+#define ORACLE_MAX_SHIFT 45
+static double FN(g_fshiftAbs)[3 * ORACLE_MAX_SHIFT];
+void FN(oracle_fep_last_fshift_abs)(double* out)
+{
+    for (int i = 0; i < 3 * ORACLE_MAX_SHIFT; i++) { out[i] = FN(g_fshiftAbs)[i]; }
+}
 
 void FN(oracle_nb_free_energy_kernel)(int nri, const int* iinr, const int* jindex, const int* jjnr,
                                       const int* shift, const int* excl_fep, const real* x,
@@ -588,6 +596,7 @@ void FN(oracle_nb_free_energy_kernel)(int nri, const int* iinr, const int* jinde
 
     real dvdlCoul = 0, dvdlVdw = 0;
     double absSums[4] = { 0, 0, 0, 0 };
+    for (int i = 0; i < 3 * ORACLE_MAX_SHIFT; i++) { FN(g_fshiftAbs)[i] = 0; }
 
     for (int n = 0; n < nri; n++)
     {
@@ -655,6 +664,12 @@ void FN(oracle_nb_free_energy_kernel)(int nri, const int* iinr, const int* jinde
                     fshift[3 * is + 0] += fIX;
                     fshift[3 * is + 1] += fIY;
                     fshift[3 * is + 2] += fIZ;
+                    if (is < ORACLE_MAX_SHIFT)
+                    {
+                        FN(g_fshiftAbs)[3 * is + 0] += fabs((double)fIX);
+                        FN(g_fshiftAbs)[3 * is + 1] += fabs((double)fIY);
+                        FN(g_fshiftAbs)[3 * is + 2] += fabs((double)fIZ);
+                    }
                 }
             }
             if (doPotential)
@@ -671,6 +686,15 @@ void FN(oracle_nb_free_energy_kernel)(int nri, const int* iinr, const int* jinde
 
 /* Energies and dV/dlambda at the current lambda (index 0) and n_lambda foreign lambdas
  * (freeenergydispatch.cpp:236-307): energies-only passes of the same kernel. */
+/* test scale: the abs sums (|V_coul|, |V_vdw|, |dV/dl_coul|, |dV/dl_vdw| over the pairs) of every lambda index of the last
+ * oracle_fep_foreign call, 4 per index, at most ORACLE_MAX_FOREIGN indices */
+#define ORACLE_MAX_FOREIGN 64
+static double FN(g_foreignAbs)[4 * ORACLE_MAX_FOREIGN];
+void FN(oracle_fep_foreign_abs_sums)(double* out, int numIndices)
+{
+    for (int i = 0; i < 4 * numIndices && i < 4 * ORACLE_MAX_FOREIGN; i++) { out[i] = FN(g_foreignAbs)[i]; }
+}
+
 void FN(oracle_fep_foreign)(int nri, const int* iinr, const int* jindex, const int* jjnr,
                             const int* shift, const int* excl_fep, const real* x, int ntype,
                             const oracle_fep_params_t* p, const real* shiftvec, const real* nbfp,
@@ -691,5 +715,9 @@ void FN(oracle_fep_foreign)(int nri, const int* iinr, const int* jindex, const i
         eCoul[i]    = Vc;
         dvdlCoul[i] = dvdl[0];
         dvdlVdw[i]  = dvdl[1];
+        if (i < ORACLE_MAX_FOREIGN)
+        {
+            for (int k = 0; k < 4; k++) { FN(g_foreignAbs)[4 * i + k] = FN(g_absSums)[k]; }
+        }
     }
 }

@@ -74,6 +74,10 @@ double oracle_calc_ewaldcoeff_lj(double rc, double rtol);
                                                REAL* fshift, double* Vc, double* Vv, double* dvdl);  \
     /* sums of |V_coul|, |V_vdw|, |dV/dl_coul|, |dV/dl_vdw| over the pairs of the last kernel call (test scale) */ \
     void oracle_fep_last_abs_sums_##SUFFIX(double* out4);                                            \
+    /* and per shift vector and component the sum of |f_i| of the i-entries booked to it (45 x 3) */ \
+    void oracle_fep_last_fshift_abs_##SUFFIX(double* out135);                                       \
+    /* and the four abs sums of every lambda index of the last oracle_fep_foreign call (4 per index) */ \
+    void oracle_fep_foreign_abs_sums_##SUFFIX(double* out, int numIndices);                         \
     void oracle_fep_foreign_##SUFFIX(int nri, const int* iinr, const int* jindex, const int* jjnr,   \
                                      const int* shift, const int* excl_fep, const REAL* x,           \
                                      int ntype, const oracle_fep_params_t* p, const REAL* shiftvec,  \

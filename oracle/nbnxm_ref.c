@@ -48,6 +48,19 @@ static double ref_pme_force_correction(double z2)
     return (1.1283791670955126 * z * exp(-z2) - erf(z)) / (z2 * z);
 }
 
+/* Test scale, not part of the kernel: per shift vector and component, the sum of |f_i| over the i-atoms whose force was booked to
+ * that shift force since the last reset — the magnitude of the terms a shift force is summed from (what a relative tolerance on
+ * that sum has to be measured against).  Accumulated once per i-entry; safe from the OpenMP variant. */
+static double FN(g_fshiftAbs)[3 * NBNXM_NUM_SHIFT_VECTORS];
+void FN(oracle_nbnxm_fshift_abs)(double* out, int reset)
+{
+    for (int i = 0; i < 3 * NBNXM_NUM_SHIFT_VECTORS; i++)
+    {
+        if (out) { out[i] = FN(g_fshiftAbs)[i]; }
+        if (reset) { FN(g_fshiftAbs)[i] = 0; }
+    }
+}
+
 static int is_ewald(int elecType)
 {
     return elecType == NBNXM_ELEC_EWALD_TAB || elecType == NBNXM_ELEC_EWALD_TAB_TWIN
@@ -83,6 +96,7 @@ void FN(oracle_nbnxm_ref)(int nsci, const nbnxn_sci_t* sci, const nbnxn_cj_packe
         const real        shX = shiftvec[3 * ish + 0], shY = shiftvec[3 * ish + 1], shZ = shiftvec[3 * ish + 2];
         double            vctot = 0, vvtot = 0;
         real              fsh[3] = { 0, 0, 0 };
+        double            fshAbs[3] = { 0, 0, 0 };
 
         if (computeEnergy && exclForces && ish == NBNXM_CENTRAL_SHIFT_INDEX && e.cjPackedEnd > e.cjPackedBegin
             && cjPacked[e.cjPackedBegin].cj[0] == e.sci * NCL)
@@ -263,6 +277,9 @@ void FN(oracle_nbnxm_ref)(int nsci, const nbnxn_sci_t* sci, const nbnxn_cj_packe
                         fsh[0] += fix;
                         fsh[1] += fiy;
                         fsh[2] += fiz;
+                        fshAbs[0] += fabs((double)fix);
+                        fshAbs[1] += fabs((double)fiy);
+                        fshAbs[2] += fabs((double)fiz);
                     }
                 }
             }
@@ -272,6 +289,11 @@ void FN(oracle_nbnxm_ref)(int nsci, const nbnxn_sci_t* sci, const nbnxn_cj_packe
             fshift[3 * ish + 0] += fsh[0];
             fshift[3 * ish + 1] += fsh[1];
             fshift[3 * ish + 2] += fsh[2];
+            for (int d = 0; d < 3; d++)
+            {
+#pragma omp atomic
+                FN(g_fshiftAbs)[3 * ish + d] += fshAbs[d];
+            }
         }
         if (computeEnergy)
         {

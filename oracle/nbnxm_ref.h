@@ -57,7 +57,10 @@ typedef struct
                                       const REAL* lj_comb, const REAL* nbfp_comb,                  \
                                       const nbnxm_ref_params_t* p, const REAL* shiftvec,           \
                                       int computeEnergy, int computeFshift, REAL* f, REAL* fshift, \
-                                      double* Vc, double* Vvdw, long long* npairsWithinCutoff);
+                                      double* Vc, double* Vvdw, long long* npairsWithinCutoff);        \
+    /* test scale: per shift vector and component the sum of |f_i| over the i-atoms booked to that shift force since the last  \
+     * reset (out: 45 x 3 doubles or NULL; reset != 0 clears the sums) */                            \
+    void oracle_nbnxm_fshift_abs_##SUFFIX(double* out, int reset);
 
 NBNXM_REF_DECL(f64, double)
 NBNXM_REF_DECL(f32, float)

@@ -98,7 +98,7 @@ def run_oracle(c, energy=True, precision="f64", foreign=False, cjPacked=None, nu
     fshift += fs_fep
     out = dict(f=f, fshift=fshift, e_lj=ref["Vv"] + fep["Vv"], e_el=ref["Vc"] + fep["Vc"],
                dvdl_coul=fep["dvdl_coul"], dvdl_vdw=fep["dvdl_vdw"], npairs=ref["npairs"],
-               parts=dict(ref=ref, fep=fep), fep_abs_sums=fep["abs_sums"])
+               parts=dict(ref=ref, fep=fep), fep_abs_sums=fep["abs_sums"], fshift_abs=ref["fshift_abs"] + fep["fshift_abs"])
     if foreign and c.n_lambda > 0:
         out["foreign"] = ob.fep_foreign(c.plist.fep, g.x_wrapped, c.ntype, fp, g.shift_vec, c.sys["nbfp"], lj_grid_table(c),
                                         c.sys["qA"], c.sys["qB"], c.sys["typeA"], c.sys["typeB"], c.lambda_coul,
@@ -122,9 +122,16 @@ def assert_parity(got, want, rel=1e-4, energy=True, label=""):
     assert ferr[worst] <= ftol[worst], \
         "%s force err %.3e on atom %d (|f| %.3e, rms |f| %.3e)" % (label, ferr[worst], worst,
                                                                  math.sqrt(float(np.sum(f_want[worst] ** 2))), frms)
-    fs_scale = max(float(np.max(np.abs(want["fshift"]))), frms)
-    fserr = float(np.max(np.abs(np.asarray(got["fshift"]) - np.asarray(want["fshift"]))))
-    assert fserr <= 10 * rel * fs_scale, "%s fshift max err %.3e (scale %.3e)" % (label, fserr, fs_scale)
+    # shift forces: each component of each shift vector against the larger of its value and the sum of |f_i| over the i-atoms booked
+    # to it — the magnitude of ITS terms, returned by the oracles (oracle_nbnxm_fshift_abs, oracle_fep_last_fshift_abs) — at rel
+    fs_want = np.asarray(want["fshift"], np.float64)
+    fs_err = np.abs(np.asarray(got["fshift"], np.float64) - fs_want)
+    if want.get("fshift_abs") is not None:
+        fs_tol = rel * np.maximum(np.maximum(np.abs(fs_want), np.asarray(want["fshift_abs"])), 1e-3 * frms)
+    else:   # (a reference without the term sums, e.g. a summed multi-domain result: the largest shift force and the rms force)
+        fs_tol = np.full_like(fs_err, rel * max(float(np.max(np.abs(fs_want))), frms))
+    w = np.unravel_index(int(np.argmax(fs_err / fs_tol)), fs_err.shape)
+    assert fs_err[w] <= fs_tol[w], "%s fshift[%d][%d] err %.3e (tolerance %.3e, value %.3e)" % (label, w[0], w[1], fs_err[w], fs_tol[w], fs_want[w])
     if energy:
         # dV/dlambda is a sum over the perturbed pairs only: measured against the magnitude of ITS terms (the oracle's sum of
         # |dV/dl| per pair), never against the energy of the whole box; energies against their own value
@@ -138,10 +145,17 @@ def assert_foreign(got, want, rel=1e-4):
     """foreign-lambda energies and dV/dlambda of a dH/dlambda step against run_oracle(..., foreign=True)"""
     fw = want["foreign"]
     e_want = fw["eVdw"] + fw["eCoul"]
-    scale = max(1.0, float(np.max(np.abs(fw["eVdw"])) + np.max(np.abs(fw["eCoul"]))))
-    assert np.max(np.abs(got["foreign"]["energies"] - e_want)) <= rel * scale
-    assert np.max(np.abs(got["foreign"]["dvdlCoul"] - fw["dvdlCoul"])) <= rel * max(1.0, float(np.max(np.abs(fw["dvdlCoul"]))))
-    assert np.max(np.abs(got["foreign"]["dvdlVdw"] - fw["dvdlVdw"])) <= rel * max(1.0, float(np.max(np.abs(fw["dvdlVdw"]))))
+    # per lambda: the energy against the magnitude of ITS two terms at THAT lambda, dV/dl against its own value at that lambda (with
+    # the floors of assert_parity) — not against the largest value over all lambda
+    for k in range(len(e_want)):
+        scale = max(1.0, abs(e_want[k]), fw["eVdwAbs"][k] + fw["eCoulAbs"][k])      # sum of |V| over the perturbed pairs at lambda k
+        assert abs(got["foreign"]["energies"][k] - e_want[k]) <= rel * scale, \
+            "foreign energy, index %d: got %.8g want %.8g" % (k, got["foreign"]["energies"][k], e_want[k])
+        for name in ("dvdlCoul", "dvdlVdw"):
+            sums = fw.get(name + "Abs")
+            scale = max(abs(fw[name][k]), sums[k] if sums is not None else 1.0, 1e-3)
+            assert abs(got["foreign"][name][k] - fw[name][k]) <= rel * scale, \
+                "foreign %s, index %d: got %.8g want %.8g (scale %.3g)" % (name, k, got["foreign"][name][k], fw[name][k], scale)
 
 
 # ---- O(N^2) evaluation (tiny systems) ------------------------------------------------------------------------

@@ -119,8 +119,10 @@ def fep_kernel(nbl, x, ntype, p, shiftvec, nbfp, nbfp_grid, qA, qB, typeA, typeB
        _ptr(f), _ptr(fshift), C.byref(Vc), C.byref(Vv), dvdl)
     sums = (C.c_double * 4)()
     getattr(lib(), "oracle_fep_last_abs_sums_" + precision)(sums)
+    fsabs = np.zeros((45, 3))
+    getattr(lib(), "oracle_fep_last_fshift_abs_" + precision)(_ptr(fsabs))
     return dict(f=f, fshift=fshift, Vc=Vc.value, Vv=Vv.value, dvdl_coul=dvdl[0], dvdl_vdw=dvdl[1],
-                abs_sums=dict(e_el=sums[0], e_lj=sums[1], dvdl_coul=sums[2], dvdl_vdw=sums[3]))
+                abs_sums=dict(e_el=sums[0], e_lj=sums[1], dvdl_coul=sums[2], dvdl_vdw=sums[3]), fshift_abs=fsabs)
 
 
 def fep_foreign(nbl, x, ntype, p, shiftvec, nbfp, nbfp_grid, qA, qB, typeA, typeB, lambda_coul,
@@ -146,7 +148,10 @@ def fep_foreign(nbl, x, ntype, p, shiftvec, nbfp, nbfp_grid, qA, qB, typeA, type
        C.c_int(ntype), C.byref(p), _ptr(sv), _ptr(nbfp_), _ptr(grid_), _ptr(qA_), _ptr(qB_),
        _ptr(tA), _ptr(tB), C.c_double(lambda_coul), C.c_double(lambda_vdw), C.c_int(nl),
        _ptr(alc), _ptr(alv), _ptr(out[0]), _ptr(out[1]), _ptr(out[2]), _ptr(out[3]))
-    return dict(eVdw=out[0], eCoul=out[1], dvdlVdw=out[2], dvdlCoul=out[3])
+    sums = np.zeros((nl + 1, 4))
+    getattr(lib(), "oracle_fep_foreign_abs_sums_" + precision)(_ptr(sums), C.c_int(nl + 1))
+    return dict(eVdw=out[0], eCoul=out[1], dvdlVdw=out[2], dvdlCoul=out[3], eCoulAbs=sums[:, 0], eVdwAbs=sums[:, 1],
+                dvdlCoulAbs=sums[:, 2], dvdlVdwAbs=sums[:, 3])
 
 
 def nbnxm_ref(sci, cjPacked, excl, xq, atype, ntype, nbfp, p, shiftvec, compute_energy=True,
@@ -171,11 +176,15 @@ def nbnxm_ref(sci, cjPacked, excl, xq, atype, ntype, nbfp, p, shiftvec, compute_
     npair = C.c_longlong(0)
     nsci = sci.size if sci.dtype.names else sci.reshape(-1, 4).shape[0]
     lead = (C.c_int(num_threads), C.c_int(n)) if num_threads > 1 else ()
+    fsabs_fn = getattr(lib(), "oracle_nbnxm_fshift_abs_" + precision)
+    fsabs_fn(None, C.c_int(1))
     fn(*lead, C.c_int(nsci), _ptr(sci), _ptr(cjPacked), _ptr(excl), _ptr(xq_), _ptr(t), C.c_int(ntype),
        _ptr(nbfp_), _ptr(ljc), _ptr(nbc), C.byref(p), _ptr(sv), C.c_int(1 if compute_energy else 0),
        C.c_int(1 if compute_fshift else 0), _ptr(f), _ptr(fshift), C.byref(Vc), C.byref(Vv),
        C.byref(npair))
-    return dict(f=f, fshift=fshift, Vc=Vc.value, Vv=Vv.value, npairs=npair.value)
+    fsabs = np.zeros((45, 3))
+    fsabs_fn(_ptr(fsabs), C.c_int(0))
+    return dict(f=f, fshift=fshift, Vc=Vc.value, Vv=Vv.value, npairs=npair.value, fshift_abs=fsabs)
 
 
 def nbnxm_simd(sci, cjPacked, excl, xq, atype, ntype, nbfp, p, shiftvec, num_threads=1):

@@ -66,14 +66,10 @@ def test_foreign_lambda_energies(elec, vdw, fused):
     c = tl.make_case(elec=elec, vdw=vdw, seed=25, n_lambda=11, **SMALL)
     got = tl.run_gpu(c, energy=True, fused=fused, dhdl=True)
     want = tl.run_oracle(c, energy=True, foreign=True)
-    fw = want["foreign"]
-    e_want = fw["eVdw"] + fw["eCoul"]
-    scale = max(1.0, float(np.max(np.abs(fw["eVdw"])) + np.max(np.abs(fw["eCoul"]))))
-    assert np.max(np.abs(got["foreign"]["energies"] - e_want)) <= 1e-4 * scale
-    assert np.max(np.abs(got["foreign"]["dvdlCoul"] - fw["dvdlCoul"])) <= 1e-4 * max(1.0, float(np.max(np.abs(fw["dvdlCoul"]))))
-    assert np.max(np.abs(got["foreign"]["dvdlVdw"] - fw["dvdlVdw"])) <= 1e-4 * max(1.0, float(np.max(np.abs(fw["dvdlVdw"]))))
+    tl.assert_foreign(got, want, rel=1e-4)      # per lambda, against the magnitude of that lambda's own terms
     # index 0 is the current lambda: must agree with the FEP part of the force/energy kernels
-    fep = want["parts"]["fep"]
+    fep, fw = want["parts"]["fep"], want["foreign"]
+    scale = max(1.0, fw["eVdwAbs"][0] + fw["eCoulAbs"][0])
     assert abs(got["foreign"]["energies"][0] - (fep["Vv"] + fep["Vc"])) <= 1e-4 * scale
 
 
