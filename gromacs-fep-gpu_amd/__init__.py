@@ -104,7 +104,7 @@ HIP_SYMBOLS = [
     "nbnxm_gpu_set_local_launch_parts", "nbnxm_gpu_launch_kernel_part", "nbnxm_hip_query_launch_plan",
 ]
 HALO_SYMBOLS = [
-    "halo_gpu_get_unique_id", "halo_gpu_create", "halo_gpu_free", "halo_gpu_last_error", "halo_gpu_reinit",
+    "halo_gpu_get_unique_id", "halo_gpu_get_unique_id_ex", "halo_gpu_create", "halo_gpu_free", "halo_gpu_last_error", "halo_gpu_reinit",
     "halo_gpu_communicate_coordinates", "halo_gpu_communicate_forces", "halo_gpu_coordinates_ready_event", "halo_gpu_forces_ready_event",
     "halo_gpu_bytes_per_step", "halo_gpu_pack_shifted", "halo_gpu_domain_force_step",
 ]

@@ -8,15 +8,26 @@
  *
  * Everything is queued on ONE stream; RCCL's send / receive are stream-ordered, so there is no host handshake per step
  * (the reference's peer-copy path exchanges event pointers with MPI_Sendrecv every step, :438-470).
+ *
+ * Second transport, selected by the unique id (halo_gpu_get_unique_id_ex(.., HALO_GPU_TRANSPORT_PEER_COPY)): in-process peer copies,
+ * the reference's thread-MPI path (:438-511): the ranks are host threads of ONE process (each with its own HaloGpu, streams and,
+ * on a node, its own device), the receiver copies device to device out of the sender's buffer (hipMemcpyAsync / hipMemcpyPeerAsync)
+ * behind an event the sender recorded, and the event handles travel through a mailbox in host memory (a mutex and a condition
+ * variable stand in for the reference's MPI_Sendrecv of event pointers).  It runs the same pack / unpack kernels, link offsets and
+ * two-locality schedule as the RCCL transport, with any number of ranks on one GPU.
  */
 #include "halo_hip.h"
 
 #include <dlfcn.h>
 
 #include <chrono>
+#include <condition_variable>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <map>
+#include <memory>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -171,6 +182,49 @@ __global__ void domainHomeRowsKernel(float* __restrict__ f, const float3* __rest
     atomicAdd(d + 2, v.z);
 }
 
+/* ---- in-process peer-copy transport -------------------------------------------------------------------------------------- */
+
+/* what a receiver needs to know about the sender of a step: where its buffers are and how its links are laid out.  Immutable;
+ * a new one is made by every halo_gpu_reinit and travels with the posts of the steps that used it. */
+struct PeerLayout
+{
+    int              device = 0;
+    const float3*    d_f       = nullptr; /* forces in the rank's atom order: the halo rows are what the owners pull */
+    const float3*    d_sendBuf = nullptr; /* packed coordinates: what the receivers pull */
+    std::vector<int> sendPeer, sendOffset, recvPeer, recvAtomOffset, recvCount;
+};
+
+enum PeerPostKind
+{
+    c_postXPacked = 0, /* the send buffer holds the packed coordinates of exchange seq */
+    c_postXPulled,     /* this rank has copied what it needs of exchange seq out of the others' send buffers */
+    c_postFReady,      /* the halo rows of d_f hold the forces of exchange seq */
+    c_postFPulled,     /* this rank has copied what it needs of exchange seq out of the others' halo rows */
+    c_numPostKinds
+};
+constexpr int c_peerRing = 4; /* posts (and their events) of the last c_peerRing exchanges stay valid; the guards keep ranks within one */
+
+struct PeerPost
+{
+    long                              seq = -1;
+    hipEvent_t                        event = nullptr;
+    std::shared_ptr<const PeerLayout> layout;
+};
+
+/* the mailbox all ranks of one in-process "communicator" share */
+struct PeerWorld
+{
+    std::mutex              mutex;
+    std::condition_variable cv;
+    int                     nranks   = 0;
+    int                     attached = 0;
+    std::vector<PeerPost>   posts; /* [(rank * c_numPostKinds + kind) * c_peerRing + seq % c_peerRing] */
+};
+
+std::mutex                                        g_worldsMutex;
+std::map<std::string, std::shared_ptr<PeerWorld>> g_worlds;
+constexpr char                                    c_peerIdMagic[8] = { 'H', 'A', 'L', 'O', 'P', 'E', 'E', 'R' };
+
 } // namespace
 
 struct HaloGpu
@@ -188,11 +242,18 @@ struct HaloGpu
     int*             d_sendMap        = nullptr;
     int*             d_sendShiftIndex = nullptr;
     float3*          d_shiftVectors   = nullptr;
-    float3*          d_sendBuf        = nullptr; /* packed coordinates out; received forces in */
+    float3*          d_sendBuf        = nullptr; /* packed coordinates out */
+    /* The forces the other ranks computed on this rank's atoms arrive in a buffer of their own (the reference's d_recvBuf_,
+     * gpuhaloexchange_impl_gpu.h): the home-rows kernel of step n reads it on the LOCAL stream while step n + 1 already packs
+     * coordinates on the non-local stream — with one shared buffer (round 2) that pack overwrote forces still being read. */
+    float3*          d_recvBuf        = nullptr;
     int              sendAlloc = 0, shiftAlloc = 0;
     /* recv side */
     std::vector<int> recvPeer, recvAtomOffset, recvCount;
     hipEvent_t       xReady = nullptr, fReady = nullptr;
+    /* recorded behind the last reader of d_recvBuf (the unpack / home-rows kernel); the next force exchange waits for it */
+    hipEvent_t       recvBufConsumed         = nullptr;
+    bool             recvBufConsumedRecorded = false;
     /* HALO_GPU_HOST_TIMING: host microseconds spent queueing the parts of halo_gpu_domain_force_step */
     double                                hostTimingUs[9] = { 0, 0, 0, 0, 0, 0, 0, 0, 0 };
     long                                  hostTimingSteps = 0;
@@ -200,7 +261,134 @@ struct HaloGpu
     int   localParts        = 1;
     float localPartFraction = c_defaultLocalPartFraction;
     std::chrono::steady_clock::time_point hostTimingLast;
+    /* in-process peer-copy transport (world != nullptr) */
+    std::shared_ptr<PeerWorld>        world;
+    std::string                       worldKey;
+    int                               device = 0;
+    std::shared_ptr<const PeerLayout> layout;
+    hipEvent_t                        peerEvents[c_numPostKinds][c_peerRing] = {};
+    long                              xSeq = 0, fSeq = 0; /* exchanges done so far */
+    std::vector<void*>                retiredBuffers;     /* buffers a peer may still be copying from: freed with the object */
+    double                            peerTimeoutSeconds = 30.0;
 };
+
+namespace
+{
+
+/* publish: exchange seq of this rank has reached `kind`; the event has been recorded on the rank's stream */
+void peerPost(HaloGpu* h, PeerPostKind kind, long seq, hipStream_t s)
+{
+    hipEvent_t ev = h->peerEvents[kind][seq % c_peerRing];
+    NBNXM_HIP_CHECK(hipEventRecord(ev, s));
+    PeerWorld& w = *h->world;
+    {
+        std::lock_guard<std::mutex> lock(w.mutex);
+        PeerPost&                   slot = w.posts[(static_cast<size_t>(h->rank) * c_numPostKinds + kind) * c_peerRing + seq % c_peerRing];
+        slot.seq                         = seq;
+        slot.event                       = ev;
+        slot.layout                      = h->layout;
+    }
+    w.cv.notify_all();
+}
+
+/* host handshake (the reference's MPI_Sendrecv of event pointers, gpuhaloexchange_impl_gpu.cpp:438-470): blocks until rank `from`
+ * has QUEUED exchange seq up to `kind`, then makes stream s wait for the event it recorded there.  A peer that never gets there
+ * is a fatal error after peerTimeoutSeconds, not a hang. */
+PeerPost peerWait(HaloGpu* h, int from, PeerPostKind kind, long seq, hipStream_t s)
+{
+    PeerWorld&                   w = *h->world;
+    std::unique_lock<std::mutex> lock(w.mutex);
+    const size_t                 idx = (static_cast<size_t>(from) * c_numPostKinds + kind) * c_peerRing + seq % c_peerRing;
+    const bool ok = w.cv.wait_for(lock, std::chrono::duration<double>(h->peerTimeoutSeconds), [&] { return w.posts[idx].seq >= seq; });
+    if (!ok)
+    {
+        char msg[256];
+        static const char* names[c_numPostKinds] = { "coordinates packed", "coordinates pulled", "forces ready", "forces pulled" };
+        std::snprintf(msg, sizeof(msg), "rank %d waited %.0f s for rank %d to reach '%s' of exchange %ld (in-process transport: every rank needs its own host thread)",
+                      h->rank, h->peerTimeoutSeconds, from, names[kind], seq);
+        fatal(__FILE__, __LINE__, "halo peer-copy handshake timed out", msg);
+    }
+    NBNXM_ASSERT(w.posts[idx].seq == seq, "a peer ran more than the ring of posts ahead (missing guard)");
+    PeerPost post = w.posts[idx];
+    lock.unlock();
+    NBNXM_HIP_CHECK(hipStreamWaitEvent(s, post.event, 0));
+    return post;
+}
+
+void peerCopy(void* dst, int dstDevice, const void* src, int srcDevice, size_t bytes, hipStream_t s)
+{
+    if (bytes == 0) { return; }
+    if (dstDevice == srcDevice) { NBNXM_HIP_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, s)); }
+    else { NBNXM_HIP_CHECK(hipMemcpyPeerAsync(dst, dstDevice, src, srcDevice, bytes, s)); }
+}
+
+/* index of the link to rank `me` in a peer's list of links (one message per peer pair and direction: halo_gpu_reinit checks it) */
+int linkTo(const std::vector<int>& peers, int me)
+{
+    for (size_t k = 0; k < peers.size(); k++)
+    {
+        if (peers[k] == me) { return static_cast<int>(k); }
+    }
+    return -1;
+}
+
+/* coordinates, peer-copy transport: pack -> publish -> every receiver pulls its block out of the sender's buffer */
+void peerExchangeCoordinates(HaloGpu* h)
+{
+    hipStream_t s = h->stream;
+    const long  q = h->xSeq;
+    /* the buffers this exchange overwrites must have been read by their last consumers: the send buffer by the ranks that pulled
+     * exchange q - 1 out of it, the halo rows of d_f (rewritten later in this step, on this stream) by their owners */
+    if (q > 0)
+    {
+        for (size_t k = 0; k < h->sendPeer.size(); k++) { peerWait(h, h->sendPeer[k], c_postXPulled, q - 1, s); }
+    }
+    if (h->fSeq > 0)
+    {
+        for (size_t k = 0; k < h->recvPeer.size(); k++) { peerWait(h, h->recvPeer[k], c_postFPulled, h->fSeq - 1, s); }
+    }
+    if (h->numSendAtoms > 0)
+    {
+        hipLaunchKernelGGL(haloPackShiftedKernel, dim3((h->numSendAtoms + c_haloThreadsPerBlock - 1) / c_haloThreadsPerBlock),
+                           dim3(c_haloThreadsPerBlock), 0, s, h->d_sendBuf, h->d_x, h->d_sendMap, h->d_sendShiftIndex, h->d_shiftVectors,
+                           h->numSendAtoms);
+        NBNXM_HIP_CHECK(hipGetLastError());
+    }
+    peerPost(h, c_postXPacked, q, s);
+    for (size_t k = 0; k < h->recvPeer.size(); k++)
+    {
+        const PeerPost    post = peerWait(h, h->recvPeer[k], c_postXPacked, q, s);
+        const PeerLayout& from = *post.layout;
+        const int         link = linkTo(from.sendPeer, h->rank);
+        NBNXM_ASSERT(link >= 0 && from.sendOffset[link + 1] - from.sendOffset[link] == h->recvCount[k],
+                     "the two sides of a halo link disagree on its size");
+        peerCopy(h->d_x + h->recvAtomOffset[k], h->device, from.d_sendBuf + from.sendOffset[link], from.device,
+                 sizeof(float3) * static_cast<size_t>(h->recvCount[k]), s);
+    }
+    peerPost(h, c_postXPulled, q, s);
+    h->xSeq = q + 1;
+}
+
+/* forces, peer-copy transport: publish the halo rows -> every owner pulls what was computed on its atoms into its receive buffer */
+void peerExchangeForces(HaloGpu* h)
+{
+    hipStream_t s = h->stream;
+    const long  q = h->fSeq;
+    peerPost(h, c_postFReady, q, s);
+    for (size_t k = 0; k < h->sendPeer.size(); k++)
+    {
+        const int n = h->sendOffset[k + 1] - h->sendOffset[k];
+        const PeerPost    post = peerWait(h, h->sendPeer[k], c_postFReady, q, s);
+        const PeerLayout& from = *post.layout;
+        const int         link = linkTo(from.recvPeer, h->rank);
+        NBNXM_ASSERT(link >= 0 && from.recvCount[link] == n, "the two sides of a halo link disagree on its size");
+        peerCopy(h->d_recvBuf + h->sendOffset[k], h->device, from.d_f + from.recvAtomOffset[link], from.device, sizeof(float3) * static_cast<size_t>(n), s);
+    }
+    peerPost(h, c_postFPulled, q, s);
+    h->fSeq = q + 1;
+}
+
+} // namespace
 
 extern "C"
 {
@@ -208,6 +396,25 @@ extern "C"
 const char* halo_gpu_last_error(void)
 {
     return g_haloError.c_str();
+}
+
+int halo_gpu_get_unique_id_ex(void* uniqueId, int transport)
+{
+    if (transport == HALO_GPU_TRANSPORT_RCCL) { return halo_gpu_get_unique_id(uniqueId); }
+    if (transport != HALO_GPU_TRANSPORT_PEER_COPY)
+    {
+        g_haloError = "unknown halo transport";
+        return 3;
+    }
+    /* an id that no RCCL id can be taken for: magic, then a process-wide counter */
+    static std::mutex counterMutex;
+    static long long  counter = 0;
+    std::memset(uniqueId, 0, HALO_GPU_UNIQUE_ID_BYTES);
+    std::memcpy(uniqueId, c_peerIdMagic, sizeof(c_peerIdMagic));
+    std::lock_guard<std::mutex> lock(counterMutex);
+    const long long             value = ++counter;
+    std::memcpy(static_cast<char*>(uniqueId) + sizeof(c_peerIdMagic), &value, sizeof(value));
+    return 0;
 }
 
 int halo_gpu_get_unique_id(void* uniqueId)
@@ -227,23 +434,64 @@ int halo_gpu_get_unique_id(void* uniqueId)
 
 HaloGpu* halo_gpu_create(const void* uniqueId, int rank, int nranks, void* stream)
 {
-    Rccl* r = rccl();
-    if (r == nullptr) { return nullptr; }
-    auto* h   = new HaloGpu;
+    if (rank < 0 || rank >= nranks)
+    {
+        g_haloError = "rank outside [0, nranks)";
+        return nullptr;
+    }
+    const bool peerCopyTransport = (std::memcmp(uniqueId, c_peerIdMagic, sizeof(c_peerIdMagic)) == 0);
+    auto*      h                 = new HaloGpu;
     h->rank   = rank;
     h->nranks = nranks;
     h->stream = static_cast<hipStream_t>(stream);
-    ncclUniqueId id;
-    std::memcpy(&id, uniqueId, sizeof(id));
-    const ncclResult_t res = r->CommInitRank(&h->comm, nranks, id, rank);
-    if (res != ncclSuccess)
+    NBNXM_HIP_CHECK(hipGetDevice(&h->device));
+    if (peerCopyTransport)
     {
-        g_haloError = std::string("ncclCommInitRank: ") + r->GetErrorString(res);
-        delete h;
-        return nullptr;
+        /* in-process peer copies: attach to the mailbox of this id (the first rank makes it); nothing collective happens here */
+        h->worldKey.assign(static_cast<const char*>(uniqueId), HALO_GPU_UNIQUE_ID_BYTES);
+        std::lock_guard<std::mutex> lock(g_worldsMutex);
+        std::shared_ptr<PeerWorld>& w = g_worlds[h->worldKey];
+        if (!w)
+        {
+            w         = std::make_shared<PeerWorld>();
+            w->nranks = nranks;
+            w->posts.resize(static_cast<size_t>(nranks) * c_numPostKinds * c_peerRing);
+        }
+        if (w->nranks != nranks)
+        {
+            g_haloError = "the ranks of one in-process halo communicator disagree on their number";
+            delete h;
+            return nullptr;
+        }
+        w->attached++;
+        h->world = w;
+        for (int k = 0; k < c_numPostKinds; k++)
+        {
+            for (int i = 0; i < c_peerRing; i++) { NBNXM_HIP_CHECK(hipEventCreateWithFlags(&h->peerEvents[k][i], hipEventDisableTiming)); }
+        }
+        if (const char* env = std::getenv("HALO_GPU_PEER_TIMEOUT")) { h->peerTimeoutSeconds = std::max(1.0, std::atof(env)); }
+    }
+    else
+    {
+        Rccl* r = rccl();
+        if (r == nullptr)
+        {
+            delete h;
+            return nullptr;
+        }
+        ncclUniqueId id;
+        std::memcpy(&id, uniqueId, sizeof(id));
+        const ncclResult_t res = r->CommInitRank(&h->comm, nranks, id, rank);
+        if (res != ncclSuccess)
+        {
+            g_haloError = std::string("ncclCommInitRank: ") + r->GetErrorString(res);
+            delete h;
+            return nullptr;
+        }
     }
     NBNXM_HIP_CHECK(hipEventCreateWithFlags(&h->xReady, hipEventDisableTiming));
     NBNXM_HIP_CHECK(hipEventCreateWithFlags(&h->fReady, hipEventDisableTiming));
+    NBNXM_HIP_CHECK(hipEventCreateWithFlags(&h->recvBufConsumed, hipEventDisableTiming));
     /* the local launch of a domain step in two parts: on by default where the exchanges leave the device (see halo_gpu_domain_force_step) */
     h->localParts = (nranks > 1) ? 2 : 1;
     if (const char* env = std::getenv("HALO_GPU_LOCAL_PARTS")) { h->localParts = (std::atoi(env) == 2) ? 2 : 1; }
@@ -267,12 +515,26 @@ void halo_gpu_free(HaloGpu* h)
         for (int i = 0; i < 9; i++) { std::fprintf(stderr, "  %-34s %7.2f\n", names[i], h->hostTimingUs[i] / h->hostTimingSteps); }
     }
     if (h->comm != nullptr) { (void)rccl()->CommDestroy(h->comm); }
+    if (h->world)
+    {
+        /* peers may still have copies out of this rank's buffers in flight: the whole device goes idle first (free is rare) */
+        (void)hipDeviceSynchronize();
+        std::lock_guard<std::mutex> lock(g_worldsMutex);
+        if (--h->world->attached == 0) { g_worlds.erase(h->worldKey); }
+        for (int k = 0; k < c_numPostKinds; k++)
+        {
+            for (int i = 0; i < c_peerRing; i++) { (void)hipEventDestroy(h->peerEvents[k][i]); }
+        }
+    }
+    for (void* b : h->retiredBuffers) { (void)hipFree(b); }
     (void)hipFree(h->d_sendMap);
     (void)hipFree(h->d_sendShiftIndex);
     (void)hipFree(h->d_shiftVectors);
     (void)hipFree(h->d_sendBuf);
+    (void)hipFree(h->d_recvBuf);
     if (h->xReady) { (void)hipEventDestroy(h->xReady); }
     if (h->fReady) { (void)hipEventDestroy(h->fReady); }
+    if (h->recvBufConsumed) { (void)hipEventDestroy(h->recvBufConsumed); }
     delete h;
 }
 
@@ -302,15 +564,46 @@ void halo_gpu_reinit(HaloGpu* h, void* d_x, void* d_f, int numHome, int numSend,
     {
         NBNXM_ASSERT(recvPeer[k] >= 0 && recvPeer[k] < h->nranks && recvAtomOffset[k] >= numHome && recvCount[k] >= 0, "bad receive link");
     }
+    /* one message per peer and direction (both transports match the links of a pair of ranks by peer) */
+    for (int k = 0; k < numSend; k++)
+    {
+        for (int l = 0; l < k; l++) { NBNXM_ASSERT(sendPeer[l] != sendPeer[k], "two send links to the same rank: merge them into one message"); }
+    }
+    for (int k = 0; k < numRecv; k++)
+    {
+        for (int l = 0; l < k; l++) { NBNXM_ASSERT(recvPeer[l] != recvPeer[k], "two receive links from the same rank: merge them into one message"); }
+    }
+    /* the device must be done with the old maps and buffers before they are replaced (search steps are rare); the home-rows kernel
+     * of the domain step reads the send map and the receive buffer on the local stream */
+    NBNXM_HIP_CHECK(hipStreamSynchronize(h->stream));
+    if (h->recvBufConsumedRecorded) { NBNXM_HIP_CHECK(hipEventSynchronize(h->recvBufConsumed)); }
     if (h->numSendAtoms > h->sendAlloc)
     {
         (void)hipFree(h->d_sendMap);
         (void)hipFree(h->d_sendShiftIndex);
-        (void)hipFree(h->d_sendBuf);
+        (void)hipFree(h->d_recvBuf);
+        /* peer-copy transport: another rank may still be copying out of the old send buffer on ITS stream: it is kept until the
+         * object goes (reallocation happens a few times per run at most) */
+        if (h->world && h->d_sendBuf != nullptr) { h->retiredBuffers.push_back(h->d_sendBuf); }
+        else { (void)hipFree(h->d_sendBuf); }
         h->sendAlloc = static_cast<int>(h->numSendAtoms * 1.2) + 1024;
         NBNXM_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&h->d_sendMap), sizeof(int) * h->sendAlloc));
         NBNXM_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&h->d_sendShiftIndex), sizeof(int) * h->sendAlloc));
         NBNXM_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&h->d_sendBuf), sizeof(float3) * h->sendAlloc));
+        NBNXM_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&h->d_recvBuf), sizeof(float3) * h->sendAlloc));
+    }
+    if (h->world)
+    {
+        auto layout            = std::make_shared<PeerLayout>();
+        layout->device         = h->device;
+        layout->d_f            = h->d_f;
+        layout->d_sendBuf      = h->d_sendBuf;
+        layout->sendPeer       = h->sendPeer;
+        layout->sendOffset     = h->sendOffset;
+        layout->recvPeer       = h->recvPeer;
+        layout->recvAtomOffset = h->recvAtomOffset;
+        layout->recvCount      = h->recvCount;
+        h->layout              = layout;
     }
     if (numShiftVectors > h->shiftAlloc)
     {
@@ -319,7 +612,6 @@ void halo_gpu_reinit(HaloGpu* h, void* d_x, void* d_f, int numHome, int numSend,
         NBNXM_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&h->d_shiftVectors), sizeof(float3) * h->shiftAlloc));
     }
     /* search steps are rare: plain synchronous copies */
-    NBNXM_HIP_CHECK(hipStreamSynchronize(h->stream));
     if (h->numSendAtoms > 0)
     {
         NBNXM_HIP_CHECK(hipMemcpy(h->d_sendMap, sendMap, sizeof(int) * h->numSendAtoms, hipMemcpyHostToDevice));
@@ -333,9 +625,15 @@ void halo_gpu_reinit(HaloGpu* h, void* d_x, void* d_f, int numHome, int numSend,
 
 void halo_gpu_communicate_coordinates(HaloGpu* h, void* dependencyEvent)
 {
-    Rccl*       r = rccl();
     hipStream_t s = h->stream;
     if (dependencyEvent != nullptr) { NBNXM_HIP_CHECK(hipStreamWaitEvent(s, static_cast<hipEvent_t>(dependencyEvent), 0)); }
+    if (h->world)
+    {
+        peerExchangeCoordinates(h);
+        NBNXM_HIP_CHECK(hipEventRecord(h->xReady, s));
+        return;
+    }
+    Rccl* r = rccl();
     if (h->numSendAtoms > 0)
     {
         hipLaunchKernelGGL(haloPackShiftedKernel, dim3((h->numSendAtoms + c_haloThreadsPerBlock - 1) / c_haloThreadsPerBlock),
@@ -364,15 +662,22 @@ void halo_gpu_communicate_coordinates(HaloGpu* h, void* dependencyEvent)
 /* the transfers of the force halo alone: halo rows out, what the others computed on this rank's atoms into the send buffer */
 static void exchangeForces(HaloGpu* h)
 {
-    Rccl*       r = rccl();
     hipStream_t s = h->stream;
+    /* the receive buffer is overwritten: its reader of the previous step (possibly on another stream) must be done */
+    if (h->recvBufConsumedRecorded) { NBNXM_HIP_CHECK(hipStreamWaitEvent(s, h->recvBufConsumed, 0)); }
+    if (h->world)
+    {
+        peerExchangeForces(h);
+        return;
+    }
+    Rccl* r = rccl();
     /* the reverse of the coordinate exchange: the halo rows of d_f go to their owners as they are (contiguous, no pack),
-     * what the others computed on this rank's atoms arrives in the send buffer, in the order of the send map */
+     * what the others computed on this rank's atoms arrives in the receive buffer, in the order of the send map */
     HALO_RCCL_CHECK(r->GroupStart());
     for (size_t k = 0; k < h->sendPeer.size(); k++)
     {
         const int n = h->sendOffset[k + 1] - h->sendOffset[k];
-        if (n > 0) { HALO_RCCL_CHECK(r->Recv(h->d_sendBuf + h->sendOffset[k], static_cast<size_t>(3) * n, ncclFloat, h->sendPeer[k], h->comm, s)); }
+        if (n > 0) { HALO_RCCL_CHECK(r->Recv(h->d_recvBuf + h->sendOffset[k], static_cast<size_t>(3) * n, ncclFloat, h->sendPeer[k], h->comm, s)); }
     }
     for (size_t k = 0; k < h->recvPeer.size(); k++)
     {
@@ -395,15 +700,16 @@ void halo_gpu_communicate_forces(HaloGpu* h, int accumulate, void* dependencyEve
         if (accumulate)
         {
             hipLaunchKernelGGL(haloUnpackForcesKernel<true>, grid, dim3(c_haloThreadsPerBlock), 0, s, reinterpret_cast<float*>(h->d_f),
-                               h->d_sendBuf, h->d_sendMap, h->numSendAtoms);
+                               h->d_recvBuf, h->d_sendMap, h->numSendAtoms);
         }
         else
         {
             hipLaunchKernelGGL(haloUnpackForcesKernel<false>, grid, dim3(c_haloThreadsPerBlock), 0, s, reinterpret_cast<float*>(h->d_f),
-                               h->d_sendBuf, h->d_sendMap, h->numSendAtoms);
+                               h->d_recvBuf, h->d_sendMap, h->numSendAtoms);
         }
         NBNXM_HIP_CHECK(hipGetLastError());
     }
+    h->recvBufConsumedRecorded = false; /* the reader ran on this very stream: stream order is enough */
     NBNXM_HIP_CHECK(hipEventRecord(h->fReady, s));
 }
 
@@ -489,9 +795,12 @@ void halo_gpu_domain_force_step(HaloGpu* h, NbnxmGpu* nb, const nbnxm_step_workl
     NBNXM_HIP_CHECK(hipStreamWaitEvent(sLocal, h->fReady, 0));
     const int n = h->numHome + h->numSendAtoms;
     hipLaunchKernelGGL(domainHomeRowsKernel, dim3((n + c_haloThreadsPerBlock - 1) / c_haloThreadsPerBlock), dim3(c_haloThreadsPerBlock), 0, sLocal,
-                       reinterpret_cast<float*>(h->d_f), reinterpret_cast<const float3*>(nb->atdat->f), nb->cell, h->numHome, h->d_sendBuf,
+                       reinterpret_cast<float*>(h->d_f), reinterpret_cast<const float3*>(nb->atdat->f), nb->cell, h->numHome, h->d_recvBuf,
                        h->d_sendMap, h->numSendAtoms);
     NBNXM_HIP_CHECK(hipGetLastError());
+    /* the receive buffer was read on the LOCAL stream: the next step's force exchange (non-local stream) must not overtake it */
+    NBNXM_HIP_CHECK(hipEventRecord(h->recvBufConsumed, sLocal));
+    h->recvBufConsumedRecorded = true;
     tick(8);
 }
 

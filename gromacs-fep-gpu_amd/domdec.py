@@ -260,29 +260,55 @@ class RankSystem:
 
 # ---- transports ---------------------------------------------------------------------------------------------------------
 
-class RcclHalo:
-    """include/halo_hip.h: the exchange inside libnbnxm_hip.so (ncclSend / ncclRecv groups on the non-local stream)"""
+TRANSPORT_RCCL, TRANSPORT_PEER_COPY = 0, 1      # include/halo_hip.h
 
-    def __init__(self, pkg, dist, rank, num_ranks, stream):
+
+def _halo_lib(pkg):
+    import ctypes as C
+    lib = pkg.hip_lib()
+    lib.halo_gpu_create.restype = C.c_void_p
+    lib.halo_gpu_last_error.restype = C.c_char_p
+    lib.halo_gpu_coordinates_ready_event.restype = C.c_void_p
+    lib.halo_gpu_forces_ready_event.restype = C.c_void_p
+    lib.halo_gpu_bytes_per_step.restype = C.c_longlong
+    return lib
+
+
+def new_halo_id(pkg, transport=TRANSPORT_RCCL):
+    """halo_gpu_get_unique_id_ex: the 128 bytes every rank of one communicator hands to its transport object; the id selects the
+    transport (RCCL | in-process peer copies)"""
+    import ctypes as C
+    lib = _halo_lib(pkg)
+    uid = np.zeros(128, np.uint8)
+    if lib.halo_gpu_get_unique_id_ex(uid.ctypes.data_as(C.c_void_p), C.c_int(transport)) != 0:
+        raise RuntimeError("halo_gpu_get_unique_id_ex: %s" % lib.halo_gpu_last_error().decode())
+    return uid
+
+
+class RcclHalo:
+    """include/halo_hip.h: the exchange inside libnbnxm_hip.so.  Default: ncclSend / ncclRecv groups on the non-local stream, one
+    process per rank, the id broadcast over `dist`.  unique_id: an id made by new_halo_id (the same bytes for every rank) — with
+    TRANSPORT_PEER_COPY the ranks are threads of this process and copy device to device out of each other's buffers; every rank then
+    needs its own host thread for the calls that exchange data (run_ranks_in_threads)."""
+
+    def __init__(self, pkg, dist, rank, num_ranks, stream, unique_id=None):
         import ctypes as C
         import torch
-        self._C, self._lib = C, pkg.hip_lib()
+        self._C, self._lib = C, _halo_lib(pkg)
         lib = self._lib
-        lib.halo_gpu_create.restype = C.c_void_p
-        lib.halo_gpu_last_error.restype = C.c_char_p
-        lib.halo_gpu_coordinates_ready_event.restype = C.c_void_p
-        lib.halo_gpu_forces_ready_event.restype = C.c_void_p
-        lib.halo_gpu_bytes_per_step.restype = C.c_longlong
-        uid = np.zeros(128, np.uint8)
-        if rank == 0:
-            if lib.halo_gpu_get_unique_id(uid.ctypes.data_as(C.c_void_p)) != 0:
-                raise RuntimeError("halo_gpu_get_unique_id: %s" % lib.halo_gpu_last_error().decode())
-        if num_ranks > 1:
-            # the id travels over the process group that exists anyway (any out-of-band channel would do)
-            backend = dist.get_backend()
-            t = torch.from_numpy(uid).to("cuda" if backend == "nccl" else "cpu")
-            dist.broadcast(t, 0)
-            uid = t.cpu().numpy()
+        if unique_id is not None:
+            uid = np.ascontiguousarray(unique_id, np.uint8)
+        else:
+            uid = np.zeros(128, np.uint8)
+            if rank == 0:
+                if lib.halo_gpu_get_unique_id(uid.ctypes.data_as(C.c_void_p)) != 0:
+                    raise RuntimeError("halo_gpu_get_unique_id: %s" % lib.halo_gpu_last_error().decode())
+            if num_ranks > 1:
+                # the id travels over the process group that exists anyway (any out-of-band channel would do)
+                backend = dist.get_backend()
+                t = torch.from_numpy(uid).to("cuda" if backend == "nccl" else "cpu")
+                dist.broadcast(t, 0)
+                uid = t.cpu().numpy()
         self._h = lib.halo_gpu_create(uid.ctypes.data_as(C.c_void_p), C.c_int(rank), C.c_int(num_ranks), C.c_void_p(stream))
         if not self._h:
             raise RuntimeError("halo_gpu_create: %s" % lib.halo_gpu_last_error().decode())
@@ -322,6 +348,29 @@ class RcclHalo:
         if getattr(self, "_h", None):
             self._lib.halo_gpu_free(self._C.c_void_p(self._h))
             self._h = None
+
+
+def run_ranks_in_threads(calls):
+    """calls: one function per in-process rank; each runs on its own host thread (the peer-copy transport blocks a rank's thread until
+    its peers have queued their side of an exchange; ctypes releases the interpreter lock inside the library).  Re-raises the first
+    exception of any rank."""
+    import threading
+    errors = [None] * len(calls)
+
+    def run(i):
+        try:
+            calls[i]()
+        except BaseException as e:      # noqa: BLE001 (handed to the caller's thread)
+            errors[i] = e
+
+    threads = [threading.Thread(target=run, args=(i,), name="halo-rank-%d" % i) for i in range(len(calls))]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    for e in errors:
+        if e is not None:
+            raise e
 
 
 class TensorHalo:

@@ -35,8 +35,21 @@ typedef struct HaloGpu HaloGpu;
 /* ncclGetUniqueId: call on ONE rank and hand the 128 bytes to all ranks (any out-of-band channel).  Returns 0 on success. */
 int halo_gpu_get_unique_id(void* uniqueId);
 
-/* ncclCommInitRank (collective over the nranks).  stream: the hipStream_t the exchanges are queued on (the non-local stream of
- * the non-bonded module).  Returns NULL on failure (halo_gpu_last_error() has the text). */
+/* The transport is chosen with the id.  HALO_GPU_TRANSPORT_RCCL: as above, one process per rank.  HALO_GPU_TRANSPORT_PEER_COPY: the
+ * ranks are host threads of ONE process (the reference's thread-MPI build, domdec/gpuhaloexchange_impl_gpu.cpp:438-511): a receiver
+ * copies device to device out of the sender's buffer (hipMemcpyAsync, hipMemcpyPeerAsync between the devices of a node) behind the
+ * event the sender recorded; the event handles go through a mailbox in host memory, where the reference sends them with MPI_Sendrecv.
+ * Every call that exchanges data blocks its host thread until the peers have QUEUED their side of that exchange, so each rank needs
+ * its own host thread (a rank that only talks to itself needs none); a peer that never arrives is a fatal error after
+ * HALO_GPU_PEER_TIMEOUT seconds (default 30), not a hang.  Any number of ranks can share one GPU with this transport — RCCL refuses
+ * that —, which is how the multi-rank schedule of halo_gpu_domain_force_step is tested on a one-GPU box. */
+#define HALO_GPU_TRANSPORT_RCCL 0
+#define HALO_GPU_TRANSPORT_PEER_COPY 1
+int halo_gpu_get_unique_id_ex(void* uniqueId, int transport);
+
+/* RCCL id: ncclCommInitRank (collective over the nranks); peer-copy id: attaches to the process's mailbox of that id (not collective).
+ * stream: the hipStream_t the exchanges are queued on (the non-local stream of the non-bonded module).  Returns NULL on failure
+ * (halo_gpu_last_error() has the text). */
 HaloGpu* halo_gpu_create(const void* uniqueId, int rank, int nranks, void* stream);
 void     halo_gpu_free(HaloGpu* h);
 const char* halo_gpu_last_error(void);

@@ -602,12 +602,16 @@ def test_halo_pack_unpack_kernels():
     pkg.halo_pack_x(s, d_x.data_ptr(), d_map.data_ptr(), 0, d_send.data_ptr(), None)
 
 
-def _check_virtual_rank_decomposition(c, ncells, oracle_threads=1, self_links=(False, False, False), rccl=False, energy=True):
+def _check_virtual_rank_decomposition(c, ncells, oracle_threads=1, self_links=(False, False, False), rccl=False, energy=True, peer_copy=False,
+                                      repeats=2):
     """All ranks of a decomposition in one process on one GPU: per rank its own grid over home + halo atoms, local and non-local
-    list, two streams, x -> xq per locality, fused cluster kernels, force reduction per locality; the halo moves through the
-    in-process test double (or, rccl=True with ONE rank that is its own neighbour, through the real RCCL transport of
-    include/halo_hip.h).  Owners must end up with the forces of the single-domain oracle; energies and dV/dlambda summed over
-    the ranks must equal the single-domain ones."""
+    list, two streams, x -> xq per locality, fused cluster kernels, force reduction per locality.  The halo moves
+      * peer_copy=True: through the library's in-process peer-copy transport, every rank on its own host thread calling the C++ step
+        halo_gpu_domain_force_step `repeats` times back to back with no host synchronisation in between (include/halo_hip.h);
+      * rccl=True, ONE rank that is its own neighbour: through the real RCCL transport, same C++ step;
+      * else: through the tensor-index test double and the schedule spelled out in Python.
+    Owners must end up with the forces of the single-domain oracle; energies and dV/dlambda summed over the ranks must equal the
+    single-domain ones."""
     import importlib
     import torch
     domdec = importlib.import_module("gromacs_fep_gpu_amd.domdec")
@@ -625,13 +629,28 @@ def _check_virtual_rank_decomposition(c, ncells, oracle_threads=1, self_links=(F
                           + system.grid.xq.reshape(-1, 4) * np.array([0, 0, 0, 1], np.float32), pkg.LOCAL)
         nb.copy_xq_to_gpu(np.full((system.grid.num_atoms, 4), 1.0e5, np.float32) * np.array([1, 1, 1, 0], np.float32)
                           + system.grid.xq.reshape(-1, 4) * np.array([0, 0, 0, 1], np.float32), pkg.NONLOCAL)
-        halo = domdec.RcclHalo(pkg, None, 0, 1, nb.stream(pkg.NONLOCAL)) if rccl else domdec.TensorHalo(peers={})
+        if peer_copy:
+            if r == 0:
+                peer_id = domdec.new_halo_id(pkg, domdec.TRANSPORT_PEER_COPY)
+            halo = domdec.RcclHalo(pkg, None, r, dd.num_ranks, nb.stream(pkg.NONLOCAL), unique_id=peer_id)
+        elif rccl:
+            halo = domdec.RcclHalo(pkg, None, 0, 1, nb.stream(pkg.NONLOCAL))
+        else:
+            halo = domdec.TensorHalo(peers={})
         st = domdec.DomainStep(pkg, nb, system, halo)
         st.d_x[plan.num_home:] = 1.0e5
         steps.append(st)
         halos.append(halo)
     torch.cuda.synchronize()
-    for repeat in range(2):                 # the second pass runs on the pruned lists and the swapped force buffers
+    if peer_copy:
+        def rank_thread(st):
+            def run():
+                for _ in range(repeats):        # back to back: no event, no host synchronisation between the steps
+                    st.step(sw)
+            return run
+        domdec.run_ranks_in_threads([rank_thread(st) for st in steps])
+        torch.cuda.synchronize()
+    for repeat in range(0 if peer_copy else repeats):     # the second pass runs on the pruned lists and the swapped force buffers
         if rccl:
             steps[0].step(sw)
         else:
@@ -676,6 +695,40 @@ def test_domain_decomposition_virtual_ranks(ncells):
     _check_virtual_rank_decomposition(tl.make_case(nm=nm, num_perturbed_molecules=3, elec="ewald", seed=78), ncells)
 
 
+@pytest.mark.parametrize("ncells", [(2, 1, 1), (3, 1, 1), (2, 2, 1), (2, 2, 2)])
+@pytest.mark.parametrize("parts", [1, 2])
+def test_cpp_domain_step_with_real_peers_over_the_peer_copy_transport(ncells, parts, monkeypatch):
+    """halo_gpu_domain_force_step — the C++ step, not the Python schedule — with peers other than itself: 2 to 8 ranks on this one
+    GPU, each on its own host thread, exchanging through the library's in-process peer-copy transport (per-peer offsets, the
+    event handshake, both streams of every rank, the local launch whole and in two parts: small domains have lists too short for
+    two sets, so part 2 is empty there).  Three steps back to back without host synchronisation."""
+    monkeypatch.setenv("HALO_GPU_LOCAL_PARTS", str(parts))
+    nm = (14, 8, 8) if ncells[0] == 3 else (10, 10, 10)
+    _check_virtual_rank_decomposition(tl.make_case(nm=nm, num_perturbed_molecules=3, elec="ewald", seed=78), ncells, peer_copy=True, repeats=3)
+
+
+@pytest.mark.parametrize("energy", [False, True])
+def test_cpp_domain_step_peer_copy_96k_box_two_part_launch(energy, monkeypatch):
+    """2 x 2 x 2 ranks of the 96k box over the peer-copy transport: 12k home atoms per rank; and 2 x 1 x 1, where the local lists are
+    long enough for the two-part launch to really cut them in two."""
+    monkeypatch.setenv("HALO_GPU_LOCAL_PARTS", "2")
+    c = tl.make_case(nm=(40, 40, 20), num_perturbed_molecules=16, elec="ewald", seed=2026, max_cjpacked_per_sci=16)
+    _check_virtual_rank_decomposition(c, (2, 1, 1), oracle_threads=8, peer_copy=True, repeats=3, energy=energy)
+    if not energy:
+        _check_virtual_rank_decomposition(c, (2, 2, 2), oracle_threads=8, peer_copy=True, repeats=2, energy=energy)
+
+
+@pytest.mark.parametrize("self_links", [(True, True, True)])
+def test_cpp_domain_step_back_to_back_without_host_synchronisation(self_links):
+    """Three halo_gpu_domain_force_step calls with coordinatesReadyEvent NULL and nothing between them, over the real RCCL groups (one
+    rank that is its own neighbour) and over the peer-copy transport: round 2 received the force halo in the buffer the next step's
+    pack kernel writes (on another stream), so the home rows could pick up packed coordinates; the forces now arrive in a buffer of
+    their own.  Home forces against the oracle after the third step."""
+    c = tl.make_case(nm=(10, 10, 10), num_perturbed_molecules=3, elec="ewald", seed=79)
+    _check_virtual_rank_decomposition(c, (1, 1, 1), self_links=self_links, rccl=True, repeats=3)
+    _check_virtual_rank_decomposition(c, (1, 1, 1), self_links=self_links, peer_copy=True, repeats=3)
+
+
 @pytest.mark.parametrize("self_links", [(True, False, False), (True, True, True)])
 def test_halo_exchange_over_rccl_with_a_rank_that_is_its_own_neighbour(self_links):
     """The RCCL transport of include/halo_hip.h on ONE GPU: a single rank whose periodic images are its halo (ncclSend / ncclRecv
@@ -709,6 +762,8 @@ def test_full_size_properties_1m():
     tl.assert_parity(fused, want, rel=1e-4, label="1M fused")
     tl.assert_parity(split, want, rel=1e-4, label="1M split")
     _check_virtual_rank_decomposition(c, (2, 2, 2), oracle_threads=8)
+    # and through the C++ step with real peers (in-process peer-copy transport, one host thread per rank, two-part local launch)
+    _check_virtual_rank_decomposition(c, (2, 2, 2), oracle_threads=8, peer_copy=True, repeats=2, energy=False)
 
 
 def test_work_partition_with_unequal_shares_covers_the_list_once():
