@@ -102,6 +102,7 @@ HIP_SYMBOLS = [
     "nbnxm_gpu_setup_short_range_work", "nbnxm_gpu_force_reduction_reinit", "nbnxm_gpu_force_reduction_execute",
     "nbnxm_gpu_halo_pack_x", "nbnxm_gpu_halo_unpack_f", "nbnxm_gpu_force_reduction_execute_range", "nbnxm_hip_query_launch_shape",
     "nbnxm_gpu_set_local_launch_parts", "nbnxm_gpu_launch_kernel_part", "nbnxm_hip_query_launch_plan",
+    "nbnxm_gpu_set_merged_localities", "nbnxm_gpu_get_merged_localities",
 ]
 HALO_SYMBOLS = [
     "halo_gpu_get_unique_id", "halo_gpu_get_unique_id_ex", "halo_gpu_create", "halo_gpu_free", "halo_gpu_last_error", "halo_gpu_reinit",
@@ -524,6 +525,10 @@ class NbnxmGpu:
     def set_local_launch_parts(self, num_parts, first_part_fraction=0.65):
         """nbnxm_gpu_set_local_launch_parts: the local list partitioned for a launch in two parts (domain decomposition)"""
         self._lib.nbnxm_gpu_set_local_launch_parts(self.h, C.c_int(num_parts), C.c_float(first_part_fraction))
+
+    def set_merged_localities(self, merged=True):
+        """nbnxm_gpu_set_merged_localities: before the lists are uploaded"""
+        self._lib.nbnxm_gpu_set_merged_localities(self.h, C.c_int(1 if merged else 0))
 
     def launch_kernel_part(self, step_work, part, iloc=LOCAL):
         self._lib.nbnxm_gpu_launch_kernel_part(self.h, C.byref(step_work), C.c_int(iloc), C.c_int(part))

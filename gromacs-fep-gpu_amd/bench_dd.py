@@ -18,7 +18,40 @@ def parse_grid(text, world, box=None, rcomm=1.2):
     return domdec.default_grid(world, box, rcomm)
 
 
-def measure(args, rank, world, dist, torch, nm, npert, reduce_device, steps, warmup, grid_text=None):
+def step_parity(pkg, wl, case_args, st, plan, rank, world, dist, torch, reduce_device):
+    """Validates the exchange, not only times it: after one step of the decomposed box, every rank's home forces against the forces
+    of the SAME box evaluated as a single domain on rank 0's GPU (same kernels, fused mode), broadcast over the process group.
+    Per atom |delta f| <= 1e-4 max(|f|, rms |f|) — the bar of the parity tests; both sides are fp32 sums in different orders.
+    Also Newton's third law over all ranks.  Returns {"max_err_over_tolerance", "net_force_over_rms", "ok"} on rank 0."""
+    f_home = torch.from_numpy(st.home_forces().astype(np.float64)).to(reduce_device)
+    natoms = int(case_args["natoms"])
+    f_ref = torch.zeros((natoms, 3), dtype=torch.float64, device=reduce_device)
+    if rank == 0:
+        c = wl.make_case(build_lists=True, **case_args["make_case"])
+        got = wl.run_gpu(c, energy=False, fused=True)
+        g = c.grid
+        real = g.atomIndices >= 0
+        ref = np.zeros((natoms, 3))
+        ref[g.atomIndices[real]] = got["f"][real]
+        f_ref = torch.from_numpy(ref).to(reduce_device)
+    if world > 1:
+        dist.broadcast(f_ref, 0)
+    mine = f_ref[torch.from_numpy(np.asarray(plan.home, np.int64)).to(reduce_device)]
+    frms = float(torch.sqrt(torch.mean(torch.sum(f_ref ** 2, dim=1))).item())
+    err = torch.sqrt(torch.sum((f_home - mine) ** 2, dim=1))
+    tol = 1e-4 * torch.clamp(torch.sqrt(torch.sum(mine ** 2, dim=1)), min=frms)
+    worst = torch.max(err / tol).reshape(1)
+    net = torch.sum(f_home, dim=0)
+    if world > 1:
+        dist.all_reduce(worst, op=dist.ReduceOp.MAX)
+        dist.all_reduce(net)
+    net_over_rms = float(torch.max(torch.abs(net)).item()) / (frms * np.sqrt(natoms))
+    return {"max_err_over_tolerance": float(worst.item()), "net_force_over_rms_sqrt_n": net_over_rms,
+            "ok": bool(worst.item() <= 1.0 and net_over_rms <= 1e-3),
+            "how": "home forces of every rank after one decomposed step against the same box as a single domain on rank 0 (1e-4 of max(|f_i|, rms |f|)); sum of all forces"}
+
+
+def measure(args, rank, world, dist, torch, nm, npert, reduce_device, steps, warmup, grid_text=None, check_parity=False):
     """A step = halo x (pack, RCCL send / receive) on the non-local stream beside the local kernel, x -> xq per locality, local
     and non-local fused cluster kernels, forces to atom order per locality, halo f.  Returns the record of the leg (rank 0) —
     pair interactions of the WHOLE system per second (strong scaling)."""
@@ -37,12 +70,21 @@ def measure(args, rank, world, dist, torch, nm, npert, reduce_device, steps, war
     system = domdec.RankSystem(pkg, plan, case.sys["box"], case.sys["qA"], case.sys["qB"], case.sys["typeA"], case.sys["typeB"], case.ntype,
                                case.sys["molId"], case.rlist, perturbed=case.perturbed, max_cjpacked_per_sci=args.max_cjpacked_per_sci)
     t_lists = time.time() - t0
-    nb = domdec.make_rank_gpu(pkg, wl, case, system, use_dynamic_pruning=not args.no_prune)
+    # merged localities (default): one device list, one cluster-kernel launch and one stream per rank and step;
+    # BENCH_DD_MERGED=0: the reference's two-locality, two-stream schedule
+    merged = os.environ.get("BENCH_DD_MERGED", "1") != "0"
+    nb = domdec.make_rank_gpu(pkg, wl, case, system, use_dynamic_pruning=not args.no_prune, merged=merged)
     nb.set_timing(False)
-    halo = domdec.RcclHalo(pkg, dist, rank, world, nb.stream(pkg.NONLOCAL))
+    halo = domdec.RcclHalo(pkg, dist, rank, world, nb.stream(pkg.LOCAL if merged else pkg.NONLOCAL))
     st = domdec.DomainStep(pkg, nb, system, halo)
     sw = pkg.step_workload(energy=False, virial=False, dhdl=False)
-    for _ in range(1 + warmup):
+    st.step(sw)
+    parity = None
+    if check_parity:
+        parity = step_parity(pkg, wl, dict(natoms=case.natoms, make_case=dict(nm=nm, num_perturbed_molecules=npert, elec="ewald", seed=2026,
+                                                                                 n_lambda=11, max_cjpacked_per_sci=args.max_cjpacked_per_sci)),
+                             st, plan, rank, world, dist, torch, reduce_device)
+    for _ in range(warmup):
         st.step(sw)
     torch.cuda.synchronize()
     pairs = 0
@@ -68,9 +110,11 @@ def measure(args, rank, world, dist, torch, nm, npert, reduce_device, steps, war
                "domain_grid": "%dx%dx%d" % ncells, "atoms": int(case.natoms), "cluster_pairs_all_ranks": int(tot[0].item()),
                "halo_atoms_per_rank_mean": float(tot[1].item()) / world, "home_atoms_per_rank_mean": float(tot[2].item()) / world,
                "halo_bytes_sent_and_received_rank0_per_step": halo.bytes_per_step(), "transport": "RCCL ncclSend/ncclRecv groups (halo_hip.h)",
-               "local_launch": ("two parts, the second behind the non-local kernel (HALO_GPU_LOCAL_PARTS)" if world > 1 and os.environ.get("HALO_GPU_LOCAL_PARTS", "2") == "2"
+               "schedule": ("merged localities: one list, one launch, one stream per rank" if merged else "two localities on two streams"),
+               "local_launch": ("one launch" if merged else
+                                "two parts, the second behind the non-local kernel (HALO_GPU_LOCAL_PARTS)" if world > 1 and os.environ.get("HALO_GPU_LOCAL_PARTS", "2") == "2"
                                 else "one launch"),
-               "host_plan_s": t_plan, "host_rank_lists_s": t_lists}
+               "host_plan_s": t_plan, "host_rank_lists_s": t_lists, "parity_of_first_step": parity}
     halo.free()
     nb.free()
     return rec

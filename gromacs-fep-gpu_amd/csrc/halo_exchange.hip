@@ -159,6 +159,13 @@ __global__ void domainHaloRowsKernel(float3* __restrict__ f, const float3* __res
     f[i] = (i < numHome) ? make_float3(0.0F, 0.0F, 0.0F) : nbnxmForce[cell[i]];
 }
 
+/* merged localities: ONE cluster kernel has written every force of the domain, so one pass moves home and halo rows to atom order */
+__global__ void domainAllRowsKernel(float3* __restrict__ f, const float3* __restrict__ nbnxmForce, const int* __restrict__ cell, const int numAtoms)
+{
+    const int i = static_cast<int>(blockIdx.x * blockDim.x + threadIdx.x);
+    if (i < numAtoms) { f[i] = nbnxmForce[cell[i]]; }
+}
+
 __global__ void domainHomeRowsKernel(float* __restrict__ f, const float3* __restrict__ nbnxmForce, const int* __restrict__ cell,
                                      const int numHome, const float3* __restrict__ received, const int* __restrict__ sendMap,
                                      const int numReceived)
@@ -741,7 +748,8 @@ void halo_gpu_domain_force_step(HaloGpu* h, NbnxmGpu* nb, const nbnxm_step_workl
 {
     hipStream_t sLocal    = static_cast<hipStream_t>(nbnxm_gpu_get_stream(nb, NBNXM_LOCAL));
     hipStream_t sNonLocal = static_cast<hipStream_t>(nbnxm_gpu_get_stream(nb, NBNXM_NONLOCAL));
-    NBNXM_ASSERT(sNonLocal == h->stream, "the halo object must have been created on the non-local stream of the non-bonded object");
+    NBNXM_ASSERT(sNonLocal == h->stream || nbnxm_gpu_get_merged_localities(nb),
+                 "the halo object must have been created on the non-local stream of the non-bonded object");
     /* the halo coordinates leave first: the pack and the RCCL kernel find the device idle at the start of a step; queued behind the
      * local kernel — which fills every wave slot — the RCCL kernel would wait for slots, and the peers with it (on one GPU the order
      * makes no difference: 0.141 ms either way) */
@@ -766,6 +774,45 @@ void halo_gpu_domain_force_step(HaloGpu* h, NbnxmGpu* nb, const nbnxm_step_workl
      * (read at halo_gpu_create: HALO_GPU_LOCAL_PARTS=1 / 2 switches it off / on — the default is on with more than one rank, where the
      * exchanges cross xGMI —, HALO_GPU_LOCAL_PART_FRACTION sets L1's share of the local work).  Lists too short for two sets of
      * one range per wave slot run as one launch. */
+    if (nbnxm_gpu_get_merged_localities(nb))
+    {
+        /* Merged localities (nbnxm_gpu_set_merged_localities): ONE cluster-kernel launch evaluates home x home and home x halo, and
+         * the whole step is ONE stream — the object's, which must then be nb's LOCAL stream:
+         *     pack -> halo x -> x to xq (all slots, one kernel) -> clear (a pointer swap) -> merged kernel -> all rows of f to atom order
+         *     -> halo f -> f_home += received
+         * Measured on one GPU (96k home + 46k halo atoms, rocprofv3 kernel trace, profiles/r03): the two-stream schedule queues ~25 HIP
+         * calls per step, a third of them event records and waits, and is bound by the host (0.10-0.11 ms to queue, 0.127 ms per step)
+         * although its kernels need ~0.10 ms; every cross-stream dependency also costs the device a few microseconds of idle time.
+         * One stream needs no event at all and one x -> xq launch instead of two.  What it gives up is the overlap of the coordinate
+         * halo (~20 us: pack, transfer, x -> xq) with local pair work; what it gains besides is one start and drain of the machine per
+         * step instead of two or three (81 us for the two cluster kernels of this domain, 58 us as one list). */
+        NBNXM_ASSERT(h->stream == sLocal, "merged localities: the halo object must have been created on the LOCAL stream of the non-bonded object");
+        nbnxm_gpu_set_local_launch_parts(nb, 1, h->localPartFraction);
+        halo_gpu_communicate_coordinates(h, coordinatesReadyEvent);
+        tick(0);
+        nbnxm_gpu_clear_outputs(nb, stepWork->computeVirial);
+        tick(1);
+        nbnxm_gpu_x_to_nbat_x(nb, h->d_x, nullptr, NBNXM_LOCAL, 0, numSlots, 0);
+        tick(2);
+        nbnxm_gpu_launch_kernel(nb, stepWork, NBNXM_LOCAL);
+        tick(3);
+        NBNXM_ASSERT(nb->reductionAtomStart == 0 && nb->reductionNumAtoms >= numAtoms, "the cell map must cover home and halo atoms");
+        hipLaunchKernelGGL(domainAllRowsKernel, dim3((numAtoms + c_haloThreadsPerBlock - 1) / c_haloThreadsPerBlock), dim3(c_haloThreadsPerBlock), 0,
+                           sLocal, h->d_f, reinterpret_cast<const float3*>(nb->atdat->f), nb->cell, numAtoms);
+        NBNXM_HIP_CHECK(hipGetLastError());
+        tick(6);
+        h->recvBufConsumedRecorded = false; /* one stream: the reader of the receive buffer is ordered by the stream */
+        exchangeForces(h);
+        tick(7);
+        if (h->numSendAtoms > 0)
+        {
+            hipLaunchKernelGGL(haloUnpackForcesKernel<true>, dim3((h->numSendAtoms + c_haloThreadsPerBlock - 1) / c_haloThreadsPerBlock),
+                               dim3(c_haloThreadsPerBlock), 0, sLocal, reinterpret_cast<float*>(h->d_f), h->d_recvBuf, h->d_sendMap, h->numSendAtoms);
+            NBNXM_HIP_CHECK(hipGetLastError());
+        }
+        tick(8);
+        return;
+    }
     const bool twoParts = (h->localParts == 2 && (h->numSendAtoms > 0 || !h->recvPeer.empty()));
     nbnxm_gpu_set_local_launch_parts(nb, twoParts ? 2 : 1, h->localPartFraction);
     halo_gpu_communicate_coordinates(h, coordinatesReadyEvent);

@@ -718,11 +718,82 @@ void nbnxm_gpu_init_atomdata(NbnxmGpu* nb, int numAtoms, int numAtomsLocal, cons
     }
 }
 
+static void uploadPairlist(NbnxmGpu* nb, int iloc, int na_c, int nsci, const nbnxn_sci_t* sci, int ncjPacked, const nbnxn_cj_packed_t* cjPacked,
+                           int nexcl, const nbnxn_excl_t* excl);
+
+void nbnxm_gpu_set_merged_localities(NbnxmGpu* nb, int merged)
+{
+    NBNXM_ASSERT(nb->bUseTwoStreams || !merged, "an object with one locality has nothing to merge");
+    nb->mergedLocalities = merged != 0;
+}
+
+int nbnxm_gpu_get_merged_localities(const NbnxmGpu* nb)
+{
+    return nb->mergedLocalities ? 1 : 0;
+}
+
 void nbnxm_gpu_init_pairlist(NbnxmGpu* nb, int iloc, int na_c, int nsci, const nbnxn_sci_t* sci,
                              int ncjPacked, const nbnxn_cj_packed_t* cjPacked, int nexcl,
                              const nbnxn_excl_t* excl)
 {
     NBNXM_ASSERT(iloc == NBNXM_LOCAL || (iloc == NBNXM_NONLOCAL && nb->bUseTwoStreams), "bad locality");
+    if (!nb->mergedLocalities)
+    {
+        uploadPairlist(nb, iloc, na_c, nsci, sci, ncjPacked, cjPacked, nexcl, excl);
+        return;
+    }
+    /* Merged localities (nbnxm_gpu_set_merged_localities): the two lists of a domain become ONE device list, local entries first,
+     * launched once per step behind the coordinate halo.  A wave of the cluster kernel owns a balanced range of the list and the
+     * launch has one wave per wave slot, so two launches pay the start and the drain of the machine twice (measured: 81 us for the
+     * two kernels of a domain with 96k home and 46k halo atoms, 62 us for the same pairs as one list).  The caller keeps the
+     * reference's call sequence — gpu_init_pairlist(Local), then (NonLocal), pairlist.cpp:4450-4452 —: the local call uploads the
+     * local list (a domain without a halo is complete with it), the non-local call uploads both as one; the non-local device list
+     * stays empty, so its launches, prunes and copy-backs are no-ops. */
+    static const nbnxn_excl_t allOnes = [] {
+        nbnxn_excl_t e;
+        for (unsigned& w : e.pair) { w = 0xFFFFFFFFU; }
+        return e;
+    }();
+    if (iloc == NBNXM_LOCAL)
+    {
+        nb->mergeLocalSci.assign(sci, sci + nsci);
+        nb->mergeLocalCj.assign(cjPacked, cjPacked + ncjPacked);
+        nb->mergeLocalExcl.assign(excl, excl + nexcl);
+        uploadPairlist(nb, NBNXM_LOCAL, na_c, nsci, sci, ncjPacked, cjPacked, nexcl, excl);
+        uploadPairlist(nb, NBNXM_NONLOCAL, na_c, 0, nullptr, 0, nullptr, 1, &allOnes);
+        nb->numMergedLocalGroups = ncjPacked;
+        return;
+    }
+    const int nsciL = static_cast<int>(nb->mergeLocalSci.size()), ncjL = static_cast<int>(nb->mergeLocalCj.size()),
+              nexclL = static_cast<int>(nb->mergeLocalExcl.size());
+    std::vector<nbnxn_sci_t>       mSci(nb->mergeLocalSci);
+    std::vector<nbnxn_cj_packed_t> mCj(nb->mergeLocalCj);
+    std::vector<nbnxn_excl_t>      mExcl(nb->mergeLocalExcl);
+    mSci.reserve(nsciL + nsci);
+    mCj.reserve(ncjL + ncjPacked);
+    mExcl.reserve(nexclL + nexcl);
+    for (int i = 0; i < nsci; i++)
+    {
+        nbnxn_sci_t e = sci[i];
+        e.cjPackedBegin += ncjL;
+        e.cjPackedEnd += ncjL;
+        mSci.push_back(e);
+    }
+    for (int j = 0; j < ncjPacked; j++)
+    {
+        nbnxn_cj_packed_t g = cjPacked[j];
+        for (auto& im : g.imei) { im.excl_ind += nexclL; } /* entry 0 of either list is the all-ones mask: it stays one */
+        mCj.push_back(g);
+    }
+    mExcl.insert(mExcl.end(), excl, excl + nexcl);
+    uploadPairlist(nb, NBNXM_LOCAL, na_c, nsciL + nsci, mSci.data(), ncjL + ncjPacked, mCj.data(), nexclL + nexcl, mExcl.data());
+    uploadPairlist(nb, NBNXM_NONLOCAL, na_c, 0, nullptr, 0, nullptr, 1, &allOnes);
+    nb->numMergedLocalGroups = ncjL;
+}
+
+static void uploadPairlist(NbnxmGpu* nb, int iloc, int na_c, int nsci, const nbnxn_sci_t* sci, int ncjPacked, const nbnxn_cj_packed_t* cjPacked,
+                           int nexcl, const nbnxn_excl_t* excl)
+{
     NBNXM_ASSERT(na_c == c_clSize, "the pair list cluster size does not match the kernels (8)");
     gpu_plist*  d = nb->plist[iloc];
     hipStream_t s = nb->deviceStreams[iloc].stream;

@@ -89,6 +89,12 @@ struct NbnxmGpu
     int   localLaunchParts    = 1;
     float localPartFraction   = 0.65F;
     int   launchPartNow       = 0; /* 0: whole launch; 1 / 2: the part nbnxm_gpu_launch_kernel_part asked for */
+    /* nbnxm_gpu_set_merged_localities: the local and the non-local list of a domain as one device list (local entries first) */
+    bool                           mergedLocalities     = false;
+    int                            numMergedLocalGroups = 0; /* packed j-groups of the local part */
+    std::vector<nbnxn_sci_t>       mergeLocalSci;
+    std::vector<nbnxn_cj_packed_t> mergeLocalCj;
+    std::vector<nbnxn_excl_t>      mergeLocalExcl;
     bool debugLaunchShape       = false;     /* diagnostics: NBNXM_HIP_DEBUG_LAUNCH_SHAPE prints the first launch's workgroup shape */
     /* work partition (gpu_plist::work*): SIMDs of the device, smallest range worth a wave (NBNXM_HIP_MIN_GROUPS_PER_WAVE) */
     int numSimds          = 1024;

@@ -596,11 +596,14 @@ class DomainMdStep(DomainStep):
         self._x_ready = self.update.x_updated_event()
 
 
-def make_rank_gpu(pkg, wl, case, system, use_dynamic_pruning=True):
-    """the NbnxmGpu object of one domain: both localities, fused perturbed pairs, home + halo atom data"""
+def make_rank_gpu(pkg, wl, case, system, use_dynamic_pruning=True, merged=False):
+    """the NbnxmGpu object of one domain: both localities, fused perturbed pairs, home + halo atom data.  merged: the two lists as ONE
+    device list and one launch per step (nbnxm_gpu_set_merged_localities; the C++ step halo_gpu_domain_force_step knows the schedule)"""
     g = system.grid
     nb = pkg.NbnxmGpu(wl.gpu_interaction_params(case, use_dynamic_pruning), g.num_types, g.nbat_nbfp(case.sys["nbfp"]),
                       local_and_nonlocal=True, fep=True, n_lambda=case.n_lambda)
+    if merged:
+        nb.set_merged_localities(True)
     sig6 = case.sc_sigma ** 6
     nb.copy_fepparams(case.sc_alpha if case.sc_coul else 0.0, case.sc_alpha, case.sc_power, sig6, sig6 if case.sc_coul else 0.0,
                       case.lambda_coul, case.lambda_vdw, case.all_lambda, case.all_lambda)

@@ -81,7 +81,9 @@ void* halo_gpu_forces_ready_event(HaloGpu* h);
  * to the home rows (mdlib/sim_util.cpp:1783-1924).  nb: the domain's non-bonded object (include/nbnxm_hip.h) with both localities, its
  * cell map uploaded with nbnxm_gpu_force_reduction_reinit(nb, numAtoms, cell, 0, .) and its atom indices with
  * nbnxm_gpu_init_x_to_nbat_x; numHomeSlots / numSlots: grid slots of the home zone / of both zones; numAtoms: home + halo atoms.
- * h must have been created on nb's non-local stream.  coordinatesReadyEvent (hipEvent_t or NULL): the home rows of d_x have been
+ * h must have been created on nb's non-local stream — on its LOCAL stream when nb runs merged localities (nbnxm_gpu_set_merged_localities):
+ * the step is then one stream and one cluster-kernel launch, pack -> halo x -> x to xq -> kernel -> rows of f -> halo f -> add.
+ * coordinatesReadyEvent (hipEvent_t or NULL): the home rows of d_x have been
  * updated (UpdateConstrainGpu's xUpdatedOnDeviceEvent) — both streams wait for it before they read coordinates.  On return everything
  * is queued; the home rows of d_f are final on nb's local stream. */
 void halo_gpu_domain_force_step(HaloGpu* h, NbnxmGpu* nb, const nbnxm_step_workload_t* stepWork, int numHomeSlots, int numSlots, int numAtoms,

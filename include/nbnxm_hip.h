@@ -384,6 +384,16 @@ void  nbnxm_gpu_debug_graph_steps(NbnxmGpu* nb, const nbnxm_step_workload_t* ste
 void nbnxm_gpu_set_local_launch_parts(NbnxmGpu* nb, int numParts, float firstPartFraction);
 void nbnxm_gpu_launch_kernel_part(NbnxmGpu* nb, const nbnxm_step_workload_t* stepWork, int iloc, int part);
 
+/* MI355X extension for domain decomposition: the local and the non-local pair list of a domain as ONE device list.  The cluster
+ * kernel's launch has one wave per wave slot of the device, each with a balanced share of the list, so a second launch for the
+ * non-local list pays the start and the drain of the whole machine again (81 us for the two kernels of a 96k + 46k-atom domain
+ * against 62 us for the same pairs as one list).  Set before the lists are uploaded.  The reference's call sequence stays —
+ * gpu_init_pairlist(Local) then (NonLocal), pairlist.cpp:4450-4452; launches / prunes / copy-backs of both localities —: the
+ * non-local device list is empty and everything about it is a no-op, the local launch evaluates both and therefore needs the
+ * halo coordinates: queue it behind x -> xq of the halo slots (halo_gpu_domain_force_step does). */
+void nbnxm_gpu_set_merged_localities(NbnxmGpu* nb, int merged);
+int  nbnxm_gpu_get_merged_localities(const NbnxmGpu* nb);
+
 /* Host arithmetic only (no device call): the workgroup shape nbnxm_gpu_launch_kernel gives the cluster-pair kernel of a flavour —
  * waves per workgroup (4, 8 or 16: larger workgroups share one copy of the LDS tables when the LJ table of numTypes types is large),
  * resident waves per SIMD (5 or 4; < 4: the tables do not fit the 160 KB LDS and the launch aborts) and the LDS bytes per workgroup.

@@ -603,13 +603,15 @@ def test_halo_pack_unpack_kernels():
 
 
 def _check_virtual_rank_decomposition(c, ncells, oracle_threads=1, self_links=(False, False, False), rccl=False, energy=True, peer_copy=False,
-                                      repeats=2):
+                                      repeats=2, merged=False):
     """All ranks of a decomposition in one process on one GPU: per rank its own grid over home + halo atoms, local and non-local
     list, two streams, x -> xq per locality, fused cluster kernels, force reduction per locality.  The halo moves
       * peer_copy=True: through the library's in-process peer-copy transport, every rank on its own host thread calling the C++ step
         halo_gpu_domain_force_step `repeats` times back to back with no host synchronisation in between (include/halo_hip.h);
       * rccl=True, ONE rank that is its own neighbour: through the real RCCL transport, same C++ step;
       * else: through the tensor-index test double and the schedule spelled out in Python.
+    merged (C++ step only): the two lists of every rank as one device list, one cluster-kernel launch per step
+    (nbnxm_gpu_set_merged_localities).
     Owners must end up with the forces of the single-domain oracle; energies and dV/dlambda summed over the ranks must equal the
     single-domain ones."""
     import importlib
@@ -623,7 +625,8 @@ def _check_virtual_rank_decomposition(c, ncells, oracle_threads=1, self_links=(F
         plan = dd.plan(r)
         system = domdec.RankSystem(pkg, plan, c.sys["box"], c.sys["qA"], c.sys["qB"], c.sys["typeA"], c.sys["typeB"], c.ntype,
                                    c.sys["molId"], c.rlist, perturbed=c.perturbed)
-        nb = domdec.make_rank_gpu(pkg, wl, c, system, use_dynamic_pruning=True)
+        assert not merged or peer_copy or rccl, "the Python schedule launches the two localities separately"
+        nb = domdec.make_rank_gpu(pkg, wl, c, system, use_dynamic_pruning=True, merged=merged)
         # garbage in the xq buffer and in the halo rows of x: x -> xq and the halo exchange must supply everything
         nb.copy_xq_to_gpu(np.full((system.grid.num_atoms, 4), 1.0e5, np.float32) * np.array([1, 1, 1, 0], np.float32)
                           + system.grid.xq.reshape(-1, 4) * np.array([0, 0, 0, 1], np.float32), pkg.LOCAL)
@@ -632,9 +635,9 @@ def _check_virtual_rank_decomposition(c, ncells, oracle_threads=1, self_links=(F
         if peer_copy:
             if r == 0:
                 peer_id = domdec.new_halo_id(pkg, domdec.TRANSPORT_PEER_COPY)
-            halo = domdec.RcclHalo(pkg, None, r, dd.num_ranks, nb.stream(pkg.NONLOCAL), unique_id=peer_id)
+            halo = domdec.RcclHalo(pkg, None, r, dd.num_ranks, nb.stream(pkg.LOCAL if merged else pkg.NONLOCAL), unique_id=peer_id)
         elif rccl:
-            halo = domdec.RcclHalo(pkg, None, 0, 1, nb.stream(pkg.NONLOCAL))
+            halo = domdec.RcclHalo(pkg, None, 0, 1, nb.stream(pkg.LOCAL if merged else pkg.NONLOCAL))
         else:
             halo = domdec.TensorHalo(peers={})
         st = domdec.DomainStep(pkg, nb, system, halo)
@@ -693,6 +696,26 @@ def _check_virtual_rank_decomposition(c, ncells, oracle_threads=1, self_links=(F
 def test_domain_decomposition_virtual_ranks(ncells):
     nm = (14, 8, 8) if ncells[0] == 3 else (10, 10, 10)
     _check_virtual_rank_decomposition(tl.make_case(nm=nm, num_perturbed_molecules=3, elec="ewald", seed=78), ncells)
+
+
+@pytest.mark.parametrize("ncells", [(2, 1, 1), (3, 1, 1), (2, 2, 1), (2, 2, 2)])
+@pytest.mark.parametrize("energy", [False, True])
+def test_cpp_domain_step_merged_localities_with_real_peers(ncells, energy):
+    """The merged-localities schedule of halo_gpu_domain_force_step (one device list and one cluster-kernel launch per rank and step,
+    behind the coordinate halo) with 2 to 8 ranks over the peer-copy transport: three steps back to back, force-only (trailing
+    workgroups: perturbed pairs, rolling prune, buffer clear) and energy steps."""
+    nm = (14, 8, 8) if ncells[0] == 3 else (10, 10, 10)
+    _check_virtual_rank_decomposition(tl.make_case(nm=nm, num_perturbed_molecules=3, elec="ewald", seed=78), ncells, peer_copy=True, repeats=3,
+                                      merged=True, energy=energy)
+
+
+def test_cpp_domain_step_merged_localities_over_rccl_and_at_size():
+    """merged localities over the real RCCL groups (one rank that is its own neighbour along x, y, z), and 2 x 2 x 2 ranks of the 96k
+    box over the peer-copy transport"""
+    c = tl.make_case(nm=(10, 10, 10), num_perturbed_molecules=3, elec="ewald", seed=79)
+    _check_virtual_rank_decomposition(c, (1, 1, 1), self_links=(True, True, True), rccl=True, repeats=3, merged=True)
+    c = tl.make_case(nm=(40, 40, 20), num_perturbed_molecules=16, elec="ewald", seed=2026, max_cjpacked_per_sci=16)
+    _check_virtual_rank_decomposition(c, (2, 2, 2), oracle_threads=8, peer_copy=True, repeats=3, merged=True)
 
 
 @pytest.mark.parametrize("ncells", [(2, 1, 1), (3, 1, 1), (2, 2, 1), (2, 2, 2)])

@@ -1,5 +1,6 @@
 """One-GPU rehearsal of bench.py's domain-decomposition leg: ONE rank that is its own neighbour along x (self-links), the real RCCL
-transport, the real two-stream step, timed like the leg.  Numbers are for orientation only (a self-exchange is a device copy)."""
+transport (or, third argument "peer", the in-process peer-copy transport), the real two-stream step, timed like the leg.  Numbers are
+for orientation only (a self-exchange is a device copy).  usage: dd_single_gpu_probe.py [24k|96k|768k] [x|xyz] [rccl|peer] [two|merged]"""
 import importlib
 import json
 import os
@@ -28,9 +29,12 @@ t0 = time.time()
 system = domdec.RankSystem(pkg, plan, case.sys["box"], case.sys["qA"], case.sys["qB"], case.sys["typeA"], case.sys["typeB"], case.ntype,
                            case.sys["molId"], case.rlist, perturbed=case.perturbed)
 t_lists = time.time() - t0
-nb = domdec.make_rank_gpu(pkg, wl, case, system)
+merged = len(sys.argv) > 4 and sys.argv[4] == "merged"
+nb = domdec.make_rank_gpu(pkg, wl, case, system, merged=merged)
 nb.set_timing(False)
-halo = domdec.RcclHalo(pkg, None, 0, 1, nb.stream(pkg.NONLOCAL))
+transport = sys.argv[3] if len(sys.argv) > 3 else "rccl"
+uid = domdec.new_halo_id(pkg, domdec.TRANSPORT_PEER_COPY) if transport == "peer" else None
+halo = domdec.RcclHalo(pkg, None, 0, 1, nb.stream(pkg.LOCAL if merged else pkg.NONLOCAL), unique_id=uid)
 st = domdec.DomainStep(pkg, nb, system, halo)
 sw = pkg.step_workload()
 for _ in range(20):
@@ -43,7 +47,7 @@ for _ in range(n):
 ms_enqueue = 1e3 * (time.perf_counter() - t1) / n      # host time to queue a step (if it equals ms_per_step, the step is launch-bound)
 torch.cuda.synchronize()
 ms = 1e3 * (time.perf_counter() - t1) / n
-print(json.dumps({"atoms": case.natoms, "self_links": links, "home": plan.num_home, "halo": plan.num_halo, "ms_per_step": ms, "ms_host_enqueue_per_step": ms_enqueue,
+print(json.dumps({"atoms": case.natoms, "transport": transport, "merged_localities": merged, "self_links": links, "home": plan.num_home, "halo": plan.num_halo, "ms_per_step": ms, "ms_host_enqueue_per_step": ms_enqueue,
                   "host_plan_s": t_plan, "host_rank_lists_s": t_lists, "halo_bytes": halo.bytes_per_step()}))
 halo.free()     # (HALO_GPU_HOST_TIMING=1: prints the host time spent queueing each part of the step)
 nb.free()
