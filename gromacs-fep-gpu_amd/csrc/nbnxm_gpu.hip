@@ -376,6 +376,10 @@ NbnxmGpu* nbnxm_gpu_init(const nbnxm_interaction_params_t* ic, int numTypes, con
     {
         nb->fepMergedFused = (std::atoi(env) != 0);
     }
+    if (const char* env = std::getenv("NBNXM_HIP_ENERGY_TAIL"))
+    {
+        nb->energyTail = std::max(0, std::min(c_energyTailCompiled, std::atoi(env)));
+    }
     if (bFEP && nb->fepConcurrent)
     {
         for (int i = 0; i < (nb->bUseTwoStreams ? 2 : 1); i++)
@@ -1038,7 +1042,9 @@ void nbnxm_gpu_clear_outputs(NbnxmGpu* nb, int computeVirial)
     const int numWindow  = nb->scalarsDirty ? nb->numWindows * ad->windowSlotStride : 0;
     nb->scalarsDirty     = false;
     if (numFloat4 == 0 && numTail == 0 && numScalars == 0 && numWindow == 0 && !computeVirial) { return; } /* nothing to clear */
-    const int nblock = std::max(1, std::min(2048, (numFloat4 + 255) / 256));
+    /* (sized by the largest of the arrays: after a swap of the force buffers only the few thousand scalars are left) */
+    const int numMost = std::max(std::max(numFloat4, numScalars), std::max(computeVirial ? c_fshiftBlockFloats : 0, numWindow));
+    const int nblock  = std::max(1, std::min(2048, (numMost + 255) / 256));
     hipLaunchKernelGGL(nbnxmClearOutputsKernel, dim3(nblock), dim3(256), 0, s, reinterpret_cast<float4*>(ad->f), numFloat4,
                        reinterpret_cast<float*>(ad->f) + 4 * static_cast<size_t>(numFloat4), numTail, nb->scalarOutputs, numScalars,
                        reinterpret_cast<float*>(ad->fShift), computeVirial ? c_fshiftBlockFloats : 0, ad->windowSlots, numWindow);
@@ -1355,11 +1361,15 @@ void nbnxm_gpu_launch_kernel(NbnxmGpu* nb, const nbnxm_step_workload_t* stepWork
         {
             fatal(__FILE__, __LINE__, "nbnxm_gpu_launch_kernel", "no kernel for this electrostatics / VdW combination");
         }
-        if (energyFlavour) { flushPendingPrune(nb, iloc); } /* only the force flavour has trailing workgroups */
+        /* which trailing workgroups this flavour carries (the force flavours: all of them) */
+        const bool tailPruneAndClear = !energyFlavour || nb->energyTail >= 1;
+        const bool tailFep           = !energyFlavour || nb->energyTail >= 2;
+        if (!tailPruneAndClear) { flushPendingPrune(nb, iloc); }
         if (plist->workRangesDirty) { updateWorkPartition(nb, iloc); }
 
         /* force-only steps: the perturbed cluster pairs ride in trailing workgroups of the cluster kernel (nbnxm_kernel_impl.h) */
-        const bool mergeFep = fused && plist->numSlowPairs > 0 && nb->fepMergedFused && !energyFlavour && !wantForeign;
+        /* (foreign-lambda energies ride only with an energy flavour; a dH/dl step without energies keeps the kernel of its own) */
+        const bool mergeFep = fused && plist->numSlowPairs > 0 && nb->fepMergedFused && tailFep && (!wantForeign || energyFlavour);
         if (fused && plist->numSlowPairs > 0 && !mergeFep && !secondPartOnly)
         {
             /* (energy / dH/dl steps, or NBNXM_HIP_FEP_MERGED=0; force-only steps: trailing workgroups of the cluster kernel, below)
@@ -1436,7 +1446,7 @@ void nbnxm_gpu_launch_kernel(NbnxmGpu* nb, const nbnxm_step_workload_t* stepWork
         /* Only the LOCAL launch does it: with two localities both kernels add to the buffer in use, and the buffer being zeroed
          * is the one the previous step's kernels wrote — the local stream has to be behind the previous NON-LOCAL kernel too,
          * whatever the caller's copy-back / reduction schedule was (nonlocalKernelDone). */
-        if (nb->fDoubleBuffer && !energyFlavour && (3 * adat->numAtoms) % 4 == 0 && iloc == NBNXM_LOCAL && withTail)
+        if (nb->fDoubleBuffer && tailPruneAndClear && (3 * adat->numAtoms) % 4 == 0 && iloc == NBNXM_LOCAL && withTail)
         {
             if (nb->bUseTwoStreams && nb->nonlocalKernelRecorded)
             {
@@ -1465,7 +1475,7 @@ void nbnxm_gpu_launch_kernel(NbnxmGpu* nb, const nbnxm_step_workload_t* stepWork
                                adat->atomTypes, adat->ljComb, reinterpret_cast<const unsigned*>(adat->fepBits),
                                plist->workRangeStart[p] + set * setRanges, plist->workFirstSci[p] + set * setRanges, setRanges, plist->groupSlowMask,
                                tail ? mergedFepItems : 0, std::max(plist->rollingPruningNumParts, 1), prunePart, tail ? pruneEntries : 0,
-                               reinterpret_cast<float4*>(nb->fSpare), tail ? clearNumFloat4 : 0);
+                               reinterpret_cast<float4*>(nb->fSpare), tail ? clearNumFloat4 : 0, (wantForeign && energyFlavour) ? nb->n_lambda : -1);
             NBNXM_HIP_CHECK(hipGetLastError());
         }
         if (nb->bDoTime) { t.nb_k.closeTimingRegion(s); }

@@ -177,6 +177,13 @@ constexpr int c_ewaldCorrTabSize = 2048;
 constexpr int c_coulombTabMaxLds = 16384; /* entries of the r-indexed table that the tabulated flavours stage into LDS (64 KB) */
 /* waves per workgroup of nbnxmFepClusterKernel */
 constexpr int c_fepClusterWavesPerBlockDef = 4;
+/* What the ENERGY flavours of the cluster kernel carry in trailing workgroups (the force flavours carry everything): 0 nothing,
+ * 1 a pending rolling-prune part and the clear of the spare force buffer, 2 also the perturbed cluster pairs (fused mode, not on
+ * dH/dlambda steps with foreign lambdas).  Compile-time ceiling; NBNXM_HIP_ENERGY_TAIL lowers it at run time. */
+#ifndef NBNXM_ENERGY_TAIL
+#define NBNXM_ENERGY_TAIL 2
+#endif
+constexpr int c_energyTailCompiled = NBNXM_ENERGY_TAIL;
 constexpr unsigned c_clearFloat4PerThread = 4; /* trailing clear workgroups of the cluster kernel: float4 stores per thread */
 
 /* nbnxm/gpu_types_common.h:297-341 */

@@ -297,7 +297,10 @@ __launch_bounds__(c_nbMaxBlockSize) __attribute__((amdgpu_waves_per_eu(c_nbWaves
                          const int pruneEntries,
                          /* force flavour: the spare force buffer, zeroed by the last trailing workgroups (or 0 float4) */
                          float4* __restrict__ clearF4,
-                         const int clearNumFloat4)
+                         const int clearNumFloat4,
+                         /* energy flavour, dH/dlambda step: the perturbed cluster pairs of the trailing workgroups also accumulate their energies
+                          * at lambda indices 0 .. mergedFepForeignLambdas (the FOREIGN flavour of fepClusterPair); -1: not such a step */
+                         const int mergedFepForeignLambdas)
 {
     constexpr bool LJ_EWALD    = VdwTraits<VDW>::ljEwald;
     constexpr bool EXCL_FORCES = (ELEC != ELK_CUT) || ENERGY || LJ_EWALD; /* nbnxm_cuda_kernel.cuh:69-78 */
@@ -329,7 +332,11 @@ __launch_bounds__(c_nbMaxBlockSize) __attribute__((amdgpu_waves_per_eu(c_nbWaves
     constexpr bool EWALD_R_TABLE = (ELEC == ELK_EWALD_TAB);
     const int      rTabBytes     = EWALD_R_TABLE ? __builtin_amdgcn_readfirstlane(coulombTabLdsBytes(nbp.coulombTabSize)) : 0;
     float2*   nbfpLds    = reinterpret_cast<float2*>(nbLds + c_ewaldTabBytes + rTabBytes);
-    if constexpr (!ENERGY)
+    /* energy flavours (NBNXM_ENERGY_TAIL, nbnxm_hip_types.h): 0 no trailing workgroups; 1 rolling prune and buffer clear; 2 also the
+     * perturbed cluster pairs with their energies and dV/dlambda */
+    constexpr bool TAIL     = !ENERGY || (NBNXM_ENERGY_TAIL >= 1);
+    constexpr bool TAIL_FEP = FUSED && (!ENERGY || (NBNXM_ENERGY_TAIL >= 2));
+    if constexpr (TAIL)
     {
         /* Trailing workgroups, behind the ones of the ranges.  The dispatcher hands workgroups out in order, so their waves start
          * as the ranges' waves retire and run in the wave slots — and issue slots — that the end of the kernel leaves idle (one
@@ -346,7 +353,7 @@ __launch_bounds__(c_nbMaxBlockSize) __attribute__((amdgpu_waves_per_eu(c_nbWaves
             /* the rolling-prune waves first: they are the longer chains (a loop over the entry's j-groups); the perturbed-pair
              * waves are short and fill what is left */
             const unsigned pruneBlocks = (static_cast<unsigned>(pruneEntries) + wavesPerBlock - 1U) / wavesPerBlock;
-            const unsigned fepBlocks   = FUSED ? (static_cast<unsigned>(mergedFepItems) + wavesPerBlock - 1U) / wavesPerBlock : 0U;
+            const unsigned fepBlocks   = TAIL_FEP ? (static_cast<unsigned>(mergedFepItems) + wavesPerBlock - 1U) / wavesPerBlock : 0U;
             if (blockIdx.x < mainBlocks + pruneBlocks)
             {
                 const int idx   = __builtin_amdgcn_readfirstlane(static_cast<int>((blockIdx.x - mainBlocks) * wavesPerBlock + wave));
@@ -355,7 +362,7 @@ __launch_bounds__(c_nbMaxBlockSize) __attribute__((amdgpu_waves_per_eu(c_nbWaves
             }
             else if (blockIdx.x < mainBlocks + pruneBlocks + fepBlocks)
             {
-                if constexpr (FUSED)
+                if constexpr (TAIL_FEP)
                 {
                     if constexpr (VdwTraits<VDW>::useTable)
                     {
@@ -365,8 +372,16 @@ __launch_bounds__(c_nbMaxBlockSize) __attribute__((amdgpu_waves_per_eu(c_nbWaves
                     const int item = __builtin_amdgcn_readfirstlane(static_cast<int>((blockIdx.x - mainBlocks - pruneBlocks) * wavesPerBlock + wave));
                     if (item < mergedFepItems)
                     {
-                        fepClusterPair<ELEC, TWIN, VDW, false, false>(atdat, nbp, plist, bCalcFshiftIn, cjPackedList, exclList, xq, ljComb, fepWords,
-                                                                      -1, item, nbfpLds);
+                        if (ENERGY && mergedFepForeignLambdas >= 0)
+                        {
+                            fepClusterPair<ELEC, TWIN, VDW, ENERGY, ENERGY>(atdat, nbp, plist, bCalcFshiftIn, cjPackedList, exclList, xq, ljComb,
+                                                                            fepWords, mergedFepForeignLambdas, item, nbfpLds);
+                        }
+                        else
+                        {
+                            fepClusterPair<ELEC, TWIN, VDW, ENERGY, false>(atdat, nbp, plist, bCalcFshiftIn, cjPackedList, exclList, xq, ljComb,
+                                                                           fepWords, -1, item, nbfpLds);
+                        }
                     }
                 }
             }
