@@ -37,7 +37,14 @@ DT_FS = 2.0                # MD time step for the kernel-bound ns/day figure
 METRIC = "ns/day + pair-interactions/s, 100k-atom FEP box @ λ=0.5, 1/2/4/8 MI355X"
 # molecules per box edge of the synthetic water boxes (3 atoms each): configs[1], configs[2], 8 x configs[2], configs[4]'s 1.02 M atoms
 BOXES = {"3k": (10, 10, 10), "24k": (20, 20, 20), "96k": (40, 40, 20), "768k": (80, 80, 40), "1m": (88, 88, 44)}
-COUNTERS_FILE = os.path.join("profiles", "r02", "counters_fused_force_kernel.json")   # written by tools/summarize_counters.py
+COUNTERS_FILE = os.path.join("profiles", "r03", "counters_fused_force_kernel.json")   # written by tools/summarize_counters.py
+# the two other roofs of the dominant kernel ("which roof"):
+PEAK_CLOCK_GHZ = 2.4                 # MI355X_MICROARCH.md; under this kernel's load the chip holds ~2.0 GHz
+VALU_CYCLES_PER_WAVE64_INSTRUCTION = 2   # SIMD-32 issues a wave64 VALU instruction over 2 cycles (quarter-rate ones take 8)
+NUM_SIMDS = 1024                     # 256 CUs x 4
+# memory-side float atomics: one 64-byte request per line an instruction touches, 13.5 ns per request and CU whatever the shape
+# (tools/ubench/atomic_shapes.hip, profiles/r03/ubench_atomic_shapes.txt; the guide's 1.3 TB/s of 256-byte instructions is the same rate)
+ATOMIC_REQUESTS_PER_S = 256 / 13.5e-9
 
 
 def parse_args(argv=None):
@@ -146,10 +153,11 @@ def host_cores():
 
 
 def algorithmic_bytes(stats, fused, fep_nri=0, fep_nrj=0):
-    """360 B per (sci, cj) entry + 2,832 B per sci entry (+ 768 B when the A/B
-    parameters of the i atoms are staged, fused kernel) + 128 B per exclusion-mask entry;
+    """SURVEY §8(d): 360 B per (sci, cj) entry + 2,832 B per sci entry + 128 B per exclusion-mask entry;
     the atom-pair FEP kernel: 64 B per pair + 68 B per i-entry."""
-    b = 360 * stats["cj_slots"] + (2832 + (768 if fused else 0)) * stats["nsci"] + 128 * stats["nexcl"]
+    # (2,832 B per sci for the fused kernel too: its main pass loads no A/B parameters per i atom — the perturbed cluster pairs are
+    # masked out of it —, so SURVEY's 3,600 B figure does not apply)
+    b = 360 * stats["cj_slots"] + 2832 * stats["nsci"] + 128 * stats["nexcl"]
     b_fep = 64 * fep_nrj + 68 * fep_nri
     return b, b_fep
 
@@ -167,6 +175,26 @@ def committed_counters(fused, args):
         return None
     rec["source"] = "%s (profiled at commit %s; not measured in this run)" % (COUNTERS_FILE, rec.get("commit", "?"))
     return rec
+
+
+def other_roofs(counters, kernel_us, hbm_frac):
+    """{"hbm_algorithmic", "valu_issue", "atomic_requests"}: fraction of each roof the dominant kernel reaches.  valu_issue is a LOWER
+    bound (2 cycles per instruction at the peak clock: the chip holds ~2.0 GHz under this load and a fifth of the instructions —
+    compares, selects, DPP adds, reciprocal square roots — issue at half or quarter rate; with the measured issue times the same
+    count gives ~0.8 at 96k atoms and ~0.95 at 1M atoms)."""
+    out = {"hbm_algorithmic": hbm_frac, "valu_issue": None, "atomic_requests": None, "binding": "valu_issue"}
+    if not counters or kernel_us <= 0:
+        return out
+    c = counters.get("counters", {})
+    t = kernel_us * 1e-6
+    if c.get("SQ_INSTS_VALU"):
+        out["valu_issue"] = c["SQ_INSTS_VALU"] * VALU_CYCLES_PER_WAVE64_INSTRUCTION / (NUM_SIMDS * PEAK_CLOCK_GHZ * 1e9 * t)
+        out["valu_instructions_per_launch"] = c["SQ_INSTS_VALU"]
+    if c.get("TCC_EA0_ATOMIC_sum"):
+        out["atomic_requests"] = c["TCC_EA0_ATOMIC_sum"] / (ATOMIC_REQUESTS_PER_S * t)
+        out["atomic_requests_per_launch"] = c["TCC_EA0_ATOMIC_sum"]
+    out["source"] = counters.get("source")
+    return out
 
 
 # ---- the ranks -------------------------------------------------------------------------------------------------------
@@ -447,7 +475,11 @@ def main(argv=None):
                      "kernel": "nbnxmKernel<%s,LJcut,F,%s>" % ("EwaldAna" if args.elec == "ewald" else "RF", "fused" if fused else "plain"),
                      "algorithmic_bytes_per_launch": bytes_nb,
                      "fp32_valu_frac_estimate": (pair_evals * 45.0 / (nb_k_us * 1e-6) / 1e12 / FP32_PEAK_TFLOPS)
-                     if nb_k_us > 0 else None},
+                     if nb_k_us > 0 else None,
+                     # the kernel's three roofs side by side: `frac` above (algorithmic bytes over the HBM peak, the contract's figure),
+                     # VALU issue and memory-side atomic requests — instruction and request counts per launch from the committed PMC
+                     # summary, divided by THIS run's kernel time
+                     "fractions": other_roofs(counters, nb_k_us, achieved / HBM_PEAK_GBS)},
         "counters": ({"lds_bank_conflict_frac": counters.get("lds_bank_conflict_frac"), "valu_issue_frac": counters.get("valu_issue_frac"),
                       "active_lanes_per_valu_instruction": counters.get("active_lanes_per_valu_instruction"),
                       "source": counters["source"]} if counters else None),

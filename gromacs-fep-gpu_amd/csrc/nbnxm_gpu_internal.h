@@ -99,7 +99,7 @@ struct NbnxmGpu
     bool debugLaunchShape       = false;     /* diagnostics: NBNXM_HIP_DEBUG_LAUNCH_SHAPE prints the first launch's workgroup shape */
     /* work partition (gpu_plist::work*): SIMDs of the device, smallest range worth a wave (NBNXM_HIP_MIN_GROUPS_PER_WAVE) */
     int numSimds          = 1024;
-    int minGroupsPerWave  = 2;
+    int minGroupsPerWave  = 1; /* (3k-atom box: 0.0156 -> 0.0133 ms per step with 1 instead of 2; larger boxes have more groups than wave slots anyway) */
     /* share of work per age class of the waves of a SIMD, [0]: 4 waves per SIMD, [1]: 5 (see WorkPartitionOut) */
     int waveClassShare[2][5] = { { 1024, 1024, 1024, 1024, 0 }, { 1100, 1060, 1024, 990, 946 } };
     int numWorkRangesOverride = 0; /* experiments: NBNXM_HIP_NUM_WORK_RANGES */

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Merges the rocprofv3 counter passes of the force-only fused cluster kernel (tools/gpu_pmc.sh fused --primary-only and
 tools/gpu_traffic.sh, each counter group in its own --pmc run as MI355X_MICROARCH.md prescribes) into ONE summary that
-bench.py quotes with its provenance: profiles/r02/counters_fused_force_kernel.json.
+bench.py quotes with its provenance: profiles/r03/counters_fused_force_kernel.json.
 
 usage: tools/summarize_counters.py <gpurun_out dir> <commit the profile was taken at> [out.json]"""
 import collections
@@ -16,7 +16,7 @@ import sys
 def main():
     src = sys.argv[1] if len(sys.argv) > 1 else "gpurun_out"
     commit = sys.argv[2] if len(sys.argv) > 2 else "?"
-    out = sys.argv[3] if len(sys.argv) > 3 else os.path.join("profiles", "r02", "counters_fused_force_kernel.json")
+    out = sys.argv[3] if len(sys.argv) > 3 else os.path.join("profiles", "r03", "counters_fused_force_kernel.json")
     want = re.compile(r"nbnxmKernel<\d+, (false|true), \d+, false, ")     # the force-only flavour
     acc = collections.defaultdict(list)
     kernel = None
