@@ -291,6 +291,37 @@ def test_two_part_launch_on_a_list_too_short_for_two_sets(fused):
     nb.free()
 
 
+@pytest.mark.parametrize("elec,vdw", [("ewald", "cut"), ("rf", "cut"), ("ewald", "fswitch"), ("ewald", "pswitch"), ("ewald_tab", "cut"), ("ewald", "ewald_geom")])
+@pytest.mark.parametrize("fused", [False, True])
+def test_excluded_atoms_on_top_of_each_other(elec, vdw, fused):
+    """Two EXCLUDED atoms at zero distance (a shell on its core; here hydrogens moved onto their oxygen, and one perturbed molecule
+    among them): the reference clamps r^2 to 3.82e-7 so that such pairs give no NaN (pairlist.h:166).  The force-only flavours of the
+    headline configurations have no clamp — their exclusion mask is a bit-wise AND that returns +0 for any masked value —, the others
+    keep it: every flavour must give finite forces equal to the oracle's, force-only and energy steps."""
+    c = tl.make_case(elec=elec, vdw=vdw, seed=91, **SMALL)
+    g = c.grid
+    xq = g.xq.reshape(-1, 4).copy()
+    xw = g.x_wrapped.copy()
+    real = np.flatnonzero(g.atomIndices >= 0)
+    slot_of = {int(g.atomIndices[s]): int(s) for s in real}
+    moved = 0
+    for mol in range(0, 60, 3):                      # 20 molecules incl. the perturbed ones (the first molecules of the box)
+        o, h = 3 * mol, 3 * mol + 1
+        if o in slot_of and h in slot_of:
+            xq[slot_of[h], :3] = xq[slot_of[o], :3]
+            xw[h] = xw[o]
+            moved += 1
+    assert moved >= 10
+    g.xq, g.x_wrapped = xq, xw
+    nb = tl.setup_gpu(c, fused=fused)
+    for energy in (False, True):
+        want = tl.run_oracle(c, energy=energy)
+        got = tl.run_gpu(c, energy=energy, fused=fused, nb=nb)
+        assert np.isfinite(got["f"]).all() and np.isfinite(want["f"]).all()
+        tl.assert_parity(got, want, rel=1e-4, energy=energy, label="coincident excluded atoms, energy=%s" % energy)
+    nb.free()
+
+
 def test_force_buffer_swap_and_pinning():
     """nbnxm_gpu_clear_outputs swaps to the force buffer that the last force-only kernel zeroed in its tail; an energy-step kernel has
     no tail (the next clear is a kernel again); nbnxm_gpu_get_f pins the buffer.  Every step of a mixed sequence must give the
