@@ -693,18 +693,27 @@ __launch_bounds__(c_nbMaxBlockSize) __attribute__((amdgpu_waves_per_eu(c_nbWaves
         {
             const unsigned laneG = laneIter;
             const unsigned wexcl = *reinterpret_cast<const unsigned*>(jData + c_jStageExclOffset + laneG * 4U);
+#ifndef NBNXM_J_FORCE_VGPR_OFFSET
+            /* The j-force add of a slot goes to f + cj * 96 bytes + (tidxj * 12 + tidxi * 4): the lane's part is the same for every
+             * slot of the group (computed once per group, from the lane id of this iteration), the cluster's part is wave-uniform and
+             * travels in the buffer instruction's SCALAR offset — no vector instruction per slot for the address (it took four, two of
+             * them half rate).  Lanes tidxi >= 3 carry an offset beyond the buffer: the hardware range check looks at the vector
+             * offset alone (raw buffers on gfx9: the scalar offset is not part of it), so they are dropped whatever the scalar offset. */
+            const int laneFjOff = ((laneG & 7U) < 3U) ? static_cast<int>((laneG >> 3) * 12U + (laneG & 7U) * 4U) : c_dropLane;
+#endif
 #pragma unroll
             for (int jm = 0; jm < c_jGroupSize; jm++)
             {
                 /* every slot ends in exactly one VMEM atomic: a skipped slot sends nothing (all lanes out of range) */
                 float          fjv    = 0.0F;
                 int            fjOff  = c_dropLane;
+                [[maybe_unused]] int fjSoff = 0;
                 const unsigned imaskJ = (imask >> (jm * c_numClPerSupercl)) & 0xFFU;
                 if (imaskJ != 0U)
                 {
                 const unsigned wexclJ = wexcl >> (jm * c_numClPerSupercl);
                 const int      cj     = (jm == 0) ? curA.x : ((jm == 1) ? curA.y : ((jm == 2) ? curA.z : curA.w));
-                const int      aj     = cj * c_clSize + static_cast<int>(tidxj);
+                [[maybe_unused]] const int aj = cj * c_clSize + static_cast<int>(tidxj);
                 const unsigned jAtom  = static_cast<unsigned>(jm) * c_clSize + (laneG >> 3);
                 const float4   xqj    = *reinterpret_cast<const float4*>(jData + jAtom * 16U);
                 int            typej  = 0;
@@ -734,7 +743,12 @@ __launch_bounds__(c_nbMaxBlockSize) __attribute__((amdgpu_waves_per_eu(c_nbWaves
 
                 /* j-force: sum over the 8 lanes of a j atom; lanes tidxi 0..2 carry x,y,z (96 contiguous bytes) */
                 fjv   = reduceXyzOver8Lanes(fcj_buf, laneG);
+#ifdef NBNXM_J_FORCE_VGPR_OFFSET /* round 2's form, kept for A/B runs */
                 fjOff = (tidxi < 3U) ? (3 * aj + static_cast<int>(tidxi)) * static_cast<int>(sizeof(float)) : c_dropLane;
+#else
+                fjOff  = laneFjOff;
+                fjSoff = cj * (c_clSize * 3 * static_cast<int>(sizeof(float)));
+#endif
 #if defined(NBNXM_TIMING_NO_J_ATOMIC) /* timing-only: the add keeps its instruction and its operands, every lane is dropped */
                 asm volatile("" : "+v"(fjv), "+v"(fjOff));
                 fjOff = c_dropLane;
@@ -743,7 +757,7 @@ __launch_bounds__(c_nbMaxBlockSize) __attribute__((amdgpu_waves_per_eu(c_nbWaves
 #ifdef NBNXM_TIMING_NO_J_INSTR
                 asm volatile("" ::"v"(fjv), "v"(fjOff));
 #else
-                __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(fjv, fRsrc, fjOff, 0, 0);
+                __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(fjv, fRsrc, fjOff, fjSoff, 0);
 #endif
             }
         }
