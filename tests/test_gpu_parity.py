@@ -634,7 +634,7 @@ def test_halo_pack_unpack_kernels():
 
 
 def _check_virtual_rank_decomposition(c, ncells, oracle_threads=1, self_links=(False, False, False), rccl=False, energy=True, peer_copy=False,
-                                      repeats=2, merged=False):
+                                      repeats=2, merged=False, reinit_between=False):
     """All ranks of a decomposition in one process on one GPU: per rank its own grid over home + halo atoms, local and non-local
     list, two streams, x -> xq per locality, fused cluster kernels, force reduction per locality.  The halo moves
       * peer_copy=True: through the library's in-process peer-copy transport, every rank on its own host thread calling the C++ step
@@ -681,6 +681,12 @@ def _check_virtual_rank_decomposition(c, ncells, oracle_threads=1, self_links=(F
             def run():
                 for _ in range(repeats):        # back to back: no event, no host synchronisation between the steps
                     st.step(sw)
+                if reinit_between:
+                    # a search step in the middle of the run: every rank re-registers its maps and buffers (halo_gpu_reinit) from its
+                    # own thread, at its own pace, while peers may still be copying out of its buffers; then more steps
+                    st.halo.reinit(st.sys.plan, st.d_x, st.d_f)
+                    for _ in range(repeats):
+                        st.step(sw)
             return run
         domdec.run_ranks_in_threads([rank_thread(st) for st in steps])
         torch.cuda.synchronize()
@@ -738,6 +744,15 @@ def test_cpp_domain_step_merged_localities_with_real_peers(ncells, energy):
     nm = (14, 8, 8) if ncells[0] == 3 else (10, 10, 10)
     _check_virtual_rank_decomposition(tl.make_case(nm=nm, num_perturbed_molecules=3, elec="ewald", seed=78), ncells, peer_copy=True, repeats=3,
                                       merged=True, energy=energy)
+
+
+@pytest.mark.parametrize("merged", [False, True])
+def test_cpp_domain_step_peer_copy_with_a_reinit_between_steps(merged):
+    """halo_gpu_reinit in the middle of a run (what every search step does), each rank from its own thread without any barrier: the
+    posts of the steps before carry their own snapshot of the sender's layout, so a rank that is still pulling step n is not confused
+    by a peer that has already re-registered for step n + 1."""
+    c = tl.make_case(nm=(10, 10, 10), num_perturbed_molecules=3, elec="ewald", seed=78)
+    _check_virtual_rank_decomposition(c, (2, 2, 1), peer_copy=True, repeats=2, merged=merged, reinit_between=True)
 
 
 def test_cpp_domain_step_merged_localities_over_rccl_and_at_size():
