@@ -276,6 +276,9 @@ struct HaloGpu
     hipEvent_t                        peerEvents[c_numPostKinds][c_peerRing] = {};
     long                              xSeq = 0, fSeq = 0; /* exchanges done so far */
     std::vector<void*>                retiredBuffers;     /* buffers a peer may still be copying from: freed with the object */
+    /* the peers of the exchanges BEFORE the last halo_gpu_reinit: a rank that is no longer a neighbour may still be copying out of
+     * this rank's buffers, so the first exchange after a reinit also waits for their "pulled" posts */
+    std::vector<int>                  formerSendPeer, formerRecvPeer;
     double                            peerTimeoutSeconds = 30.0;
 };
 
@@ -349,11 +352,15 @@ void peerExchangeCoordinates(HaloGpu* h)
     if (q > 0)
     {
         for (size_t k = 0; k < h->sendPeer.size(); k++) { peerWait(h, h->sendPeer[k], c_postXPulled, q - 1, s); }
+        for (int peer : h->formerSendPeer) { peerWait(h, peer, c_postXPulled, q - 1, s); }
     }
     if (h->fSeq > 0)
     {
         for (size_t k = 0; k < h->recvPeer.size(); k++) { peerWait(h, h->recvPeer[k], c_postFPulled, h->fSeq - 1, s); }
+        for (int peer : h->formerRecvPeer) { peerWait(h, peer, c_postFPulled, h->fSeq - 1, s); }
     }
+    h->formerSendPeer.clear();
+    h->formerRecvPeer.clear();
     if (h->numSendAtoms > 0)
     {
         hipLaunchKernelGGL(haloPackShiftedKernel, dim3((h->numSendAtoms + c_haloThreadsPerBlock - 1) / c_haloThreadsPerBlock),
@@ -552,6 +559,12 @@ void halo_gpu_reinit(HaloGpu* h, void* d_x, void* d_f, int numHome, int numSend,
     h->d_x     = static_cast<float3*>(d_x);
     h->d_f     = static_cast<float3*>(d_f);
     h->numHome = numHome;
+    if (h->world)
+    {
+        /* (every rank posts "pulled" for every exchange, neighbour or not, so waiting for a former peer cannot block for good) */
+        h->formerSendPeer.insert(h->formerSendPeer.end(), h->sendPeer.begin(), h->sendPeer.end());
+        h->formerRecvPeer.insert(h->formerRecvPeer.end(), h->recvPeer.begin(), h->recvPeer.end());
+    }
     h->sendPeer.assign(sendPeer, sendPeer + numSend);
     h->sendOffset.assign(sendOffset, sendOffset + numSend + 1);
     h->numSendAtoms = h->sendOffset[numSend];
