@@ -21,12 +21,14 @@
 
 constexpr int c_workBlockSize = 256;
 #ifndef NBNXM_WEIGHT_GROUP
-#define NBNXM_WEIGHT_SLOT 0
-#define NBNXM_WEIGHT_GROUP 34
-#define NBNXM_WEIGHT_ENTRY 60
+#define NBNXM_WEIGHT_SLOT 4
+#define NBNXM_WEIGHT_GROUP 16
+#define NBNXM_WEIGHT_ENTRY 128
 #endif
-/* refitted in round 2 (tools/calibrate_weights.py on the kernel of profiles/r02): the i-entry start got cheaper (lane-swap reduction of the
- * i-forces), the group relatively dearer; a non-empty slot no longer shows (round 1: 2 / 30 / 76; the fit says 0 / 38 / 41, measured best between the two: 0 / 34 / 60) */
+/* slot / group / i-entry start, relative to 8 per cluster pair.  Round 1: 2 / 30 / 76; round 2 (lane-swap reduction of the i-forces): 0 / 34 / 60;
+ * round 3 (tools/calibrate_weights.py on the kernel of profiles/r03: the pair block and the slot got cheaper — no clamp, no address arithmetic per
+ * slot —, which makes an entry start, with its i-atom loads and the transposed force write, relatively dearer): the fit says 4.4 / 15.4 / 127,
+ * and 4 / 16 / 128 measured 56.1 us against 56.9 - 57.9 us for 0 / 34 / 60 (2 / 24 / 96: 56.2; 0 / 34 / 120: 56.4 - 56.8) */
 constexpr int c_weightPair    = 8;
 constexpr int c_weightSlot    = NBNXM_WEIGHT_SLOT;
 constexpr int c_weightGroup   = NBNXM_WEIGHT_GROUP;

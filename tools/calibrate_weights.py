@@ -68,7 +68,7 @@ print("SIMDs %d; per-SIMD finish: mean %.1f std %.2f us; features per SIMD mean 
 print("fit: us per cluster pair %.5f, per slot %.5f, per group %.5f, per piece %.5f, per cluster pair with exclusion mask %.5f, const %.2f; "
       "residual std %.2f us" % (*coef, (y - pred).std()))
 w = coef[:5] / coef[0] * 8
-print("weights relative to 8 per cluster pair: slot %.1f group %.1f piece %.1f excl-pair %.1f (current 0 / 34 / 60 / 0)" % (w[1], w[2], w[3], w[4]))
+print("weights relative to 8 per cluster pair: slot %.1f group %.1f piece %.1f excl-pair %.1f (current 4 / 16 / 128 / 0)" % (w[1], w[2], w[3], w[4]))
 A4 = np.concatenate([X[:, :4], np.ones((len(uk), 1))], axis=1)
 c4 = np.linalg.lstsq(A4, y, rcond=None)[0]
 print("without the exclusion feature: residual std %.2f us" % (y - A4 @ c4).std())
@@ -84,7 +84,7 @@ order = np.argsort(end)[-200:]
 print("the 200 last waves: mean cluster pairs %.0f slots %.0f groups %.1f pieces %.2f empty %.2f; SIMD-mates' mean end %.1f" % (
     feat[order, 0].mean(), feat[order, 1].mean(), feat[order, 2].mean(), feat[order, 3].mean(), nempty[order].mean(),
     np.mean([end[(key == key[w_])].mean() for w_ in order])))
-cur = feat[:, :4] @ np.array([8, 0, 34, 60.0])
+cur = feat[:, :4] @ np.array([8, 4, 16, 128.0])
 print("current weight per wave: mean %.0f std %.1f (%.2f %%)" % (cur.mean(), cur.std(), 100 * cur.std() / cur.mean()))
 # a second launch of the same work: is a slow SIMD slow again?
 nb.clear_outputs(False); nb.launch_kernel(sw)
