@@ -130,6 +130,29 @@ NB_DEVINL float waveSum(float v)
     return v;
 }
 
+/* Four wave sums at the price of one and a half: a, b, c, d are transposed while they are reduced (as reduceXyzOver8Lanes does for
+ * three), so that lane l ends up with the sum of a (l & 3 == 0), b (1), c (2) or d (3) over all 64 lanes.  7 adds (5 DPP, 2 through the
+ * LDS crossbar) and 6 selects; four waveSum calls take 24 adds, 8 of them through the crossbar. */
+NB_DEVINL float waveSum4Transposed(const float a, const float b, const float c, const float d, const unsigned lane)
+{
+    const bool bit0 = (lane & 1U) != 0U;
+    const bool bit1 = (lane & 2U) != 0U;
+    float       ab     = bit0 ? b : a;
+    const float abGive = bit0 ? a : b;
+    ab += dppMove<0xB1>(abGive); /* lane ^ 1: even lanes a + a', odd lanes b + b' */
+    float       cd     = bit0 ? d : c;
+    const float cdGive = bit0 ? c : d;
+    cd += dppMove<0xB1>(cdGive); /* even lanes c + c', odd lanes d + d' */
+    float       v    = bit1 ? cd : ab;
+    const float give = bit1 ? ab : cd;
+    v += dppMove<0x4E>(give);  /* lane ^ 2: lane & 3 == 0: a over the quad, 1: b, 2: c, 3: d */
+    v += dppMove<0x124>(v);    /* row_ror:4 and row_ror:8 keep lane & 3: the four quads of a 16-lane row */
+    v += dppMove<0x128>(v);
+    v += __shfl_xor(v, 16);
+    v += __shfl_xor(v, 32);
+    return v;
+}
+
 /* ---- math ------------------------------------------------------------------------------------ */
 
 /* [d/dz (erf z / z)] / z as a function of z^2; definition as gmx::pmeForceCorrection

@@ -199,12 +199,8 @@ NB_DEVINL void fepClusterPair(const NBAtomDataGpu& atdat,
 
     if constexpr (ENERGY)
     {
-        E_lj    = waveSum(E_lj);
-        E_el    = waveSum(E_el);
-        DVDL_lj = waveSum(DVDL_lj);
-        DVDL_el = waveSum(DVDL_el);
         const int   slot = item & (c_numEnergySlots - 1);
-        const float v    = (lane == 0U) ? E_lj : ((lane == 1U) ? E_el : ((lane == 2U) ? DVDL_lj : DVDL_el));
+        const float v    = waveSum4Transposed(E_lj, E_el, DVDL_lj, DVDL_el, lane); /* lanes 0 .. 3: the four sums */
         if (lane < 4U) { atomicAdd(energySlots + slot * c_energySlotStride + static_cast<int>(lane), v); }
     }
 
@@ -234,15 +230,11 @@ NB_DEVINL void fepClusterPair(const NBAtomDataGpu& atdat,
                 fepPair<FEP_ELEC, VDW == VDK_PSWITCH, false, true>(nbp, Lf, r2, included, false, qq, c6AB, c12AB, fscal, fE_lj, fE_el, fDVDL_lj,
                                                                    fDVDL_el, c6gridAB);
             }
-            const float s0 = waveSum(fE_lj);
-            const float s1 = waveSum(fE_el);
-            const float s2 = waveSum(fDVDL_lj);
-            const float s3 = waveSum(fDVDL_el);
+            const float v = waveSum4Transposed(fE_lj, fE_el, fDVDL_lj, fDVDL_el, lane); /* lanes 0 .. 3: the four sums */
             if (lane < 4U)
             {
                 /* into this wave's accumulator slot (NBAtomDataGpu::foreignSlots): thousands of waves adding to the same
                  * 48 addresses serialise in L2 (measured +0.28 ms per dH/dl step) */
-                const float v    = (lane == 0U) ? s0 : ((lane == 1U) ? s1 : ((lane == 2U) ? s2 : s3));
                 float*      slot = foreignSlots + (item & (c_numForeignSlots - 1)) * atdat.foreignSlotStride;
                 if (v != 0.0F) { atomicAdd(slot + static_cast<int>(lane) * (numForeignLambda + 1) + fidx, v); }
             }
