@@ -43,3 +43,24 @@ def test_rank_count_mismatch_is_an_error():
     # a launcher that started 1 rank for --gpus 2 must not produce a line labelled 2
     p, lines = run_bench("--gpus", "2", env_extra={"RANK": "0", "WORLD_SIZE": "1", "LOCAL_RANK": "0"})
     assert p.returncode != 0 and not lines
+
+
+def test_decomposition_leg_state_is_at_the_top_level_of_the_line(capsys):
+    """A failed, timed-out or wrong (first step differs from the single-domain forces) decomposition leg must show as "dd_leg_ok": false
+    with its reason at the TOP level of the JSON line and on stderr — not only inside the nested record."""
+    sys.path.insert(0, ROOT)
+    import importlib
+    bench = importlib.import_module("bench")
+    out = {}
+    bench.mark_dd_leg(out, {"error": "no result within 150 s"})
+    assert out["dd_leg_ok"] is False and "150 s" in out["dd_leg_error"]
+    assert "DOMAIN-DECOMPOSITION LEG FAILED" in capsys.readouterr().err
+    out = {}
+    bench.mark_dd_leg(out, None)          # (a rank other than 0 hands None: never printed, but must not raise)
+    assert out["dd_leg_ok"] is False
+    out = {}
+    bench.mark_dd_leg(out, {"ms_per_step": 0.1, "parity_of_first_step": {"ok": False, "max_err_over_tolerance": 37.0}})
+    assert out["dd_leg_ok"] is False and "single-domain" in out["dd_leg_error"]
+    out = {}
+    bench.mark_dd_leg(out, {"ms_per_step": 0.1, "parity_of_first_step": {"ok": True, "max_err_over_tolerance": 0.01}})
+    assert out["dd_leg_ok"] is True and out["dd_leg_error"] is None
