@@ -13,6 +13,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -1470,12 +1471,20 @@ void nbnxm_gpu_launch_kernel(NbnxmGpu* nb, const nbnxm_step_workload_t* stepWork
                                                     + (clearNumFloat4 + clearChunk - 1) / clearChunk
                                           : 0);
             NBNXM_ASSERT(numBlocks > 0, "empty cluster-kernel launch");
+#ifdef NBNXM_HOST_LAUNCH_TIMING /* diagnostics: host microseconds inside hipLaunchKernelGGL of the cluster kernel */
+            static double s_us = 0; static long s_n = 0;
+            const auto t0_ = std::chrono::steady_clock::now();
+#endif
             hipLaunchKernelGGL(kernel, dim3(numBlocks), dim3(wavesPerBlock * c_waveSize), ldsBytes, s,
                                *adat, *nbp, *plist, stepWork->computeVirial, plist->sciSorted, plist->cjPacked, plist->excl, adat->xq,
                                adat->atomTypes, adat->ljComb, reinterpret_cast<const unsigned*>(adat->fepBits),
                                plist->workRangeStart[p] + set * setRanges, plist->workFirstSci[p] + set * setRanges, setRanges, plist->groupSlowMask,
                                tail ? mergedFepItems : 0, std::max(plist->rollingPruningNumParts, 1), prunePart, tail ? pruneEntries : 0,
                                reinterpret_cast<float4*>(nb->fSpare), tail ? clearNumFloat4 : 0, (wantForeign && energyFlavour) ? nb->n_lambda : -1);
+#ifdef NBNXM_HOST_LAUNCH_TIMING
+            s_us += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0_).count();
+            if (++s_n % 200 == 0) { std::fprintf(stderr, "cluster kernel launch call: %.2f us on the host (mean of %ld)\n", s_us / s_n, s_n); }
+#endif
             NBNXM_HIP_CHECK(hipGetLastError());
         }
         if (nb->bDoTime) { t.nb_k.closeTimingRegion(s); }

@@ -47,7 +47,16 @@ for _ in range(n):
 ms_enqueue = 1e3 * (time.perf_counter() - t1) / n      # host time to queue a step (if it equals ms_per_step, the step is launch-bound)
 torch.cuda.synchronize()
 ms = 1e3 * (time.perf_counter() - t1) / n
-print(json.dumps({"atoms": case.natoms, "transport": transport, "merged_localities": merged, "self_links": links, "home": plan.num_home, "halo": plan.num_halo, "ms_per_step": ms, "ms_host_enqueue_per_step": ms_enqueue,
+# the host's own cost of queueing a step: with an empty queue every time (no back-pressure from a device that is behind)
+t_q = 0.0
+for _ in range(100):
+    torch.cuda.synchronize()
+    t2 = time.perf_counter()
+    st.step(sw)
+    t_q += time.perf_counter() - t2
+torch.cuda.synchronize()
+ms_enqueue_idle = 1e3 * t_q / 100
+print(json.dumps({"ms_host_enqueue_per_step_empty_queue": ms_enqueue_idle, "atoms": case.natoms, "transport": transport, "merged_localities": merged, "self_links": links, "home": plan.num_home, "halo": plan.num_halo, "ms_per_step": ms, "ms_host_enqueue_per_step": ms_enqueue,
                   "host_plan_s": t_plan, "host_rank_lists_s": t_lists, "halo_bytes": halo.bytes_per_step()}))
 halo.free()     # (HALO_GPU_HOST_TIMING=1: prints the host time spent queueing each part of the step)
 nb.free()
