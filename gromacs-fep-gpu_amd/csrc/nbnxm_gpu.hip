@@ -889,6 +889,10 @@ void nbnxm_gpu_init_feppairlist(NbnxmGpu* nb, int iloc, int nri, const int* iinr
 {
     NBNXM_ASSERT(iloc == NBNXM_LOCAL || (iloc == NBNXM_NONLOCAL && nb->bUseTwoStreams), "bad locality");
     NBNXM_ASSERT(nb->nbparam->bFEP, "FEP pair list given to a non-FEP object");
+    /* merged localities: the non-local launch is a no-op (its device list is empty), so an atom-pair list of that locality would never
+     * run; the fused mode, which needs no atom-pair list, is the one that goes with merged localities */
+    NBNXM_ASSERT(!(nb->mergedLocalities && iloc == NBNXM_NONLOCAL && nri > 0),
+                 "merged localities take the perturbed pairs from the cluster list (nbnxm_gpu_set_fep_mode(nb, 1)): no non-local atom-pair list");
     gpu_feplist* d = nb->feplist[iloc];
     hipStream_t  s = nb->deviceStreams[iloc].stream;
     const int    numAtoms = nb->atdat->numAtoms;

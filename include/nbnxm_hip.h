@@ -390,7 +390,8 @@ void nbnxm_gpu_launch_kernel_part(NbnxmGpu* nb, const nbnxm_step_workload_t* ste
  * against 62 us for the same pairs as one list).  Set before the lists are uploaded.  The reference's call sequence stays —
  * gpu_init_pairlist(Local) then (NonLocal), pairlist.cpp:4450-4452; launches / prunes / copy-backs of both localities —: the
  * non-local device list is empty and everything about it is a no-op, the local launch evaluates both and therefore needs the
- * halo coordinates: queue it behind x -> xq of the halo slots (halo_gpu_domain_force_step does). */
+ * halo coordinates: queue it behind x -> xq of the halo slots (halo_gpu_domain_force_step does).  Perturbed pairs: fused mode
+ * (nbnxm_gpu_set_fep_mode(nb, 1)); a non-local atom-pair list is refused. */
 void nbnxm_gpu_set_merged_localities(NbnxmGpu* nb, int merged);
 int  nbnxm_gpu_get_merged_localities(const NbnxmGpu* nb);
 
