@@ -1090,8 +1090,12 @@ static void updateWorkPartition(NbnxmGpu* nb, int iloc)
     gpu_plist*  d = nb->plist[iloc];
     hipStream_t s = nb->deviceStreams[iloc].stream;
     d->workRangesDirty = false;
-#ifdef NBNXM_WAVE_TIMELINE
-    if (d->debugTimeline == nullptr) { allocateDeviceBuffer(&d->debugTimeline, 4 * 16384); }
+#if defined(NBNXM_WAVE_TIMELINE) || defined(NBNXM_BLOCK_STATS)
+    if (d->debugTimeline == nullptr)
+    {
+        allocateDeviceBuffer(&d->debugTimeline, 4 * 16384);
+        NBNXM_HIP_CHECK(hipMemset(d->debugTimeline, 0, sizeof(unsigned long long) * 4 * 16384));
+    }
 #endif
     if (d->nsci == 0 || d->ncjPacked == 0)
     {
@@ -1806,7 +1810,7 @@ void* nbnxm_gpu_debug_get_cjpacked(NbnxmGpu* nb, int iloc)
     return nb->plist[iloc]->cjPacked;
 }
 
-#ifdef NBNXM_WAVE_TIMELINE
+#if defined(NBNXM_WAVE_TIMELINE) || defined(NBNXM_BLOCK_STATS)
 /* diagnostics build only: copies the per-wave timeline of the last cluster-pair kernel launch */
 void nbnxm_gpu_debug_timeline(NbnxmGpu* nb, unsigned long long* out, int numWaves)
 {

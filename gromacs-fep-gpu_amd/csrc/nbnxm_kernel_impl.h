@@ -195,6 +195,35 @@ NB_DEVINL void pruneEntry(const NBAtomDataGpu& atdat, const NBParamGpu& nbp, con
  * kernel's register arrays (xqi, trow, fci_buf) directly: a lambda capturing them by reference sends them to
  * scratch memory.  Diagonal rule: on the central image a cluster paired with itself keeps only j > i
  * (wave-uniform, rare: the empty asm keeps it a scalar branch instead of a per-pair select chain). */
+/* diagnostics build (-DNBNXM_BLOCK_STATS, tools/block_stats_probe.py): how the lanes of the LISTED pair blocks are used — per block the
+ * ballot of the lanes within the cut-off; counters (64-bit, behind the timeline area of gpu_plist::debugTimeline): 0 listed blocks,
+ * 1 executed blocks (any lane active), 2 / 3 executed blocks whose lower / upper 32-lane half is empty, 4 sum of active lanes,
+ * 5 executed blocks with at least one empty 16-lane quarter, 6 sum of empty quarters over the executed blocks */
+#ifdef NBNXM_BLOCK_STATS
+#define NBNXM_BLOCK_STATS_HOOK \
+    { \
+        const unsigned long long bal_ = __ballot(active); \
+        if (laneIdNow() == 0U && plist.debugTimeline != nullptr) \
+        { \
+            unsigned long long* st_ = plist.debugTimeline + 4 * 16384 - 64; \
+            const unsigned      lo_ = static_cast<unsigned>(bal_), hi_ = static_cast<unsigned>(bal_ >> 32); \
+            int                 eq_ = 0; \
+            for (int q_ = 0; q_ < 4; q_++) { eq_ += (((bal_ >> (16 * q_)) & 0xFFFFULL) == 0ULL) ? 1 : 0; } \
+            atomicAdd(st_ + 0, 1ULL); \
+            if (bal_ != 0ULL) \
+            { \
+                atomicAdd(st_ + 1, 1ULL); \
+                if (lo_ == 0U) { atomicAdd(st_ + 2, 1ULL); } \
+                if (hi_ == 0U) { atomicAdd(st_ + 3, 1ULL); } \
+                atomicAdd(st_ + 4, static_cast<unsigned long long>(__popcll(bal_))); \
+                if (eq_ > 0) { atomicAdd(st_ + 5, 1ULL); } \
+                atomicAdd(st_ + 6, static_cast<unsigned long long>(eq_)); \
+            } \
+        } \
+    }
+#else
+#define NBNXM_BLOCK_STATS_HOOK
+#endif
 #define NBNXM_PAIR_LOOP(HAS_EXCL)                                                                          \
     _Pragma("unroll") \
                     for (int i = 0; i < c_numClPerSupercl; i++) \
@@ -218,6 +247,7 @@ NB_DEVINL void pruneEntry(const NBAtomDataGpu& atdat, const NBParamGpu& nbp, con
                                 } \
                                 else { active = active && (intMask != 0); } \
                             } \
+                            NBNXM_BLOCK_STATS_HOOK \
                             if (active) \
                             { \
                                 float c6, c12; \
