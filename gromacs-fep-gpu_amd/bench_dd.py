@@ -63,7 +63,11 @@ def measure(args, rank, world, dist, torch, nm, npert, reduce_device, steps, war
     # the synthetic system (topology-order arrays) is generated on every rank; grid and lists are built for the rank's own domain only
     case = wl.make_case(nm=nm, num_perturbed_molecules=npert, elec="ewald", seed=2026, n_lambda=11, build_lists=False)
     ncells = parse_grid(grid_text if grid_text is not None else args.dd_grid, world, case.sys["box"], case.rlist + 0.1)
-    dd = domdec.DomainDecomposition(case.sys["x"], case.sys["box"], case.sys["molId"], ncells, case.rlist)
+    # BENCH_DD_SELF_LINKS=x|xyz (one-GPU rehearsal): a dimension with one cell is its own neighbour through the periodic boundary, so that
+    # a single rank has a real halo, real RCCL groups (to itself) and non-empty non-local lists — the code path of a multi-rank leg
+    links = os.environ.get("BENCH_DD_SELF_LINKS", "")
+    self_links = tuple(d in links for d in "xyz")
+    dd = domdec.DomainDecomposition(case.sys["x"], case.sys["box"], case.sys["molId"], ncells, case.rlist, self_links=self_links)
     plan = dd.plan(rank)
     t_plan = time.time() - t0
     t0 = time.time()
@@ -92,9 +96,12 @@ def measure(args, rank, world, dist, torch, nm, npert, reduce_device, steps, war
         st.step(sw)
     torch.cuda.synchronize()
     pairs = 0
-    for pl, iloc in ((system.local, pkg.LOCAL), (system.nonlocal_, pkg.NONLOCAL)):
-        if len(pl.cjPacked):
-            cj = pkg.download_cjpacked(nb, len(pl.cjPacked), iloc)
+    # (merged localities: the local DEVICE list holds both lists, local entries first; the non-local device list is empty)
+    device_lists = ([(len(system.local.cjPacked) + len(system.nonlocal_.cjPacked), pkg.LOCAL)] if merged
+                    else [(len(system.local.cjPacked), pkg.LOCAL), (len(system.nonlocal_.cjPacked), pkg.NONLOCAL)])
+    for ncj, iloc in device_lists:
+        if ncj:
+            cj = pkg.download_cjpacked(nb, ncj, iloc)
             pairs += int(np.unpackbits(np.ascontiguousarray(cj["imei"][:, 0]["imask"]).view(np.uint8)).sum())
     tot = torch.tensor([float(pairs), float(plan.num_halo), float(plan.num_home)], device=reduce_device, dtype=torch.float64)
     if world > 1:
