@@ -767,8 +767,11 @@ void nbnxm_gpu_init_pairlist(NbnxmGpu* nb, int iloc, int na_c, int nsci, const n
         uploadPairlist(nb, NBNXM_LOCAL, na_c, nsci, sci, ncjPacked, cjPacked, nexcl, excl);
         uploadPairlist(nb, NBNXM_NONLOCAL, na_c, 0, nullptr, 0, nullptr, 1, &allOnes);
         nb->numMergedLocalGroups = ncjPacked;
+        nb->mergeLocalIsFresh    = true;
         return;
     }
+    NBNXM_ASSERT(nb->mergeLocalIsFresh, "merged localities: gpu_init_pairlist(NonLocal) must follow gpu_init_pairlist(Local) of the same search");
+    nb->mergeLocalIsFresh = false;
     const int nsciL = static_cast<int>(nb->mergeLocalSci.size()), ncjL = static_cast<int>(nb->mergeLocalCj.size()),
               nexclL = static_cast<int>(nb->mergeLocalExcl.size());
     std::vector<nbnxn_sci_t>       mSci(nb->mergeLocalSci);

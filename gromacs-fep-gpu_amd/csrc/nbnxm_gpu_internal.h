@@ -93,6 +93,7 @@ struct NbnxmGpu
     /* nbnxm_gpu_set_merged_localities: the local and the non-local list of a domain as one device list (local entries first) */
     bool                           mergedLocalities     = false;
     int                            numMergedLocalGroups = 0; /* packed j-groups of the local part */
+    bool                           mergeLocalIsFresh    = false; /* the stashed local list is this search's (not yet merged) */
     std::vector<nbnxn_sci_t>       mergeLocalSci;
     std::vector<nbnxn_cj_packed_t> mergeLocalCj;
     std::vector<nbnxn_excl_t>      mergeLocalExcl;
