@@ -79,7 +79,8 @@ def measure(args, rank, world, dist, torch, nm, npert, reduce_device, steps, war
     merged = os.environ.get("BENCH_DD_MERGED", "1") != "0"
     nb = domdec.make_rank_gpu(pkg, wl, case, system, use_dynamic_pruning=not args.no_prune, merged=merged)
     nb.set_timing(False)
-    halo = domdec.RcclHalo(pkg, dist, rank, world, nb.stream(pkg.LOCAL if merged else pkg.NONLOCAL))
+    # (dist.peer_copy_id: the ranks are threads of this process — domdec.ThreadRanks, a rehearsal — and use the in-process transport)
+    halo = domdec.RcclHalo(pkg, dist, rank, world, nb.stream(pkg.LOCAL if merged else pkg.NONLOCAL), unique_id=getattr(dist, "peer_copy_id", None))
     st = domdec.DomainStep(pkg, nb, system, halo)
     sw = pkg.step_workload(energy=False, virial=False, dhdl=False)
     st.step(sw)
@@ -120,7 +121,9 @@ def measure(args, rank, world, dist, torch, nm, npert, reduce_device, steps, war
         rec = {"pair_interactions_per_s": 64.0 * float(tot[0].item()) * steps / elapsed, "ms_per_step": 1e3 * elapsed / steps, "steps": steps,
                "domain_grid": "%dx%dx%d" % ncells, "atoms": int(case.natoms), "cluster_pairs_all_ranks": int(tot[0].item()),
                "halo_atoms_per_rank_mean": float(tot[1].item()) / world, "home_atoms_per_rank_mean": float(tot[2].item()) / world,
-               "halo_bytes_sent_and_received_rank0_per_step": halo.bytes_per_step(), "transport": "RCCL ncclSend/ncclRecv groups (halo_hip.h)",
+               "halo_bytes_sent_and_received_rank0_per_step": halo.bytes_per_step(),
+               "transport": ("in-process peer copies between rank threads (halo_hip.h; a rehearsal)" if getattr(dist, "peer_copy_id", None) is not None
+                             else "RCCL ncclSend/ncclRecv groups (halo_hip.h)"),
                "schedule": ("merged localities: one list, one launch, one stream per rank" if merged else "two localities on two streams"),
                "local_launch": ("one launch" if merged else
                                 "two parts, the second behind the non-local kernel (HALO_GPU_LOCAL_PARTS)" if world > 1 and os.environ.get("HALO_GPU_LOCAL_PARTS", "2") == "2"

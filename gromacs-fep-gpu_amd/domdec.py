@@ -373,6 +373,59 @@ def run_ranks_in_threads(calls):
             raise e
 
 
+class ThreadRanks:
+    """A stand-in for torch.distributed among the host THREADS of one process (the ranks of the in-process peer-copy transport): just
+    what bench_dd.measure uses — broadcast, all_reduce (sum | max), barrier.  One `view(rank)` per thread.  It exists so that the
+    decomposition leg of bench.py can be walked through with several ranks on a one-GPU box (tests/test_gpu_bench_dd.py); nothing in
+    the product path uses it."""
+
+    class ReduceOp:
+        SUM, MAX = "sum", "max"
+
+    def __init__(self, pkg, world):
+        import threading
+        self.world = int(world)
+        self._barrier = threading.Barrier(self.world)
+        self._slots = [None] * self.world
+        self.peer_copy_id = new_halo_id(pkg, TRANSPORT_PEER_COPY)
+
+    def view(self, rank):
+        outer = self
+
+        class View:
+            ReduceOp = ThreadRanks.ReduceOp
+            peer_copy_id = outer.peer_copy_id
+
+            def is_initialized(self):
+                return True
+
+            def get_world_size(self):
+                return outer.world
+
+            def get_backend(self):
+                return "threads"
+
+            def barrier(self):
+                outer._barrier.wait()
+
+            def broadcast(self, t, src):
+                outer._slots[rank] = t
+                outer._barrier.wait()
+                if rank != src:
+                    t.copy_(outer._slots[src])
+                outer._barrier.wait()
+
+            def all_reduce(self, t, op="sum"):
+                import torch
+                outer._slots[rank] = t.clone()
+                outer._barrier.wait()
+                parts = torch.stack([outer._slots[r].to(t.device) for r in range(outer.world)])
+                t.copy_(parts.max(dim=0).values if op == "max" else parts.sum(dim=0))
+                outer._barrier.wait()
+
+        return View()
+
+
 class TensorHalo:
     """TEST DOUBLE of the transport (CPU tests with gloo, and all ranks of a decomposition inside one process): the same
     schedule — pack with the image shift, one message per peer, coordinates land in place, forces are added through the send

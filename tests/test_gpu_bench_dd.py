@@ -30,3 +30,42 @@ def test_decomposition_leg_rehearsal_with_self_links(merged):
     assert leg["parity_of_first_step"]["ok"] and leg["parity_of_first_step"]["max_err_over_tolerance"] < 1.0
     assert leg["halo_atoms_per_rank_mean"] > 0 and leg["cluster_pairs_all_ranks"] > 200000
     assert ("merged" in leg["schedule"]) == (merged == "1")
+
+
+@pytest.mark.parametrize("ncells,merged", [((2, 2, 2), "1"), ((2, 2, 2), "0"), ((4, 2, 1), "1"), ((2, 1, 1), "1")])
+def test_decomposition_leg_with_several_ranks_as_threads(ncells, merged, monkeypatch):
+    """bench_dd.measure — the function every rank of bench.py's decomposition leg runs — with 2 and 8 ranks at once: host threads of this
+    process over the in-process peer-copy transport, with a thread-based stand-in for torch.distributed (domdec.ThreadRanks).  What a
+    one-rank rehearsal cannot reach: per-rank plans and lists on a real domain grid, the first-step parity check with its broadcast of
+    the single-domain forces, the sums over the ranks.  The pair total of all ranks must equal the single-domain count of the same box
+    up to the cluster pairs that straddle a domain border differently."""
+    import importlib
+    import types
+    import numpy as np
+    sys.path.insert(0, ROOT)
+    from __graft_entry__ import load_package
+    pkg = load_package()
+    import torch
+    domdec = importlib.import_module("gromacs_fep_gpu_amd.domdec")
+    bench_dd = importlib.import_module("gromacs_fep_gpu_amd.bench_dd")
+    monkeypatch.setenv("BENCH_DD_MERGED", merged)
+    monkeypatch.setenv("BENCH_DD_CONDITION_STEPS", "3")
+    monkeypatch.setenv("HALO_GPU_PEER_TIMEOUT", "120")
+    world = int(np.prod(ncells))
+    ranks = domdec.ThreadRanks(pkg, world)
+    args = types.SimpleNamespace(dd_grid="%dx%dx%d" % ncells, max_cjpacked_per_sci=16, no_prune=False)
+    recs = [None] * world
+
+    def rank_call(r):
+        def run():
+            recs[r] = bench_dd.measure(args, r, world, ranks.view(r), torch, (20, 20, 20), 3, "cuda", 5, 2, check_parity=True)
+        return run
+
+    domdec.run_ranks_in_threads([rank_call(r) for r in range(world)])
+    rec = recs[0]
+    assert all(r is None for r in recs[1:]) and rec is not None
+    assert rec["domain_grid"] == "%dx%dx%d" % ncells and rec["atoms"] == 24000
+    assert rec["parity_of_first_step"]["ok"], rec["parity_of_first_step"]
+    assert abs(rec["home_atoms_per_rank_mean"] * world - 24000) < 1e-6
+    assert rec["halo_atoms_per_rank_mean"] > 0
+    assert 0.9 * 271960 < rec["cluster_pairs_all_ranks"] < 1.5 * 271960     # 271,960 cluster pairs as one domain (profiles/r03/sizes.txt)
