@@ -82,12 +82,15 @@ NB_DEVINL FepPairData loadFepPair(const NBAtomDataGpu& atdat, const NBParamGpu& 
     return d;
 }
 
+/* The 64 list pairs p0 .. p0 + 63 by one wavefront: the body of nbnxmFepKernel, also run as trailing workgroups of the cluster kernel
+ * (nbnxm_kernel_impl.h) so that a caller who keeps the reference's atom-pair list pays for no second kernel, no second stream and no
+ * fork / join events.  No LDS, no barrier.  slotIndex: which energy accumulator slot this wave adds to. */
 template<int ELEC, bool PSWITCH, bool ENERGY>
-__launch_bounds__(c_fepBlockSize) __global__
-        void nbnxmFepKernel(const NBAtomDataGpu atdat, const NBParamGpu nbp, const gpu_feplist feplist, const int bCalcFshift)
+NB_DEVINL void fepAtomPairWave(const NBAtomDataGpu& atdat, const NBParamGpu& nbp, const gpu_feplist& feplist, const int bCalcFshift, const int p0,
+                               const int slotIndex)
 {
     const unsigned lane = threadIdx.x & (c_waveSize - 1);
-    const int      p    = static_cast<int>(blockIdx.x) * c_fepBlockSize + static_cast<int>(threadIdx.x);
+    const int      p    = p0 + static_cast<int>(lane);
     float*         f    = reinterpret_cast<float*>(atdat.f);
 
     const FepLambda   L = makeFepLambda(nbp.lambda_q, nbp.lambda_v, nbp.lam_power, nbp.alpha_coul, nbp.alpha_vdw);
@@ -131,31 +134,22 @@ __launch_bounds__(c_fepBlockSize) __global__
 
     if constexpr (ENERGY)
     {
-        __shared__ float red[c_fepBlockSize / c_waveSize][4];
-        E_lj    = waveSum(E_lj);
-        E_el    = waveSum(E_el);
-        DVDL_lj = waveSum(DVDL_lj);
-        DVDL_el = waveSum(DVDL_el);
-        const unsigned w = threadIdx.x / c_waveSize;
-        if (lane == 0U)
+        /* into one of the accumulator slots the cluster kernel uses (same layout: E_lj, E_el, dV/dl_lj, dV/dl_el; summed on the host
+         * with the staged scalars): hundreds of waves adding to ONE set of addresses serialise in L2 */
+        const float v = waveSum4Transposed(E_lj, E_el, DVDL_lj, DVDL_el, lane); /* lanes 0 .. 3: the four sums */
+        if (lane < 4U && v != 0.0F)
         {
-            red[w][0] = E_lj;
-            red[w][1] = E_el;
-            red[w][2] = DVDL_lj;
-            red[w][3] = DVDL_el;
-        }
-        __syncthreads();
-        if (threadIdx.x < 4U)
-        {
-            float s = 0.0F;
-#pragma unroll
-            for (int k = 0; k < c_fepBlockSize / c_waveSize; k++) { s += red[k][threadIdx.x]; }
-            /* into one of the accumulator slots the cluster kernel uses (same layout: E_lj, E_el, dV/dl_lj, dV/dl_el; summed
-             * on the host with the staged scalars): hundreds of work-groups adding to ONE set of addresses serialise in L2 */
-            float* out = atdat.energySlots + (blockIdx.x & (c_numEnergySlots - 1)) * c_energySlotStride + threadIdx.x;
-            if (s != 0.0F) { atomicAdd(out, s); }
+            atomicAdd(atdat.energySlots + (slotIndex & (c_numEnergySlots - 1)) * c_energySlotStride + static_cast<int>(lane), v);
         }
     }
+}
+
+template<int ELEC, bool PSWITCH, bool ENERGY>
+__launch_bounds__(c_fepBlockSize) __global__
+        void nbnxmFepKernel(const NBAtomDataGpu atdat, const NBParamGpu nbp, const gpu_feplist feplist, const int bCalcFshift)
+{
+    const int wave = static_cast<int>(blockIdx.x) * (c_fepBlockSize / c_waveSize) + static_cast<int>(threadIdx.x) / c_waveSize;
+    fepAtomPairWave<ELEC, PSWITCH, ENERGY>(atdat, nbp, feplist, bCalcFshift, wave * c_waveSize, wave);
 }
 
 /* Energies and dV/dlambda at lambda index 0 (current) .. n_lambda (foreign); results go to

@@ -377,6 +377,10 @@ NbnxmGpu* nbnxm_gpu_init(const nbnxm_interaction_params_t* ic, int numTypes, con
     {
         nb->fepMergedFused = (std::atoi(env) != 0);
     }
+    if (const char* env = std::getenv("NBNXM_HIP_FEP_LIST_MERGED"))
+    {
+        nb->fepListMerged = (std::atoi(env) != 0);
+    }
     if (const char* env = std::getenv("NBNXM_HIP_ENERGY_TAIL"))
     {
         nb->energyTail = std::max(0, std::min(c_energyTailCompiled, std::atoi(env)));
@@ -1311,10 +1315,17 @@ void nbnxm_gpu_launch_kernel(NbnxmGpu* nb, const nbnxm_step_workload_t* stepWork
                              && ((nbp->softcoreType == NBNXM_SOFTCORE_GAPSYS) ? (nbp->gapsysLinpointCoul != 0.0F || nbp->gapsysLinpointVdw != 0.0F)
                                                                                : (nbp->alpha_coul != 0.0F || nbp->alpha_vdw != 0.0F));
     bool       fepForked = false;
+    /* Atom-pair list (reference shape): its force / energy kernel rides in trailing workgroups of the cluster kernel whenever that
+     * kernel runs and carries a tail for this flavour (NBNXM_HIP_FEP_LIST_MERGED=0: always a kernel of its own, on the FEP stream):
+     * 0.0844 -> 0.0566 ms per force step of the 96k box in this mode — no second kernel competing for the wave slots, no second
+     * stream, no fork / join events.  The foreign-lambda kernel of dH/dl steps stays a kernel of its own. */
+    const bool energyStep    = stepWork->computeEnergy != 0;
+    const bool tailCarriesFep = !energyStep || nb->energyTail >= 2;
+    const bool mergeFepList  = nbp->bFEP && !fused && nb->fepListMerged && tailCarriesFep && plist->nsci > 0 && nb->feplist[iloc]->nrj > 0;
     if (nbp->bFEP && !fused && !secondPartOnly)
     {
         gpu_feplist* feplist   = nb->feplist[iloc];
-        const bool   doForce   = true;
+        const bool   doForce   = !mergeFepList;
         const bool   doForeign = wantForeign;
         if (feplist->nri > 0 && feplist->nrj > 0 && (doForce || doForeign))
         {
@@ -1449,7 +1460,10 @@ void nbnxm_gpu_launch_kernel(NbnxmGpu* nb, const nbnxm_step_workload_t* stepWork
         const int          firstSet = plan.firstSet, lastSet = plan.firstSet + plan.numSets - 1, setRanges = plan.setRanges;
         const bool         withTail = plan.withTail; /* false whenever nothing is launched: no state is consumed then */
         NBNXM_ASSERT(plan.numSets == 0 || (firstSet + plan.numSets) * setRanges <= numRanges, "launch plan beyond the range arrays");
-        const int mergedFepItems = (mergeFep && withTail) ? plist->numSlowPairs : 0;
+        const int mergedFepItems = !withTail ? 0
+                                   : mergeFep ? plist->numSlowPairs
+                                   : mergeFepList ? (nb->feplist[iloc]->nrj + c_waveSize - 1) / c_waveSize
+                                                  : 0;
         const int pruneEntries   = (plist->pendingPrunePart >= 0 && withTail) ? plist->pendingPruneEntries : 0;
         const int prunePart      = std::max(plist->pendingPrunePart, 0);
         if (withTail) { plist->pendingPrunePart = -1; }
@@ -1491,7 +1505,8 @@ void nbnxm_gpu_launch_kernel(NbnxmGpu* nb, const nbnxm_step_workload_t* stepWork
                                adat->atomTypes, adat->ljComb, reinterpret_cast<const unsigned*>(adat->fepBits),
                                plist->workRangeStart[p] + set * setRanges, plist->workFirstSci[p] + set * setRanges, setRanges, plist->groupSlowMask,
                                tail ? mergedFepItems : 0, std::max(plist->rollingPruningNumParts, 1), prunePart, tail ? pruneEntries : 0,
-                               reinterpret_cast<float4*>(nb->fSpare), tail ? clearNumFloat4 : 0, (wantForeign && energyFlavour) ? nb->n_lambda : -1);
+                               reinterpret_cast<float4*>(nb->fSpare), tail ? clearNumFloat4 : 0, (wantForeign && energyFlavour) ? nb->n_lambda : -1,
+                               *nb->feplist[iloc]);
 #ifdef NBNXM_HOST_LAUNCH_TIMING
             s_us += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0_).count();
             if (++s_n % 200 == 0) { std::fprintf(stderr, "cluster kernel launch call: %.2f us on the host (mean of %ld)\n", s_us / s_n, s_n); }

@@ -66,6 +66,8 @@ struct NbnxmGpu
     bool           fSpareCleared               = false;
     bool           scalarsDirty                = true;  /* energies / dV/dl / foreign / window slots written since the last clear */
     int            energyTail                  = c_energyTailCompiled; /* see NBNXM_ENERGY_TAIL (nbnxm_hip_types.h) */
+    bool           fepListMerged               = true;  /* atom-pair list mode: the list's force / energy kernel rides in trailing
+                                                           workgroups of the cluster kernel (NBNXM_HIP_FEP_LIST_MERGED=0: own kernel) */
     bool           pruneMerged                 = true;  /* rolling pruning rides in trailing workgroups of the next force-only
                                                           * cluster kernel (NBNXM_HIP_PRUNE_MERGED=0: own kernel, at once) */
     bool           fepConcurrentFused          = false; /* fused mode: perturbed-cluster-pair kernel on the FEP stream */

@@ -86,6 +86,7 @@ NB_DEVINL void ljFromComb(int vdwKind, const float2& a, const float2& b, float& 
 }
 
 #include "nbnxm_fep_cluster_body.h"
+#include "nbnxm_fep_kernel_impl.h" /* fepAtomPairWave: the atom-pair list (reference shape) in trailing workgroups */
 
 /* First-pass / rolling list pruning of ONE i-entry by one wavefront (nbnxm/cuda/nbnxm_cuda_kernel_pruneonly.cuh:100-316): a cluster
  * pair is kept when any of its 64 atom pairs is within range, and the same mask is written to both halves of the split-2 entry.
@@ -330,7 +331,10 @@ __launch_bounds__(c_nbMaxBlockSize) __attribute__((amdgpu_waves_per_eu(c_nbWaves
                          const int clearNumFloat4,
                          /* energy flavour, dH/dlambda step: the perturbed cluster pairs of the trailing workgroups also accumulate their energies
                           * at lambda indices 0 .. mergedFepForeignLambdas (the FOREIGN flavour of fepClusterPair); -1: not such a step */
-                         const int mergedFepForeignLambdas)
+                         const int mergedFepForeignLambdas,
+                         /* not FUSED (the reference's shape: perturbed pairs carved out of the cluster list into an atom-pair list): that list,
+                          * evaluated by trailing workgroups — mergedFepItems waves of 64 list pairs each — instead of a kernel of its own */
+                         const gpu_feplist feplist)
 {
     constexpr bool LJ_EWALD    = VdwTraits<VDW>::ljEwald;
     constexpr bool EXCL_FORCES = (ELEC != ELK_CUT) || ENERGY || LJ_EWALD; /* nbnxm_cuda_kernel.cuh:69-78 */
@@ -365,7 +369,9 @@ __launch_bounds__(c_nbMaxBlockSize) __attribute__((amdgpu_waves_per_eu(c_nbWaves
     /* energy flavours (NBNXM_ENERGY_TAIL, nbnxm_hip_types.h): 0 no trailing workgroups; 1 rolling prune and buffer clear; 2 also the
      * perturbed cluster pairs with their energies and dV/dlambda */
     constexpr bool TAIL     = !ENERGY || (NBNXM_ENERGY_TAIL >= 1);
-    constexpr bool TAIL_FEP = FUSED && (!ENERGY || (NBNXM_ENERGY_TAIL >= 2));
+    constexpr bool TAIL_FEP = !ENERGY || (NBNXM_ENERGY_TAIL >= 2);
+    /* the perturbed-pair math has three electrostatics forms (nbnxm_kernels_fep.hip: selectFepKernel) */
+    constexpr int FEP_LIST_ELEC = (ELEC == ELK_CUT || ELEC == ELK_RF) ? ELK_RF : ELEC;
     if constexpr (TAIL)
     {
         /* Trailing workgroups, behind the ones of the ranges.  The dispatcher hands workgroups out in order, so their waves start
@@ -392,7 +398,15 @@ __launch_bounds__(c_nbMaxBlockSize) __attribute__((amdgpu_waves_per_eu(c_nbWaves
             }
             else if (blockIdx.x < mainBlocks + pruneBlocks + fepBlocks)
             {
-                if constexpr (TAIL_FEP)
+                if constexpr (TAIL_FEP && !FUSED)
+                {
+                    const int item = __builtin_amdgcn_readfirstlane(static_cast<int>((blockIdx.x - mainBlocks - pruneBlocks) * wavesPerBlock + wave));
+                    if (item < mergedFepItems)
+                    {
+                        fepAtomPairWave<FEP_LIST_ELEC, VDW == VDK_PSWITCH, ENERGY>(atdat, nbp, feplist, bCalcFshiftIn, item * c_waveSize, item);
+                    }
+                }
+                if constexpr (TAIL_FEP && FUSED)
                 {
                     if constexpr (VdwTraits<VDW>::useTable)
                     {
