@@ -144,6 +144,89 @@ NB_DEVINL void fepAtomPairWave(const NBAtomDataGpu& atdat, const NBParamGpu& nbp
     }
 }
 
+/* One item of the list regrouped by cluster pair (gpu_feplist::clItem) by one wavefront, lane = tidxj * 8 + tidxi as in the cluster
+ * kernels: lane l owns the atom pair (i-atom tidxi of cluster ci, j-atom tidxj of cluster cj) and evaluates it if the list holds it.
+ * Coalesced loads (two clusters), no dependent index chain, i- and j-force reductions over the 8 x 8 layout with 24-lane adds, the
+ * four energy sums in one transposing pass.  Runs as trailing workgroups of the cluster kernel (nbnxm_kernel_impl.h). */
+template<int ELEC, bool PSWITCH, bool ENERGY>
+NB_DEVINL void fepListClusterItem(const NBAtomDataGpu& atdat, const NBParamGpu& nbp, const gpu_feplist& feplist, const int bCalcFshift, const int item)
+{
+    const unsigned lane  = threadIdx.x & (c_waveSize - 1);
+    const unsigned tidxi = lane & 7U;
+    const unsigned tidxj = lane >> 3;
+    const int4     it    = feplist.clItem[item];
+    const int      ci = __builtin_amdgcn_readfirstlane(it.x), cj = __builtin_amdgcn_readfirstlane(it.y);
+    const int      shiftIdx = __builtin_amdgcn_readfirstlane(it.z);
+    const uint2    listed2  = feplist.clListed[item];
+    const uint2    incl2    = feplist.clIncl[item];
+    const bool     listed   = (((lane < 32U ? listed2.x : listed2.y) >> (lane & 31U)) & 1U) != 0U;
+    const bool     included = (((lane < 32U ? incl2.x : incl2.y) >> (lane & 31U)) & 1U) != 0U;
+
+    float* __restrict__ f = reinterpret_cast<float*>(atdat.f);
+    const __amdgpu_buffer_rsrc_t fRsrc =
+            __builtin_amdgcn_make_buffer_rsrc(f, 0, atdat.numAtoms * 3 * static_cast<int>(sizeof(float)), 0x00020000);
+    const int    ai  = ci * c_clSize + static_cast<int>(tidxi);
+    const int    aj  = cj * c_clSize + static_cast<int>(tidxj);
+    const float3 sh  = atdat.shiftVec[shiftIdx];
+    const float4 xi  = atdat.xq[ai];
+    const float4 xj  = atdat.xq[aj];
+    const float4 q4i = atdat.q4[ai];
+    const float4 q4j = atdat.q4[aj];
+    const int4   t4i = atdat.atomTypes4[ai];
+    const int4   t4j = atdat.atomTypes4[aj];
+    const float3 rv  = make_float3(xi.x + sh.x - xj.x, xi.y + sh.y - xj.y, xi.z + sh.z - xj.z);
+    const float  r2  = rv.x * rv.x + rv.y * rv.y + rv.z * rv.z;
+
+    float E_lj = 0.0F, E_el = 0.0F, DVDL_lj = 0.0F, DVDL_el = 0.0F;
+    float fscal = 0.0F;
+    if (listed)
+    {
+        const float  qq[2]  = { nbp.epsfac * q4i.x * q4j.x, nbp.epsfac * q4i.y * q4j.y };
+        const float2 pA     = nbp.nbfp[atdat.numTypes * t4i.x + t4j.x];
+        const float2 pB     = nbp.nbfp[atdat.numTypes * t4i.y + t4j.y];
+        const float  c6[2]  = { pA.x, pB.x };
+        const float  c12[2] = { pA.y, pB.y };
+        float        c6grid[2];
+        ljGridC6AB(nbp, t4i, t4j, c6grid);
+        const FepLambda L    = makeFepLambda(nbp.lambda_q, nbp.lambda_v, nbp.lam_power, nbp.alpha_coul, nbp.alpha_vdw);
+        float           fs   = 0.0F;
+        const bool      done = fepPair<ELEC, PSWITCH, true, ENERGY>(nbp, L, r2, included, ai == aj, qq, c6, c12, fs, E_lj, E_el, DVDL_lj, DVDL_el,
+                                                                    c6grid);
+        fscal                = done ? fs : 0.0F;
+    }
+    const float3 f_ij = make_float3(rv.x * fscal, rv.y * fscal, rv.z * fscal);
+    {
+        /* i-forces: sum over tidxj, lanes tidxj 0..2 carry x, y, z; j-forces: sum over tidxi, lanes tidxi 0..2 */
+        const float fix = reduceOverTidxj(f_ij.x), fiy = reduceOverTidxj(f_ij.y), fiz = reduceOverTidxj(f_ij.z);
+        const float vi  = (tidxj == 0U) ? fix : ((tidxj == 1U) ? fiy : fiz);
+        const int   oi  = (tidxj < 3U) ? (3 * ai + static_cast<int>(tidxj)) * static_cast<int>(sizeof(float)) : 0x7FFFFFF0;
+        __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(vi, fRsrc, oi, 0, 0);
+        const float fjx = reduceOver8Lanes(-f_ij.x), fjy = reduceOver8Lanes(-f_ij.y), fjz = reduceOver8Lanes(-f_ij.z);
+        const float vj  = (tidxi == 0U) ? fjx : ((tidxi == 1U) ? fjy : fjz);
+        const int   oj  = (tidxi < 3U) ? (3 * aj + static_cast<int>(tidxi)) * static_cast<int>(sizeof(float)) : 0x7FFFFFF0;
+        __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(vj, fRsrc, oj, 0, 0);
+    }
+    if (bCalcFshift && shiftIdx != c_centralShiftIndex)
+    {
+        const float sx = waveSum(f_ij.x);
+        const float sy = waveSum(f_ij.y);
+        const float sz = waveSum(f_ij.z);
+        if (lane < 3U)
+        {
+            const float v = (lane == 0U) ? sx : ((lane == 1U) ? sy : sz);
+            atomicAdd(reinterpret_cast<float*>(atdat.fShift) + 3 * shiftIdx + static_cast<int>(lane), v);
+        }
+    }
+    if constexpr (ENERGY)
+    {
+        const float v = waveSum4Transposed(E_lj, E_el, DVDL_lj, DVDL_el, lane); /* lanes 0 .. 3: the four sums */
+        if (lane < 4U && v != 0.0F)
+        {
+            atomicAdd(atdat.energySlots + (item & (c_numEnergySlots - 1)) * c_energySlotStride + static_cast<int>(lane), v);
+        }
+    }
+}
+
 template<int ELEC, bool PSWITCH, bool ENERGY>
 __launch_bounds__(c_fepBlockSize) __global__
         void nbnxmFepKernel(const NBAtomDataGpu atdat, const NBParamGpu nbp, const gpu_feplist feplist, const int bCalcFshift)

@@ -19,6 +19,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <unordered_map>
 #include <vector>
 
 #include "nbnxm_gpu_internal.h"
@@ -574,6 +575,9 @@ void nbnxm_gpu_free(NbnxmGpu* nb)
             freeDeviceBuffer(&nb->feplist[i]->jjnr);
             freeDeviceBuffer(&nb->feplist[i]->excl_fep);
             freeDeviceBuffer(&nb->feplist[i]->pairEntry);
+            freeDeviceBuffer(&nb->feplist[i]->clItem);
+            freeDeviceBuffer(&nb->feplist[i]->clListed);
+            freeDeviceBuffer(&nb->feplist[i]->clIncl);
             delete nb->feplist[i];
         }
     }
@@ -961,6 +965,58 @@ void nbnxm_gpu_init_feppairlist(NbnxmGpu* nb, int iloc, int nri, const int* iinr
     copyToDeviceBuffer(&d->jjnr, nb->h_jjnr.data, 0, nrj, s, true);
     copyToDeviceBuffer(&d->excl_fep, nb->h_exclFep.data, 0, nrj, s, true);
     copyToDeviceBuffer(&d->pairEntry, nb->h_pairEntry.data, 0, nrj, s, true);
+
+    /* the same list regrouped by (i-cluster, j-cluster, shift): what the trailing workgroups of the cluster kernel evaluate, one wave per
+     * item (gpu_feplist::clItem; fepListClusterItem) */
+    {
+        std::unordered_map<long long, int> itemOf;
+        std::vector<int4>                  items;
+        std::vector<uint2>                 listed, incl;
+        itemOf.reserve(static_cast<size_t>(nrj) / 4 + 16);
+        const long long numClusters = numAtoms / c_clSize + 1;
+        for (int k = 0; k < nrj; k++)
+        {
+            const int       n   = nb->h_pairEntry.data[k];
+            const int       ai  = nb->h_iinr.data[n], aj = nb->h_jjnr.data[k];
+            const int       ci  = ai / c_clSize, cj = aj / c_clSize;
+            const long long key = (static_cast<long long>(ci) * numClusters + cj) * c_numShiftVectors + nb->h_shift.data[n];
+            auto            found = itemOf.find(key);
+            int             idx;
+            if (found == itemOf.end())
+            {
+                idx = static_cast<int>(items.size());
+                itemOf.emplace(key, idx);
+                items.push_back(make_int4(ci, cj, nb->h_shift.data[n], 0));
+                listed.push_back(make_uint2(0U, 0U));
+                incl.push_back(make_uint2(0U, 0U));
+            }
+            else { idx = found->second; }
+            const unsigned bit  = static_cast<unsigned>((aj % c_clSize) * c_clSize + ai % c_clSize); /* the lane tidxj * 8 + tidxi */
+            unsigned&      lw   = (bit < 32U) ? listed[idx].x : listed[idx].y;
+            unsigned&      iw   = (bit < 32U) ? incl[idx].x : incl[idx].y;
+            NBNXM_ASSERT((lw & (1U << (bit & 31U))) == 0U, "the FEP list holds an atom pair twice");
+            lw |= 1U << (bit & 31U);
+            if (nb->h_exclFep.data[k] != 0) { iw |= 1U << (bit & 31U); }
+        }
+        const int numItems = static_cast<int>(items.size());
+        if (numItems > d->clItem_nalloc)
+        {
+            freeDeviceBuffer(&d->clItem);
+            freeDeviceBuffer(&d->clListed);
+            freeDeviceBuffer(&d->clIncl);
+            d->clItem_nalloc = static_cast<int>(numItems * 1.2) + 64;
+            allocateDeviceBuffer(&d->clItem, d->clItem_nalloc);
+            allocateDeviceBuffer(&d->clListed, d->clItem_nalloc);
+            allocateDeviceBuffer(&d->clIncl, d->clItem_nalloc);
+        }
+        d->numClusterItems = numItems;
+        if (numItems > 0)
+        {
+            NBNXM_HIP_CHECK(hipMemcpy(d->clItem, items.data(), sizeof(int4) * numItems, hipMemcpyHostToDevice));
+            NBNXM_HIP_CHECK(hipMemcpy(d->clListed, listed.data(), sizeof(uint2) * numItems, hipMemcpyHostToDevice));
+            NBNXM_HIP_CHECK(hipMemcpy(d->clIncl, incl.data(), sizeof(uint2) * numItems, hipMemcpyHostToDevice));
+        }
+    }
     NBNXM_HIP_CHECK(hipStreamSynchronize(s));
 }
 
@@ -1462,7 +1518,7 @@ void nbnxm_gpu_launch_kernel(NbnxmGpu* nb, const nbnxm_step_workload_t* stepWork
         NBNXM_ASSERT(plan.numSets == 0 || (firstSet + plan.numSets) * setRanges <= numRanges, "launch plan beyond the range arrays");
         const int mergedFepItems = !withTail ? 0
                                    : mergeFep ? plist->numSlowPairs
-                                   : mergeFepList ? (nb->feplist[iloc]->nrj + c_waveSize - 1) / c_waveSize
+                                   : mergeFepList ? nb->feplist[iloc]->numClusterItems
                                                   : 0;
         const int pruneEntries   = (plist->pendingPrunePart >= 0 && withTail) ? plist->pendingPruneEntries : 0;
         const int prunePart      = std::max(plist->pendingPrunePart, 0);

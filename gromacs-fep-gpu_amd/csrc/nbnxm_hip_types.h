@@ -268,6 +268,18 @@ struct gpu_feplist
      * (one lane per pair, 64 consecutive pairs per wave) */
     int* pairEntry; /* nrj */
     int  pairEntry_nalloc;
+
+    /* MI355X extension: the same list regrouped by cluster pair (built on the host by gpu_init_feppairlist): item k is the
+     * (i-cluster, j-cluster, shift) combination clItem[k] = {ci, cj, shift index, 0} with the 8 x 8 bit masks — bit tidxj * 8 + tidxi,
+     * i.e. the lane of the cluster kernel's layout — of the atom pairs the list holds (clListed) and of those among them that are not
+     * topology exclusions (clIncl, excl_fep != 0).  One wavefront per item evaluates it with coalesced loads and the structured 8 x 8
+     * reductions of the cluster kernels (fepListClusterItem); the flattened form above needs four levels of dependent loads and
+     * segmented reductions. */
+    int    numClusterItems;
+    int4*  clItem;
+    uint2* clListed;
+    uint2* clIncl;
+    int    clItem_nalloc;
 };
 
 /* Per-wave LDS staging of the j-side of one packed group (4 j-clusters):

@@ -333,7 +333,8 @@ __launch_bounds__(c_nbMaxBlockSize) __attribute__((amdgpu_waves_per_eu(c_nbWaves
                           * at lambda indices 0 .. mergedFepForeignLambdas (the FOREIGN flavour of fepClusterPair); -1: not such a step */
                          const int mergedFepForeignLambdas,
                          /* not FUSED (the reference's shape: perturbed pairs carved out of the cluster list into an atom-pair list): that list,
-                          * evaluated by trailing workgroups — mergedFepItems waves of 64 list pairs each — instead of a kernel of its own */
+                          * evaluated by trailing workgroups — mergedFepItems waves, one per cluster-pair item of the regrouped list
+                          * (gpu_feplist::clItem) — instead of a kernel of its own */
                          const gpu_feplist feplist)
 {
     constexpr bool LJ_EWALD    = VdwTraits<VDW>::ljEwald;
@@ -403,7 +404,7 @@ __launch_bounds__(c_nbMaxBlockSize) __attribute__((amdgpu_waves_per_eu(c_nbWaves
                     const int item = __builtin_amdgcn_readfirstlane(static_cast<int>((blockIdx.x - mainBlocks - pruneBlocks) * wavesPerBlock + wave));
                     if (item < mergedFepItems)
                     {
-                        fepAtomPairWave<FEP_LIST_ELEC, VDW == VDK_PSWITCH, ENERGY>(atdat, nbp, feplist, bCalcFshiftIn, item * c_waveSize, item);
+                        fepListClusterItem<FEP_LIST_ELEC, VDW == VDK_PSWITCH, ENERGY>(atdat, nbp, feplist, bCalcFshiftIn, item);
                     }
                 }
                 if constexpr (TAIL_FEP && FUSED)
