@@ -387,6 +387,9 @@ __launch_bounds__(c_nbMaxBlockSize) __attribute__((amdgpu_waves_per_eu(c_nbWaves
         if (blockIdx.x >= mainBlocks)
         {
             __builtin_amdgcn_s_setprio(0);
+#ifdef NBNXM_WAVE_TIMELINE
+            const unsigned long long tlTailStart = wall_clock64();
+#endif
             /* the rolling-prune waves first: they are the longer chains (a loop over the entry's j-groups); the perturbed-pair
              * waves are short and fill what is left */
             const unsigned pruneBlocks = (static_cast<unsigned>(pruneEntries) + wavesPerBlock - 1U) / wavesPerBlock;
@@ -439,6 +442,23 @@ __launch_bounds__(c_nbMaxBlockSize) __attribute__((amdgpu_waves_per_eu(c_nbWaves
                 const unsigned end   = min((idx + 1U) * chunk, static_cast<unsigned>(clearNumFloat4));
                 for (unsigned i = idx * chunk + threadIdx.x; i < end; i += blockSize) { clearF4[i] = make_float4(0.0F, 0.0F, 0.0F, 0.0F); }
             }
+#ifdef NBNXM_WAVE_TIMELINE
+            {
+                /* the trailing waves' records follow the ranges' ones; word 1 = 1 prune, 2 perturbed pairs, 3 clear */
+                const unsigned rec = static_cast<unsigned>(numWorkRanges) + (blockIdx.x - mainBlocks) * wavesPerBlock + wave;
+                if (lane == 0U && rec < 16384U && plist.debugTimeline != nullptr)
+                {
+                    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+                    unsigned hwId, xccId;
+                    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwId));
+                    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xccId));
+                    plist.debugTimeline[4 * rec + 0] = tlTailStart;
+                    plist.debugTimeline[4 * rec + 1] = (blockIdx.x < mainBlocks + pruneBlocks) ? 1U : ((blockIdx.x < mainBlocks + pruneBlocks + fepBlocks) ? 2U : 3U);
+                    plist.debugTimeline[4 * rec + 2] = wall_clock64();
+                    plist.debugTimeline[4 * rec + 3] = (static_cast<unsigned long long>(xccId) << 32) | hwId;
+                }
+            }
+#endif
             return;
         }
     }

@@ -50,6 +50,27 @@ cs = lambda a: np.concatenate([[0], np.cumsum(a)])
 feat = np.stack([cs(popc)[ranges[1:]] - cs(popc)[ranges[:-1]], cs(slots)[ranges[1:]] - cs(slots)[ranges[:-1]],
                  cs(groups)[ranges[1:]] - cs(groups)[ranges[:-1]], cs(starts)[ranges[1:]] - cs(starts)[ranges[:-1]] + 1,
                  cs(xpairs)[ranges[1:]] - cs(xpairs)[ranges[:-1]]], axis=1).astype(np.float64)
+if "--executed" in sys.argv:
+    # sixth feature: the cluster pairs of the range that have an atom pair within the cut-off, i.e. whose pair block executes its inner
+    # part (26 of the block's 33 vector instructions) -- the partition weighs every listed cluster pair alike
+    xq = np.asarray(case.grid.xq, np.float64)[:, :3].reshape(-1, 8, 3)
+    shift_vec = np.asarray(case.grid.shift_vec, np.float64).reshape(-1, 3)
+    sci_of = np.zeros(len(imask), np.int64); shift_of = np.zeros(len(imask), np.int64)
+    for e in pl.sci:
+        sci_of[e["cjPackedBegin"]:e["cjPackedEnd"]] = e["sci"]; shift_of[e["cjPackedBegin"]:e["cjPackedEnd"]] = e["shift"]
+    cjs = cj["cj"].astype(np.int64)                       # (groups, 4)
+    executed = np.zeros(len(imask), np.int64)
+    rc2 = float(case.rc) ** 2 if hasattr(case, "rc") else 1.0
+    for g0 in range(0, len(imask), 4096):
+        g1 = min(g0 + 4096, len(imask))
+        xi = xq[sci_of[g0:g1, None] * 8 + np.arange(8)[None, :]] + shift_vec[shift_of[g0:g1]][:, None, None, :]      # (G, 8 ci, 8 atoms, 3)
+        xj = xq[np.clip(cjs[g0:g1], 0, len(xq) - 1)]                                                                   # (G, 4 cj, 8 atoms, 3)
+        d2 = ((xi[:, None, :, :, None, :] - xj[:, :, None, None, :, :]) ** 2).sum(-1)                                  # (G, 4, 8, 8, 8)
+        within = (d2 < rc2).any(axis=(-1, -2))                                                                         # (G, 4, 8)
+        bits = ((imask[g0:g1, None, None] >> (np.arange(4)[None, :, None] * 8 + np.arange(8)[None, None, :])) & 1).astype(bool)
+        executed[g0:g1] = (within & bits).sum(axis=(1, 2))
+    print("cluster pairs with an atom pair within the cut-off: %.3f of the listed ones" % (executed.sum() / popc.sum()))
+    feat = np.concatenate([feat, (cs(executed)[ranges[1:]] - cs(executed)[ranges[:-1]])[:, None].astype(np.float64)], axis=1)
 buf = (C.c_ulonglong * (4 * n))()
 lib.nbnxm_gpu_debug_timeline(C.c_void_p(nb._h), buf, n)
 a = np.frombuffer(buf, dtype=np.uint64).reshape(n, 4)
@@ -65,6 +86,18 @@ A = np.concatenate([X, np.ones((len(uk), 1))], axis=1)
 coef, res, *_ = np.linalg.lstsq(A, y, rcond=None)
 pred = A @ coef
 print("SIMDs %d; per-SIMD finish: mean %.1f std %.2f us; features per SIMD mean %s" % (len(uk), y.mean(), y.std(), X.mean(axis=0).round(1)))
+if X.shape[1] == 6:
+    A5 = np.concatenate([X[:, :5], np.ones((len(uk), 1))], axis=1)
+    c5 = np.linalg.lstsq(A5, y, rcond=None)[0]
+    print("WITH the executed-block feature: residual std %.2f us (without it %.2f us); us per listed cluster pair %.5f, per executed one %.5f; "
+          "executed per SIMD std/mean %.4f, listed %.4f" % ((y - pred).std(), (y - A5 @ c5).std(), coef[0], coef[5], X[:, 5].std() / X[:, 5].mean(), X[:, 0].std() / X[:, 0].mean()))
+    # per wave: duration against the wave's own features (waves share their SIMD, so this is only indicative)
+    Aw = np.concatenate([feat, np.ones((n, 1))], axis=1)
+    durw = end - (a[:, 0] - t0).astype(np.float64) / 100.0
+    cw = np.linalg.lstsq(Aw, durw, rcond=None)[0]
+    cw5 = np.linalg.lstsq(Aw[:, [0, 1, 2, 3, 4, 6]], durw, rcond=None)[0]
+    print("per wave: duration std %.2f us, residual with / without the executed feature %.2f / %.2f us" % (durw.std(), (durw - Aw @ cw).std(), (durw - Aw[:, [0, 1, 2, 3, 4, 6]] @ cw5).std()))
+    coef = c5; X = X[:, :5]; A = A5; pred = A5 @ c5; feat = feat[:, :5]
 print("fit: us per cluster pair %.5f, per slot %.5f, per group %.5f, per piece %.5f, per cluster pair with exclusion mask %.5f, const %.2f; "
       "residual std %.2f us" % (*coef, (y - pred).std()))
 w = coef[:5] / coef[0] * 8

@@ -39,4 +39,19 @@ print("distinct SIMDs %d, waves per SIMD: min %d max %d, histogram %s" % (len(uk
 simd_end = np.array([end[key == k].max() for k in uk])
 print("per-SIMD last end us: p10 %.1f p50 %.1f p90 %.1f max %.1f" % tuple(np.percentile(simd_end, [10, 50, 90, 100])))
 print("xcc counts", np.bincount(xcc.astype(np.int64)).tolist())
+# the trailing workgroups' waves (records behind the ranges' ones; word 1 = 1 rolling prune, 2 perturbed pairs, 3 buffer clear)
+nt = 16384
+buf2 = (ctypes.c_ulonglong * (4 * nt))()
+lib.nbnxm_gpu_debug_timeline(ctypes.c_void_p(nb._h), buf2, nt)
+b = np.frombuffer(buf2, dtype=np.uint64).reshape(nt, 4)[n:]
+b = b[(b[:, 0] != 0) & (b[:, 1] <= 3)]
+for kind, name in ((1, "rolling prune"), (2, "perturbed pairs"), (3, "buffer clear")):
+    t = b[b[:, 1] == kind]
+    if len(t) == 0:
+        continue
+    ts = (t[:, 0] - t0).astype(np.float64) / 100.0
+    te = (t[:, 2] - t0).astype(np.float64) / 100.0
+    print("tail waves, %-15s %5d: start us min %.1f p50 %.1f max %.1f | end us p50 %.1f p90 %.1f max %.1f | duration p50 %.1f max %.1f"
+          % (name, len(t), ts.min(), np.median(ts), ts.max(), np.median(te), np.percentile(te, 90), te.max(), np.median(te - ts), (te - ts).max()))
+    print("   waves ending after the last range wave (%.1f us): %d" % (end.max(), int((te > end.max()).sum())))
 np.save(os.path.join(ROOT, "gpurun_out", "timeline_%s.npy" % mode), a)
