@@ -883,9 +883,10 @@ __launch_bounds__(c_nbMaxBlockSize) __attribute__((amdgpu_waves_per_eu(c_nbWaves
         {
             const float v = (lane == 0U) ? sx : ((lane == 1U) ? sy : sz);
             /* one of c_numFshiftSlots copies (nbnxm_hip_types.h): the same few shift indices from thousands of pieces */
-            atomicAdd(reinterpret_cast<float*>(atdat.fShift) + (1 + (sci & (c_numFshiftSlots - 1))) * c_fshiftSlotStride + 3 * shiftIdx
-                              + static_cast<int>(lane),
-                      v);
+            /* (switch flavours: the lane id in place — the offset hoisted out of the loops is what they spilled to scratch; the
+             * other flavours keep the hoisted one: 0.2 us faster on the headline kernel, whose allocation has room for it) */
+            const int laneS = (VDW == VDK_FSWITCH || VDW == VDK_PSWITCH) ? static_cast<int>(laneIdNow()) : static_cast<int>(lane);
+            atomicAdd(reinterpret_cast<float*>(atdat.fShift) + (1 + (sci & (c_numFshiftSlots - 1))) * c_fshiftSlotStride + 3 * shiftIdx + laneS, v);
         }
     }
     if constexpr (ENERGY)

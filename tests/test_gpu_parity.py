@@ -29,6 +29,23 @@ def test_split_path_matches_oracle(elec, energy):
     tl.assert_parity(got, want, rel=1e-4, energy=energy, label=elec)
 
 
+@pytest.mark.parametrize("elec,vdw", [("rf", "cut"), ("ewald", "cut"), ("ewald", "pswitch")])
+@pytest.mark.parametrize("energy", [False, True])
+def test_split_path_with_the_atom_pair_kernel_of_its_own(elec, vdw, energy, monkeypatch):
+    # by default the atom-pair list is regrouped by cluster pair and evaluated in the cluster kernel's trailing workgroups
+    # (fepListClusterItem); NBNXM_HIP_FEP_LIST_MERGED=0 (read when the object is created) keeps the reference's shape: nbnxmFepKernel
+    # on the flattened list, on its own stream.  Both against the oracle, and against each other.
+    c = tl.make_case(elec=elec, vdw=vdw, seed=21, nm=(10, 10, 10), num_perturbed_molecules=16)
+    want = tl.run_oracle(c, energy=True)
+    merged = tl.run_gpu(c, energy=energy, fused=False)
+    tl.assert_parity(merged, want, rel=1e-4, energy=energy, label="list in the tail " + elec)
+    monkeypatch.setenv("NBNXM_HIP_FEP_LIST_MERGED", "0")
+    own = tl.run_gpu(c, energy=energy, fused=False)
+    tl.assert_parity(own, want, rel=1e-4, energy=energy, label="own kernel " + elec)
+    frms = math.sqrt(float(np.mean(np.sum(np.asarray(want["f"], np.float64) ** 2, axis=1))))
+    assert np.max(np.abs(np.asarray(own["f"], np.float64) - np.asarray(merged["f"], np.float64))) <= 1e-4 * frms
+
+
 @pytest.mark.parametrize("elec", ["rf", "cut", "ewald", "ewald_tab"])
 @pytest.mark.parametrize("energy", [False, True])
 def test_fused_path_matches_oracle(elec, energy):
