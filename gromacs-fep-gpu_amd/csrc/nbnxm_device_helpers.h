@@ -380,7 +380,7 @@ NB_DEVINL void nbPair(const NBParamGpu& nbp,
         float nm = fmaf(qq, inv_r, lj) * inv_r2;
         asm("v_and_b32 %0, %1, %2" : "=v"(nm) : "v"(intMask), "v"(nm));
         if constexpr (ELEC == ELK_RF) { F_invr = fmaf(qq, -nbp.two_k_rf, nm); }
-        else if constexpr (ELEC == ELK_EWALD_ANA) { F_invr = fmaf(qq, fmaf(__builtin_amdgcn_fractf(xs), t.y, t.x), nm); }
+        else if constexpr (ELEC == ELK_EWALD_ANA) { F_invr = fmaf(qq, fmaf(t.y, r2, t.x), nm); } /* {intercept, slope} in r^2: no fraction needed */
         else
         {
             const float fr = __builtin_amdgcn_fractf(xs);
@@ -491,8 +491,8 @@ NB_DEVINL void nbPair(const NBParamGpu& nbp,
                 }
                 else
                 {
-                    const float2 t = ewaldCorrLds[idx];
-                    F_invr += qq * (inv_r3m + fmaf(__builtin_amdgcn_fractf(xs), t.y, t.x));
+                    const float2 t = ewaldCorrLds[idx]; /* {intercept, slope} of the interval's line in r^2 */
+                    F_invr += qq * (inv_r3m + fmaf(t.y, r2, t.x));
                 }
             }
             else

@@ -154,9 +154,10 @@ struct NBParamGpu
     float rvdw;
 
     /* MI355X extension, analytical Ewald flavours: the real-space force correction beta^3 F((beta r)^2) on a
-     * uniform grid in x = (beta r)^2 over [0, (beta rc)^2], c_ewaldCorrTabSize intervals, as {value, step to the
-     * next value}; the cluster kernel keeps it in LDS (one ds_read_b64 + one FMA per pair instead of a [5/4]
-     * rational with a reciprocal, ~5 instead of ~14 issue slots).  Linear interpolation error <= 1.2e-6 relative,
+     * uniform grid in x = (beta r)^2 over [0, (beta rc)^2], c_ewaldCorrTabSize intervals, as the interval's line
+     * {intercept, slope} in r^2 (value = a + b r^2: the FMA takes the r^2 the pair block holds, no fraction of the table
+     * coordinate); the cluster kernel keeps it in LDS (one ds_read_b64 + one FMA per pair instead of a [5/4]
+     * rational with a reciprocal, ~4 instead of ~14 issue slots).  Linear interpolation error <= 1.2e-6 relative,
      * the class of the rational fit (pme_corr_coeffs.h).  ewaldCorrTabScale = intervals per unit of r^2. */
     float2* ewaldCorrTab;
     float   ewaldCorrTabScale;
