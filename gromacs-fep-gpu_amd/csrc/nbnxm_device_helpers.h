@@ -304,11 +304,10 @@ NB_DEVINL void nbPair(const NBParamGpu& nbp,
         }
         else
         {
-            const float fr = __builtin_amdgcn_fractf(xs);
-            F_invr         = fmaf(qq, fmaf(fr, t.y, t.x), nm);
-            float eel      = inv_r - nbp.sh_ewald;
+            F_invr    = fmaf(qq, fmaf(t.y, r2, t.x), nm); /* both corrections as {intercept, slope} in r^2 */
+            float eel = inv_r - nbp.sh_ewald;
             asm("v_and_b32 %0, %1, %2" : "=v"(eel) : "v"(intMask), "v"(eel));
-            E_el = qq * (eel - fmaf(fr, t.w, t.z));
+            E_el = qq * (eel - fmaf(t.w, r2, t.z));
         }
         return;
     }
@@ -484,10 +483,9 @@ NB_DEVINL void nbPair(const NBParamGpu& nbp,
                 if constexpr (ENERGY)
                 {
                     /* the energy flavours' table carries the potential correction too */
-                    const float4 t  = reinterpret_cast<const float4*>(ewaldCorrLds)[idx];
-                    const float  fr = __builtin_amdgcn_fractf(xs);
-                    F_invr += qq * (inv_r3m + fmaf(fr, t.y, t.x));
-                    corrV = fmaf(fr, t.w, t.z);
+                    const float4 t = reinterpret_cast<const float4*>(ewaldCorrLds)[idx];
+                    F_invr += qq * (inv_r3m + fmaf(t.y, r2, t.x));
+                    corrV = fmaf(t.w, r2, t.z);
                 }
                 else
                 {
@@ -531,7 +529,7 @@ NB_DEVINL void nbPair(const NBParamGpu& nbp,
                 const float    xs2  = r2 * nbp.ewaldCorrTabScale;
                 const unsigned idx2 = static_cast<unsigned>(xs2);
                 LdsFloat*      tabV = reinterpret_cast<LdsFloat*>(static_cast<uintptr_t>(idx2 * 8U));
-                E_el = qq * (int_bit * (inv_r - nbp.sh_ewald) - fmaf(__builtin_amdgcn_fractf(xs2), tabV[1], tabV[0]));
+                E_el = qq * (int_bit * (inv_r - nbp.sh_ewald) - fmaf(tabV[1], r2, tabV[0]));
             }
             else { E_el = qq * (inv_r * (int_bit - erff(r2 * inv_r * beta)) - int_bit * nbp.sh_ewald); }
         }

@@ -160,11 +160,13 @@ void uploadEwaldCorrectionTable(NbnxmGpu* nb)
         const double t0 = b3 * F(xMax * k / n), t1 = b3 * F(xMax * (k + 1) / n);
         const double v0 = beta * V(xMax * k / n), v1 = beta * V(xMax * (k + 1) / n);
         /* force flavours: the interval's line as {intercept, slope} in r^2 itself, value = a + b r^2 — one FMA with the r^2 the pair
-         * block already holds, no fraction of the table coordinate (energy flavours below: {value, step} of the table coordinate) */
+         * block already holds, no fraction of the table coordinate (energy flavours below: the same for both corrections) */
         const double u0 = xMax * k / n / (beta * beta), du = xMax / n / (beta * beta);
         const double slope = (t1 - t0) / du;
         nb->h_ewaldCorrTab.data[k]   = make_float2(static_cast<float>(t0 - slope * u0), static_cast<float>(slope));
-        nb->h_ewaldCorrTabFV.data[k] = make_float4(static_cast<float>(t0), static_cast<float>(t1 - t0), static_cast<float>(v0), static_cast<float>(v1 - v0));
+        const double slopeV = (v1 - v0) / du;
+        nb->h_ewaldCorrTabFV.data[k] = make_float4(static_cast<float>(t0 - slope * u0), static_cast<float>(slope), static_cast<float>(v0 - slopeV * u0),
+                                                   static_cast<float>(slopeV));
     }
     if (nbp->ewaldCorrTab == nullptr)
     {

@@ -161,7 +161,7 @@ struct NBParamGpu
      * the class of the rational fit (pme_corr_coeffs.h).  ewaldCorrTabScale = intervals per unit of r^2. */
     float2* ewaldCorrTab;
     float   ewaldCorrTabScale;
-    /* the same grid with the potential correction beside the force correction, for the energy flavours: {beta^3 F, step, beta V, step}
+    /* the same grid with the potential correction beside the force correction, for the energy flavours: {intercept, slope} of beta^3 F and of beta V, both in r^2,
      * with V(x) = erf(z)/z, x = z^2 (gmx::pmePotentialCorrection, simd/simd_math.h:1660-1760): one ds_read_b128 and two FMAs per pair
      * instead of two [5/4] rationals with a reciprocal each */
     float4* ewaldCorrTabFV;
