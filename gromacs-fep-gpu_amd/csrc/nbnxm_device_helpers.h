@@ -228,6 +228,18 @@ NB_DEVINL void ljGridC6AB(const NBParamGpu& nbp, const int4& t4i, const int4& t4
     }
 }
 
+/* Byte address of the Ewald correction table's entry for r^2 (entries of STRIDE bytes from the table's base; NBParamGpu::ewaldCorrTab):
+ * y = r^2 * (STRIDE * entries per unit of r^2) + 2^23 is a float with an integer ulp, so its low mantissa bits ARE round(r^2 * ...):
+ * one FMA and one AND (which drops the bits below the stride) give the entry's address — no separate multiply, no convert, no
+ * shift.  Entry k is therefore the line over [(k - 1/16) h, (k + 15/16) h] for STRIDE 8 (uploadEwaldCorrectionTable), from (k - 1/32) h
+ * for the 16-byte entries of the energy flavours (four bits dropped). */
+template<int STRIDE>
+NB_DEVINL unsigned ewaldTabAddress(const float r2, const float scaleTimesStride)
+{
+    const float y = fmaf(r2, scaleTimesStride, 8388608.0F);
+    return __builtin_bit_cast(unsigned, y) & static_cast<unsigned>((c_ewaldCorrTabSize * STRIDE - 1) & ~(STRIDE - 1));
+}
+
 /* ---- non-perturbed atom pair (nbnxm_cuda_kernel.cuh:518-645) ---------------------------------- */
 
 template<int ELEC, bool TWIN, int VDW, bool ENERGY, bool EXCL_FORCES, bool HAS_EXCL = true, bool CORR_TABLE = true>
@@ -277,10 +289,8 @@ NB_DEVINL void nbPair(const NBParamGpu& nbp,
         [[maybe_unused]] float  xs = 0.0F;
         if constexpr (ELEC == ELK_EWALD_ANA)
         {
-            xs                 = r2 * nbp.ewaldCorrTabScale;
-            const unsigned idx = static_cast<unsigned>(xs);
             typedef __attribute__((address_space(3))) const float LdsFloat;
-            LdsFloat* tab = reinterpret_cast<LdsFloat*>(static_cast<uintptr_t>(idx * 16U));
+            LdsFloat* tab = reinterpret_cast<LdsFloat*>(static_cast<uintptr_t>(ewaldTabAddress<16>(r2, nbp.ewaldCorrTabScale16)));
             t.x           = tab[0];
             t.y           = tab[1];
             t.z           = tab[2];
@@ -327,10 +337,8 @@ NB_DEVINL void nbPair(const NBParamGpu& nbp,
         if constexpr (ELEC == ELK_EWALD_ANA)
         {
             /* the table read is issued first: its LDS round trip overlaps the reciprocal square root and the LJ part */
-            xs                 = r2 * nbp.ewaldCorrTabScale;
-            const unsigned idx = static_cast<unsigned>(xs);
-            /* the table sits at LDS address 0 (nbnxmKernel checks it): the address is idx * 8, no base to add */
-            LdsFloat* tab = reinterpret_cast<LdsFloat*>(static_cast<uintptr_t>(idx * 8U));
+            /* the table sits at LDS address 0 (nbnxmKernel checks it): no base to add */
+            LdsFloat* tab = reinterpret_cast<LdsFloat*>(static_cast<uintptr_t>(ewaldTabAddress<8>(r2, nbp.ewaldCorrTabScale8)));
             t.x           = tab[0];
             t.y           = tab[1];
             (void)ewaldCorrLds;
@@ -478,18 +486,18 @@ NB_DEVINL void nbPair(const NBParamGpu& nbp,
             {
                 /* beta^3 F((beta r)^2) by linear interpolation in the LDS table; only pairs within rcoulomb get here,
                  * which is what bounds the index */
-                const float    xs  = r2 * nbp.ewaldCorrTabScale;
-                const unsigned idx = static_cast<unsigned>(xs);
+                const unsigned char* tabBase = reinterpret_cast<const unsigned char*>(ewaldCorrLds);
                 if constexpr (ENERGY)
                 {
                     /* the energy flavours' table carries the potential correction too */
-                    const float4 t = reinterpret_cast<const float4*>(ewaldCorrLds)[idx];
+                    const float4 t = *reinterpret_cast<const float4*>(tabBase + ewaldTabAddress<16>(r2, nbp.ewaldCorrTabScale16));
                     F_invr += qq * (inv_r3m + fmaf(t.y, r2, t.x));
                     corrV = fmaf(t.w, r2, t.z);
                 }
                 else
                 {
-                    const float2 t = ewaldCorrLds[idx]; /* {intercept, slope} of the interval's line in r^2 */
+                    /* {intercept, slope} of the entry's line in r^2 */
+                    const float2 t = *reinterpret_cast<const float2*>(tabBase + ewaldTabAddress<8>(r2, nbp.ewaldCorrTabScale8));
                     F_invr += qq * (inv_r3m + fmaf(t.y, r2, t.x));
                 }
             }
@@ -526,9 +534,8 @@ NB_DEVINL void nbPair(const NBParamGpu& nbp,
             {
                 /* cluster kernel, tabulated flavours: erf(beta r)/r = beta V((beta r)^2) from the potential table at LDS address 0 */
                 typedef __attribute__((address_space(3))) const float LdsFloat;
-                const float    xs2  = r2 * nbp.ewaldCorrTabScale;
-                const unsigned idx2 = static_cast<unsigned>(xs2);
-                LdsFloat*      tabV = reinterpret_cast<LdsFloat*>(static_cast<uintptr_t>(idx2 * 8U));
+                /* (the potential half of the 16-byte entries, staged as 8-byte entries: same spans, half the address) */
+                LdsFloat* tabV = reinterpret_cast<LdsFloat*>(static_cast<uintptr_t>(ewaldTabAddress<16>(r2, nbp.ewaldCorrTabScale16) >> 1));
                 E_el = qq * (int_bit * (inv_r - nbp.sh_ewald) - fmaf(tabV[1], r2, tabV[0]));
             }
             else { E_el = qq * (inv_r * (int_bit - erff(r2 * inv_r * beta)) - int_bit * nbp.sh_ewald); }

@@ -155,18 +155,27 @@ void uploadEwaldCorrectionTable(NbnxmGpu* nb)
     nb->h_ewaldCorrTab.resize(n);
     nb->h_ewaldCorrTabFV.resize(n);
     const double b3 = beta * beta * beta;
+    /* entry k: the line through the function at (k - 1/16) h and (k + 15/16) h in u = r^2, h = u_max / (n - 1): the kernel rounds
+     * 8 r^2 / h to an integer and drops its low three bits (ewaldTabAddress), which selects exactly that span; entry 0 reaches to
+     * -h/16 (F and V are analytic at 0: the series) and entry n - 1 covers the cut-off.
+     * Force flavours {intercept, slope} of beta^3 F, energy flavours the same for beta^3 F and beta V: value = a + b r^2, one FMA with
+     * the r^2 the pair block already holds. */
+    const double uMax = xMax / (beta * beta), du = uMax / (n - 1);
+    /* (the 16-byte entries of the energy flavours: 16 r^2 / h rounded, four bits dropped: spans from (k - 1/32) h) */
+    auto line = [&](auto&& fn, double scale, int k, double eighth, double& a, double& b) {
+        const double uL = (k - eighth) * du, uR = (k + 1.0 - eighth) * du;
+        const double y0 = scale * fn(beta * beta * uL), y1 = scale * fn(beta * beta * uR);
+        b = (y1 - y0) / du;
+        a = y0 - b * uL;
+    };
     for (int k = 0; k < n; k++)
     {
-        const double t0 = b3 * F(xMax * k / n), t1 = b3 * F(xMax * (k + 1) / n);
-        const double v0 = beta * V(xMax * k / n), v1 = beta * V(xMax * (k + 1) / n);
-        /* force flavours: the interval's line as {intercept, slope} in r^2 itself, value = a + b r^2 — one FMA with the r^2 the pair
-         * block already holds, no fraction of the table coordinate (energy flavours below: the same for both corrections) */
-        const double u0 = xMax * k / n / (beta * beta), du = xMax / n / (beta * beta);
-        const double slope = (t1 - t0) / du;
-        nb->h_ewaldCorrTab.data[k]   = make_float2(static_cast<float>(t0 - slope * u0), static_cast<float>(slope));
-        const double slopeV = (v1 - v0) / du;
-        nb->h_ewaldCorrTabFV.data[k] = make_float4(static_cast<float>(t0 - slope * u0), static_cast<float>(slope), static_cast<float>(v0 - slopeV * u0),
-                                                   static_cast<float>(slopeV));
+        double a, b, aV, bV;
+        line(F, b3, k, 1.0 / 16.0, a, b);
+        nb->h_ewaldCorrTab.data[k] = make_float2(static_cast<float>(a), static_cast<float>(b));
+        line(F, b3, k, 1.0 / 32.0, a, b);
+        line(V, beta, k, 1.0 / 32.0, aV, bV);
+        nb->h_ewaldCorrTabFV.data[k] = make_float4(static_cast<float>(a), static_cast<float>(b), static_cast<float>(aV), static_cast<float>(bV));
     }
     if (nbp->ewaldCorrTab == nullptr)
     {
@@ -175,7 +184,8 @@ void uploadEwaldCorrectionTable(NbnxmGpu* nb)
     }
     copyToDeviceBuffer(&nbp->ewaldCorrTab, nb->h_ewaldCorrTab.data, 0, n, nb->deviceStreams[0].stream, true);
     copyToDeviceBuffer(&nbp->ewaldCorrTabFV, nb->h_ewaldCorrTabFV.data, 0, n, nb->deviceStreams[0].stream, true);
-    nbp->ewaldCorrTabScale = static_cast<float>(beta * beta * n / xMax);
+    nbp->ewaldCorrTabScale8  = static_cast<float>(8.0 / du);
+    nbp->ewaldCorrTabScale16 = static_cast<float>(16.0 / du);
 }
 
 bool canSkipNonbondedWork(const NbnxmGpu& nb, int iloc)

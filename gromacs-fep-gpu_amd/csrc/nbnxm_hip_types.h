@@ -158,9 +158,11 @@ struct NBParamGpu
      * {intercept, slope} in r^2 (value = a + b r^2: the FMA takes the r^2 the pair block holds, no fraction of the table
      * coordinate); the cluster kernel keeps it in LDS (one ds_read_b64 + one FMA per pair instead of a [5/4]
      * rational with a reciprocal, ~4 instead of ~14 issue slots).  Linear interpolation error <= 1.2e-6 relative,
-     * the class of the rational fit (pme_corr_coeffs.h).  ewaldCorrTabScale = intervals per unit of r^2. */
+     * the class of the rational fit (pme_corr_coeffs.h).  Entry k is the line over [(k - 1/16) h, (k + 15/16) h], h = r_c^2 / (size - 1): the
+     * span the kernel's address arithmetic selects (ewaldTabAddress, nbnxm_device_helpers.h).  ewaldCorrTabScale8 / 16 = 8 or 16 bytes per entry / h. */
     float2* ewaldCorrTab;
-    float   ewaldCorrTabScale;
+    float   ewaldCorrTabScale8;
+    float   ewaldCorrTabScale16;
     /* the same grid with the potential correction beside the force correction, for the energy flavours: {intercept, slope} of beta^3 F and of beta V, both in r^2,
      * with V(x) = erf(z)/z, x = z^2 (gmx::pmePotentialCorrection, simd/simd_math.h:1660-1760): one ds_read_b128 and two FMAs per pair
      * instead of two [5/4] rationals with a reciprocal each */
