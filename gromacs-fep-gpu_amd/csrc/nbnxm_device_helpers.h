@@ -237,6 +237,8 @@ template<int STRIDE>
 NB_DEVINL unsigned ewaldTabAddress(const float r2, const float scaleTimesStride)
 {
     const float y = fmaf(r2, scaleTimesStride, 8388608.0F);
+    /* (measured and not kept: the scale in a VGPR with the 2^23 as the literal of a v_fmaak, +2.0 us; the AND's mask from an SGPR instead of a
+     * literal, +1.1 us) */
     return __builtin_bit_cast(unsigned, y) & static_cast<unsigned>((c_ewaldCorrTabSize * STRIDE - 1) & ~(STRIDE - 1));
 }
 
