@@ -84,6 +84,22 @@ void setCutoffParameters(NBParamGpu* nbp, const nbnxm_interaction_params_t* ic)
     }
 }
 
+/* The electrostatics kernel type that runs for the caller's pick.  The reference picks the TABULATED Ewald kernels by default on AMD
+ * devices (nbnxm_gpu_data_mgmt.cpp:120-145; analytical on NVIDIA) — a speed decision, both evaluate the same real-space Ewald term.
+ * Here the analytical flavours are the fast ones (their correction is one LDS read and one FMA, nbnxm_device_helpers.h: 0.0515 against
+ * 0.0624 ms per force step on the 96k box), so a tabulated pick runs them whenever beta r_c is inside the range their table and the
+ * perturbed-pair fit cover; NBNXM_HIP_KEEP_TAB_KERNELS=1 keeps the caller's pick (the reference's r-indexed table staged in LDS). */
+int kernelElecType(const NbnxmGpu* nb, const nbnxm_interaction_params_t* ic)
+{
+    const bool tabulated  = (ic->elecType == NBNXM_ELEC_EWALD_TAB || ic->elecType == NBNXM_ELEC_EWALD_TAB_TWIN);
+    const bool fitCovers  = ic->ewaldcoeff_q * ic->ewaldcoeff_q * ic->rcoulomb * ic->rcoulomb <= 12.0F;
+    if (tabulated && fitCovers && !nb->keepTabulatedKernels)
+    {
+        return ic->elecType == NBNXM_ELEC_EWALD_TAB ? NBNXM_ELEC_EWALD_ANA : NBNXM_ELEC_EWALD_ANA_TWIN;
+    }
+    return ic->elecType;
+}
+
 void uploadCoulombTable(NbnxmGpu* nb, const nbnxm_interaction_params_t* ic)
 {
     NBParamGpu* nbp = nb->nbparam;
@@ -441,6 +457,7 @@ NbnxmGpu* nbnxm_gpu_init(const nbnxm_interaction_params_t* ic, int numTypes, con
     }
 
     if (const char* env = std::getenv("NBNXM_HIP_KEEP_COMB_KERNELS")) { nb->keepCombinationKernels = (std::atoi(env) != 0); }
+    if (const char* env = std::getenv("NBNXM_HIP_KEEP_TAB_KERNELS")) { nb->keepTabulatedKernels = (std::atoi(env) != 0); }
     nb->debugLaunchShape = (std::getenv("NBNXM_HIP_DEBUG_LAUNCH_SHAPE") != nullptr);
 
     /* pinned staging (gpu_init :573-583) */
@@ -471,7 +488,8 @@ NbnxmGpu* nbnxm_gpu_init(const nbnxm_interaction_params_t* ic, int numTypes, con
 
     /* initNbparam :421-489 */
     NBParamGpu* nbp = nb->nbparam;
-    nbp->elecType   = ic->elecType;
+    NBNXM_ASSERT(ic->elecType >= 0 && ic->elecType < NBNXM_ELEC_COUNT, "unknown electrostatics kernel type");
+    nbp->elecType   = kernelElecType(nb, ic);
     nbp->vdwType    = ic->vdwType;
     nbp->bFEP       = bFEP != 0;
     setCutoffParameters(nbp, ic);
@@ -489,7 +507,7 @@ NbnxmGpu* nbnxm_gpu_init(const nbnxm_interaction_params_t* ic, int numTypes, con
     }
     uploadCoulombTable(nb, ic);
     uploadEwaldCorrectionTable(nb);
-    if (ic->elecType == NBNXM_ELEC_EWALD_ANA || ic->elecType == NBNXM_ELEC_EWALD_ANA_TWIN)
+    if (nbp->elecType == NBNXM_ELEC_EWALD_ANA || nbp->elecType == NBNXM_ELEC_EWALD_ANA_TWIN)
     {
         /* domain of the fitted analytical correction (pme_corr_coeffs.h): (beta r)^2 <= 12 */
         NBNXM_ASSERT(ic->ewaldcoeff_q * ic->ewaldcoeff_q * ic->rcoulomb * ic->rcoulomb <= 12.0F,
@@ -669,7 +687,7 @@ void nbnxm_gpu_copy_fepparams(NbnxmGpu* nb, int bFEP, float alpha_coul, float al
 
 void nbnxm_gpu_pme_loadbal_update_param(NbnxmGpu* nb, const nbnxm_interaction_params_t* ic)
 {
-    nb->nbparam->elecType = ic->elecType;
+    nb->nbparam->elecType = kernelElecType(nb, ic);
     setCutoffParameters(nb->nbparam, ic);
     uploadCoulombTable(nb, ic);
     uploadEwaldCorrectionTable(nb);

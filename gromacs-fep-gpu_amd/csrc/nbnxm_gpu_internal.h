@@ -87,6 +87,7 @@ struct NbnxmGpu
 
     int nbWavesPerBlock = c_nbWavesPerBlock; /* tunable: NBNXM_HIP_WAVES_PER_BLOCK = 1..4 */
     bool keepCombinationKernels = false;     /* diagnostics: NBNXM_HIP_KEEP_COMB_KERNELS=1 */
+    bool keepTabulatedKernels   = false;     /* NBNXM_HIP_KEEP_TAB_KERNELS=1: a caller that picks the tabulated Ewald kernels gets them */
     /* domain decomposition: the local force-only launch in two parts (nbnxm_gpu_set_local_launch_parts), the second one behind the
      * non-local kernel so that it runs beside the force halo */
     int   localLaunchParts    = 1;

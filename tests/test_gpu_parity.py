@@ -539,6 +539,30 @@ def test_local_and_nonlocal_streams():
     nb.free()
 
 
+@pytest.mark.parametrize("rvdw", [None, 0.9])
+def test_a_tabulated_ewald_pick_runs_the_analytical_kernels(rvdw, monkeypatch):
+    # the reference picks the tabulated flavours by default on AMD devices; here the analytical ones are faster and run instead
+    # (NBNXM_HIP_KEEP_TAB_KERNELS=1, set by conftest.py for every other test, keeps the caller's pick)
+    monkeypatch.delenv("NBNXM_HIP_KEEP_TAB_KERNELS", raising=False)
+    lib = pkg.hip_lib()
+    got = {}
+    for elec in ("ewald_tab", "ewald"):
+        c = tl.make_case(elec=elec, rvdw=rvdw, seed=45, **SMALL)
+        nb = tl.setup_gpu(c, fused=True)
+        assert lib.nbnxm_gpu_is_kernel_ewald_analytical(nb.h) == 1
+        got[elec] = tl.run_gpu(c, energy=True, nb=nb)
+        nb.free()
+        tl.assert_parity(got[elec], tl.run_oracle(c, energy=True), rel=1e-4, label=elec)
+    for key in ("e_el", "e_lj", "dvdl_coul", "dvdl_vdw"):
+        assert abs(got["ewald_tab"][key] - got["ewald"][key]) <= 2e-6 * max(1.0, abs(got["ewald"][key])), key
+    frms = math.sqrt(float(np.mean(np.sum(got["ewald"]["f"] ** 2, axis=1))))
+    assert np.max(np.abs(got["ewald_tab"]["f"] - got["ewald"]["f"])) <= 2e-5 * frms     # same kernels; the adds arrive in a different order
+    monkeypatch.setenv("NBNXM_HIP_KEEP_TAB_KERNELS", "1")
+    nb = tl.setup_gpu(tl.make_case(elec="ewald_tab", rvdw=rvdw, seed=45, **SMALL), fused=True)
+    assert lib.nbnxm_gpu_is_kernel_ewald_analytical(nb.h) == 0
+    nb.free()
+
+
 def test_timing_and_query_entry_points():
     c = tl.make_case(elec="ewald", seed=44, n_lambda=3, **SMALL)
     nb = tl.setup_gpu(c)

@@ -22,6 +22,8 @@ for elec, vdw, rvdw in FLAVOURS:
     name = "%s/%s%s" % (elec, vdw, "" if rvdw is None else "/twin")
     if only and name not in only.split(","):
         continue
+    # (a tabulated pick runs the analytical kernels by default, csrc/nbnxm_gpu.hip: kernelElecType; these rows time the tabulated kernels)
+    os.environ["NBNXM_HIP_KEEP_TAB_KERNELS"] = "1" if elec == "ewald_tab" else "0"
     c = wl.make_case(nm=(40, 40, 20), num_perturbed_molecules=16, elec=elec, vdw=vdw, rvdw=rvdw, seed=2026, n_lambda=11, max_cjpacked_per_sci=16)
     nb = wl.setup_gpu(c, fused=True, use_dynamic_pruning=True)
     nb.set_timing(False)
