@@ -764,7 +764,9 @@ __launch_bounds__(c_nbMaxBlockSize) __attribute__((amdgpu_waves_per_eu(c_nbWaves
              * travels in the buffer instruction's SCALAR offset — no vector instruction per slot for the address (it took four, two of
              * them half rate).  Lanes tidxi >= 3 carry an offset beyond the buffer: the hardware range check looks at the vector
              * offset alone (raw buffers on gfx9: the scalar offset is not part of it), so they are dropped whatever the scalar offset. */
-            const int laneFjOff = ((laneG & 7U) < 3U) ? static_cast<int>((laneG >> 3) * 12U + (laneG & 7U) * 4U) : c_dropLane;
+            /* (tidxj * 12 as shift-adds: a v_mul_lo_u32 is a quarter-rate instruction) */
+            const unsigned tj        = laneG >> 3;
+            const int      laneFjOff = ((laneG & 7U) < 3U) ? static_cast<int>((((tj << 1) + tj) + (laneG & 7U)) << 2) : c_dropLane;
 #endif
 #pragma unroll
             for (int jm = 0; jm < c_jGroupSize; jm++)
@@ -779,19 +781,22 @@ __launch_bounds__(c_nbMaxBlockSize) __attribute__((amdgpu_waves_per_eu(c_nbWaves
                 const unsigned wexclJ = wexcl >> (jm * c_numClPerSupercl);
                 const int      cj     = (jm == 0) ? curA.x : ((jm == 1) ? curA.y : ((jm == 2) ? curA.z : curA.w));
                 [[maybe_unused]] const int aj = cj * c_clSize + static_cast<int>(tidxj);
-                const unsigned jAtom  = static_cast<unsigned>(jm) * c_clSize + (laneG >> 3);
-                const float4   xqj    = *reinterpret_cast<const float4*>(jData + jAtom * 16U);
+                /* (lane part and slot part of the staging addresses kept apart: the slot part is a constant of the unrolled loop and
+                 * belongs in the ds_read's offset field, not in a vector add per slot) */
+                const unsigned char* jLane16 = jData + (laneG >> 3) * 16U;
+                const unsigned char* jLane4  = jData + c_jStageLjOffset + (laneG >> 3) * 4U;
+                const float4   xqj    = *reinterpret_cast<const float4*>(jLane16 + static_cast<unsigned>(jm) * (c_clSize * 16U));
                 int            typej  = 0;
                 float2         ljcp_j = make_float2(0.0F, 0.0F);
                 if constexpr (USE_TABLE)
                 {
-                    typej = *reinterpret_cast<const int*>(jData + c_jStageLjOffset + jAtom * 4U);
+                    typej = *reinterpret_cast<const int*>(jLane4 + static_cast<unsigned>(jm) * (c_clSize * 4U));
                     if constexpr (LJ_EWALD) { ljcp_j = nbfpLds[numTypes * numTypes + typej]; }
                 }
                 else
                 {
-                    ljcp_j.x = *reinterpret_cast<const float*>(jData + c_jStageLjOffset + jAtom * 4U);
-                    ljcp_j.y = *reinterpret_cast<const float*>(jData + c_jStageLjOffset + 128U + jAtom * 4U);
+                    ljcp_j.x = *reinterpret_cast<const float*>(jLane4 + static_cast<unsigned>(jm) * (c_clSize * 4U));
+                    ljcp_j.y = *reinterpret_cast<const float*>(jLane4 + 128U + static_cast<unsigned>(jm) * (c_clSize * 4U));
                 }
 
                 const unsigned fastMask = imaskJ;
@@ -819,6 +824,8 @@ __launch_bounds__(c_nbMaxBlockSize) __attribute__((amdgpu_waves_per_eu(c_nbWaves
                 fjOff = c_dropLane;
 #endif
                 }
+                /* (the add at the merge point of the two paths costs one register copy per slot — its offset operand is a phi; with an
+                 * add in each path instead, the compiler restructures the slot loop and spills 19 values: tried, not kept) */
 #ifdef NBNXM_TIMING_NO_J_INSTR
                 asm volatile("" ::"v"(fjv), "v"(fjOff));
 #else
