@@ -236,9 +236,10 @@ NB_DEVINL void ljGridC6AB(const NBParamGpu& nbp, const int4& t4i, const int4& t4
 template<int STRIDE>
 NB_DEVINL unsigned ewaldTabAddress(const float r2, const float scaleTimesStride)
 {
+    /* (the scale arrives in a vector register, nbnxmKernel sets it once: an FMA with a scalar operand issues at half rate, with a literal
+     * addend — v_fmaak — at full rate: tools/ubench/valu_rate3.hip, 1.90 against 1.18 ns per wave instruction and SIMD.  Measured and not
+     * kept: the AND's mask from an SGPR instead of a literal, +1.1 us) */
     const float y = fmaf(r2, scaleTimesStride, 8388608.0F);
-    /* (measured and not kept: the scale in a VGPR with the 2^23 as the literal of a v_fmaak, +2.0 us; the AND's mask from an SGPR instead of a
-     * literal, +1.1 us) */
     return __builtin_bit_cast(unsigned, y) & static_cast<unsigned>((c_ewaldCorrTabSize * STRIDE - 1) & ~(STRIDE - 1));
 }
 
@@ -255,7 +256,9 @@ NB_DEVINL void nbPair(const NBParamGpu& nbp,
                       float&            F_invr,
                       float&            E_lj,
                       float&            E_el,
-                      [[maybe_unused]] float c6grid = 0.0F /* LJ-PME flavours: C6 of the grid part for this pair */)
+                      [[maybe_unused]] float c6grid = 0.0F, /* LJ-PME flavours: C6 of the grid part for this pair */
+                      [[maybe_unused]] float ewaldTabScaleV = 0.0F /* cluster kernel, analytical Ewald: NBParamGpu::ewaldCorrTabScale8 (16 on
+                                                                    * energy steps) in a VECTOR register, set once per kernel */)
 {
     /* r^2 >= c_nbnxnMinDistanceSquared (pairlist.h:166) exists so that EXCLUDED pairs at zero distance — an atom's pair with itself,
      * a shell on its core — do not turn the sums into NaN.  The force-only one-mask block below removes everything an exclusion
@@ -272,6 +275,21 @@ NB_DEVINL void nbPair(const NBParamGpu& nbp,
     constexpr bool c_oneMaskForceBlock = false;
 #endif
     if constexpr (!c_oneMaskForceBlock) { r2 = fmaxf(r2, c_nbnxnMinDistanceSquared); }
+    /* force-only analytical Ewald: the correction's table read goes out before anything else — its LDS round trip is the longest
+     * latency of the block, and left to the scheduler it is issued behind the multiplies that wait for the reciprocal square root */
+    [[maybe_unused]] float2 tEarly = make_float2(0.0F, 0.0F);
+    constexpr bool          c_earlyTableRead = c_oneMaskForceBlock && ELEC == ELK_EWALD_ANA;
+    if constexpr (c_earlyTableRead)
+    {
+        typedef __attribute__((address_space(3))) const float LdsFloatE;
+        /* the table sits at LDS address 0 (nbnxmKernel checks it): no base to add */
+        LdsFloatE* tab = reinterpret_cast<LdsFloatE*>(static_cast<uintptr_t>(ewaldTabAddress<8>(r2, ewaldTabScaleV)));
+        tEarly.x       = tab[0];
+        tEarly.y       = tab[1];
+#ifndef NBNXM_NO_SCHED_BARRIER
+        __builtin_amdgcn_sched_barrier(0);
+#endif
+    }
     const float inv_r  = __frsqrt_rn(r2);
     const float inv_r2 = inv_r * inv_r;
     float       inv_r6 = inv_r2 * inv_r2 * inv_r2;
@@ -292,7 +310,7 @@ NB_DEVINL void nbPair(const NBParamGpu& nbp,
         if constexpr (ELEC == ELK_EWALD_ANA)
         {
             typedef __attribute__((address_space(3))) const float LdsFloat;
-            LdsFloat* tab = reinterpret_cast<LdsFloat*>(static_cast<uintptr_t>(ewaldTabAddress<16>(r2, nbp.ewaldCorrTabScale16)));
+            LdsFloat* tab = reinterpret_cast<LdsFloat*>(static_cast<uintptr_t>(ewaldTabAddress<16>(r2, ewaldTabScaleV)));
             t.x           = tab[0];
             t.y           = tab[1];
             t.z           = tab[2];
@@ -338,11 +356,14 @@ NB_DEVINL void nbPair(const NBParamGpu& nbp,
         typedef __attribute__((address_space(3))) const float LdsFloat;
         if constexpr (ELEC == ELK_EWALD_ANA)
         {
-            /* the table read is issued first: its LDS round trip overlaps the reciprocal square root and the LJ part */
-            /* the table sits at LDS address 0 (nbnxmKernel checks it): no base to add */
-            LdsFloat* tab = reinterpret_cast<LdsFloat*>(static_cast<uintptr_t>(ewaldTabAddress<8>(r2, nbp.ewaldCorrTabScale8)));
-            t.x           = tab[0];
-            t.y           = tab[1];
+            if constexpr (c_earlyTableRead) { t = tEarly; }
+            else
+            {
+                /* the table sits at LDS address 0 (nbnxmKernel checks it): no base to add */
+                LdsFloat* tab = reinterpret_cast<LdsFloat*>(static_cast<uintptr_t>(ewaldTabAddress<8>(r2, ewaldTabScaleV)));
+                t.x           = tab[0];
+                t.y           = tab[1];
+            }
             (void)ewaldCorrLds;
         }
         if constexpr (ELEC == ELK_EWALD_TAB)
@@ -389,7 +410,12 @@ NB_DEVINL void nbPair(const NBParamGpu& nbp,
         float nm = fmaf(qq, inv_r, lj) * inv_r2;
         asm("v_and_b32 %0, %1, %2" : "=v"(nm) : "v"(intMask), "v"(nm));
         if constexpr (ELEC == ELK_RF) { F_invr = fmaf(qq, -nbp.two_k_rf, nm); }
-        else if constexpr (ELEC == ELK_EWALD_ANA) { F_invr = fmaf(qq, fmaf(t.y, r2, t.x), nm); } /* {intercept, slope} in r^2: no fraction needed */
+        else if constexpr (ELEC == ELK_EWALD_ANA)
+        {
+            /* (the table entry is not touched before the masked part is done: its wait then sits behind the whole LJ / Coulomb chain) */
+            if constexpr (c_earlyTableRead) { asm volatile("" : "+v"(t.x), "+v"(t.y) : "v"(nm)); }
+            F_invr = fmaf(qq, fmaf(t.y, r2, t.x), nm); /* {intercept, slope} in r^2: no fraction needed */
+        }
         else
         {
             const float fr = __builtin_amdgcn_fractf(xs);
@@ -492,14 +518,14 @@ NB_DEVINL void nbPair(const NBParamGpu& nbp,
                 if constexpr (ENERGY)
                 {
                     /* the energy flavours' table carries the potential correction too */
-                    const float4 t = *reinterpret_cast<const float4*>(tabBase + ewaldTabAddress<16>(r2, nbp.ewaldCorrTabScale16));
+                    const float4 t = *reinterpret_cast<const float4*>(tabBase + ewaldTabAddress<16>(r2, ewaldTabScaleV));
                     F_invr += qq * (inv_r3m + fmaf(t.y, r2, t.x));
                     corrV = fmaf(t.w, r2, t.z);
                 }
                 else
                 {
                     /* {intercept, slope} of the entry's line in r^2 */
-                    const float2 t = *reinterpret_cast<const float2*>(tabBase + ewaldTabAddress<8>(r2, nbp.ewaldCorrTabScale8));
+                    const float2 t = *reinterpret_cast<const float2*>(tabBase + ewaldTabAddress<8>(r2, ewaldTabScaleV));
                     F_invr += qq * (inv_r3m + fmaf(t.y, r2, t.x));
                 }
             }
@@ -537,7 +563,7 @@ NB_DEVINL void nbPair(const NBParamGpu& nbp,
                 /* cluster kernel, tabulated flavours: erf(beta r)/r = beta V((beta r)^2) from the potential table at LDS address 0 */
                 typedef __attribute__((address_space(3))) const float LdsFloat;
                 /* (the potential half of the 16-byte entries, staged as 8-byte entries: same spans, half the address) */
-                LdsFloat* tabV = reinterpret_cast<LdsFloat*>(static_cast<uintptr_t>(ewaldTabAddress<16>(r2, nbp.ewaldCorrTabScale16) >> 1));
+                LdsFloat* tabV = reinterpret_cast<LdsFloat*>(static_cast<uintptr_t>(ewaldTabAddress<16>(r2, ewaldTabScaleV) >> 1));
                 E_el = qq * (int_bit * (inv_r - nbp.sh_ewald) - fmaf(tabV[1], r2, tabV[0]));
             }
             else { E_el = qq * (inv_r * (int_bit - erff(r2 * inv_r * beta)) - int_bit * nbp.sh_ewald); }

@@ -262,7 +262,7 @@ NB_DEVINL void pruneEntry(const NBAtomDataGpu& atdat, const NBParamGpu& nbp, con
                                 float F_invr, E_lj_p = 0.0F, E_el_p = 0.0F, c6grid = 0.0F; \
                                 if constexpr (LJ_EWALD) { c6grid = ljGridC6(VDW, ljcpi[i], ljcp_j); } \
                                 nbPair<ELEC, TWIN, VDW, ENERGY, EXCL_FORCES, HAS_EXCL>(nbp, ewaldCorrLds, r2, intMask, xqi[i].w * xqj.w, c6, c12, \
-                                                                                       F_invr, E_lj_p, E_el_p, c6grid); \
+                                                                                       F_invr, E_lj_p, E_el_p, c6grid, ewaldTabScaleV); \
                                 if constexpr (ENERGY) \
                                 { \
                                     E_lj += E_lj_p; \
@@ -499,6 +499,14 @@ __launch_bounds__(c_nbMaxBlockSize) __attribute__((amdgpu_waves_per_eu(c_nbWaves
             dst[t]          = make_float2(fv.z, fv.w);
         }
     }
+
+    /* the table scale of ewaldTabAddress in a vector register, for the whole kernel (a scalar operand would halve the FMA's issue rate) */
+    [[maybe_unused]] float ewaldTabScaleV = 0.0F;
+    if constexpr (EWALD_CORR_TABLE)
+    {
+        asm volatile("v_mov_b32 %0, %1" : "=v"(ewaldTabScaleV) : "s"(ENERGY ? nbp.ewaldCorrTabScale16 : nbp.ewaldCorrTabScale8));
+    }
+    if constexpr (EWALD_V_TABLE) { asm volatile("v_mov_b32 %0, %1" : "=v"(ewaldTabScaleV) : "s"(nbp.ewaldCorrTabScale16)); }
 
     /* nbPair addresses the Ewald table with absolute LDS addresses from 0: the kernel has no static LDS, so the dynamic block starts there */
     if ((EWALD_CORR_TABLE || EWALD_R_TABLE) && reinterpret_cast<uintptr_t>((__attribute__((address_space(3))) unsigned char*)nbLds) != 0) { __builtin_trap(); }
