@@ -46,6 +46,39 @@ def test_split_path_with_the_atom_pair_kernel_of_its_own(elec, vdw, energy, monk
     assert np.max(np.abs(np.asarray(own["f"], np.float64) - np.asarray(merged["f"], np.float64))) <= 1e-4 * frms
 
 
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_atom_pair_lists_of_any_shape(seed, monkeypatch):
+    # what gpu_init_feppairlist regroups by cluster pair must not depend on how the caller cut the list: a random subset of the pairs,
+    # i-entries split at random places and put in random order, exclusion flags flipped at random — the same list goes to the oracle,
+    # to the trailing workgroups of the cluster kernel and to the atom-pair kernel of its own
+    c = tl.make_case(elec="ewald", seed=30 + seed, nm=(10, 10, 10), num_perturbed_molecules=12)
+    rng = np.random.default_rng(seed)
+    fep = c.plist.fep
+    iinr, shift, jindex, jjnr, excl = [], [], [0], [], []
+    order = rng.permutation(len(fep["iinr"]))
+    for e in order:
+        b, e1 = int(fep["jindex"][e]), int(fep["jindex"][e + 1])
+        keep = np.nonzero(rng.random(e1 - b) < 0.7)[0] + b
+        cuts = np.sort(rng.choice(np.arange(1, max(2, len(keep))), size=min(2, max(0, len(keep) - 1)), replace=False)) if len(keep) > 2 else []
+        for part in np.split(keep, cuts):
+            if len(part) == 0:
+                continue
+            iinr.append(fep["iinr"][e]); shift.append(fep["shift"][e])
+            jjnr.extend(fep["jjnr"][part]); excl.extend(np.where(rng.random(len(part)) < 0.1, 1 - fep["excl_fep"][part], fep["excl_fep"][part]))
+            jindex.append(len(jjnr))
+    # (a self pair keeps its flag: the reference's list flags it excluded)
+    iin, jj, ex = np.repeat(np.asarray(iinr), np.diff(jindex)), np.asarray(jjnr), np.asarray(excl)
+    ex[iin == jj] = 0
+    c.plist.fep = dict(iinr=np.asarray(iinr, np.int32), shift=np.asarray(shift, np.int32), jindex=np.asarray(jindex, np.int32),
+                       jjnr=jj.astype(np.int32), excl_fep=ex.astype(np.int32))
+    want = tl.run_oracle(c, energy=True)
+    merged = tl.run_gpu(c, energy=True, fused=False)
+    tl.assert_parity(merged, want, rel=1e-4, label="regrouped list %d" % seed)
+    monkeypatch.setenv("NBNXM_HIP_FEP_LIST_MERGED", "0")
+    own = tl.run_gpu(c, energy=True, fused=False)
+    tl.assert_parity(own, want, rel=1e-4, label="flattened list %d" % seed)
+
+
 @pytest.mark.parametrize("elec", ["rf", "cut", "ewald", "ewald_tab"])
 @pytest.mark.parametrize("energy", [False, True])
 def test_fused_path_matches_oracle(elec, energy):
@@ -515,10 +548,20 @@ def test_local_and_nonlocal_streams():
     nb.init_pairlist(sci[0::2], c.plist.cjPacked, c.plist.excl, iloc=pkg.LOCAL)
     nb.init_pairlist(sci[1::2], c.plist.cjPacked, c.plist.excl, iloc=pkg.NONLOCAL)
     fep = c.plist.fep
-    empty = dict(iinr=np.zeros(0, np.int32), shift=np.zeros(0, np.int32), jindex=np.zeros(1, np.int32),
-                 jjnr=np.zeros(0, np.int32), excl_fep=np.zeros(0, np.int32))
-    nb.init_feppairlist(fep, g.atomIndices, iloc=pkg.LOCAL)
-    nb.init_feppairlist(empty, g.atomIndices, iloc=pkg.NONLOCAL)
+
+    def entries(which):
+        """the i-entries `which` of the atom-pair list as a list of their own (the atom-pair list is dealt to the localities too:
+        each locality's part rides in the tail of that locality's cluster kernel)"""
+        ji = fep["jindex"]
+        lens = (ji[1:] - ji[:-1])[which]
+        take = np.concatenate([np.arange(ji[e], ji[e + 1]) for e in which]) if len(which) else np.zeros(0, np.int64)
+        return dict(iinr=fep["iinr"][which], shift=fep["shift"][which], jindex=np.concatenate([[0], np.cumsum(lens)]).astype(np.int32),
+                    jjnr=fep["jjnr"][take], excl_fep=fep["excl_fep"][take])
+
+    nri = len(fep["iinr"])
+    assert nri > 4
+    nb.init_feppairlist(entries(np.arange(0, nri, 2)), g.atomIndices, iloc=pkg.LOCAL)
+    nb.init_feppairlist(entries(np.arange(1, nri, 2)), g.atomIndices, iloc=pkg.NONLOCAL)
     nb.upload_shiftvec(g.shift_vec)
     sw = pkg.step_workload(energy=True, virial=True)
     nb.clear_outputs(True)
