@@ -9,7 +9,7 @@ import fep_testlib as tl
 pkg = tl.pkg
 mdloop = importlib.import_module("gromacs_fep_gpu_amd.mdloop")
 for npert, dt, nsteps, every in ((0, 0.0001, 150, 5), (0, 0.00005, 300, 10), (3, 0.00005, 300, 10)):
-    c = tl.make_case(nm=(8, 8, 8), num_perturbed_molecules=npert, elec="rf", seed=5)
+    c = tl.make_case(nm=(8, 8, 8), num_perturbed_molecules=npert, elec=os.environ.get("NVE_ELEC", "rf"), seed=5)
     g = c.grid
     nb = tl.setup_gpu(c, fused=True)
     n = c.natoms
