@@ -357,6 +357,24 @@ def main(argv=None):
         ms_virial_only = timed(pkg.step_workload(energy=False, virial=True, dhdl=False))
         ms_energy_only = timed(pkg.step_workload(energy=True, virial=False, dhdl=False))
 
+    # the same force step in the reference's shape (secondary figure): the carved cluster list + the atom-pair list of make_fep_list through
+    # gpu_init_feppairlist, no nbnxm_gpu_set_fep_mode -- a second object on the same box, conditioned by the loop above
+    ms_reference_shape = None
+    if fused and world == 1 and not args.primary_only:
+        nb_split = wl.setup_gpu(case, fused=False, use_dynamic_pruning=not args.no_prune)
+        nb_split.set_timing(False)
+        for _ in range(200):
+            nb_split.clear_outputs(False)
+            nb_split.launch_kernel(sw_f)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(500):
+            nb_split.clear_outputs(False)
+            nb_split.launch_kernel(sw_f)
+        torch.cuda.synchronize()
+        ms_reference_shape = 1e3 * (time.perf_counter() - t1) / 500
+        nb_split.free()
+
     # GPU-resident MD steps between two searches (secondary figure): x -> xq, clear, kernels, force reduction, leap-frog and
     # SETTLE with coordinates, velocities and forces staying in HBM; 0.5 fs steps so that the list stays valid over the run
     ms_md_step = ms_md_step_sequence = ms_md_step_prune = None
@@ -475,6 +493,7 @@ def main(argv=None):
         "ms_per_energy_step": ms_energy_step, "ms_per_dhdl_step_11_foreign_lambdas": ms_dhdl_step,
         "ms_per_virial_only_step": ms_virial_only, "ms_per_energy_only_step": ms_energy_only,
         "ms_per_step_with_pinned_force_buffer": ms_pinned,
+        "ms_per_step_reference_shape_atom_pair_list": ms_reference_shape,
         "ms_per_gpu_resident_md_step": ms_md_step, "ms_per_gpu_resident_md_step_unfused_update": ms_md_step_sequence,
         "ms_per_gpu_resident_md_step_with_rolling_prune_8": ms_md_step_prune,
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
