@@ -590,6 +590,22 @@ class NbnxmGpu:
             pass
 
 
+_PINNED_KEEPALIVE = []
+
+
+def pinned_copy(arr):
+    """A copy of a numpy array (structured dtypes too) in page-locked host memory, as the reference keeps its pair lists and atom data
+    (HostVector with the pinning allocator): nbnxm_gpu_init_pairlist reads such arrays in place instead of staging them.
+    Needs torch with a GPU (the tensor that owns the memory is kept alive for the life of the process)."""
+    import torch
+    a = np.ascontiguousarray(arr)
+    t = torch.empty(max(1, a.nbytes), dtype=torch.uint8).pin_memory()
+    _PINNED_KEEPALIVE.append(t)
+    out = t.numpy()[:a.nbytes].view(a.dtype).reshape(a.shape)
+    out[...] = a
+    return out
+
+
 def download_cjpacked(nb, ncj, iloc=LOCAL):
     """Test helper: reads the device copy of the packed j-list back (after pruning)."""
     lib = hip_lib()

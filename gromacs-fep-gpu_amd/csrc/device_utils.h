@@ -100,6 +100,20 @@ void copyToDeviceBuffer(DeviceBuffer<T>* buffer, const T* hostBuffer, size_t sta
     if (!async) { NBNXM_HIP_CHECK(hipStreamSynchronize(stream)); }
 }
 
+/* Is this host pointer page-locked memory the runtime knows (hipHostMalloc / hipHostRegister — what the reference's HostVector
+ * with its pinning allocator hands over)?  Then a hipMemcpyAsync from it is a DMA of its own and needs no staging copy. */
+inline bool isPinnedHostMemory(const void* p)
+{
+    if (p == nullptr) { return false; }
+    hipPointerAttribute_t attr;
+    if (hipPointerGetAttributes(&attr, p) != hipSuccess)
+    {
+        (void)hipGetLastError(); /* pageable memory is "invalid value" here: an answer, not an error */
+        return false;
+    }
+    return attr.type == hipMemoryTypeHost;
+}
+
 template<typename T>
 void copyFromDeviceBuffer(T* hostBuffer, DeviceBuffer<T>* buffer, size_t startingOffset, size_t numValues,
                           hipStream_t stream, bool async)

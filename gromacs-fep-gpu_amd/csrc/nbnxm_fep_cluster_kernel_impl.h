@@ -51,10 +51,16 @@ __launch_bounds__(c_fepClusterWavesPerBlock* c_waveSize) __global__
 
     /* few, short, latency-bound waves next to (or between) kernels with thousands: top priority */
     __builtin_amdgcn_s_setprio(3);
-    const int item = __builtin_amdgcn_readfirstlane(static_cast<int>(blockIdx.x) * c_fepClusterWavesPerBlock + static_cast<int>(wave));
-    if (item >= plist.numSlowPairs) { return; }
-    fepClusterPair<ELEC, TWIN, VDW, ENERGY, FOREIGN>(atdat, nbp, plist, bCalcFshift, cjPackedList, exclList, xq, ljComb, fepWords,
-                                                     numForeignLambda, item, nbfpLds);
+    /* the launch is sized by the host's figure (the previous list's while a new list's count is still on its way), the items are
+     * counted on the device: the waves stride over them */
+    const int firstItem = __builtin_amdgcn_readfirstlane(static_cast<int>(blockIdx.x) * c_fepClusterWavesPerBlock + static_cast<int>(wave));
+    const int numItems  = __builtin_amdgcn_readfirstlane(min(*plist.slowCount, plist.slowPairs_nalloc));
+    const int stride    = static_cast<int>(gridDim.x) * c_fepClusterWavesPerBlock;
+    for (int item = firstItem; item < numItems; item += stride)
+    {
+        fepClusterPair<ELEC, TWIN, VDW, ENERGY, FOREIGN>(atdat, nbp, plist, bCalcFshift, cjPackedList, exclList, xq, ljComb, fepWords,
+                                                         numForeignLambda, item, nbfpLds);
+    }
 }
 
 #endif

@@ -553,6 +553,11 @@ void nbnxm_gpu_free(NbnxmGpu* nb)
     {
         if (st.stream) { (void)hipStreamSynchronize(st.stream); }
     }
+    for (hipEvent_t& e : nb->slowCountReady)
+    {
+        if (e != nullptr) { (void)hipEventDestroy(e); }
+        e = nullptr;
+    }
     NBAtomDataGpu* ad  = nb->atdat;
     NBParamGpu*    nbp = nb->nbparam;
     freeDeviceBuffer(&ad->xq);
@@ -745,12 +750,19 @@ void nbnxm_gpu_init_atomdata(NbnxmGpu* nb, int numAtoms, int numAtomsLocal, cons
         NBNXM_ASSERT(qA && qB && typeA && typeB, "FEP needs the A/B charges and types");
         nb->h_q4.resize(numAtoms);
         nb->h_atomTypes4.resize(numAtoms);
+        /* (range check as one min / max reduction, packing as branch-free loops: the compiler vectorises both — per-atom asserts
+         * inside the packing loop were most of this call's 0.2 ms at 96k atoms) */
+        int tLo = 0, tHi = 0;
         for (int i = 0; i < numAtoms; i++)
         {
-            NBNXM_ASSERT(typeA[i] >= 0 && typeA[i] < ad->numTypes && typeB[i] >= 0 && typeB[i] < ad->numTypes, "atom type out of range");
-            nb->h_q4.data[i]         = make_float4(qA[i], qB[i], 0.0F, 0.0F);
-            nb->h_atomTypes4.data[i] = make_int4(typeA[i], typeB[i], 0, 0);
+            tLo = std::min(tLo, std::min(typeA[i], typeB[i]));
+            tHi = std::max(tHi, std::max(typeA[i], typeB[i]));
         }
+        NBNXM_ASSERT(tLo >= 0 && tHi < ad->numTypes, "atom type out of range");
+        float4* __restrict__ q4h = nb->h_q4.data;
+        int4* __restrict__   t4h = nb->h_atomTypes4.data;
+        for (int i = 0; i < numAtoms; i++) { q4h[i] = make_float4(qA[i], qB[i], 0.0F, 0.0F); }
+        for (int i = 0; i < numAtoms; i++) { t4h[i] = make_int4(typeA[i], typeB[i], 0, 0); }
         copyToDeviceBuffer(&ad->q4, nb->h_q4.data, 0, numAtoms, s, true);
         copyToDeviceBuffer(&ad->atomTypes4, nb->h_atomTypes4.data, 0, numAtoms, s, true);
         /* lj_combA / lj_combB (NBAtomDataGpu::ljComb4 of the reference, nbnxm_fep_cuda_kernel.cuh:357-375) are not uploaded: the
@@ -759,10 +771,13 @@ void nbnxm_gpu_init_atomdata(NbnxmGpu* nb, int numAtoms, int numAtomsLocal, cons
         (void)lj_combA;
         (void)lj_combB;
     }
+    int lo = 0, hi = 0;
     for (int i = 0; i < numAtoms; i++)
     {
-        NBNXM_ASSERT(type[i] >= 0 && type[i] < ad->numTypes, "atom type out of range");
+        lo = std::min(lo, type[i]);
+        hi = std::max(hi, type[i]);
     }
+    NBNXM_ASSERT(lo >= 0 && hi < ad->numTypes, "atom type out of range");
 }
 
 static void uploadPairlist(NbnxmGpu* nb, int iloc, int na_c, int nsci, const nbnxn_sci_t* sci, int ncjPacked, const nbnxn_cj_packed_t* cjPacked,
@@ -872,25 +887,39 @@ static void uploadPairlist(NbnxmGpu* nb, int iloc, int na_c, int nsci, const nbn
     reallocateDeviceBuffer(&d->cjPacked, ncjPacked, &d->ncjPacked, &d->cjPacked_nalloc);
     reallocateDeviceBuffer(&d->imask, static_cast<size_t>(ncjPacked) * NBNXM_GPU_CLUSTERPAIR_SPLIT, &d->nimask, &d->imask_nalloc);
     reallocateDeviceBuffer(&d->excl, nexcl, &d->nexcl, &d->excl_nalloc);
-    nb->h_sci.resize(nsci);
-    nb->h_cjPacked.resize(ncjPacked);
-    nb->h_excl.resize(nexcl);
-    if (nsci) { std::memcpy(nb->h_sci.data, sci, sizeof(nbnxn_sci_t) * nsci); }
-    if (ncjPacked) { std::memcpy(nb->h_cjPacked.data, cjPacked, sizeof(nbnxn_cj_packed_t) * ncjPacked); }
-    if (nexcl) { std::memcpy(nb->h_excl.data, excl, sizeof(nbnxn_excl_t) * nexcl); }
-    /* pinned copies are per object, not per locality: finish the upload before they can be reused */
-    copyToDeviceBuffer(&d->sci, nb->h_sci.data, 0, nsci, s, true);
-    copyToDeviceBuffer(&d->cjPacked, nb->h_cjPacked.data, 0, ncjPacked, s, true);
-    copyToDeviceBuffer(&d->excl, nb->h_excl.data, 0, nexcl, s, true);
+    /* The three arrays go up as DMAs from page-locked memory.  A caller that keeps its lists in pinned memory (the reference does:
+     * HostVector with the pinning allocator, pairlist.h) is read in place; other memory is staged through the object's pinned buffers,
+     * the larger two first, each DMA queued as soon as its staging copy is done so that it runs beside the next one (4 MB of staging
+     * copies are 0.25 ms of a 0.38 ms upload on the 96k box).  The staging buffers are per object, not per locality: the upload is
+     * complete — the stream synchronised, below — before they can be reused; that also ends the caller's obligation to keep its
+     * arrays, whichever path was taken. */
+    auto upload = [s](auto* deviceBuffer, auto& staging, const auto* src, int n) {
+        if (n == 0) { return; }
+        if (isPinnedHostMemory(src)) { copyToDeviceBuffer(deviceBuffer, src, 0, n, s, true); }
+        else
+        {
+            staging.resize(n);
+            std::memcpy(staging.data, src, sizeof(*src) * n);
+            copyToDeviceBuffer(deviceBuffer, staging.data, 0, n, s, true);
+        }
+    };
+    upload(&d->cjPacked, nb->h_cjPacked, cjPacked, ncjPacked);
+    upload(&d->excl, nb->h_excl, excl, nexcl);
+    upload(&d->sci, nb->h_sci, sci, nsci);
     /* the i-entries ordered by their j-group range, for the work partition (empty entries first among equals) */
     {
         int dummy = 0;
         reallocateDeviceBuffer(&d->sciSorted, nsci, &dummy, &d->sciSorted_nalloc);
         nb->h_sciSorted.resize(nsci);
         if (nsci) { std::memcpy(nb->h_sciSorted.data, sci, sizeof(nbnxn_sci_t) * nsci); }
-        std::sort(nb->h_sciSorted.data, nb->h_sciSorted.data + nsci, [](const nbnxn_sci_t& a, const nbnxn_sci_t& b) {
+        auto byGroupRange = [](const nbnxn_sci_t& a, const nbnxn_sci_t& b) {
             return a.cjPackedBegin != b.cjPackedBegin ? a.cjPackedBegin < b.cjPackedBegin : a.cjPackedEnd < b.cjPackedEnd;
-        });
+        };
+        /* (a list builder appends j-groups entry by entry: the entries usually come in this order already) */
+        if (!std::is_sorted(nb->h_sciSorted.data, nb->h_sciSorted.data + nsci, byGroupRange))
+        {
+            std::sort(nb->h_sciSorted.data, nb->h_sciSorted.data + nsci, byGroupRange);
+        }
         for (int i = 1; i < nsci; i++)
         {
             NBNXM_ASSERT(nb->h_sciSorted.data[i].cjPackedBegin >= nb->h_sciSorted.data[i - 1].cjPackedEnd,
@@ -916,6 +945,14 @@ static void uploadPairlist(NbnxmGpu* nb, int iloc, int na_c, int nsci, const nbn
         copyToDeviceBuffer(&d->sciSorted, nb->h_sciSorted.data, 0, nWork, s, true);
     }
     NBNXM_HIP_CHECK(hipStreamSynchronize(s));
+    {
+        /* the first-pass prune cuts every entry into waves of a few groups: 4 groups per wave unless that makes more than 64 waves per entry */
+        int longest = 0;
+        for (int i = 0; i < nsci; i++) { longest = std::max(longest, sci[i].cjPackedEnd - sci[i].cjPackedBegin); }
+        constexpr int c_pruneGroupsPerWave = 4, c_maxPruneWavesPerEntry = 64;
+        d->pruneGroupsPerWave = std::max(c_pruneGroupsPerWave, (longest + c_maxPruneWavesPerEntry - 1) / c_maxPruneWavesPerEntry);
+        d->pruneWavesPerEntry = std::max(1, (longest + d->pruneGroupsPerWave - 1) / d->pruneGroupsPerWave);
+    }
     d->workRangesDirty        = true;
     d->slowListDirty          = true;
     d->haveFreshList          = true;
@@ -1075,7 +1112,6 @@ void nbnxm_gpu_init_fep_cluster_bits(NbnxmGpu* nb, int numClusters, const unsign
         {
             pl->workRangesDirty = true;
             pl->slowListDirty   = true;
-            pl->workShareCount[0] = pl->workShareCount[1] = -1; /* the default shares depend on the mode */
         }
     }
 }
@@ -1083,13 +1119,17 @@ void nbnxm_gpu_init_fep_cluster_bits(NbnxmGpu* nb, int numClusters, const unsign
 void nbnxm_gpu_set_fep_mode(NbnxmGpu* nb, int fused)
 {
     NBNXM_ASSERT(!fused || nb->atdat->fepBits != nullptr, "fused FEP mode needs nbnxm_gpu_init_fep_cluster_bits first");
-    nb->fusedFep = fused != 0;
+    const bool changed = (nb->fusedFep != (fused != 0));
+    nb->fusedFep       = fused != 0;
     for (gpu_plist* pl : nb->plist)
     {
         if (pl)
         {
             pl->workRangesDirty = true;
             pl->slowListDirty   = true;
+            /* the default shares of the ranges depend on the mode (updateWorkPartition); they survive everything else — in particular
+             * the perturbed-atom bits of every search step, which used to drop them: two allocations and two blocking copies per search */
+            if (changed) { pl->workShareCount[0] = pl->workShareCount[1] = -1; }
         }
     }
 }
@@ -1181,6 +1221,23 @@ static void setWorkShares(gpu_plist* d, int p, const float* share, int n, hipStr
     d->workRangesDirty = true;
 }
 
+/* the count of perturbed cluster pairs of the current list, if its copy has arrived (updateWorkPartition queued it) */
+static void pickUpSlowCount(NbnxmGpu* nb, int iloc)
+{
+    gpu_plist* d = nb->plist[iloc];
+    if (!d->slowCountPending) { return; }
+    if (hipEventQuery(nb->slowCountReady[iloc]) != hipSuccess)
+    {
+        (void)hipGetLastError(); /* "not ready" is an answer, not an error for the launch checks that follow */
+        return;
+    }
+    d->numSlowPairs     = nb->h_slowCount.data[iloc];
+    d->slowCountPending = false;
+    d->slowCountKnown   = true;
+    NBNXM_ASSERT(d->numSlowPairs <= d->slowPairs_nalloc,
+                 "more perturbed cluster pairs than the fused mode provides for (use the atom-pair list mode for large perturbed regions)");
+}
+
 /* (Re)computes the work partition of a list on its stream; cheap (three launches over ncjPacked ints). */
 static void updateWorkPartition(NbnxmGpu* nb, int iloc)
 {
@@ -1229,17 +1286,24 @@ static void updateWorkPartition(NbnxmGpu* nb, int iloc)
     NBNXM_HIP_CHECK(hipGetLastError());
     if (buildSlow)
     {
-        /* the launch of the perturbed-cluster-pair kernel (and the room left for it, below) needs the count on the
-         * host: one small synchronous copy per new list (not per prune) */
-        nb->h_slowCount.resize(1);
-        NBNXM_HIP_CHECK(hipMemcpyAsync(nb->h_slowCount.data, d->slowCount, sizeof(int), hipMemcpyDeviceToHost, s));
-        NBNXM_HIP_CHECK(hipStreamSynchronize(s));
-        d->numSlowPairs  = nb->h_slowCount.data[0];
-        d->slowListDirty = false;
-        NBNXM_ASSERT(d->numSlowPairs <= d->slowPairs_nalloc,
-                     "more perturbed cluster pairs than the fused mode provides for (use the atom-pair list mode for large perturbed regions)");
+        /* The host only needs the count to SIZE launches (the kernels stride over the device's count).  The first list of an object
+         * waits for it; later lists queue the copy, size their first launches from the previous count plus a margin, and pick the
+         * exact figure up when it has arrived (pickUpSlowCount): no host round trip in a search step. */
+        if (nb->h_slowCount.size < 2) { nb->h_slowCount.resize(2); }
+        if (nb->slowCountReady[iloc] == nullptr) { NBNXM_HIP_CHECK(hipEventCreateWithFlags(&nb->slowCountReady[iloc], hipEventDisableTiming)); }
+        NBNXM_HIP_CHECK(hipMemcpyAsync(nb->h_slowCount.data + iloc, d->slowCount, sizeof(int), hipMemcpyDeviceToHost, s));
+        NBNXM_HIP_CHECK(hipEventRecord(nb->slowCountReady[iloc], s));
+        d->slowCountPending = true;
+        d->slowListDirty    = false;
+        if (!d->slowCountKnown) { NBNXM_HIP_CHECK(hipStreamSynchronize(s)); }
+        else { d->numSlowPairs = std::min(d->slowPairs_nalloc, std::max(256, d->numSlowPairs + d->numSlowPairs / 4 + 64)); }
+        pickUpSlowCount(nb, iloc);
     }
-    if (!fused) { d->numSlowPairs = 0; }
+    if (!fused)
+    {
+        d->numSlowPairs     = 0;
+        d->slowCountPending = false;
+    }
 
     WorkPartitionOut out[2];
     for (int p = 0; p < 2; p++)
@@ -1341,7 +1405,9 @@ void nbnxm_gpu_launch_kernel_pruneonly(NbnxmGpu* nb, int iloc, int numParts)
     {
         if (nb->bDoTime) { t.prune_k.openTimingRegion(s); }
         const PruneKernelPtr kernel = selectPruneKernel(plist->haveFreshList);
-        hipLaunchKernelGGL(kernel, dim3(numSciInPart), dim3(c_waveSize), 0, s, *nb->atdat, *nb->nbparam, *plist, numParts, part);
+        /* (first pass: several waves per i-entry, see nbnxmPruneKernel) */
+        const int wavesPerEntry = plist->haveFreshList ? std::max(1, plist->pruneWavesPerEntry) : 1;
+        hipLaunchKernelGGL(kernel, dim3(numSciInPart, wavesPerEntry), dim3(c_waveSize), 0, s, *nb->atdat, *nb->nbparam, *plist, numParts, part);
         NBNXM_HIP_CHECK(hipGetLastError());
         if (nb->bDoTime) { t.prune_k.closeTimingRegion(s); }
     }
@@ -1449,12 +1515,15 @@ void nbnxm_gpu_launch_kernel(NbnxmGpu* nb, const nbnxm_step_workload_t* stepWork
         }
     }
 
-    /* fused mode: the list of perturbed cluster pairs is built from the masks of the unpruned list */
-    if (fused && plist->slowListDirty && plist->nsci > 0) { updateWorkPartition(nb, iloc); }
     if (nbp->useDynamicPruning && plist->haveFreshList)
     {
         nbnxm_gpu_launch_kernel_pruneonly(nb, iloc, 1);
     }
+    /* fused mode: the list of perturbed cluster pairs is built by the partition pass — behind the first prune, from the OUTER masks it
+     * leaves in plist->imask (a superset of what any later rolling prune keeps), in the same pass that weighs the inner-pruned
+     * working masks for the ranges: one partition pass per search step (it ran twice, once ahead of the prune for this list) */
+    if (fused && plist->slowListDirty && plist->nsci > 0) { updateWorkPartition(nb, iloc); }
+    pickUpSlowCount(nb, iloc);
 
     if (plist->nsci > 0)
     {

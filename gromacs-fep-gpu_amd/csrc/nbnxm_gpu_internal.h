@@ -108,7 +108,8 @@ struct NbnxmGpu
     int waveClassShare[2][5] = { { 1024, 1024, 1024, 1024, 0 }, { 1100, 1060, 1024, 990, 946 } };
     int numWorkRangesOverride = 0; /* experiments: NBNXM_HIP_NUM_WORK_RANGES */
     PinnedBuffer<nbnxn_sci_t> h_sciSorted;
-    PinnedBuffer<int>         h_slowCount;
+    PinnedBuffer<int>         h_slowCount;        /* one per locality */
+    hipEvent_t                slowCountReady[2] = { nullptr, nullptr }; /* behind the copy of gpu_plist::slowCount to h_slowCount */
 
     /* coordinate / force buffer operations (nbnxm_buffer_ops.hip; nbnxm_cuda_types.h:131-142) */
     int* atomIndices        = nullptr; /* grid slot -> atom index, -1 for fillers */

@@ -211,6 +211,10 @@ struct gpu_plist
     int                excl_nalloc;
 
     bool haveFreshList;
+    /* first-pass prune (nbnxmPruneKernel<true>): every i-entry goes to pruneWavesPerEntry waves of pruneGroupsPerWave packed groups
+     * (set by gpu_init_pairlist from the longest entry) */
+    int  pruneGroupsPerWave;
+    int  pruneWavesPerEntry;
     bool firstPruneDone; /* host bookkeeping: the first-pass prune of this list has run, imask[] holds the outer-pruned masks */
     int  rollingPruningNumParts;
     int  rollingPruningPart;
@@ -230,8 +234,11 @@ struct gpu_plist
     unsigned*    groupSlowMask;   /* ncjPacked: fused mode, the cluster pairs of each group that touch a perturbed atom */
     int*         slowPairs;       /* numSlowPairs: group * 32 + jm * 8 + i of every listed cluster pair with a perturbed atom */
     int*         slowPairSci;     /* ... and its i-entry as sci * 64 + shift index */
-    int*         slowCount;       /* device counter behind numSlowPairs */
-    int          numSlowPairs;
+    int*         slowCount;       /* the number of entries of slowPairs, counted on the device */
+    int          numSlowPairs;    /* the host's figure for sizing launches: exact once the count of this list has arrived, the previous
+                                   * list's (plus a margin) until then — the kernels stride over *slowCount items either way */
+    bool         slowCountPending; /* host bookkeeping: the copy of *slowCount for this list has been queued, not read yet */
+    bool         slowCountKnown;   /* ... a count has been read at least once for this object */
     int          slowPairs_nalloc;
     bool         slowListDirty;   /* the list, fepBits or the mode changed since groupSlowMask / slowGroups were built */
     int*         groupWeight;     /* ncjPacked, scratch */

@@ -93,13 +93,15 @@ NB_DEVINL void ljFromComb(int vdwKind, const float2& a, const float2& b, float& 
  * The i-atoms a lane meets (atom tidxi of the 8 i-clusters) stay in registers: no LDS, no barrier, so the function serves the
  * prune kernel and the trailing workgroups of the force kernel alike. */
 template<bool haveFreshList>
-NB_DEVINL void pruneEntry(const NBAtomDataGpu& atdat, const NBParamGpu& nbp, const gpu_plist& plist, const int entry)
+NB_DEVINL void pruneEntry(const NBAtomDataGpu& atdat, const NBParamGpu& nbp, const gpu_plist& plist, const int entry,
+                          const int firstGroupOfChunk = 0, const int groupsPerChunk = 0x7FFFFFFF /* first pass: a part of the entry */)
 {
     const unsigned lane  = threadIdx.x & (c_waveSize - 1);
     const unsigned tidxi = lane & 7U;
     const unsigned tidxj = lane >> 3;
 
     const nbnxn_sci_t nb_sci   = plist.sci[entry];
+    if (haveFreshList && firstGroupOfChunk >= nb_sci.cjPackedEnd - nb_sci.cjPackedBegin) { return; } /* a chunk beyond this entry's end */
     const int         shiftIdx = nb_sci.shift & NBNXM_CI_SHIFT_MASK;
     float4            xi[c_numClPerSupercl];
     {
@@ -147,10 +149,39 @@ NB_DEVINL void pruneEntry(const NBAtomDataGpu& atdat, const NBParamGpu& nbp, con
 
     if constexpr (haveFreshList)
     {
-        for (int jPacked = nb_sci.cjPackedBegin; jPacked < nb_sci.cjPackedEnd; jPacked++)
+        const int chunkBegin = nb_sci.cjPackedBegin + firstGroupOfChunk;
+        const int chunkEnd   = min(nb_sci.cjPackedEnd, chunkBegin + min(groupsPerChunk, nb_sci.cjPackedEnd - chunkBegin));
+        for (int jPacked = chunkBegin; jPacked < chunkEnd; jPacked++)
         {
-            unsigned       imaskFull = plist.cjPacked[jPacked].imei[0].imask;
-            const unsigned imaskNew  = checkGroup(jPacked, imaskFull, imaskFull, 0U);
+            /* the whole group at once: its record as two 16-byte loads, then the four j-clusters' coordinates side by side (every cj
+             * of a record is a valid cluster, gpu_init_pairlist checks it) — two round trips per group instead of one per j-cluster */
+            const nb_int4* rec = reinterpret_cast<const nb_int4*>(&plist.cjPacked[jPacked]);
+            const nb_int4  cjs = rec[0];
+            unsigned       imaskFull = static_cast<unsigned>(rec[1].x);
+            const float4   xj0 = atdat.xq[cjs.x * c_clSize + static_cast<int>(tidxj)];
+            const float4   xj1 = atdat.xq[cjs.y * c_clSize + static_cast<int>(tidxj)];
+            const float4   xj2 = atdat.xq[cjs.z * c_clSize + static_cast<int>(tidxj)];
+            const float4   xj3 = atdat.xq[cjs.w * c_clSize + static_cast<int>(tidxj)];
+            unsigned       imaskNew = 0U;
+            const unsigned imaskCheck = imaskFull;
+#pragma unroll
+            for (int jm = 0; jm < c_jGroupSize; jm++)
+            {
+                if (!(imaskCheck & (0xFFU << (jm * c_numClPerSupercl)))) { continue; }
+                const float4 xj = (jm == 0) ? xj0 : ((jm == 1) ? xj1 : ((jm == 2) ? xj2 : xj3));
+#pragma unroll
+                for (int i = 0; i < c_numClPerSupercl; i++)
+                {
+                    const unsigned mask_ji = 1U << (jm * c_numClPerSupercl + i);
+                    if (imaskCheck & mask_ji)
+                    {
+                        const float dx = xi[i].x - xj.x, dy = xi[i].y - xj.y, dz = xi[i].z - xj.z;
+                        const float r2 = dx * dx + dy * dy + dz * dz;
+                        if (__ballot(r2 < rlistOuter_sq) == 0ULL) { imaskFull &= ~mask_ji; }
+                        if (__ballot(r2 < rlistInner_sq) != 0ULL) { imaskNew |= mask_ji; }
+                    }
+                }
+            }
             if (lane == 0U)
             {
                 plist.imask[jPacked * NBNXM_GPU_CLUSTERPAIR_SPLIT]     = imaskFull;
@@ -417,8 +448,14 @@ __launch_bounds__(c_nbMaxBlockSize) __attribute__((amdgpu_waves_per_eu(c_nbWaves
                         for (int t = threadIdx.x; t < numTypes * numTypes; t += blockSize) { nbfpLds[t] = nbp.nbfp[t]; }
                         __syncthreads();
                     }
-                    const int item = __builtin_amdgcn_readfirstlane(static_cast<int>((blockIdx.x - mainBlocks - pruneBlocks) * wavesPerBlock + wave));
-                    if (item < mergedFepItems)
+                    /* mergedFepItems is the size of the launch, the number of items is on the device (gpu_plist::slowCount): behind a
+                     * new list the host queues this launch without waiting for the count — it sizes the launch from the previous
+                     * list's — and the waves stride over whatever the partition pass has found */
+                    const int firstItem = __builtin_amdgcn_readfirstlane(static_cast<int>((blockIdx.x - mainBlocks - pruneBlocks) * wavesPerBlock + wave));
+                    const int numItems  = __builtin_amdgcn_readfirstlane(min(*plist.slowCount, plist.slowPairs_nalloc));
+                    const int stride    = static_cast<int>(fepBlocks * wavesPerBlock);
+#pragma clang loop unroll(disable)
+                    for (int item = firstItem; item < numItems; item += stride)
                     {
                         if (ENERGY && mergedFepForeignLambdas >= 0)
                         {
@@ -955,14 +992,20 @@ __launch_bounds__(c_nbMaxBlockSize) __attribute__((amdgpu_waves_per_eu(c_nbWaves
     }
 }
 
-/* One wavefront per i-entry `blockIdx.x * numParts + part` (pruneEntry above). */
+/* One wavefront per i-entry `blockIdx.x * numParts + part` (pruneEntry above).  First pass (haveFreshList): the groups of an entry
+ * are a dependent chain per group (list word -> j-coordinates -> 32 pair checks), so an entry goes to gridDim.y waves of
+ * plist.pruneGroupsPerWave groups each — waves beyond the entry's end leave at once: 63 -> 30 us for the 96k box's 60k groups. */
 template<bool haveFreshList>
 __launch_bounds__(c_waveSize) __global__
         void nbnxmPruneKernel(const NBAtomDataGpu atdat, const NBParamGpu nbp, const gpu_plist plist, const int numParts, const int part)
 {
     const int entry = static_cast<int>(blockIdx.x) * numParts + part;
     if (entry >= plist.nsci) { return; }
-    pruneEntry<haveFreshList>(atdat, nbp, plist, entry);
+    if constexpr (haveFreshList)
+    {
+        pruneEntry<true>(atdat, nbp, plist, entry, static_cast<int>(blockIdx.y) * plist.pruneGroupsPerWave, plist.pruneGroupsPerWave);
+    }
+    else { pruneEntry<false>(atdat, nbp, plist, entry); }
 }
 
 #endif

@@ -33,9 +33,14 @@ def timed(fn, n=1):
     return 1e3 * (time.perf_counter() - t0) / n
 
 
+# the caller's lists in page-locked memory, as the reference keeps them (argument "pageable": plain numpy arrays, staged by the library)
+if "pageable" not in sys.argv:
+    pl_sci, pl_cj, pl_excl = pkg.pinned_copy(pl.sci), pkg.pinned_copy(pl.cjPacked), pkg.pinned_copy(pl.excl)
+else:
+    pl_sci, pl_cj, pl_excl = pl.sci, pl.cjPacked, pl.excl
 for rep in range(4):
     t_atom = timed(lambda: nb.init_atomdata(g.num_atoms, g.type, qA=g.qA, qB=g.qB, typeA=g.typeA, typeB=g.typeB))
-    t_list = timed(lambda: nb.init_pairlist(pl.sci, pl.cjPacked, pl.excl))
+    t_list = timed(lambda: nb.init_pairlist(pl_sci, pl_cj, pl_excl))
     t_bits = timed(lambda: nb.init_fep_cluster_bits(g.fepBits))
     t_xq = timed(lambda: nb.copy_xq_to_gpu(g.xq))
 
