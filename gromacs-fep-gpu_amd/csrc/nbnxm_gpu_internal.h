@@ -143,6 +143,9 @@ struct NbnxmGpu
      * kind (A.4: the reference frees its temporaries right after queuing the copies) */
     PinnedBuffer<float4> h_q4;
     PinnedBuffer<int4>   h_atomTypes4;
+    std::vector<int>     fepInverse;           /* gpu_init_feppairlist: topology id -> grid index */
+    PinnedBuffer<int4>   h_clItem;             /* gpu_feplist::clItem / clListed / clIncl staging */
+    PinnedBuffer<uint2>  h_clListed, h_clIncl;
     PinnedBuffer<int>    h_atomTypes, h_iinr, h_jjnr, h_shift, h_jindex, h_exclFep, h_pairEntry;
     PinnedBuffer<float2> h_ljComb;
     PinnedBuffer<float4> h_xq;

@@ -14,8 +14,9 @@ wl = importlib.import_module("gromacs_fep_gpu_amd.workload")
 import torch  # noqa: E402
 
 c = wl.make_case(nm=(40, 40, 20), num_perturbed_molecules=16, elec="ewald", seed=2026, n_lambda=11, max_cjpacked_per_sci=16)
-g, pl = c.grid, c.plist_fused
-nb = wl.setup_gpu(c, fused=True, use_dynamic_pruning=True)
+SPLIT = "split" in sys.argv      # the reference's shape: carved cluster list + atom-pair list through gpu_init_feppairlist
+g, pl = c.grid, (c.plist if SPLIT else c.plist_fused)
+nb = wl.setup_gpu(c, fused=not SPLIT, use_dynamic_pruning=True)
 nb.set_timing(False)
 sw = pkg.step_workload(energy=False, virial=False, dhdl=False)
 
@@ -41,7 +42,7 @@ else:
 for rep in range(4):
     t_atom = timed(lambda: nb.init_atomdata(g.num_atoms, g.type, qA=g.qA, qB=g.qB, typeA=g.typeA, typeB=g.typeB))
     t_list = timed(lambda: nb.init_pairlist(pl_sci, pl_cj, pl_excl))
-    t_bits = timed(lambda: nb.init_fep_cluster_bits(g.fepBits))
+    t_bits = timed((lambda: nb.init_feppairlist(c.plist.fep, g.atomIndices)) if SPLIT else (lambda: nb.init_fep_cluster_bits(g.fepBits)))
     t_xq = timed(lambda: nb.copy_xq_to_gpu(g.xq))
 
     def first_step():
@@ -49,6 +50,6 @@ for rep in range(4):
         nb.launch_kernel(sw)
     t_first = timed(first_step)
     t_next = timed(first_step, 100)
-    print("search step %d: atom data %.3f  list upload %.3f  fep bits %.3f  xq %.3f  first step (prune + partition + kernel) %.3f  | later steps %.4f ms"
+    print("search step %d: atom data %.3f  list upload %.3f  fep bits / atom-pair list %.3f  xq %.3f  first step (prune + partition + kernel) %.3f  | later steps %.4f ms"
           % (rep, t_atom, t_list, t_bits, t_xq, t_first, t_next), flush=True)
 nb.free()
