@@ -357,6 +357,28 @@ def main(argv=None):
         ms_virial_only = timed(pkg.step_workload(energy=False, virial=True, dhdl=False))
         ms_energy_only = timed(pkg.step_workload(energy=True, virial=False, dhdl=False))
 
+    # what a search step costs on the GPU side (secondary figure): atom data, list (from page-locked memory, as the reference keeps it),
+    # perturbed-atom bits and coordinates uploaded again, then the first launch on the fresh list (first-pass prune, work partition,
+    # force kernel) -- the part of every nstlist-th step that this module owns; the host's list building is the caller's
+    ms_search_step = None
+    if fused and world == 1 and not args.primary_only:
+        g = case.grid
+        p_sci, p_cj, p_excl = pkg.pinned_copy(pl.sci), pkg.pinned_copy(pl.cjPacked), pkg.pinned_copy(pl.excl)
+        samples = []
+        for _ in range(4):
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            nb.init_atomdata(g.num_atoms, g.type, qA=g.qA, qB=g.qB, typeA=g.typeA, typeB=g.typeB)
+            nb.init_pairlist(p_sci, p_cj, p_excl)
+            nb.init_fep_cluster_bits(g.fepBits)
+            nb.copy_xq_to_gpu(g.xq)
+            one_step()
+            torch.cuda.synchronize()
+            samples.append(1e3 * (time.perf_counter() - t1))
+            for _ in range(20):
+                one_step()
+        ms_search_step = sorted(samples[1:])[1]      # median of the last three (the first re-allocates nothing either, but warms the path)
+
     # the same force step in the reference's shape (secondary figure): the carved cluster list + the atom-pair list of make_fep_list through
     # gpu_init_feppairlist, no nbnxm_gpu_set_fep_mode -- a second object on the same box, conditioned by the loop above
     ms_reference_shape = None
@@ -494,6 +516,9 @@ def main(argv=None):
         "ms_per_virial_only_step": ms_virial_only, "ms_per_energy_only_step": ms_energy_only,
         "ms_per_step_with_pinned_force_buffer": ms_pinned,
         "ms_per_step_reference_shape_atom_pair_list": ms_reference_shape,
+        "ms_per_search_step_gpu_side": ms_search_step,
+        "ns_per_day_kernel_bound_with_a_search_every_100_steps": (86400.0 * 2e-6 / ((100 * elapsed / args.steps + 1e-3 * ms_search_step) / 100)
+                                                                  if ms_search_step is not None else None),
         "ms_per_gpu_resident_md_step": ms_md_step, "ms_per_gpu_resident_md_step_unfused_update": ms_md_step_sequence,
         "ms_per_gpu_resident_md_step_with_rolling_prune_8": ms_md_step_prune,
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
