@@ -557,6 +557,8 @@ void nbnxm_gpu_free(NbnxmGpu* nb)
         if (e != nullptr) { (void)hipEventDestroy(e); }
         e = nullptr;
     }
+    if (nb->listStagingFree != nullptr) { (void)hipEventDestroy(nb->listStagingFree); }
+    nb->listStagingFree = nullptr;
     NBAtomDataGpu* ad  = nb->atdat;
     NBParamGpu*    nbp = nb->nbparam;
     freeDeviceBuffer(&ad->xq);
@@ -862,25 +864,6 @@ static void uploadPairlist(NbnxmGpu* nb, int iloc, int na_c, int nsci, const nbn
     gpu_plist*  d = nb->plist[iloc];
     hipStream_t s = nb->deviceStreams[iloc].stream;
     const int numAtoms = nb->atdat->numAtoms;
-    /* shape checks: an out-of-range index in the list would fault on the device */
-    for (int i = 0; i < nsci; i++)
-    {
-        NBNXM_ASSERT(sci[i].cjPackedBegin >= 0 && sci[i].cjPackedEnd <= ncjPacked && sci[i].cjPackedBegin <= sci[i].cjPackedEnd,
-                     "sci entry points outside cjPacked");
-        NBNXM_ASSERT(sci[i].sci >= 0 && (sci[i].sci + 1) * c_superClSize <= numAtoms, "sci entry outside the atom range");
-        NBNXM_ASSERT((sci[i].shift & NBNXM_CI_SHIFT_MASK) < c_numShiftVectors, "shift index out of range");
-    }
-    for (int j = 0; j < ncjPacked; j++)
-    {
-        for (int m = 0; m < c_jGroupSize; m++)
-        {
-            NBNXM_ASSERT(cjPacked[j].cj[m] >= 0 && (cjPacked[j].cj[m] + 1) * c_clSize <= numAtoms, "j-cluster outside the atom range");
-        }
-        for (const auto& im : cjPacked[j].imei)
-        {
-            NBNXM_ASSERT(im.excl_ind >= 0 && im.excl_ind < nexcl, "exclusion index out of range");
-        }
-    }
     d->na_c = na_c;
     reallocateDeviceBuffer(&d->sci, nsci, &d->nsci, &d->sci_nalloc);
     reallocateDeviceBuffer(&d->cjPacked, ncjPacked, &d->ncjPacked, &d->cjPacked_nalloc);
@@ -902,9 +885,45 @@ static void uploadPairlist(NbnxmGpu* nb, int iloc, int na_c, int nsci, const nbn
             copyToDeviceBuffer(deviceBuffer, staging.data, 0, n, s, true);
         }
     };
+    /* (the staging buffers of the previous upload — the other locality's, or the last search step's sorted entries — are free?) */
+    if (nb->listStagingBusy)
+    {
+        NBNXM_HIP_CHECK(hipEventSynchronize(nb->listStagingFree));
+        nb->listStagingBusy = false;
+    }
+    const bool inPlace = isPinnedHostMemory(cjPacked) && isPinnedHostMemory(excl) && isPinnedHostMemory(sci);
     upload(&d->cjPacked, nb->h_cjPacked, cjPacked, ncjPacked);
     upload(&d->excl, nb->h_excl, excl, nexcl);
     upload(&d->sci, nb->h_sci, sci, nsci);
+    /* shape checks, while the DMAs run: an out-of-range index in the list would fault on the device (nothing has been launched on it
+     * yet, and a failed check ends the process).  The j-side as min / max reductions the compiler vectorises (per-entry asserts over
+     * 60 k groups were 0.05 ms of this call). */
+    for (int i = 0; i < nsci; i++)
+    {
+        NBNXM_ASSERT(sci[i].cjPackedBegin >= 0 && sci[i].cjPackedEnd <= ncjPacked && sci[i].cjPackedBegin <= sci[i].cjPackedEnd,
+                     "sci entry points outside cjPacked");
+        NBNXM_ASSERT(sci[i].sci >= 0 && (sci[i].sci + 1) * c_superClSize <= numAtoms, "sci entry outside the atom range");
+        NBNXM_ASSERT((sci[i].shift & NBNXM_CI_SHIFT_MASK) < c_numShiftVectors, "shift index out of range");
+    }
+    {
+        int cjLo = 0, cjHi = 0, exLo = 0, exHi = 0;
+        for (int j = 0; j < ncjPacked; j++)
+        {
+            for (int m = 0; m < c_jGroupSize; m++)
+            {
+                cjLo = std::min(cjLo, cjPacked[j].cj[m]);
+                cjHi = std::max(cjHi, cjPacked[j].cj[m]);
+            }
+            for (const auto& im : cjPacked[j].imei)
+            {
+                exLo = std::min(exLo, im.excl_ind);
+                exHi = std::max(exHi, im.excl_ind);
+            }
+        }
+        NBNXM_ASSERT(cjLo >= 0 && (cjHi + 1) * c_clSize <= numAtoms, "j-cluster outside the atom range");
+        NBNXM_ASSERT(exLo >= 0 && (ncjPacked == 0 || exHi < nexcl), "exclusion index out of range");
+    }
+
     /* the i-entries ordered by their j-group range, for the work partition (empty entries first among equals) */
     {
         int dummy = 0;
@@ -943,7 +962,18 @@ static void uploadPairlist(NbnxmGpu* nb, int iloc, int na_c, int nsci, const nbn
         d->nsciWork = nWork;
         copyToDeviceBuffer(&d->sciSorted, nb->h_sciSorted.data, 0, nWork, s, true);
     }
-    NBNXM_HIP_CHECK(hipStreamSynchronize(s));
+    /* Lists read in place from page-locked memory: no wait — the copies run beside what the host does next in its search step, and
+     * the caller keeps the arrays unchanged until the list's stream has passed them, as the reference's caller does
+     * (nbnxm_gpu_data_mgmt.cpp:706-735, GpuApiCallBehavior::Async from its pinned HostVectors); the one staging buffer this path uses
+     * (the sorted entries) is guarded by an event until the next upload.  Staged lists: the upload is complete on return, the caller's
+     * arrays are free. */
+    if (inPlace)
+    {
+        if (nb->listStagingFree == nullptr) { NBNXM_HIP_CHECK(hipEventCreateWithFlags(&nb->listStagingFree, hipEventDisableTiming)); }
+        NBNXM_HIP_CHECK(hipEventRecord(nb->listStagingFree, s));
+        nb->listStagingBusy = true;
+    }
+    else { NBNXM_HIP_CHECK(hipStreamSynchronize(s)); }
     {
         /* the first-pass prune cuts every entry into waves of a few groups: 4 groups per wave unless that makes more than 64 waves per entry */
         int longest = 0;

@@ -109,6 +109,8 @@ struct NbnxmGpu
     int numWorkRangesOverride = 0; /* experiments: NBNXM_HIP_NUM_WORK_RANGES */
     PinnedBuffer<nbnxn_sci_t> h_sciSorted;
     PinnedBuffer<int>         h_slowCount;        /* one per locality */
+    hipEvent_t                listStagingFree = nullptr; /* behind the last copy out of the list staging buffers (uploadPairlist) */
+    bool                      listStagingBusy = false;
     hipEvent_t                slowCountReady[2] = { nullptr, nullptr }; /* behind the copy of gpu_plist::slowCount to h_slowCount */
 
     /* coordinate / force buffer operations (nbnxm_buffer_ops.hip; nbnxm_cuda_types.h:131-142) */

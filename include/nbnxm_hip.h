@@ -217,7 +217,11 @@ void nbnxm_gpu_init_atomdata(NbnxmGpu* nb, int numAtoms, int numAtomsLocal, cons
                              const int* typeA, const int* typeB, const float* lj_combA,
                              const float* lj_combB);
 
-/* Nbnxm::gpu_init_pairlist — nbnxm/gpu_data_mgmt.h:99-101, nbnxm_gpu_data_mgmt.cpp:667-759 */
+/* Nbnxm::gpu_init_pairlist — nbnxm/gpu_data_mgmt.h:99-101, nbnxm_gpu_data_mgmt.cpp:667-759.
+ * Arrays in page-locked host memory known to the HIP runtime (hipHostMalloc / hipHostRegister: what the reference's pinned HostVectors
+ * are) are read in place and asynchronously, as the reference reads them (:706-735): keep them unchanged until the locality's stream
+ * has passed the copies — the reference's caller keeps its lists for the whole search interval.  Arrays in any other memory are copied
+ * before the call returns. */
 void nbnxm_gpu_init_pairlist(NbnxmGpu* nb, int iloc, int na_c, int nsci, const nbnxn_sci_t* sci,
                              int ncjPacked, const nbnxn_cj_packed_t* cjPacked, int nexcl,
                              const nbnxn_excl_t* excl);
