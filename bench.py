@@ -36,7 +36,7 @@ FP32_PEAK_TFLOPS = 157.3   # vector fp32
 DT_FS = 2.0                # MD time step for the kernel-bound ns/day figure
 METRIC = "ns/day + pair-interactions/s, 100k-atom FEP box @ λ=0.5, 1/2/4/8 MI355X"
 # molecules per box edge of the synthetic water boxes (3 atoms each): configs[1], configs[2], 8 x configs[2], configs[4]'s 1.02 M atoms
-BOXES = {"3k": (10, 10, 10), "24k": (20, 20, 20), "96k": (40, 40, 20), "768k": (80, 80, 40), "1m": (88, 88, 44)}
+BOXES = {"3k": (10, 10, 10), "12k": (20, 20, 10), "24k": (20, 20, 20), "48k": (40, 20, 20), "96k": (40, 40, 20), "192k": (40, 40, 40), "768k": (80, 80, 40), "1m": (88, 88, 44)}
 COUNTERS_FILE = os.path.join("profiles", "r03", "counters_fused_force_kernel.json")   # written by tools/summarize_counters.py
 # the two other roofs of the dominant kernel ("which roof"):
 PEAK_CLOCK_GHZ = 2.4                 # MI355X_MICROARCH.md; under this kernel's load the chip holds ~2.0 GHz
@@ -53,7 +53,7 @@ def parse_args(argv=None):
     ap.add_argument("--steps", type=int, default=500)
     ap.add_argument("--warmup", type=int, default=50)
     ap.add_argument("--mode", choices=["fused", "split"], default="fused")
-    ap.add_argument("--atoms", choices=["3k", "24k", "96k", "768k", "1m"], default="96k")
+    ap.add_argument("--atoms", choices=list(BOXES), default="96k")
     ap.add_argument("--elec", choices=["ewald", "rf"], default="ewald", help="rf: BASELINE configs[1] (with --atoms 24k)")
     ap.add_argument("--max-cjpacked-per-sci", type=int, default=16)
     ap.add_argument("--no-cpu-baseline", action="store_true")

@@ -1367,13 +1367,19 @@ static void updateWorkPartition(NbnxmGpu* nb, int iloc)
         const int  want     = twoParts ? 2 * slots : slots;
         d->workParts[p]     = twoParts ? 2 : 1;
         d->numWorkRanges[p] = std::max(1, std::min(want, d->ncjPacked / nb->minGroupsPerWave));
+        /* Short lists (under 4.5 packed groups per wave slot: boxes up to ~40k atoms, or the domains of a decomposed one): the
+         * five-waves-per-SIMD partition cuts ranges of one to three groups, and every range pays a wave's prologue and an i-entry
+         * start; four ranges per SIMD are faster there (12k atoms 0.0203 -> 0.0176 ms per force step, 24k 0.0221 -> 0.0208, 48k equal,
+         * 96k 0.0510 -> 0.0556 the other way; tools/gpu_ranges_sizes.sh).  Equal shares (the age-class shares belong to five waves). */
+        const bool shortList = (p == 1 && !twoParts && nb->numWorkRangesOverride <= 0 && 2 * static_cast<long long>(d->ncjPacked) < 9LL * slots);
+        if (shortList) { d->numWorkRanges[p] = std::max(1, std::min(nb->numSimds * 4, d->ncjPacked / nb->minGroupsPerWave)); }
         if (nb->numWorkRangesOverride > 0) { d->numWorkRanges[p] = std::min(nb->numWorkRangesOverride, d->ncjPacked); }
         reallocateDeviceBuffer(&d->workRangeStart[p], d->numWorkRanges[p] + 1, &dummy, &d->work_nalloc[p]);
         out[p].numRanges = d->numWorkRanges[p];
         /* shares: only for the launch they are meant for, one wave per slot of every SIMD; they start from the age classes
          * (the waves of a SIMD are dispatched numRanges / classes apart) and survive new lists of the same size */
         const float fraction = twoParts ? nb->localPartFraction : 1.0F;
-        if (d->numWorkRanges[p] == want && (d->workShareCount[p] != want || d->workPartFraction[p] != fraction))
+        if (d->numWorkRanges[p] == want && !shortList && (d->workShareCount[p] != want || d->workPartFraction[p] != fraction))
         {
             const int          classes = 4 + p, perClass = slots / classes;
             std::vector<float> share(want);
@@ -1387,7 +1393,7 @@ static void updateWorkPartition(NbnxmGpu* nb, int iloc)
             setWorkShares(d, p, share.data(), want, s);
             d->workPartFraction[p] = fraction;
         }
-        out[p].shareCum = (d->numWorkRanges[p] == want) ? d->workShareCum[p] : nullptr;
+        out[p].shareCum = (d->numWorkRanges[p] == want && !shortList) ? d->workShareCum[p] : nullptr;
     }
     /* workFirstSci shares work_nalloc with workRangeStart: reallocate when that one grew */
     for (int p = 0; p < 2; p++)
