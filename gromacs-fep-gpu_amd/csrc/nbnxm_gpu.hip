@@ -51,8 +51,53 @@ __global__ void nbnxmClearOutputsKernel(float4* __restrict__ f4, int numFloat4, 
     for (int i = gid; i < numWindowFloats; i += stride) { windowSlots[i] = 0.0F; }
 }
 
+/* Shape check of an uploaded pair list ON the device (gpu_init_pairlist): a j-cluster or an exclusion index outside its array would
+ * fault in the kernels.  One thread per packed group; a bad value is replaced by 0 — nothing can fault — and reported through a flag
+ * in mapped host memory, which the host looks at when it next launches or finishes on the object (a fatal error then).  On the host the
+ * same check means reading the whole list once more — 0.12 ms for the 96k box's 60 k groups, cold from DRAM — in a call that otherwise
+ * only queues DMAs. */
+__global__ void nbnxmValidateListKernel(nbnxn_cj_packed_t* __restrict__ cjPacked, const int ncjPacked, const int numClusters, const int nexcl,
+                                        int* __restrict__ errorFlag)
+{
+    const int j = static_cast<int>(blockIdx.x * blockDim.x + threadIdx.x);
+    if (j >= ncjPacked) { return; }
+    nbnxn_cj_packed_t g   = cjPacked[j];
+    int               bad = 0;
+    for (int m = 0; m < c_jGroupSize; m++)
+    {
+        if (g.cj[m] < 0 || g.cj[m] >= numClusters)
+        {
+            g.cj[m] = 0;
+            bad |= 1;
+        }
+    }
+    for (auto& im : g.imei)
+    {
+        if (im.excl_ind < 0 || im.excl_ind >= nexcl)
+        {
+            im.excl_ind = 0;
+            bad |= 2;
+        }
+    }
+    if (bad != 0)
+    {
+        cjPacked[j] = g;
+        atomicOr(errorFlag, bad);
+        __threadfence_system();
+    }
+}
+
 namespace
 {
+
+/* the flag of nbnxmValidateListKernel: 1 = j-cluster outside the atom range, 2 = exclusion index out of range */
+void checkListErrorFlag(const NbnxmGpu* nb)
+{
+    if (nb->h_listError == nullptr) { return; }
+    const int e = *static_cast<volatile const int*>(nb->h_listError);
+    NBNXM_ASSERT((e & 1) == 0, "pair list: j-cluster outside the atom range");
+    NBNXM_ASSERT((e & 2) == 0, "pair list: exclusion index out of range");
+}
 
 void setCutoffParameters(NBParamGpu* nbp, const nbnxm_interaction_params_t* ic)
 {
@@ -557,6 +602,8 @@ void nbnxm_gpu_free(NbnxmGpu* nb)
         if (e != nullptr) { (void)hipEventDestroy(e); }
         e = nullptr;
     }
+    if (nb->h_listError != nullptr) { (void)hipHostFree(nb->h_listError); }
+    nb->h_listError = nullptr;
     if (nb->listStagingFree != nullptr) { (void)hipEventDestroy(nb->listStagingFree); }
     nb->listStagingFree = nullptr;
     NBAtomDataGpu* ad  = nb->atdat;
@@ -864,6 +911,12 @@ static void uploadPairlist(NbnxmGpu* nb, int iloc, int na_c, int nsci, const nbn
     gpu_plist*  d = nb->plist[iloc];
     hipStream_t s = nb->deviceStreams[iloc].stream;
     const int numAtoms = nb->atdat->numAtoms;
+#ifdef NBNXM_HOST_UPLOAD_TIMING /* diagnostics: host microseconds by section of this call */
+    std::vector<std::chrono::steady_clock::time_point> tp_{ std::chrono::steady_clock::now() };
+#define NBNXM_TP tp_.push_back(std::chrono::steady_clock::now());
+#else
+#define NBNXM_TP
+#endif
     d->na_c = na_c;
     reallocateDeviceBuffer(&d->sci, nsci, &d->nsci, &d->sci_nalloc);
     reallocateDeviceBuffer(&d->cjPacked, ncjPacked, &d->ncjPacked, &d->cjPacked_nalloc);
@@ -891,13 +944,15 @@ static void uploadPairlist(NbnxmGpu* nb, int iloc, int na_c, int nsci, const nbn
         NBNXM_HIP_CHECK(hipEventSynchronize(nb->listStagingFree));
         nb->listStagingBusy = false;
     }
+    NBNXM_TP
     const bool inPlace = isPinnedHostMemory(cjPacked) && isPinnedHostMemory(excl) && isPinnedHostMemory(sci);
+    NBNXM_TP
     upload(&d->cjPacked, nb->h_cjPacked, cjPacked, ncjPacked);
     upload(&d->excl, nb->h_excl, excl, nexcl);
     upload(&d->sci, nb->h_sci, sci, nsci);
-    /* shape checks, while the DMAs run: an out-of-range index in the list would fault on the device (nothing has been launched on it
-     * yet, and a failed check ends the process).  The j-side as min / max reductions the compiler vectorises (per-entry asserts over
-     * 60 k groups were 0.05 ms of this call). */
+    NBNXM_TP
+    /* shape checks, while the DMAs run: an out-of-range index in the list would fault on the device.  The i-entries here (a failed
+     * check ends the process before anything is launched on the list), the 60 k groups on the device */
     for (int i = 0; i < nsci; i++)
     {
         NBNXM_ASSERT(sci[i].cjPackedBegin >= 0 && sci[i].cjPackedEnd <= ncjPacked && sci[i].cjPackedBegin <= sci[i].cjPackedEnd,
@@ -905,60 +960,96 @@ static void uploadPairlist(NbnxmGpu* nb, int iloc, int na_c, int nsci, const nbn
         NBNXM_ASSERT(sci[i].sci >= 0 && (sci[i].sci + 1) * c_superClSize <= numAtoms, "sci entry outside the atom range");
         NBNXM_ASSERT((sci[i].shift & NBNXM_CI_SHIFT_MASK) < c_numShiftVectors, "shift index out of range");
     }
+    NBNXM_TP
+    if (ncjPacked > 0)
     {
-        int cjLo = 0, cjHi = 0, exLo = 0, exHi = 0;
-        for (int j = 0; j < ncjPacked; j++)
+        /* the j-side of the check runs on the device, behind the copy (nbnxmValidateListKernel) */
+        if (nb->h_listError == nullptr)
         {
-            for (int m = 0; m < c_jGroupSize; m++)
-            {
-                cjLo = std::min(cjLo, cjPacked[j].cj[m]);
-                cjHi = std::max(cjHi, cjPacked[j].cj[m]);
-            }
-            for (const auto& im : cjPacked[j].imei)
-            {
-                exLo = std::min(exLo, im.excl_ind);
-                exHi = std::max(exHi, im.excl_ind);
-            }
+            NBNXM_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&nb->h_listError), sizeof(int), hipHostMallocMapped));
+            *nb->h_listError = 0;
+            NBNXM_HIP_CHECK(hipHostGetDevicePointer(reinterpret_cast<void**>(&nb->d_listError), nb->h_listError, 0));
         }
-        NBNXM_ASSERT(cjLo >= 0 && (cjHi + 1) * c_clSize <= numAtoms, "j-cluster outside the atom range");
-        NBNXM_ASSERT(exLo >= 0 && (ncjPacked == 0 || exHi < nexcl), "exclusion index out of range");
+        constexpr int c_validateBlock = 256;
+        hipLaunchKernelGGL(nbnxmValidateListKernel, dim3((ncjPacked + c_validateBlock - 1) / c_validateBlock), dim3(c_validateBlock), 0, s, d->cjPacked,
+                           ncjPacked, numAtoms / c_clSize, nexcl, nb->d_listError);
+        NBNXM_HIP_CHECK(hipGetLastError());
     }
+    NBNXM_TP
 
     /* the i-entries ordered by their j-group range, for the work partition (empty entries first among equals) */
     {
         int dummy = 0;
         reallocateDeviceBuffer(&d->sciSorted, nsci, &dummy, &d->sciSorted_nalloc);
-        nb->h_sciSorted.resize(nsci);
-        if (nsci) { std::memcpy(nb->h_sciSorted.data, sci, sizeof(nbnxn_sci_t) * nsci); }
+        /* (worked on in ordinary memory and copied to the pinned staging buffer once: the passes below over page-locked memory took
+         * 140 us for 6 k entries) */
+        std::vector<nbnxn_sci_t>& w = nb->sciWorkHost;
+        NBNXM_TP
+        w.assign(sci, sci + nsci);
+        NBNXM_TP
         auto byGroupRange = [](const nbnxn_sci_t& a, const nbnxn_sci_t& b) {
             return a.cjPackedBegin != b.cjPackedBegin ? a.cjPackedBegin < b.cjPackedBegin : a.cjPackedEnd < b.cjPackedEnd;
         };
         /* (a list builder appends j-groups entry by entry: the entries usually come in this order already) */
-        if (!std::is_sorted(nb->h_sciSorted.data, nb->h_sciSorted.data + nsci, byGroupRange))
+        if (!std::is_sorted(w.begin(), w.end(), byGroupRange))
         {
-            std::sort(nb->h_sciSorted.data, nb->h_sciSorted.data + nsci, byGroupRange);
-        }
-        for (int i = 1; i < nsci; i++)
-        {
-            NBNXM_ASSERT(nb->h_sciSorted.data[i].cjPackedBegin >= nb->h_sciSorted.data[i - 1].cjPackedEnd,
-                         "the j-group ranges of two sci entries overlap");
+            /* (a producer that concatenates per-thread lists: sorted as 64-bit keys {begin, end, index} while the three fit 21 bits
+             * each — 6 k entries in 35 instead of 110 us —, with the comparator beyond) */
+            if (ncjPacked < (1 << 21) && nsci < (1 << 21))
+            {
+                std::vector<unsigned long long>& keys = nb->sciSortKeys;
+                keys.resize(nsci);
+                for (int i = 0; i < nsci; i++)
+                {
+                    keys[i] = (static_cast<unsigned long long>(sci[i].cjPackedBegin) << 42) | (static_cast<unsigned long long>(sci[i].cjPackedEnd) << 21)
+                              | static_cast<unsigned long long>(i);
+                }
+                /* (sorted runs, one per thread of the producer: merged pairwise, O(n log runs), instead of a full sort) */
+                std::vector<int>& runs = nb->sciSortRuns;
+                runs.clear();
+                runs.push_back(0);
+                for (int i = 1; i < nsci; i++)
+                {
+                    if (keys[i] < keys[i - 1]) { runs.push_back(i); }
+                }
+                runs.push_back(nsci);
+                if (runs.size() > 66) { std::sort(keys.begin(), keys.end()); }
+                else
+                {
+                    for (size_t width = 1; width + 1 < runs.size(); width *= 2)
+                    {
+                        for (size_t r = 0; r + width + 1 <= runs.size() - 1; r += 2 * width)
+                        {
+                            const size_t last = std::min(r + 2 * width, runs.size() - 1);
+                            std::inplace_merge(keys.begin() + runs[r], keys.begin() + runs[r + width], keys.begin() + runs[last]);
+                        }
+                    }
+                }
+                for (int i = 0; i < nsci; i++) { w[i] = sci[keys[i] & ((1ULL << 21) - 1ULL)]; }
+            }
+            else { std::sort(w.begin(), w.end(), byGroupRange); }
         }
         /* A list builder that balances for GPUs by i-entry count (pairlist.cpp:2283-2400) cuts the j-list of one (super-cluster,
          * shift) into consecutive entries.  The cluster kernel balances by wave-slot ranges that cut through entries, and every
          * entry start costs it an i-side staging and a force reduction (19,551 instead of 2,637 entries on the 96k box: 83.6 vs
          * 61.6 us), so its own entry list joins such pieces again; list pruning keeps working on the caller's entries (d->sci). */
-        int nWork = 0;
+        int nWork = 0, prevEnd = 0;
         for (int i = 0; i < nsci; i++)
         {
-            nbnxn_sci_t*       w = nb->h_sciSorted.data;
-            const nbnxn_sci_t& e = w[i];
+            const nbnxn_sci_t e = w[i];
             if (e.cjPackedBegin == e.cjPackedEnd) { continue; }
+            NBNXM_ASSERT(e.cjPackedBegin >= prevEnd, "the j-group ranges of two sci entries overlap");
+            prevEnd = e.cjPackedEnd;
             if (nWork > 0 && w[nWork - 1].sci == e.sci && w[nWork - 1].shift == e.shift && w[nWork - 1].cjPackedEnd == e.cjPackedBegin)
             {
                 w[nWork - 1].cjPackedEnd = e.cjPackedEnd;
             }
             else { w[nWork++] = e; }
         }
+        NBNXM_TP
+        nb->h_sciSorted.resize(nWork);
+        if (nWork) { std::memcpy(nb->h_sciSorted.data, w.data(), sizeof(nbnxn_sci_t) * nWork); }
+        NBNXM_TP
         d->nsciWork = nWork;
         copyToDeviceBuffer(&d->sciSorted, nb->h_sciSorted.data, 0, nWork, s, true);
     }
@@ -967,6 +1058,14 @@ static void uploadPairlist(NbnxmGpu* nb, int iloc, int na_c, int nsci, const nbn
      * (nbnxm_gpu_data_mgmt.cpp:706-735, GpuApiCallBehavior::Async from its pinned HostVectors); the one staging buffer this path uses
      * (the sorted entries) is guarded by an event until the next upload.  Staged lists: the upload is complete on return, the caller's
      * arrays are free. */
+    NBNXM_TP
+#ifdef NBNXM_HOST_UPLOAD_TIMING
+    {
+        std::fprintf(stderr, "uploadPairlist host us:");
+        for (size_t k = 1; k < tp_.size(); k++) { std::fprintf(stderr, " %.1f", std::chrono::duration<double, std::micro>(tp_[k] - tp_[k - 1]).count()); }
+        std::fprintf(stderr, "  (realloc+wait | pinned? | 3 copies queued | sci checks | validate kernel queued | realloc sorted | assign | sort+join | to pinned | copy queued)\n");
+    }
+#endif
     if (inPlace)
     {
         if (nb->listStagingFree == nullptr) { NBNXM_HIP_CHECK(hipEventCreateWithFlags(&nb->listStagingFree, hipEventDisableTiming)); }
@@ -1493,6 +1592,7 @@ void nbnxm_gpu_launch_kernel_pruneonly(NbnxmGpu* nb, int iloc, int numParts)
 
 void nbnxm_gpu_launch_kernel(NbnxmGpu* nb, const nbnxm_step_workload_t* stepWork, int iloc)
 {
+    checkListErrorFlag(nb);
     NBNXM_ASSERT(iloc == NBNXM_LOCAL || (iloc == NBNXM_NONLOCAL && nb->bUseTwoStreams), "bad locality");
     NBAtomDataGpu*     adat  = nb->atdat;
     NBParamGpu*        nbp   = nb->nbparam;
@@ -1819,6 +1919,7 @@ static int finishTask(NbnxmGpu* nb, const nbnxm_step_workload_t* stepWork, int a
             if (!nb->deviceStreams[iloc].completed()) { return 0; }
         }
         else { nb->deviceStreams[iloc].synchronize(); }
+        checkListErrorFlag(nb); /* (the list check runs on the device: gpu_init_pairlist) */
         accumulateTimings(nb, iloc);
         if (iloc == NBNXM_LOCAL)
         {

@@ -109,6 +109,8 @@ struct NbnxmGpu
     int numWorkRangesOverride = 0; /* experiments: NBNXM_HIP_NUM_WORK_RANGES */
     PinnedBuffer<nbnxn_sci_t> h_sciSorted;
     PinnedBuffer<int>         h_slowCount;        /* one per locality */
+    int*                      h_listError = nullptr; /* mapped host memory: nbnxmValidateListKernel's flag, and its device address */
+    int*                      d_listError = nullptr;
     hipEvent_t                listStagingFree = nullptr; /* behind the last copy out of the list staging buffers (uploadPairlist) */
     bool                      listStagingBusy = false;
     hipEvent_t                slowCountReady[2] = { nullptr, nullptr }; /* behind the copy of gpu_plist::slowCount to h_slowCount */
@@ -145,6 +147,9 @@ struct NbnxmGpu
      * kind (A.4: the reference frees its temporaries right after queuing the copies) */
     PinnedBuffer<float4> h_q4;
     PinnedBuffer<int4>   h_atomTypes4;
+    std::vector<unsigned long long> sciSortKeys;
+    std::vector<int>         sciSortRuns;
+    std::vector<nbnxn_sci_t> sciWorkHost;      /* uploadPairlist: the entries sorted and joined, before they go to the pinned staging buffer */
     std::vector<int>     fepInverse;           /* gpu_init_feppairlist: topology id -> grid index */
     PinnedBuffer<int4>   h_clItem;             /* gpu_feplist::clItem / clListed / clIncl staging */
     PinnedBuffer<uint2>  h_clListed, h_clIncl;

@@ -606,6 +606,39 @@ def test_a_tabulated_ewald_pick_runs_the_analytical_kernels(rvdw, monkeypatch):
     nb.free()
 
 
+def test_a_malformed_list_is_caught_on_the_device(tmp_path):
+    # gpu_init_pairlist checks the i-entries on the host and the packed groups on the device (nbnxmValidateListKernel): a j-cluster
+    # outside the atom range is replaced by cluster 0 — nothing faults — and ends the process at the next launch or finish, with a message
+    import subprocess
+    import sys
+    code = """
+import sys
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+import numpy as np
+import fep_testlib as tl
+pkg = tl.pkg
+c = tl.make_case(elec="rf", seed=46, nm=(10, 10, 10), num_perturbed_molecules=3)
+nb = tl.setup_gpu(c, fused=True)
+cj = c.plist_fused.cjPacked.copy()
+cj["cj"][7, 2] = c.grid.num_atoms // 8 + 5
+nb.init_pairlist(c.plist_fused.sci, cj, c.plist_fused.excl)
+sw = pkg.step_workload(energy=False, virial=False, dhdl=False)
+nb.clear_outputs(False)
+nb.launch_kernel(sw)
+f = np.zeros((c.grid.num_atoms, 3), np.float32)
+nb.launch_cpyback(f, sw)
+nb.wait_finish_task(sw, c.have_soft_core)
+print("NOT CAUGHT")
+""" % (tl.ROOT if hasattr(tl, "ROOT") else ".", "tests")
+    log = tmp_path / "fatal.log"
+    import os
+    env = dict(os.environ, NBNXM_HIP_FATAL_LOG=str(log))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, env=env,
+                       cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert r.returncode != 0 and "NOT CAUGHT" not in r.stdout, (r.returncode, r.stdout[-500:], r.stderr[-500:])
+    assert "j-cluster outside the atom range" in (r.stderr + (log.read_text() if log.exists() else ""))
+
+
 def test_timing_and_query_entry_points():
     c = tl.make_case(elec="ewald", seed=44, n_lambda=3, **SMALL)
     nb = tl.setup_gpu(c)

@@ -52,4 +52,19 @@ for rep in range(4):
     t_next = timed(first_step, 100)
     print("search step %d: atom data %.3f  list upload %.3f  fep bits / atom-pair list %.3f  xq %.3f  first step (prune + partition + kernel) %.3f  | later steps %.4f ms"
           % (rep, t_atom, t_list, t_bits, t_xq, t_first, t_next), flush=True)
+# host time of each call without waiting for the device (what the caller's thread spends), then the wait for everything
+if "host" in sys.argv:
+    p_xq = pkg.pinned_copy(g.xq)
+    for rep in range(4):
+        sync()
+        t = [time.perf_counter()]
+        nb.init_atomdata(g.num_atoms, g.type, qA=g.qA, qB=g.qB, typeA=g.typeA, typeB=g.typeB); t.append(time.perf_counter())
+        nb.init_pairlist(pl_sci, pl_cj, pl_excl); t.append(time.perf_counter())
+        nb.init_fep_cluster_bits(g.fepBits); t.append(time.perf_counter())
+        nb.copy_xq_to_gpu(p_xq); t.append(time.perf_counter())
+        nb.clear_outputs(False); nb.launch_kernel(sw); t.append(time.perf_counter())
+        sync(); t.append(time.perf_counter())
+        d = [1e3 * (b - a) for a, b in zip(t[:-1], t[1:])]
+        print("host ms: atom data %.3f  list %.3f  bits %.3f  xq %.3f  first launch %.3f  | wait for the device %.3f  | total %.3f"
+              % (d[0], d[1], d[2], d[3], d[4], d[5], 1e3 * (t[-1] - t[0])), flush=True)
 nb.free()
