@@ -961,20 +961,6 @@ static void uploadPairlist(NbnxmGpu* nb, int iloc, int na_c, int nsci, const nbn
         NBNXM_ASSERT((sci[i].shift & NBNXM_CI_SHIFT_MASK) < c_numShiftVectors, "shift index out of range");
     }
     NBNXM_TP
-    if (ncjPacked > 0)
-    {
-        /* the j-side of the check runs on the device, behind the copy (nbnxmValidateListKernel) */
-        if (nb->h_listError == nullptr)
-        {
-            NBNXM_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&nb->h_listError), sizeof(int), hipHostMallocMapped));
-            *nb->h_listError = 0;
-            NBNXM_HIP_CHECK(hipHostGetDevicePointer(reinterpret_cast<void**>(&nb->d_listError), nb->h_listError, 0));
-        }
-        constexpr int c_validateBlock = 256;
-        hipLaunchKernelGGL(nbnxmValidateListKernel, dim3((ncjPacked + c_validateBlock - 1) / c_validateBlock), dim3(c_validateBlock), 0, s, d->cjPacked,
-                           ncjPacked, numAtoms / c_clSize, nexcl, nb->d_listError);
-        NBNXM_HIP_CHECK(hipGetLastError());
-    }
     NBNXM_TP
 
     /* the i-entries ordered by their j-group range, for the work partition (empty entries first among equals) */
@@ -1052,6 +1038,20 @@ static void uploadPairlist(NbnxmGpu* nb, int iloc, int na_c, int nsci, const nbn
         NBNXM_TP
         d->nsciWork = nWork;
         copyToDeviceBuffer(&d->sciSorted, nb->h_sciSorted.data, 0, nWork, s, true);
+    }
+    if (ncjPacked > 0)
+    {
+        /* the j-side of the check runs on the device, behind the copies (nbnxmValidateListKernel) */
+        if (nb->h_listError == nullptr)
+        {
+            NBNXM_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&nb->h_listError), sizeof(int), hipHostMallocMapped));
+            *nb->h_listError = 0;
+            NBNXM_HIP_CHECK(hipHostGetDevicePointer(reinterpret_cast<void**>(&nb->d_listError), nb->h_listError, 0));
+        }
+        constexpr int c_validateBlock = 256;
+        hipLaunchKernelGGL(nbnxmValidateListKernel, dim3((ncjPacked + c_validateBlock - 1) / c_validateBlock), dim3(c_validateBlock), 0, s, d->cjPacked,
+                           ncjPacked, numAtoms / c_clSize, nexcl, nb->d_listError);
+        NBNXM_HIP_CHECK(hipGetLastError());
     }
     /* Lists read in place from page-locked memory: no wait — the copies run beside what the host does next in its search step, and
      * the caller keeps the arrays unchanged until the list's stream has passed them, as the reference's caller does
