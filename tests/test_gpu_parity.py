@@ -606,6 +606,22 @@ def test_a_tabulated_ewald_pick_runs_the_analytical_kernels(rvdw, monkeypatch):
     nb.free()
 
 
+def test_lists_in_page_locked_memory_are_read_in_place():
+    # the reference keeps its pair lists in pinned HostVectors and gpu_init_pairlist reads them without a wait; so does this library for
+    # arrays in page-locked memory (other memory is staged and complete on return): same forces either way, twice in a row on one object
+    c = tl.make_case(elec="ewald", seed=47, **SMALL)
+    want = tl.run_oracle(c, energy=True)
+    pl = c.plist_fused
+    pinned = (pkg.pinned_copy(pl.sci), pkg.pinned_copy(pl.cjPacked), pkg.pinned_copy(pl.excl))
+    nb = tl.setup_gpu(c, fused=True)
+    for lists in (pinned, (pl.sci, pl.cjPacked, pl.excl), pinned):
+        nb.init_pairlist(*lists)
+        nb.init_fep_cluster_bits(c.grid.fepBits)
+        got = tl.run_gpu(c, energy=True, fused=True, nb=nb)
+        tl.assert_parity(got, want, rel=1e-4, label="pinned lists")
+    nb.free()
+
+
 def test_a_malformed_list_is_caught_on_the_device(tmp_path):
     # gpu_init_pairlist checks the i-entries on the host and the packed groups on the device (nbnxmValidateListKernel): a j-cluster
     # outside the atom range is replaced by cluster 0 — nothing faults — and ends the process at the next launch or finish, with a message
