@@ -606,6 +606,37 @@ def test_a_tabulated_ewald_pick_runs_the_analytical_kernels(rvdw, monkeypatch):
     nb.free()
 
 
+def test_many_search_steps_in_a_row_on_one_object():
+    # a run is searches and steps in turn: twelve times the same atom data, list (from page-locked memory, no wait), perturbed-atom bits
+    # and coordinates, each followed by forty force-only steps with a rolling-prune part pending and an energy step — the count of
+    # perturbed cluster pairs of each new list is picked up a step or two late (the launches stride over the device's count), the
+    # ranges' shares survive, the first-pass prune runs in chunks.  Same forces and energies every time, equal to the oracle's.
+    c = tl.make_case(elec="ewald", seed=48, nm=(20, 10, 10), num_perturbed_molecules=6)
+    want = tl.run_oracle(c, energy=True)
+    pl, g = c.plist_fused, c.grid
+    lists = (pkg.pinned_copy(pl.sci), pkg.pinned_copy(pl.cjPacked), pkg.pinned_copy(pl.excl))
+    nb = tl.setup_gpu(c, fused=True, use_dynamic_pruning=True)
+    sw_f = pkg.step_workload(energy=False, virial=False, dhdl=False)
+    first = None
+    for search in range(12):
+        nb.init_atomdata(g.num_atoms, g.type, qA=g.qA, qB=g.qB, typeA=g.typeA, typeB=g.typeB)
+        nb.init_pairlist(*lists)
+        nb.init_fep_cluster_bits(g.fepBits)
+        nb.copy_xq_to_gpu(g.xq)
+        for step in range(40):
+            if step > 0:
+                nb.launch_kernel_pruneonly(num_parts=8)
+            nb.clear_outputs(False)
+            nb.launch_kernel(sw_f)
+        got = tl.run_gpu(c, energy=True, fused=True, nb=nb)
+        tl.assert_parity(got, want, rel=1e-4, label="search %d" % search)
+        if first is None:
+            first = got
+        else:
+            assert abs(got["e_el"] - first["e_el"]) <= 1e-5 * abs(first["e_el"]) and abs(got["e_lj"] - first["e_lj"]) <= 1e-5 * abs(first["e_lj"]) + 1e-3
+    nb.free()
+
+
 def test_lists_in_page_locked_memory_are_read_in_place():
     # the reference keeps its pair lists in pinned HostVectors and gpu_init_pairlist reads them without a wait; so does this library for
     # arrays in page-locked memory (other memory is staged and complete on return): same forces either way, twice in a row on one object
