@@ -659,7 +659,8 @@ def test_a_malformed_list_is_caught_on_the_device(tmp_path):
     import subprocess
     import sys
     code = """
-import sys
+import resource, sys
+resource.setrlimit(resource.RLIMIT_CORE, (0, 0))     # the process ends in abort(): no core file
 sys.path.insert(0, %r); sys.path.insert(0, %r)
 import numpy as np
 import fep_testlib as tl
