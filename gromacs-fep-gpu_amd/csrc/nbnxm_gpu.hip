@@ -1108,6 +1108,12 @@ void nbnxm_gpu_init_feppairlist(NbnxmGpu* nb, int iloc, int nri, const int* iinr
     const int    numAtoms = nb->atdat->numAtoms;
     NBNXM_ASSERT(nri == 0 || (jindex[0] == 0 && jindex[nri] == nrj), "FEP list jindex does not cover jjnr");
 
+#ifdef NBNXM_HOST_UPLOAD_TIMING
+    std::vector<std::chrono::steady_clock::time_point> tq_{ std::chrono::steady_clock::now() };
+#define NBNXM_TQ tq_.push_back(std::chrono::steady_clock::now());
+#else
+#define NBNXM_TQ
+#endif
     /* topology id -> grid index (inverse of gridSet.atomIndices(), :766-790) */
     std::vector<int>& inverse = nb->fepInverse; /* (kept with the object: no allocation per search step) */
     inverse.clear();
@@ -1131,6 +1137,7 @@ void nbnxm_gpu_init_feppairlist(NbnxmGpu* nb, int iloc, int nri, const int* iinr
         NBNXM_ASSERT(g >= 0 && g < numAtoms, "FEP list atom outside the atom range");
         return g;
     };
+    NBNXM_TQ
     nb->h_iinr.resize(nri);
     nb->h_shift.resize(nri);
     nb->h_jindex.resize(nri + 1);
@@ -1152,6 +1159,7 @@ void nbnxm_gpu_init_feppairlist(NbnxmGpu* nb, int iloc, int nri, const int* iinr
             nb->h_exclFep.data[k]   = (excl_fep != nullptr) ? excl_fep[k] : 1;
         }
     }
+    NBNXM_TQ
     reallocateDeviceBuffer(&d->iinr, nri, &d->nri, &d->maxnri);
     reallocateDeviceBuffer(&d->shift, nri, &d->nshift, &d->maxnshift);
     reallocateDeviceBuffer(&d->jindex, nri + 1, &d->njidx, &d->maxnjidx);
@@ -1166,6 +1174,7 @@ void nbnxm_gpu_init_feppairlist(NbnxmGpu* nb, int iloc, int nri, const int* iinr
     copyToDeviceBuffer(&d->excl_fep, nb->h_exclFep.data, 0, nrj, s, true);
     copyToDeviceBuffer(&d->pairEntry, nb->h_pairEntry.data, 0, nrj, s, true);
 
+    NBNXM_TQ
     /* the same list regrouped by (i-cluster, j-cluster, shift): what the trailing workgroups of the cluster kernel evaluate, one wave per
      * item (gpu_feplist::clItem; fepListClusterItem) */
     {
@@ -1212,6 +1221,7 @@ void nbnxm_gpu_init_feppairlist(NbnxmGpu* nb, int iloc, int nri, const int* iinr
                 if (nb->h_exclFep.data[k] != 0) { iw |= 1U << (bit & 31U); }
             }
         }
+        NBNXM_TQ
         const int numItems = static_cast<int>(items.size());
         if (numItems > d->clItem_nalloc)
         {
@@ -1238,7 +1248,16 @@ void nbnxm_gpu_init_feppairlist(NbnxmGpu* nb, int iloc, int nri, const int* iinr
             copyToDeviceBuffer(&d->clIncl, nb->h_clIncl.data, 0, numItems, s, true);
         }
     }
+    NBNXM_TQ
     NBNXM_HIP_CHECK(hipStreamSynchronize(s));
+    NBNXM_TQ
+#ifdef NBNXM_HOST_UPLOAD_TIMING
+    {
+        std::fprintf(stderr, "init_feppairlist host us:");
+        for (size_t k = 1; k < tq_.size(); k++) { std::fprintf(stderr, " %.1f", std::chrono::duration<double, std::micro>(tq_[k] - tq_[k - 1]).count()); }
+        std::fprintf(stderr, "  (inverse map | remap | 6 copies queued | regroup | 3 copies queued | wait)\n");
+    }
+#endif
 }
 
 void nbnxm_gpu_init_fep_cluster_bits(NbnxmGpu* nb, int numClusters, const unsigned char* fepBits)
