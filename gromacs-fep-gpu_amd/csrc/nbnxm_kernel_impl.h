@@ -519,7 +519,11 @@ __launch_bounds__(c_nbMaxBlockSize) __attribute__((amdgpu_waves_per_eu(c_nbWaves
         /* force flavours: {F, step} (16 KB); energy flavours: {F, step, V, step} (32 KB, they run at 4 waves per SIMD) */
         const float4* __restrict__ src = ENERGY ? nbp.ewaldCorrTabFV : reinterpret_cast<const float4*>(nbp.ewaldCorrTab);
         float4*                    dst = reinterpret_cast<float4*>(nbLds);
+#ifdef NBNXM_TIMING_NO_TABLE_STAGE /* timing-only diagnostics build: what the 16 KB per workgroup cost at the start of the kernel (results wrong) */
+        for (int t = threadIdx.x; t < 64; t += blockSize) { dst[t] = src[t]; }
+#else
         for (int t = threadIdx.x; t < c_ewaldTabBytes / static_cast<int>(sizeof(float4)); t += blockSize) { dst[t] = src[t]; }
+#endif
     }
 
     if constexpr (EWALD_R_TABLE)
