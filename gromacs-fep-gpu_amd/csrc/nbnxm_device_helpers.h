@@ -260,6 +260,11 @@ NB_DEVINL void nbPair(const NBParamGpu& nbp,
                       [[maybe_unused]] float ewaldTabScaleV = 0.0F /* cluster kernel, analytical Ewald: NBParamGpu::ewaldCorrTabScale8 (16 on
                                                                     * energy steps) in a VECTOR register, set once per kernel */)
 {
+    /* (Round 4, advisor finding: NON-excluded pairs at zero distance exist as well — the reference parks all filler atoms of its grid on
+     * ONE point (atomdata.cpp:148-184) and lists filler-filler pairs, with zero charge and zero LJ parameters.  Without the clamp such a
+     * pair is 0 x inf = NaN, which the AND with an all-ones mask keeps.  The cluster kernel therefore starts its sum of squares from
+     * c_r2Floor = 1e-12 nm^2: below half an ulp of any r^2 > 2e-5 nm^2, so no real pair sees it, and at r = 0 it makes 1/r = 1e6,
+     * r^-6 = 1e36 finite, times the fillers' zero parameters = 0.  tests/test_gpu_parity.py::test_filler_atoms_on_one_point.) */
     /* r^2 >= c_nbnxnMinDistanceSquared (pairlist.h:166) exists so that EXCLUDED pairs at zero distance — an atom's pair with itself,
      * a shell on its core — do not turn the sums into NaN.  The force-only one-mask block below removes everything an exclusion
      * removes with a bit-wise AND, which gives +0 whatever the masked value is (infinity and NaN included), its Ewald term is finite

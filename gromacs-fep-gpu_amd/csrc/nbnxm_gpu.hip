@@ -649,6 +649,7 @@ void nbnxm_gpu_free(NbnxmGpu* nb)
             {
                 freeDeviceBuffer(&nb->plist[i]->workRangeStart[p]);
                 freeDeviceBuffer(&nb->plist[i]->workFirstSci[p]);
+                freeDeviceBuffer(&nb->plist[i]->workDesc[p]);
                 freeDeviceBuffer(&nb->plist[i]->workShare[p]);
                 freeDeviceBuffer(&nb->plist[i]->workShareCum[p]);
             }
@@ -1416,8 +1417,9 @@ static void updateWorkPartition(NbnxmGpu* nb, int iloc)
 #if defined(NBNXM_WAVE_TIMELINE) || defined(NBNXM_BLOCK_STATS)
     if (d->debugTimeline == nullptr)
     {
-        allocateDeviceBuffer(&d->debugTimeline, 4 * 16384);
-        NBNXM_HIP_CHECK(hipMemset(d->debugTimeline, 0, sizeof(unsigned long long) * 4 * 16384));
+        /* (second half: four more time stamps per range wave, the steps of its prologue) */
+        allocateDeviceBuffer(&d->debugTimeline, 8 * 16384);
+        NBNXM_HIP_CHECK(hipMemset(d->debugTimeline, 0, sizeof(unsigned long long) * 8 * 16384));
     }
 #endif
     if (d->nsci == 0 || d->ncjPacked == 0)
@@ -1531,6 +1533,14 @@ static void updateWorkPartition(NbnxmGpu* nb, int iloc)
     }
     hipLaunchKernelGGL(nbnxmWorkRangesKernel, dim3(numBlocks), dim3(c_workBlockSize), 0, s, d->groupWeight, d->weightBlockSum,
                        d->ncjPacked, numBlocks, d->sciSorted, d->nsciWork, out[0], out[1]);
+    NBNXM_HIP_CHECK(hipGetLastError());
+    /* the start record of every range (NbWorkDesc): one scalar load at the top of a wave instead of four dependent round trips */
+    for (int p = 0; p < 2; p++)
+    {
+        reallocateDeviceBuffer(&d->workDesc[p], d->numWorkRanges[p], &dummy, &d->workDesc_nalloc[p]);
+        hipLaunchKernelGGL(nbnxmWorkDescKernel, dim3((d->numWorkRanges[p] + c_workBlockSize - 1) / c_workBlockSize), dim3(c_workBlockSize), 0, s,
+                           d->workRangeStart[p], d->workFirstSci[p], d->numWorkRanges[p], d->sciSorted, d->nsciWork, d->cjPacked, d->workDesc[p]);
+    }
     NBNXM_HIP_CHECK(hipGetLastError());
     d->workRangesDirty = false; /* (setWorkShares above marks the ranges dirty: they have just been computed with the new shares) */
 }
@@ -1842,7 +1852,7 @@ void nbnxm_gpu_launch_kernel(NbnxmGpu* nb, const nbnxm_step_workload_t* stepWork
             hipLaunchKernelGGL(kernel, dim3(numBlocks), dim3(wavesPerBlock * c_waveSize), ldsBytes, s,
                                *adat, *nbp, *plist, stepWork->computeVirial, plist->sciSorted, plist->cjPacked, plist->excl, adat->xq,
                                adat->atomTypes, adat->ljComb, reinterpret_cast<const unsigned*>(adat->fepBits),
-                               plist->workRangeStart[p] + set * setRanges, plist->workFirstSci[p] + set * setRanges, setRanges, plist->groupSlowMask,
+                               plist->workDesc[p] + set * setRanges, setRanges, plist->groupSlowMask,
                                tail ? mergedFepItems : 0, std::max(plist->rollingPruningNumParts, 1), prunePart, tail ? pruneEntries : 0,
                                reinterpret_cast<float4*>(nb->fSpare), tail ? clearNumFloat4 : 0, (wantForeign && energyFlavour) ? nb->n_lambda : -1,
                                *nb->feplist[iloc]);

@@ -33,6 +33,9 @@ constexpr int c_maxTypesAtFullOccupancy = 28; /* 8 ntype^2 bytes + 16 KB Ewald t
 constexpr int c_ldsAllocGranularity = 1280; /* LDS allocation granule of gfx950, bytes (measured: five workgroups of 31,872 B are resident per CU, five of 32,336 B are not) */
 /* nbnxm/pairlist.h:166: keeps r^-12 finite in fp32 */
 constexpr float c_nbnxnMinDistanceSquared = 3.82e-07F;
+/* The cluster kernel's sum of squares starts from this (nm^2): invisible to any real pair distance in fp32, finite 1/r and r^-6 at r = 0
+ * (filler atoms parked on one point, atomdata.cpp:148-184); see nbPair */
+constexpr float c_r2Floor = 1.0e-12F;
 /* nb_free_energy.cpp:107: cap on r^-6 in the perturbed-pair math */
 constexpr float c_maxRInvSix = 1.0e15F;
 constexpr int c_numEnergySlots   = 128;
@@ -189,6 +192,23 @@ constexpr int c_fepClusterWavesPerBlockDef = 4;
 constexpr int c_energyTailCompiled = NBNXM_ENERGY_TAIL;
 constexpr unsigned c_clearFloat4PerThread = 4; /* trailing clear workgroups of the cluster kernel: float4 stores per thread */
 
+/* MI355X extension: the start of one work range of the cluster kernel as ONE 64-byte record, so that a wave's prologue is one scalar
+ * load followed directly by the i-atom loads and the first group's j-side loads (before: range borders -> i-entry -> list words ->
+ * j data, four dependent round trips).  Written by nbnxmWorkDescKernel behind the range borders, whenever the partition changes.
+ * Only what no pruning changes is copied: the i-entry record, the first group's j-cluster indices and exclusion-mask indices (the
+ * group's imask — rewritten by every rolling-prune part — is read through the list-word ring like any other group's). */
+struct NbWorkDesc
+{
+    int         rangeBegin, rangeEnd; /* packed j-groups [rangeBegin, rangeEnd); empty when no i-entry owns a group of the range */
+    int         sciIdx;               /* index into sciSorted of `entry` */
+    int         firstGroup;           /* max(rangeBegin, entry.cjPackedBegin): the group whose indices follow */
+    nbnxn_sci_t entry;                /* the first i-entry that owns a group of the range */
+    int         cj[4];                /* cjPacked[firstGroup].cj */
+    int         exclInd[2];           /* cjPacked[firstGroup].imei[0 / 1].excl_ind */
+    int         pad[2];
+};
+static_assert(sizeof(NbWorkDesc) == 64, "one scalar load of 16 dwords");
+
 /* nbnxm/gpu_types_common.h:297-341 */
 struct gpu_plist
 {
@@ -247,6 +267,8 @@ struct gpu_plist
     int          weightBlockSum_nalloc;
     int*         workRangeStart[2];
     int*         workFirstSci[2];
+    NbWorkDesc*  workDesc[2];       /* numWorkRanges: what a wave needs to start its range, in one 64-byte record (nbnxmWorkDescKernel) */
+    int          workDesc_nalloc[2];
     int          numWorkRanges[2];
     int          work_nalloc[2];
     int          workFirstSciAlloc[2];

@@ -55,6 +55,22 @@ NB_DEVINL void ldsDirectLoad4(unsigned ldsBase, unsigned offset, const void* bas
 
 typedef int nb_int4 __attribute__((ext_vector_type(4)));
 
+/* An i-entry record through the scalar unit, whatever the compiler thinks of the memory behind the pointer: inside the piece loop —
+ * behind the force atomics — it no longer proves the list read-only and loads the record's words one by one through the VECTOR
+ * memory pipeline, each followed by a vmcnt(0), i.e. by a wait for the memory-side atomics the wave has just sent (measured: + 0.65 us
+ * per piece of a range, + 2 - 3 us on the waves with three or four pieces, which are the last ones to finish on a 24k-atom box). */
+NB_DEVINL nbnxn_sci_t scalarLoadSci(const nbnxn_sci_t* __restrict__ entry)
+{
+    nb_int4 r;
+    asm volatile("s_load_dwordx4 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(r) : "s"(entry) : "memory");
+    nbnxn_sci_t e;
+    e.sci           = r.x;
+    e.shift         = r.y;
+    e.cjPackedBegin = r.z;
+    e.cjPackedEnd   = r.w;
+    return e;
+}
+
 /* lane index within the wave, recomputed in place (2 VALU ops, no live register): volatile so that it is
  * neither hoisted out of a loop nor merged with an earlier copy */
 NB_DEVINL unsigned laneIdNow()
@@ -263,7 +279,8 @@ NB_DEVINL void pruneEntry(const NBAtomDataGpu& atdat, const NBParamGpu& nbp, con
                         if (fastMask & (1U << i)) \
                         { \
                             const float3 rv      = make_float3(xqi[i].x - xqj.x, xqi[i].y - xqj.y, xqi[i].z - xqj.z); \
-                            const float  r2      = rv.x * rv.x + rv.y * rv.y + rv.z * rv.z; \
+                            /* (the sum starts from c_r2Floor, see nbPair: same instruction count, a v_fmaak instead of a v_mul) */ \
+                            const float  r2      = fmaf(rv.z, rv.z, fmaf(rv.y, rv.y, fmaf(rv.x, rv.x, c_r2Floor))); \
                             int          intMask = -1; \
                             bool         active  = (r2 < rcoulomb_sq); \
                             if constexpr (HAS_EXCL) \
@@ -345,11 +362,10 @@ __launch_bounds__(c_nbMaxBlockSize) __attribute__((amdgpu_waves_per_eu(c_nbWaves
                          const int* __restrict__ atomTypes,
                          const float2* __restrict__ ljComb,
                          const unsigned* __restrict__ fepWords, /* atdat.fepBits viewed as dwords (scalar loads) */
-                         /* work partition (gpu_plist::work*): wave w owns the packed j-groups
-                          * [workRangeStart[w], workRangeStart[w+1]) and starts in entry workFirstSci[w] of sciList,
-                          * which is the list's i-entries ordered by cjPackedBegin */
-                         const int* __restrict__ workRangeStart,
-                         const int* __restrict__ workFirstSci,
+                         /* work partition (gpu_plist::work*): wave w owns the packed j-groups [workDesc[w].rangeBegin, .rangeEnd) and
+                          * starts in entry workDesc[w].sciIdx of sciList, which is the list's i-entries ordered by cjPackedBegin;
+                          * the record also carries that entry and the first group's indices (NbWorkDesc) */
+                         const NbWorkDesc* __restrict__ workDesc,
                          const int numWorkRanges,
                          const unsigned* __restrict__ groupSlowMask, /* FUSED: perturbed cluster pairs of each group */
                          const int mergedFepItems, /* FUSED force flavour: perturbed cluster pairs for the trailing workgroups, or 0 */
@@ -372,6 +388,9 @@ __launch_bounds__(c_nbMaxBlockSize) __attribute__((amdgpu_waves_per_eu(c_nbWaves
     constexpr bool EXCL_FORCES = (ELEC != ELK_CUT) || ENERGY || LJ_EWALD; /* nbnxm_cuda_kernel.cuh:69-78 */
     constexpr bool USE_TABLE   = VdwTraits<VDW>::useTable;
 
+#ifdef NBNXM_WAVE_TIMELINE
+    const unsigned long long tlTop = wall_clock64(); /* the wave's first instruction */
+#endif
     /* wave-uniform values are pinned to SGPRs with readfirstlane so that everything derived from them
      * (list walk, branches, list loads) stays on the scalar unit */
     const unsigned blockSize = __builtin_amdgcn_readfirstlane(blockDim.x);
@@ -506,69 +525,36 @@ __launch_bounds__(c_nbMaxBlockSize) __attribute__((amdgpu_waves_per_eu(c_nbWaves
     /* (tabulated Ewald on energy steps: the r-indexed table sits behind the potential table) */
     [[maybe_unused]] const float2* ewaldCorrLds = reinterpret_cast<const float2*>(nbLds + (EWALD_V_TABLE ? c_ewaldTabBytes : 0));
     unsigned char* jStage = nbLds + tableBytes + wave * (2 * c_jStageBytes + c_jRingBytes);
-    if constexpr (USE_TABLE)
-    {
-        for (int t = threadIdx.x; t < numTypes * numTypes; t += blockSize) { nbfpLds[t] = nbp.nbfp[t]; }
-        if constexpr (LJ_EWALD)
-        {
-            for (int t = threadIdx.x; t < numTypes; t += blockSize) { nbfpLds[numTypes * numTypes + t] = nbp.nbfp_comb[t]; }
-        }
-    }
-    if constexpr (EWALD_CORR_TABLE)
-    {
-        /* force flavours: {F, step} (16 KB); energy flavours: {F, step, V, step} (32 KB, they run at 4 waves per SIMD) */
-        const float4* __restrict__ src = ENERGY ? nbp.ewaldCorrTabFV : reinterpret_cast<const float4*>(nbp.ewaldCorrTab);
-        float4*                    dst = reinterpret_cast<float4*>(nbLds);
-#ifdef NBNXM_TIMING_NO_TABLE_STAGE /* timing-only diagnostics build: what the 16 KB per workgroup cost at the start of the kernel (results wrong) */
-        for (int t = threadIdx.x; t < 64; t += blockSize) { dst[t] = src[t]; }
-#else
-        for (int t = threadIdx.x; t < c_ewaldTabBytes / static_cast<int>(sizeof(float4)); t += blockSize) { dst[t] = src[t]; }
-#endif
-    }
-
-    if constexpr (EWALD_R_TABLE)
-    {
-        float* dst = reinterpret_cast<float*>(nbLds + (EWALD_V_TABLE ? c_ewaldTabBytes : 0));
-        for (int t = threadIdx.x; t < nbp.coulombTabSize; t += blockSize) { dst[t] = nbp.coulomb_tab[t]; }
-    }
-    if constexpr (EWALD_V_TABLE)
-    {
-        float2* dst = reinterpret_cast<float2*>(nbLds);
-        for (int t = threadIdx.x; t < c_ewaldCorrTabSize; t += blockSize)
-        {
-            const float4 fv = nbp.ewaldCorrTabFV[t];
-            dst[t]          = make_float2(fv.z, fv.w);
-        }
-    }
-
-    /* the table scale of ewaldTabAddress in a vector register, for the whole kernel (a scalar operand would halve the FMA's issue rate) */
-    [[maybe_unused]] float ewaldTabScaleV = 0.0F;
-    if constexpr (EWALD_CORR_TABLE)
-    {
-        asm volatile("v_mov_b32 %0, %1" : "=v"(ewaldTabScaleV) : "s"(ENERGY ? nbp.ewaldCorrTabScale16 : nbp.ewaldCorrTabScale8));
-    }
-    if constexpr (EWALD_V_TABLE) { asm volatile("v_mov_b32 %0, %1" : "=v"(ewaldTabScaleV) : "s"(nbp.ewaldCorrTabScale16)); }
-
-    /* nbPair addresses the Ewald table with absolute LDS addresses from 0: the kernel has no static LDS, so the dynamic block starts there */
-    if ((EWALD_CORR_TABLE || EWALD_R_TABLE) && reinterpret_cast<uintptr_t>((__attribute__((address_space(3))) unsigned char*)nbLds) != 0) { __builtin_trap(); }
-
-    __syncthreads(); /* the table is in place; from here on the waves of the workgroup are independent */
-
     /* Every wave of the launch gets the same amount of pair work: a contiguous range of packed j-groups cut
      * out of the list by weight (nbnxmWorkRangesKernel), regardless of i-entry borders; the launch has one
      * wave per resident wave slot.  Inside its range the wave walks "pieces": the part of an i-entry's j-list
-     * that lies in the range. */
-    const int workItem = __builtin_amdgcn_readfirstlane(static_cast<int>(blockIdx.x * (blockSize / c_waveSize) + wave));
-    if (workItem >= numWorkRanges) { return; }
+     * that lies in the range.
+     * The start of the range is ONE scalar load (NbWorkDesc: borders, the first i-entry, the first group's cluster and exclusion
+     * indices), issued before anything else; what depends on it — the list words of the first groups, the first group's j-side and
+     * the i-atoms — goes out in one batch, and the staging of the tables into LDS runs beside that batch: two dependent round
+     * trips between the start of a wave and its first pair, where there were four (range borders -> i-entry -> list words -> j
+     * data) behind the table staging. */
+    /* (For the compiler's wait-count pass the trailing workgroups' branch above is a predecessor of this code — the structurizer routes
+     * its exits through a common block —, so it believes that loads into the registers used below may be pending and puts a
+     * vmcnt(0) in front of every write to them: between the LDS-direct loads of the batch, which it cannot see, that is a full round
+     * trip each.  A wait it CAN see, here, where this wave has nothing in flight, clears that state: vmcnt(0), expcnt and lgkmcnt left alone.) */
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+    const int         workItem = __builtin_amdgcn_readfirstlane(static_cast<int>(blockIdx.x * (blockSize / c_waveSize) + wave));
+    const bool        inLaunch = (workItem < numWorkRanges);
+    const NbWorkDesc  desc     = workDesc[inLaunch ? workItem : 0];
 #ifdef NBNXM_WAVE_TIMELINE
-    /* diagnostics build only (tools/gpu_timeline.sh): per wave {start, end of main loops, end, HW_ID} in 100 MHz ticks */
+    /* diagnostics build only (tools/timeline_budget.py): per wave {start, first group's data arrived, end, HW_ID} in 100 MHz ticks */
     const unsigned long long tlStart = wall_clock64();
-    unsigned long long       tlMain  = 0;
     unsigned long long       tlFirst = 0; /* first group's data has arrived */
 #endif
-    const int rangeBegin = workRangeStart[workItem];
-    const int rangeEnd   = workRangeStart[workItem + 1];
-    int       sciIdx     = workFirstSci[workItem];
+    const int  rangeBegin = desc.rangeBegin;
+    const int  rangeEnd   = desc.rangeEnd;
+    const bool hasWork    = inLaunch && (rangeBegin < rangeEnd);
+#ifdef NBNXM_WAVE_TIMELINE
+    asm volatile("s_waitcnt lgkmcnt(0)" ::"s"(rangeEnd) : "memory");
+    const unsigned long long tlDesc = wall_clock64(); /* the start record has arrived */
+#endif
+    int        sciIdx     = desc.sciIdx;
 
     float* __restrict__ f   = reinterpret_cast<float*>(atdat.f);
     const float rcoulomb_sq = nbp.rcoulomb_sq;
@@ -625,6 +611,20 @@ __launch_bounds__(c_nbMaxBlockSize) __attribute__((amdgpu_waves_per_eu(c_nbWaves
         const unsigned char* rec = ring + (static_cast<unsigned>(g) & 3U) * c_ringRecordBytes;                 \
         const int      cjl   = *reinterpret_cast<const int*>(rec + ((lane >> 3) & 3U) * 4U);                   \
         const int      exl   = *reinterpret_cast<const int*>(rec + 20U + half * 8U);                           \
+        NBNXM_STAGE_GROUP_LOADS(buf)                                                                           \
+    }
+/* the same for the range's first group, whose indices arrived with the range's start record (scalar registers) */
+#define NBNXM_STAGE_GROUP_DESC(buf)                                                                            \
+    {                                                                                                          \
+        const unsigned lane  = laneIdNow();                                                                    \
+        const unsigned half  = lane >> 5;                                                                      \
+        const unsigned slot  = (lane >> 3) & 3U;                                                               \
+        const int      cjl   = (slot == 0U) ? desc.cj[0] : ((slot == 1U) ? desc.cj[1] : ((slot == 2U) ? desc.cj[2] : desc.cj[3])); \
+        const int      exl   = (half == 0U) ? desc.exclInd[0] : desc.exclInd[1];                               \
+        NBNXM_STAGE_GROUP_LOADS(buf)                                                                           \
+    }
+#define NBNXM_STAGE_GROUP_LOADS(buf)                                                                           \
+    {                                                                                                          \
         const unsigned ajl   = static_cast<unsigned>(cjl) * c_clSize + (lane & 7U);                            \
         const unsigned base  = jStageLds + static_cast<unsigned>(buf) * c_jStageBytes;                         \
         if constexpr (USE_TABLE)                                                                               \
@@ -665,77 +665,159 @@ __launch_bounds__(c_nbMaxBlockSize) __attribute__((amdgpu_waves_per_eu(c_nbWaves
 
     int curBuf      = 0;  /* staging buffer that holds (or receives) the j-side of group stagedGroup */
     int stagedGroup = -1;
-    /* the list words of the range's first groups are requested before the first i-entry is looked up: their round trip overlaps that
-     * scalar load (the first piece starts at rangeBegin unless groups there belong to no entry; 3k-atom box: 15.9 -> 15.4 us per step) */
-    int wordsRequestedFor = -1;
-    if (rangeBegin < rangeEnd)
+
+    /* ---- the first piece: everything that depends on the start record, in one batch ------------------------------------ */
+    nbnxn_sci_t nb_sci        = desc.entry;
+    int         cjPackedBegin = desc.firstGroup;
+    int         cjPackedEnd   = min(rangeEnd, nb_sci.cjPackedEnd);
+    if (hasWork)
     {
-        NBNXM_STAGE_WORDS(rangeBegin)
-        NBNXM_STAGE_WORDS(rangeBegin + 1)
-        NBNXM_STAGE_WORDS(rangeBegin + 2)
-        wordsRequestedFor = rangeBegin;
+        NBNXM_STAGE_WORDS(cjPackedBegin)
+        NBNXM_STAGE_WORDS(cjPackedBegin + 1)
+        NBNXM_STAGE_WORDS(cjPackedBegin + 2)
+        NBNXM_STAGE_GROUP_DESC(curBuf)
+        NBNXM_DUMMY_ATOMIC();
+        NBNXM_DUMMY_ATOMIC();
+        NBNXM_DUMMY_ATOMIC();
+        NBNXM_DUMMY_ATOMIC();
+        stagedGroup = cjPackedBegin;
     }
+
+    /* ---- the i-atoms of a piece: the 8 atoms a lane meets stay in registers for the whole piece --------------------------- */
+    float4 xqi[c_numClPerSupercl];
+    int    trow[c_numClPerSupercl];  /* byte offset of row type_i of the LDS table (table flavours) */
+    float2 ljcpi[c_numClPerSupercl]; /* combination-rule flavours */
+/* The i-side of a piece.  Every lane needs atom tidxi of all 8 clusters — the same 8 atoms for the 8 lanes that share a tidxi.  Loaded
+ * where they are used that is 8 dwordx4 + 8 dword instructions in which 64 lanes fetch 8 distinct addresses: 160 cycles of the CU's
+ * address path per wave, and at the start of the kernel all 20 waves of a CU do it at once (measured with the prologue's time stamps:
+ * 1.4 - 2.0 us between the start record and the arrival of the batch).  Instead lane l moves atom l, once: the 64 coordinates go to the
+ * staging buffer the group loop is not using (LDS-direct, 1 KB), the 64 type rows arrive in one dword per lane, and the lanes pick up
+ * their 8 atoms with 8 ds_read_b128 (same address for the lanes of a tidxi: a broadcast) and 8 ds_bpermute: 20 cycles of the address
+ * path.  Two parts, so that the prologue can put the table staging between them:
+ *   NBNXM_I_ATOMS_REQUEST  issues the loads (the buffer: the one the next J(g + 1) goes to, free until the group loop's first iteration);
+ *   NBNXM_I_ATOMS_COLLECT  behind a vmcnt(0): registers xqi / trow / ljcpi; ends with lgkmcnt(0), because the group loop's first
+ *                          staging step hands the buffer back to the memory pipeline. */
+#define NBNXM_I_ATOMS_REQUEST                                                                                  \
+    const unsigned iLane = laneIdNow();                                                                        \
+    const int      iAtom = nb_sci.sci * c_superClSize + static_cast<int>(iLane);                               \
+    ldsDirectLoad16(jStageLds + static_cast<unsigned>(curBuf ^ 1) * c_jStageBytes, static_cast<unsigned>(iAtom) * 16U, xq); \
+    [[maybe_unused]] int    iTypeLane = 0;                                                                     \
+    [[maybe_unused]] float2 iCombLane = make_float2(0.0F, 0.0F);                                               \
+    if constexpr (USE_TABLE) { iTypeLane = atomTypes[iAtom]; }                                                 \
+    else { iCombLane = ljComb[iAtom]; }                                                                        \
+    const float3 iShift = atdat.shiftVec[nb_sci.shift & NBNXM_CI_SHIFT_MASK];
+/* (LJ-PME: the per-type grid parameters come from the LDS copy, except ahead of the table staging: GRID_FROM_LDS false) */
+#define NBNXM_I_ATOMS_COLLECT(GRID_FROM_LDS)                                                                   \
+    {                                                                                                          \
+        const unsigned char* iBuf  = jStage + (curBuf ^ 1) * c_jStageBytes + (iLane & 7U) * 16U;               \
+        const int            iPick = static_cast<int>((iLane & 7U) << 2); /* byte address of lane tidxi for ds_bpermute */ \
+        [[maybe_unused]] int iRowLane = 0;                                                                     \
+        if constexpr (USE_TABLE && !LJ_EWALD) { iRowLane = numTypes * iTypeLane * static_cast<int>(sizeof(float2)) + rTabBytes; } \
+        _Pragma("unroll") for (int i = 0; i < c_numClPerSupercl; i++)                                          \
+        {                                                                                                      \
+            float4 v = *reinterpret_cast<const float4*>(iBuf + i * (c_clSize * 16));                           \
+            v.x += iShift.x;                                                                                   \
+            v.y += iShift.y;                                                                                   \
+            v.z += iShift.z;                                                                                   \
+            v.w *= nbp.epsfac;                                                                                 \
+            xqi[i] = v;                                                                                        \
+            const int pick = iPick + i * (c_clSize * 4);                                                       \
+            if constexpr (USE_TABLE && !LJ_EWALD) { trow[i] = __builtin_amdgcn_ds_bpermute(pick, iRowLane); }  \
+            else if constexpr (USE_TABLE)                                                                      \
+            {                                                                                                  \
+                const int ti = __builtin_amdgcn_ds_bpermute(pick, iTypeLane);                                  \
+                trow[i]      = numTypes * ti * static_cast<int>(sizeof(float2)) + rTabBytes;                   \
+                ljcpi[i]     = (GRID_FROM_LDS) ? nbfpLds[numTypes * numTypes + ti] : nbp.nbfp_comb[ti];        \
+            }                                                                                                  \
+            else                                                                                               \
+            {                                                                                                  \
+                ljcpi[i].x = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(pick, __builtin_bit_cast(int, iCombLane.x))); \
+                ljcpi[i].y = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(pick, __builtin_bit_cast(int, iCombLane.y))); \
+            }                                                                                                  \
+        }                                                                                                      \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                     \
+    }
+    /* (waves without work load the i-atoms of the record's zeroed entry — super-cluster 0 —, and leave behind the barrier) */
+    NBNXM_I_ATOMS_REQUEST
+
+    /* ---- the tables, staged beside that batch ----------------------------------------------------------------------------- */
+    if constexpr (EWALD_CORR_TABLE)
+    {
+        /* force flavours: {F, step} (16 KB); energy flavours: {F, step, V, step} (32 KB, they run at 4 waves per SIMD).
+         * LDS-direct, 1 KB per instruction, the chunks dealt out over the waves of the workgroup: nothing to wait for here — a copy
+         * through registers is a round trip per loop iteration (four of them at 16 KB and four waves), which the batch above has
+         * made the longest chain of the prologue.  The table sits at LDS address 0 (checked below). */
+        const void* src = ENERGY ? static_cast<const void*>(nbp.ewaldCorrTabFV) : static_cast<const void*>(nbp.ewaldCorrTab);
+#ifdef NBNXM_TIMING_NO_TABLE_STAGE /* timing-only diagnostics build: what the 16 KB per workgroup cost at the start of the kernel (results wrong) */
+        constexpr unsigned c_tabChunks = 1U;
+#else
+        constexpr unsigned c_tabChunks = static_cast<unsigned>(c_ewaldTabBytes) / 1024U;
+#endif
+        const unsigned laneT = laneIdNow();
+        for (unsigned chunk = wave; chunk < c_tabChunks; chunk += blockSize / c_waveSize)
+        {
+            ldsDirectLoad16(chunk * 1024U, chunk * 1024U + laneT * 16U, src);
+        }
+    }
+    if constexpr (USE_TABLE)
+    {
+        for (int t = threadIdx.x; t < numTypes * numTypes; t += blockSize) { nbfpLds[t] = nbp.nbfp[t]; }
+        if constexpr (LJ_EWALD)
+        {
+            for (int t = threadIdx.x; t < numTypes; t += blockSize) { nbfpLds[numTypes * numTypes + t] = nbp.nbfp_comb[t]; }
+        }
+    }
+
+    if constexpr (EWALD_R_TABLE)
+    {
+        float* dst = reinterpret_cast<float*>(nbLds + (EWALD_V_TABLE ? c_ewaldTabBytes : 0));
+        for (int t = threadIdx.x; t < nbp.coulombTabSize; t += blockSize) { dst[t] = nbp.coulomb_tab[t]; }
+    }
+    if constexpr (EWALD_V_TABLE)
+    {
+        float2* dst = reinterpret_cast<float2*>(nbLds);
+        for (int t = threadIdx.x; t < c_ewaldCorrTabSize; t += blockSize)
+        {
+            const float4 fv = nbp.ewaldCorrTabFV[t];
+            dst[t]          = make_float2(fv.z, fv.w);
+        }
+    }
+
+    /* the table scale of ewaldTabAddress in a vector register, for the whole kernel (a scalar operand would halve the FMA's issue rate) */
+    [[maybe_unused]] float ewaldTabScaleV = 0.0F;
+    if constexpr (EWALD_CORR_TABLE)
+    {
+        asm volatile("v_mov_b32 %0, %1" : "=v"(ewaldTabScaleV) : "s"(ENERGY ? nbp.ewaldCorrTabScale16 : nbp.ewaldCorrTabScale8));
+    }
+    if constexpr (EWALD_V_TABLE) { asm volatile("v_mov_b32 %0, %1" : "=v"(ewaldTabScaleV) : "s"(nbp.ewaldCorrTabScale16)); }
+
+    /* nbPair addresses the Ewald table with absolute LDS addresses from 0: the kernel has no static LDS, so the dynamic block starts there */
+    if ((EWALD_CORR_TABLE || EWALD_R_TABLE) && reinterpret_cast<uintptr_t>((__attribute__((address_space(3))) unsigned char*)nbLds) != 0) { __builtin_trap(); }
+
+
+#ifdef NBNXM_WAVE_TIMELINE
+    const unsigned long long tlIssued = wall_clock64(); /* batch and table staging issued */
+#endif
+    NBNXM_WAIT_VMEM(0); /* the batch has arrived: list words, first group, i-atoms (and the table loads in front of it) */
+#ifdef NBNXM_WAVE_TIMELINE
+    const unsigned long long tlArrived = wall_clock64();
+#endif
+    NBNXM_I_ATOMS_COLLECT(false)
+    __syncthreads();    /* the tables are in place; from here on the waves of the workgroup are independent */
+    if (!hasWork) { return; }
+#ifdef NBNXM_WAVE_TIMELINE
+    const unsigned long long tlBarrier = wall_clock64();
+#endif
 
     float E_lj = 0.0F, E_el = 0.0F;
 
     /* ---- the pieces of this wave's range: one per i-entry it touches ---------------------------------- */
 #pragma unroll 1
-    for (; rangeBegin < rangeEnd && sciIdx < plist.nsciWork; sciIdx++)
+    for (;;)
     {
-    const nbnxn_sci_t nb_sci        = sciList[sciIdx];
-    const int         cjPackedBegin = max(rangeBegin, nb_sci.cjPackedBegin);
-    const int         cjPackedEnd   = min(rangeEnd, nb_sci.cjPackedEnd);
-    if (nb_sci.cjPackedBegin >= rangeEnd) { break; }
-    if (cjPackedBegin >= cjPackedEnd) { continue; }
-    const int         sci           = nb_sci.sci;
-    const int         shiftIdx      = nb_sci.shift & NBNXM_CI_SHIFT_MASK;
-    const bool        central       = (shiftIdx == c_centralShiftIndex);
-
-#ifdef NBNXM_WAVE_TIMELINE
-    tlMain -= wall_clock64();
-#endif
-    if (stagedGroup != cjPackedBegin)
-    {
-        /* (re)start the pipeline: at the first piece, or behind groups that belong to no i-entry */
-        if (cjPackedBegin != wordsRequestedFor)
-        {
-            NBNXM_STAGE_WORDS(cjPackedBegin)
-            NBNXM_STAGE_WORDS(cjPackedBegin + 1)
-            NBNXM_STAGE_WORDS(cjPackedBegin + 2)
-        }
-        NBNXM_WAIT_VMEM(0);
-        NBNXM_STAGE_GROUP(cjPackedBegin, curBuf)
-        NBNXM_DUMMY_ATOMIC();
-        NBNXM_DUMMY_ATOMIC();
-        NBNXM_DUMMY_ATOMIC();
-        NBNXM_DUMMY_ATOMIC();
-    }
-
-    /* ---- stage the i-atoms ---------------------------------------------------------------------- */
-    float4 xqi[c_numClPerSupercl];
-    int    trow[c_numClPerSupercl];  /* byte offset of row type_i of the LDS table (table flavours) */
-    float2 ljcpi[c_numClPerSupercl]; /* combination-rule flavours */
-    {
-        const float3 sh = atdat.shiftVec[shiftIdx];
-#pragma unroll
-        for (int i = 0; i < c_numClPerSupercl; i++)
-        {
-            const int ai = (sci * c_numClPerSupercl + i) * c_clSize + static_cast<int>(tidxi);
-            float4    v  = xq[ai];
-            v.x += sh.x;
-            v.y += sh.y;
-            v.z += sh.z;
-            v.w *= nbp.epsfac;
-            xqi[i] = v;
-            if constexpr (USE_TABLE)
-            {
-                const int ti = atomTypes[ai];
-                trow[i]      = numTypes * ti * static_cast<int>(sizeof(float2)) + rTabBytes;
-                if constexpr (LJ_EWALD) { ljcpi[i] = nbfpLds[numTypes * numTypes + ti]; }
-            }
-            else { ljcpi[i] = ljComb[ai]; }
-        }
-    }
+    const int  sci      = nb_sci.sci;
+    const int  shiftIdx = nb_sci.shift & NBNXM_CI_SHIFT_MASK;
+    const bool central  = (shiftIdx == c_centralShiftIndex);
 
     if constexpr (ENERGY && EXCL_FORCES)
     {
@@ -885,9 +967,6 @@ __launch_bounds__(c_nbMaxBlockSize) __attribute__((amdgpu_waves_per_eu(c_nbWaves
         curBuf ^= 1;
     }
     stagedGroup = cjPackedEnd;
-#ifdef NBNXM_WAVE_TIMELINE
-    tlMain += wall_clock64();
-#endif
 
     /* i-forces: reduce over tidxj; lane (tidxj, tidxi) keeps the sum of cluster tidxj, atom tidxi */
     float3 mine;
@@ -962,8 +1041,46 @@ __launch_bounds__(c_nbMaxBlockSize) __attribute__((amdgpu_waves_per_eu(c_nbWaves
             E_lj = E_el = 0.0F;
         }
     }
+
+    /* ---- the next piece: the next i-entry that owns a group of the range ------------------------------------------------- */
+    bool more = false;
+    for (sciIdx++; sciIdx < plist.nsciWork; sciIdx++)
+    {
+        nb_sci = scalarLoadSci(sciList + sciIdx);
+        if (nb_sci.cjPackedBegin >= rangeEnd) { break; }
+        cjPackedBegin = max(rangeBegin, nb_sci.cjPackedBegin);
+        cjPackedEnd   = min(rangeEnd, nb_sci.cjPackedEnd);
+        if (cjPackedBegin < cjPackedEnd)
+        {
+            more = true;
+            break;
+        }
+    }
+    if (!more) { break; }
+    if (stagedGroup != cjPackedBegin)
+    {
+        /* restart the pipeline behind groups that belong to no i-entry */
+        NBNXM_STAGE_WORDS(cjPackedBegin)
+        NBNXM_STAGE_WORDS(cjPackedBegin + 1)
+        NBNXM_STAGE_WORDS(cjPackedBegin + 2)
+        NBNXM_WAIT_VMEM(0);
+        NBNXM_STAGE_GROUP(cjPackedBegin, curBuf)
+        NBNXM_DUMMY_ATOMIC();
+        NBNXM_DUMMY_ATOMIC();
+        NBNXM_DUMMY_ATOMIC();
+        NBNXM_DUMMY_ATOMIC();
+    }
+    {
+        NBNXM_I_ATOMS_REQUEST
+        NBNXM_WAIT_VMEM(0);
+        NBNXM_I_ATOMS_COLLECT(true)
+    }
     } /* pieces */
 #undef NBNXM_STAGE_GROUP
+#undef NBNXM_STAGE_GROUP_DESC
+#undef NBNXM_STAGE_GROUP_LOADS
+#undef NBNXM_I_ATOMS_REQUEST
+#undef NBNXM_I_ATOMS_COLLECT
 #undef NBNXM_STAGE_WORDS
 #undef NBNXM_STAGE_GROUP_L
 #undef NBNXM_STAGE_WORDS_L
@@ -982,6 +1099,10 @@ __launch_bounds__(c_nbMaxBlockSize) __attribute__((amdgpu_waves_per_eu(c_nbWaves
         g_nbTimeline[4 * workItem + 1] = tlFirst;
         g_nbTimeline[4 * workItem + 2] = wall_clock64();
         g_nbTimeline[4 * workItem + 3] = (static_cast<unsigned long long>(xccId) << 32) | hwId;
+        g_nbTimeline[4 * 16384 + 4 * workItem + 0] = tlTop;
+        g_nbTimeline[4 * 16384 + 4 * workItem + 1] = tlDesc;
+        g_nbTimeline[4 * 16384 + 4 * workItem + 2] = tlIssued;
+        g_nbTimeline[4 * 16384 + 4 * workItem + 3] = (tlArrived << 32) | (tlBarrier & 0xFFFFFFFFULL);
     }
 #endif
 

@@ -240,4 +240,45 @@ __launch_bounds__(c_workBlockSize) __global__
     }
 }
 
+/* One thread per range: the range's start record (NbWorkDesc, nbnxm_hip_types.h) from the borders the kernel above has written. */
+__launch_bounds__(c_workBlockSize) __global__
+        void nbnxmWorkDescKernel(const int* __restrict__               rangeStart,
+                                 const int* __restrict__               firstSci,
+                                 const int                             numRanges,
+                                 const nbnxn_sci_t* __restrict__       sciSorted,
+                                 const int                             nsci,
+                                 const nbnxn_cj_packed_t* __restrict__ cjPacked,
+                                 NbWorkDesc* __restrict__              desc)
+{
+    const int r = static_cast<int>(blockIdx.x) * c_workBlockSize + static_cast<int>(threadIdx.x);
+    if (r >= numRanges) { return; }
+    const int  b = rangeStart[r], e = rangeStart[r + 1];
+    NbWorkDesc d;
+    d.rangeBegin = d.rangeEnd = b; /* empty unless an i-entry owns a group of [b, e) */
+    d.sciIdx     = nsci;
+    d.firstGroup = b;
+    d.entry      = nbnxn_sci_t{ 0, 0, 0, 0 };
+    d.cj[0] = d.cj[1] = d.cj[2] = d.cj[3] = 0;
+    d.exclInd[0] = d.exclInd[1] = 0;
+    d.pad[0] = d.pad[1] = 0;
+    for (int k = firstSci[r]; b < e && k < nsci; k++)
+    {
+        const nbnxn_sci_t s = sciSorted[k];
+        if (s.cjPackedBegin >= e) { break; }
+        const int pb = max(b, s.cjPackedBegin), pe = min(e, s.cjPackedEnd);
+        if (pb < pe)
+        {
+            d.rangeEnd   = e;
+            d.sciIdx     = k;
+            d.firstGroup = pb;
+            d.entry      = s;
+            for (int jm = 0; jm < c_jGroupSize; jm++) { d.cj[jm] = cjPacked[pb].cj[jm]; }
+            d.exclInd[0] = cjPacked[pb].imei[0].excl_ind;
+            d.exclInd[1] = cjPacked[pb].imei[1].excl_ind;
+            break;
+        }
+    }
+    desc[r] = d;
+}
+
 #endif

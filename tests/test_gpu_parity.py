@@ -372,6 +372,33 @@ def test_excluded_atoms_on_top_of_each_other(elec, vdw, fused):
     nb.free()
 
 
+@pytest.mark.parametrize("elec,vdw", [("ewald", "cut"), ("rf", "cut"), ("ewald", "fswitch"), ("rf", "comb_geom"), ("ewald_tab", "cut")])
+@pytest.mark.parametrize("fused", [False, True])
+def test_filler_atoms_on_one_point(elec, vdw, fused):
+    """The reference parks ALL filler atoms of its grid on one point (atomdata.cpp:148-184: x = y = z = -1e6) and the shim hands
+    nbat->x() over unchanged, so filler-filler pairs — listed, NOT excluded, zero charge, zero LJ type — sit at r = 0 (this repo's own
+    grid builder spreads its fillers, so no other test sees them).  The force-only one-mask block has no r^2 clamp: without the floor
+    the kernel's sum of squares starts from (c_r2Floor) such a pair is 0 x inf = NaN in the fillers' force slots and, through the
+    i-force sum, in the shift forces of a virial step.  Forces and shift forces must be finite and equal to the oracle's (which
+    clamps like the reference), on force-only, force + virial and energy steps."""
+    c = tl.make_case(elec=elec, vdw=vdw, seed=93, **SMALL)
+    g = c.grid
+    xq = g.xq.reshape(-1, 4).copy()
+    fillers = np.flatnonzero(g.atomIndices < 0)
+    assert len(fillers) >= 8, "the test box has to end in a partly filled cluster"
+    xq[fillers, :3] = -1.0e6
+    g.xq = xq
+    nb = tl.setup_gpu(c, fused=fused)
+    for energy in (False, True):
+        want = tl.run_oracle(c, energy=energy)
+        got = tl.run_gpu(c, energy=energy, fused=fused, nb=nb)       # run_gpu asks for the virial too (shift forces)
+        assert np.isfinite(got["f"]).all(), "NaN / inf in the forces (%d filler slots)" % len(fillers)
+        assert np.isfinite(np.asarray(got["fshift"])).all(), "NaN / inf in the shift forces"
+        assert np.all(np.asarray(got["f"])[fillers] == 0.0), "a filler atom received a force"
+        tl.assert_parity(got, want, rel=1e-4, energy=energy, label="fillers on one point, energy=%s" % energy)
+    nb.free()
+
+
 def test_force_buffer_swap_and_pinning():
     """nbnxm_gpu_clear_outputs swaps to the force buffer that the last force-only kernel zeroed in its tail; an energy-step kernel has
     no tail (the next clear is a kernel again); nbnxm_gpu_get_f pins the buffer.  Every step of a mixed sequence must give the

@@ -16,7 +16,10 @@ import torch
 import fep_testlib as tl
 pkg = tl.pkg
 
-case = tl.make_case(nm=(40, 40, 20), num_perturbed_molecules=16, elec="ewald", seed=2026, n_lambda=11, max_cjpacked_per_sci=16)
+BOX = os.environ.get("CAL_BOX", "96k")       # CAL_BOX=24k CAL_ELEC=rf: BASELINE configs[1]
+NM = {"12k": (20, 20, 10), "24k": (20, 20, 20), "48k": (40, 20, 20), "96k": (40, 40, 20)}[BOX]
+case = tl.make_case(nm=NM, num_perturbed_molecules=3 if BOX == "24k" else 16, elec=os.environ.get("CAL_ELEC", "ewald"), seed=2026, n_lambda=11,
+                    max_cjpacked_per_sci=16)
 FUSED = "--split" not in sys.argv   # split mode: the atom-pair FEP kernels run beside the cluster kernel and disturb the SIMD times
 nb = tl.setup_gpu(case, fused=FUSED, use_dynamic_pruning=True)
 sw = pkg.step_workload(energy=False, virial=False, dhdl=False)
@@ -109,6 +112,8 @@ print("per-SIMD features: std/mean %s" % (X.std(axis=0) / X.mean(axis=0)).round(
 start_t = (a[:, 0] - t0).astype(np.float64) / 100.0
 dur = end - start_t
 nempty = cs(empty)[ranges[1:]] - cs(empty)[ranges[:-1]]
+np.savez(os.path.join(ROOT, "gpurun_out", "calibrate_%s_%s.npz" % (BOX, os.environ.get("CAL_TAG", "x"))), feat=feat, ranges=ranges, start=start_t, end=end, key=key,
+         nempty=nempty, sci=np.asarray(sci_sorted), joined=joined, imask=imask)
 print("slowest waves (work item: end us, duration us | cluster pairs, slots, non-empty groups, pieces, empty groups | waves' mean):")
 for w_ in np.argsort(end)[-12:][::-1]:
     print("  %5d: %.1f %.1f | %d %d %d %d %d" % (w_, end[w_], dur[w_], feat[w_, 0], feat[w_, 1], feat[w_, 2], feat[w_, 3], nempty[w_]))
