@@ -416,6 +416,13 @@ NbnxmGpu* nbnxm_gpu_init(const nbnxm_interaction_params_t* ic, int numTypes, con
         nb->numSimds = prop.multiProcessorCount * 4; /* CDNA: 4 SIMDs per CU */
         if (const char* env = std::getenv("NBNXM_HIP_NUM_WORK_RANGES")) { nb->numWorkRangesOverride = std::atoi(env); }
         if (const char* env = std::getenv("NBNXM_HIP_MIN_GROUPS_PER_WAVE")) { nb->minGroupsPerWave = std::max(1, std::atoi(env)); }
+        if (const char* env = std::getenv("NBNXM_HIP_WORK_WEIGHTS"))
+        {
+            if (std::sscanf(env, "%d,%d,%d", &nb->workWeightsOverride[0], &nb->workWeightsOverride[1], &nb->workWeightsOverride[2]) != 3)
+            {
+                nb->workWeightsOverride[0] = -1;
+            }
+        }
         /* NBNXM_HIP_CLASS_SHARES4 / 5 = "s0,s1,.." in 1/1024 of an average range, oldest wave of a SIMD first (renormalised) */
         for (int p = 0; p < 2; p++)
         {
@@ -496,7 +503,7 @@ NbnxmGpu* nbnxm_gpu_init(const nbnxm_interaction_params_t* ic, int numTypes, con
     if (const char* env = std::getenv("NBNXM_HIP_WAVES_PER_BLOCK"))
     {
         const int w = std::atoi(env);
-        NBNXM_ASSERT(w >= 1 && w <= c_nbWavesPerBlock, "NBNXM_HIP_WAVES_PER_BLOCK must be 1..4");
+        NBNXM_ASSERT(w == 1 || w == 2 || w == 4, "NBNXM_HIP_WAVES_PER_BLOCK must be 1, 2 or 4");
         nb->nbWavesPerBlock = w;
     }
 
@@ -1450,9 +1457,27 @@ static void updateWorkPartition(NbnxmGpu* nb, int iloc)
     if (buildSlow) { clearDeviceBufferAsync(&d->slowCount, 0, 1, s); }
     /* a list that has been through its first prune: the working masks are inner-pruned, the outer-pruned ones are in d->imask */
     const unsigned* outerMask = (!d->haveFreshList && d->firstPruneDone) ? d->imask : nullptr;
+    /* the cost model (nbnxm_work_partition.h), in units of 1/8 cluster pair */
+    NbWorkWeights weights = { c_weightPair, c_weightSlot, c_weightGroup, c_weightEmptyGroup, c_weightEntry };
+    /* Short lists (the rule of the force flavour's partition below: under 4.5 packed groups per wave slot — boxes up to ~40k atoms, the
+     * domains of a decomposed box): a wave has three or four groups and one to four pieces, it is bound by the LATENCY of its own
+     * chain, not by its SIMD's issue rate, and the last waves of a launch are the ones with many groups and pieces.  Swept on the
+     * 24k-atom box (tools/gpu_r4h.sh, slot / group / entry): 4 / 16 / 128 20.5 - 20.9 us, 0 / 48 / 200 and 4 / 48 / 200 18.5 - 18.8 us,
+     * 0 / 64 / 260 19.0, 0 / 48 / 260 19.7; 12k atoms flat (16.8 - 17.0 us); 48k and 96k atoms — long lists — flat or best at 4 / 16 / 128. */
+    if (2 * static_cast<long long>(d->ncjPacked) < 9LL * nb->numSimds * 5 && nb->numWorkRangesOverride <= 0)
+    {
+        weights.group = weights.emptyGroup = c_weightGroupShortList;
+        weights.entry = c_weightEntryShortList;
+    }
+    if (nb->workWeightsOverride[0] >= 0)
+    {
+        weights.slot  = nb->workWeightsOverride[0];
+        weights.group = weights.emptyGroup = nb->workWeightsOverride[1];
+        weights.entry = nb->workWeightsOverride[2];
+    }
     hipLaunchKernelGGL(nbnxmWorkWeightKernel, dim3(numBlocks), dim3(c_workBlockSize), 0, s, d->cjPacked, d->ncjPacked, d->sciSorted,
                        d->nsciWork, fused ? nb->atdat->fepBits : nullptr, buildSlow ? 1 : 0, outerMask, d->groupSlowMask, d->slowPairs, d->slowPairSci,
-                       d->slowPairs_nalloc, d->slowCount, d->groupWeight, d->weightBlockSum);
+                       d->slowPairs_nalloc, d->slowCount, d->groupWeight, d->weightBlockSum, weights);
     hipLaunchKernelGGL(nbnxmWorkScanKernel, dim3(1), dim3(c_workBlockSize), 0, s, d->weightBlockSum, numBlocks);
     NBNXM_HIP_CHECK(hipGetLastError());
     if (buildSlow)
@@ -1788,6 +1813,9 @@ void nbnxm_gpu_launch_kernel(NbnxmGpu* nb, const nbnxm_step_workload_t* stepWork
                                                         nb->nbWavesPerBlock);
         NBNXM_ASSERT(shape.wavesPerSimd >= 1, "too many atom types: the LJ parameter table does not fit the 160 KB LDS");
         const int wavesPerBlock = shape.wavesPerBlock, wavesPerSimd = shape.wavesPerSimd, ldsBytes = shape.ldsBytes;
+        int       wavesPerBlockLog2 = 0;
+        while ((1 << wavesPerBlockLog2) < wavesPerBlock) { wavesPerBlockLog2++; }
+        NBNXM_ASSERT((1 << wavesPerBlockLog2) == wavesPerBlock, "the cluster kernel's workgroups are 1, 2, 4, 8 or 16 waves");
         if (nb->debugLaunchShape)
         {
             std::fprintf(stderr, "nbnxm_hip: cluster kernel launch shape: %d types, %d waves per workgroup, %d waves per SIMD, %d LDS bytes per workgroup\n",
@@ -1850,9 +1878,9 @@ void nbnxm_gpu_launch_kernel(NbnxmGpu* nb, const nbnxm_step_workload_t* stepWork
             const auto t0_ = std::chrono::steady_clock::now();
 #endif
             hipLaunchKernelGGL(kernel, dim3(numBlocks), dim3(wavesPerBlock * c_waveSize), ldsBytes, s,
+                               plist->workDesc[p] + set * setRanges, setRanges, wavesPerBlockLog2,
                                *adat, *nbp, *plist, stepWork->computeVirial, plist->sciSorted, plist->cjPacked, plist->excl, adat->xq,
-                               adat->atomTypes, adat->ljComb, reinterpret_cast<const unsigned*>(adat->fepBits),
-                               plist->workDesc[p] + set * setRanges, setRanges, plist->groupSlowMask,
+                               adat->atomTypes, adat->ljComb, reinterpret_cast<const unsigned*>(adat->fepBits), plist->groupSlowMask,
                                tail ? mergedFepItems : 0, std::max(plist->rollingPruningNumParts, 1), prunePart, tail ? pruneEntries : 0,
                                reinterpret_cast<float4*>(nb->fSpare), tail ? clearNumFloat4 : 0, (wantForeign && energyFlavour) ? nb->n_lambda : -1,
                                *nb->feplist[iloc]);

@@ -107,6 +107,7 @@ struct NbnxmGpu
     /* share of work per age class of the waves of a SIMD, [0]: 4 waves per SIMD, [1]: 5 (see WorkPartitionOut) */
     int waveClassShare[2][5] = { { 1024, 1024, 1024, 1024, 0 }, { 1100, 1060, 1024, 990, 946 } };
     int numWorkRangesOverride = 0; /* experiments: NBNXM_HIP_NUM_WORK_RANGES */
+    int workWeightsOverride[3] = { -1, -1, -1 }; /* experiments: NBNXM_HIP_WORK_WEIGHTS=slot,group,entry (relative to 8 per cluster pair) */
     PinnedBuffer<nbnxn_sci_t> h_sciSorted;
     PinnedBuffer<int>         h_slowCount;        /* one per locality */
     int*                      h_listError = nullptr; /* mapped host memory: nbnxmValidateListKernel's flag, and its device address */

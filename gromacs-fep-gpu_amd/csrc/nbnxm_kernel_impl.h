@@ -349,7 +349,15 @@ constexpr int c_nbWavesPerEu = ENERGY ? 4
  * left to nbnxmFepClusterKernel; otherwise the kernel is the plain one */
 template<int ELEC, bool TWIN, int VDW, bool ENERGY, bool FUSED>
 __launch_bounds__(c_nbMaxBlockSize) __attribute__((amdgpu_waves_per_eu(c_nbWavesPerEu<VDW, ENERGY>))) __global__
-        void nbnxmKernel(const NBAtomDataGpu atdat,
+        void nbnxmKernel(/* work partition (gpu_plist::work*): wave w owns the packed j-groups [workDesc[w].rangeBegin, .rangeEnd) and
+                          * starts in entry workDesc[w].sciIdx of sciList, which is the list's i-entries ordered by cjPackedBegin;
+                          * the record also carries that entry and the first group's indices (NbWorkDesc).  First in the list: the
+                          * head of the wave's dependency chain (with kernel-argument preloading they arrive in registers) */
+                         const NbWorkDesc* __restrict__ workDesc,
+                         const int numWorkRanges,
+                         const int wavesPerBlockLog2, /* the launch's workgroup size as log2(waves): with the two arguments above all a wave
+                                                       * needs to address its start record, without a load from the dispatch packet */
+                         const NBAtomDataGpu atdat,
                          const NBParamGpu    nbp,
                          const gpu_plist     plist,
                          const int           bCalcFshiftIn,
@@ -362,11 +370,6 @@ __launch_bounds__(c_nbMaxBlockSize) __attribute__((amdgpu_waves_per_eu(c_nbWaves
                          const int* __restrict__ atomTypes,
                          const float2* __restrict__ ljComb,
                          const unsigned* __restrict__ fepWords, /* atdat.fepBits viewed as dwords (scalar loads) */
-                         /* work partition (gpu_plist::work*): wave w owns the packed j-groups [workDesc[w].rangeBegin, .rangeEnd) and
-                          * starts in entry workDesc[w].sciIdx of sciList, which is the list's i-entries ordered by cjPackedBegin;
-                          * the record also carries that entry and the first group's indices (NbWorkDesc) */
-                         const NbWorkDesc* __restrict__ workDesc,
-                         const int numWorkRanges,
                          const unsigned* __restrict__ groupSlowMask, /* FUSED: perturbed cluster pairs of each group */
                          const int mergedFepItems, /* FUSED force flavour: perturbed cluster pairs for the trailing workgroups, or 0 */
                          /* force flavour: i-entries idx * pruneNumParts + prunePart, idx < pruneEntries, are rolling-pruned by trailing workgroups */
@@ -393,11 +396,21 @@ __launch_bounds__(c_nbMaxBlockSize) __attribute__((amdgpu_waves_per_eu(c_nbWaves
 #endif
     /* wave-uniform values are pinned to SGPRs with readfirstlane so that everything derived from them
      * (list walk, branches, list loads) stays on the scalar unit */
-    const unsigned blockSize = __builtin_amdgcn_readfirstlane(blockDim.x);
+    const unsigned blockSize = static_cast<unsigned>(c_waveSize) << wavesPerBlockLog2;
     const unsigned lane      = threadIdx.x & (c_waveSize - 1);
     const unsigned wave      = __builtin_amdgcn_readfirstlane(threadIdx.x / c_waveSize);
     const unsigned tidxi     = lane & 7U;
     const unsigned tidxj     = lane >> 3;
+    /* The start of this wave's range is ONE scalar load (NbWorkDesc: borders, the first i-entry, the first group's cluster and exclusion
+     * indices), and it is the first thing the wave does: its address needs the preloaded arguments, the workgroup id and the wave's
+     * number only.  (Trailing workgroups load record 0 and ignore it.) */
+    const int        workItem = __builtin_amdgcn_readfirstlane(static_cast<int>((blockIdx.x << wavesPerBlockLog2) + wave));
+    const bool       inLaunch = (workItem < numWorkRanges);
+    /* (as asm: left to the compiler the load sinks to its first use, behind the trailing workgroups' branch and behind the round trip of the
+     * other kernel arguments; its wait is the s_waitcnt where the record is unpacked, NBNXM_DESC_ARRIVED) */
+    typedef int nb_int16 __attribute__((ext_vector_type(16)));
+    nb_int16 descWords;
+    asm volatile("s_load_dwordx16 %0, %1, 0x0" : "=s"(descWords) : "s"(workDesc + (inLaunch ? workItem : 0)) : "memory");
 
     /* LDS (all dynamic, sized by nbLdsBytes()): the LJ parameter table shared by the waves of the workgroup,
      * then per wave: two staging buffers for the j-side of a packed group (filled by LDS-direct loads, see the
@@ -432,8 +445,8 @@ __launch_bounds__(c_nbMaxBlockSize) __attribute__((amdgpu_waves_per_eu(c_nbWaves
          *     rewrites list masks that the ranges may be reading: either value is right for this step (a cluster pair that is
          *     pruned has no atom pair within the inner list radius, so it adds exactly zero);
          *  2. FUSED, mergedFepItems > 0: one perturbed cluster pair per wave, what nbnxmFepClusterKernel does in a kernel of its own. */
-        const unsigned wavesPerBlock = blockSize / c_waveSize;
-        const unsigned mainBlocks    = (static_cast<unsigned>(numWorkRanges) + wavesPerBlock - 1U) / wavesPerBlock;
+        const unsigned wavesPerBlock = 1U << wavesPerBlockLog2;
+        const unsigned mainBlocks    = (static_cast<unsigned>(numWorkRanges) + wavesPerBlock - 1U) >> wavesPerBlockLog2;
         if (blockIdx.x >= mainBlocks)
         {
             __builtin_amdgcn_s_setprio(0);
@@ -442,8 +455,8 @@ __launch_bounds__(c_nbMaxBlockSize) __attribute__((amdgpu_waves_per_eu(c_nbWaves
 #endif
             /* the rolling-prune waves first: they are the longer chains (a loop over the entry's j-groups); the perturbed-pair
              * waves are short and fill what is left */
-            const unsigned pruneBlocks = (static_cast<unsigned>(pruneEntries) + wavesPerBlock - 1U) / wavesPerBlock;
-            const unsigned fepBlocks   = TAIL_FEP ? (static_cast<unsigned>(mergedFepItems) + wavesPerBlock - 1U) / wavesPerBlock : 0U;
+            const unsigned pruneBlocks = (static_cast<unsigned>(pruneEntries) + wavesPerBlock - 1U) >> wavesPerBlockLog2;
+            const unsigned fepBlocks   = TAIL_FEP ? (static_cast<unsigned>(mergedFepItems) + wavesPerBlock - 1U) >> wavesPerBlockLog2 : 0U;
             if (blockIdx.x < mainBlocks + pruneBlocks)
             {
                 const int idx   = __builtin_amdgcn_readfirstlane(static_cast<int>((blockIdx.x - mainBlocks) * wavesPerBlock + wave));
@@ -539,19 +552,28 @@ __launch_bounds__(c_nbMaxBlockSize) __attribute__((amdgpu_waves_per_eu(c_nbWaves
      * vmcnt(0) in front of every write to them: between the LDS-direct loads of the batch, which it cannot see, that is a full round
      * trip each.  A wait it CAN see, here, where this wave has nothing in flight, clears that state: vmcnt(0), expcnt and lgkmcnt left alone.) */
     __builtin_amdgcn_s_waitcnt(0x0F70);
-    const int         workItem = __builtin_amdgcn_readfirstlane(static_cast<int>(blockIdx.x * (blockSize / c_waveSize) + wave));
-    const bool        inLaunch = (workItem < numWorkRanges);
-    const NbWorkDesc  desc     = workDesc[inLaunch ? workItem : 0];
 #ifdef NBNXM_WAVE_TIMELINE
     /* diagnostics build only (tools/timeline_budget.py): per wave {start, first group's data arrived, end, HW_ID} in 100 MHz ticks */
     const unsigned long long tlStart = wall_clock64();
     unsigned long long       tlFirst = 0; /* first group's data has arrived */
 #endif
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(descWords)::"memory");
+    NbWorkDesc desc;
+    desc.rangeBegin = descWords[0];
+    desc.rangeEnd   = descWords[1];
+    desc.sciIdx     = descWords[2];
+    desc.firstGroup = descWords[3];
+    desc.entry      = nbnxn_sci_t{ descWords[4], descWords[5], descWords[6], descWords[7] };
+    desc.cj[0]      = descWords[8];
+    desc.cj[1]      = descWords[9];
+    desc.cj[2]      = descWords[10];
+    desc.cj[3]      = descWords[11];
+    desc.exclInd[0] = descWords[12];
+    desc.exclInd[1] = descWords[13];
     const int  rangeBegin = desc.rangeBegin;
     const int  rangeEnd   = desc.rangeEnd;
     const bool hasWork    = inLaunch && (rangeBegin < rangeEnd);
 #ifdef NBNXM_WAVE_TIMELINE
-    asm volatile("s_waitcnt lgkmcnt(0)" ::"s"(rangeEnd) : "memory");
     const unsigned long long tlDesc = wall_clock64(); /* the start record has arrived */
 #endif
     int        sciIdx     = desc.sciIdx;

@@ -8,9 +8,9 @@
 
 #include "nbnxm_hip_types.h"
 
-using NbKernelPtr = void (*)(NBAtomDataGpu, NBParamGpu, gpu_plist, int, const nbnxn_sci_t*, const nbnxn_cj_packed_t*,
-                             const nbnxn_excl_t*, const float4*, const int*, const float2*, const unsigned*, const NbWorkDesc*,
-                             int, const unsigned*, int, int, int, int, float4*, int, int, gpu_feplist);
+using NbKernelPtr = void (*)(const NbWorkDesc*, int, int, NBAtomDataGpu, NBParamGpu, gpu_plist, int, const nbnxn_sci_t*, const nbnxn_cj_packed_t*,
+                             const nbnxn_excl_t*, const float4*, const int*, const float2*, const unsigned*,
+                             const unsigned*, int, int, int, int, float4*, int, int, gpu_feplist);
 using FepClusterKernelPtr = void (*)(NBAtomDataGpu, NBParamGpu, gpu_plist, int, const nbnxn_sci_t*, const nbnxn_cj_packed_t*,
                                      const nbnxn_excl_t*, const float4*, const int*, const float2*, const unsigned*, int);
 using FepKernelPtr   = void (*)(NBAtomDataGpu, NBParamGpu, gpu_feplist, int);

@@ -37,6 +37,15 @@ constexpr int c_weightGroup   = NBNXM_WEIGHT_GROUP;
 #endif
 constexpr int c_weightEmptyGroup = NBNXM_WEIGHT_EMPTY_GROUP;
 constexpr int c_weightEntry   = NBNXM_WEIGHT_ENTRY;
+/* short lists (updateWorkPartition): group and i-entry start weigh more where a wave has only a few of either */
+constexpr int c_weightGroupShortList = 48;
+constexpr int c_weightEntryShortList = 200;
+
+/* the cost model as a kernel argument: the host picks it by the kind of list (updateWorkPartition) */
+struct NbWorkWeights
+{
+    int pair, slot, group, emptyGroup, entry;
+};
 
 /* largest k with sciSorted[k].cjPackedBegin <= group (entries ordered by (cjPackedBegin, cjPackedEnd)); -1 if none */
 __device__ __forceinline__ int findSciOfGroup(const nbnxn_sci_t* __restrict__ sciSorted, int nsci, int group)
@@ -84,7 +93,8 @@ __launch_bounds__(c_workBlockSize) __global__
                                    const int                             slowCapacity,
                                    int* __restrict__                     slowCount,
                                    int* __restrict__                     groupWeight,
-                                   int* __restrict__                     blockSum)
+                                   int* __restrict__                     blockSum,
+                                   const NbWorkWeights                   weights)
 {
     __shared__ int lds[c_workBlockSize];
     const int      g = static_cast<int>(blockIdx.x) * c_workBlockSize + static_cast<int>(threadIdx.x);
@@ -139,8 +149,8 @@ __launch_bounds__(c_workBlockSize) __global__
         for (int jm = 0; jm < c_jGroupSize; jm++) { slots += ((fast >> (jm * c_numClPerSupercl)) & 0xFFU) != 0U ? 1 : 0; }
         /* a group with nothing left for this kernel (pruned away, or all of it perturbed) still costs the wave its pipeline step: a run of
          * them at weight 0 ends up in ONE range (3k-atom box with 48 perturbed atoms: 47 groups in one range, kernel 23.6 instead of 12 us) */
-        w = c_weightPair * __popc(fast) + c_weightSlot * slots + (fast != 0U ? c_weightGroup : c_weightEmptyGroup);
-        if (owned && sciSorted[k].cjPackedBegin == g) { w += c_weightEntry; }
+        w = weights.pair * __popc(fast) + weights.slot * slots + (fast != 0U ? weights.group : weights.emptyGroup);
+        if (owned && sciSorted[k].cjPackedBegin == g) { w += weights.entry; }
         groupWeight[g] = w;
     }
     int total;
