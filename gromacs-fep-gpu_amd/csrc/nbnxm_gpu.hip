@@ -1425,8 +1425,8 @@ static void updateWorkPartition(NbnxmGpu* nb, int iloc)
     if (d->debugTimeline == nullptr)
     {
         /* (second half: four more time stamps per range wave, the steps of its prologue) */
-        allocateDeviceBuffer(&d->debugTimeline, 8 * 16384);
-        NBNXM_HIP_CHECK(hipMemset(d->debugTimeline, 0, sizeof(unsigned long long) * 8 * 16384));
+        allocateDeviceBuffer(&d->debugTimeline, 12 * 16384);
+        NBNXM_HIP_CHECK(hipMemset(d->debugTimeline, 0, sizeof(unsigned long long) * 12 * 16384));
     }
 #endif
     if (d->nsci == 0 || d->ncjPacked == 0)

@@ -82,12 +82,13 @@ if len(tail):
     print("        trailing waves %d: start min %.1f p50 %.1f | end p50 %.1f max %.1f" % (len(tail), ts.min(), np.median(ts), np.median(te), te.max()))
 np.save(os.path.join(ROOT, "gpurun_out", "timeline_budget_%s_%s.npy" % (size, elec)), allrec)
 # the steps of the prologue (second half of the buffer; builds that record them)
-buf2 = (ctypes.c_ulonglong * (4 * 32768))()
+buf2 = (ctypes.c_ulonglong * (4 * 49152))()
 if os.environ.get("TIMELINE_PROLOGUE", "0") != "1":
     sys.exit(0)
 try:
-    lib.nbnxm_gpu_debug_timeline(ctypes.c_void_p(nb._h), buf2, 32768)
-    ex = np.frombuffer(buf2, dtype=np.uint64).reshape(32768, 4)[16384:16384 + n]
+    lib.nbnxm_gpu_debug_timeline(ctypes.c_void_p(nb._h), buf2, 49152)
+    allex = np.frombuffer(buf2, dtype=np.uint64).reshape(49152, 4)
+    ex = allex[16384:16384 + n]
     ok = ex[:, 0] != 0
     if ok.sum() > 0:
         ex = ex[ok]; st = allrec[:n][ok]
@@ -102,5 +103,13 @@ try:
               % (f(top), f(desc), f(issued), f(arrived), f(barrier), f(fd)))
         print("   per wave, medians of the differences: first instruction -> record %.2f, -> issued %.2f, -> arrived %.2f, -> barrier %.2f, -> first data %.2f"
               % (np.median(desc - top), np.median(issued - desc), np.median(arrived - issued), np.median(barrier - arrived), np.median(fd - barrier)))
+    tr = allex[32768:32768 + n].astype(np.float64)
+    cnt = tr[:, 0].sum()
+    if cnt > 0:
+        dur = (end - start)
+        print("piece transitions: %.2f per wave; per transition: loop end -> request (i-force reduction, atomics, next entry) %.2f us, request -> arrived "
+              "(behind the atomics) %.2f us, collect %.2f us; share of the waves' time: %.1f %% / %.1f %% / %.1f %%"
+              % (cnt / n, tr[:, 1].sum() / cnt / 100, tr[:, 2].sum() / cnt / 100, tr[:, 3].sum() / cnt / 100,
+                 tr[:, 1].sum() / dur.sum(), tr[:, 2].sum() / dur.sum(), tr[:, 3].sum() / dur.sum()))
 except Exception as e:   # older builds: no second half
     print("no prologue stamps:", e)
