@@ -245,6 +245,74 @@ NB_DEVINL unsigned ewaldTabAddress(const float r2, const float scaleTimesStride)
 
 /* ---- non-perturbed atom pair (nbnxm_cuda_kernel.cuh:518-645) ---------------------------------- */
 
+/* Energy steps of the headline flavours (reaction field or analytical Ewald, LJ cut-off from the type table or a combination rule,
+ * one cut-off): nbPairEnergy below. */
+template<int ELEC, bool TWIN, int VDW, bool ENERGY>
+constexpr bool c_energyHeadlineBlock = ENERGY && !TWIN && (VDW == VDK_CUT || VDW == VDK_COMB_GEOM || VDW == VDK_COMB_LB)
+                                       && (ELEC == ELK_RF || ELEC == ELK_EWALD_ANA);
+
+/* The sums of an energy step that nbPairEnergy feeds; NbEnergySums::finish turns them into E_lj and E_el once per wave (or piece). */
+struct NbEnergySums
+{
+    float ljTimes12 = 0.0F; /* sum of 12 E_lj without the potential shift: c12 r^-12 - 2 c6 r^-6 (c6 = 6 C6, c12 = 12 C12) */
+    float c12Masked = 0.0F; /* sum of c12 over the interacting pairs within the cut-off: times cpot_rep / 12 = the repulsion shift */
+    float c6Masked  = 0.0F; /* ... of c6: times -cpot_disp / 6 = the dispersion shift */
+    float el        = 0.0F; /* E_el without the Ewald potential shift */
+    float qqMasked  = 0.0F; /* sum of q q over the interacting pairs within the cut-off: times -sh_ewald */
+};
+
+/* One pair of an energy step, with the sums it feeds (nbnxm_cuda_kernel.cuh:533-536,602-607,633-640 are the terms).  43 -> 38 vector
+ * instructions per executed pair block against the form that returned F/r, E_lj and E_el for the caller to add up:
+ *   - the exclusion bit masks 1/r ONCE (and the constant 1.0): r^-2, r^-6 and everything built from them is then zero for an excluded
+ *     pair, where there were three masked results;
+ *   - E_lj is summed as 12 E = c12 r^-12 - 2 c6 r^-6 = r^2 (F_lj / r) - c6 r^-6: the force's own product plus one FMA; the two
+ *     potential shifts leave the pair — the sums of c12 and of c6 over the interacting pairs, one FMA each, times their constants
+ *     once per wave (before: both shifts and both 1/12, 1/6 factors per pair, six instructions);
+ *   - the Ewald potential shift leaves the pair the same way: sum of q q (1/r masked - beta V) here, the sum of q q over the interacting
+ *     pairs times sh_ewald once per wave;
+ *   - no r^2 clamp: the kernel's sum of squares starts from c_r2Floor, so 1/r is finite, and an excluded pair's 1/r is masked.
+ * (With 16-byte table entries {c6, c12, 12 sh, 2 c6} the block is one instruction shorter still; not done: it doubles the LJ table in LDS,
+ * which is what bounds the number of atom types at full occupancy.) */
+template<int ELEC>
+NB_DEVINL void nbPairEnergy(const NBParamGpu& nbp, const float r2, const int intMask, const float qq, const float c6, const float c12,
+                            const float ewaldTabScaleV, float& F_invr, NbEnergySums& sums)
+{
+    [[maybe_unused]] float4 t = make_float4(0.0F, 0.0F, 0.0F, 0.0F);
+    if constexpr (ELEC == ELK_EWALD_ANA)
+    {
+        /* {intercept, slope} of beta^3 F and of beta V in r^2, one ds_read_b128; the table sits at LDS address 0 */
+        typedef __attribute__((address_space(3))) const float LdsFloat;
+        LdsFloat* tab = reinterpret_cast<LdsFloat*>(static_cast<uintptr_t>(ewaldTabAddress<16>(r2, ewaldTabScaleV)));
+        t.x           = tab[0];
+        t.y           = tab[1];
+        t.z           = tab[2];
+        t.w           = tab[3];
+    }
+    float inv_r   = __frsqrt_rn(r2);
+    float int_bit = 1.0F;
+    asm("v_and_b32 %0, %1, %2" : "=v"(inv_r) : "v"(intMask), "v"(inv_r));
+    asm("v_and_b32 %0, %1, %2" : "=v"(int_bit) : "v"(intMask), "v"(int_bit));
+    const float inv_r2 = inv_r * inv_r;
+    const float inv_r6 = inv_r2 * inv_r2 * inv_r2;
+    const float lj     = fmaf(c12, inv_r6, -c6) * inv_r6; /* r^2 (F_lj / r) = c12 r^-12 - c6 r^-6 */
+    const float nm     = fmaf(qq, inv_r, lj) * inv_r2;
+    sums.ljTimes12     = fmaf(-c6, inv_r6, sums.ljTimes12 + lj);
+    sums.c12Masked     = fmaf(c12, int_bit, sums.c12Masked);
+    sums.c6Masked      = fmaf(c6, int_bit, sums.c6Masked);
+    if constexpr (ELEC == ELK_RF)
+    {
+        F_invr = fmaf(qq, -nbp.two_k_rf, nm);
+        /* (the reaction-field constant belongs to excluded pairs too: not masked) */
+        sums.el = fmaf(qq, inv_r + fmaf(0.5F * nbp.two_k_rf, r2, -nbp.c_rf), sums.el);
+    }
+    else
+    {
+        F_invr        = fmaf(qq, fmaf(t.y, r2, t.x), nm);
+        sums.el       = fmaf(qq, inv_r - fmaf(t.w, r2, t.z), sums.el);
+        sums.qqMasked = fmaf(qq, int_bit, sums.qqMasked);
+    }
+}
+
 template<int ELEC, bool TWIN, int VDW, bool ENERGY, bool EXCL_FORCES, bool HAS_EXCL = true, bool CORR_TABLE = true>
 NB_DEVINL void nbPair(const NBParamGpu& nbp,
                       const float2*     ewaldCorrLds, /* analytical Ewald: NBParamGpu::ewaldCorrTab in LDS */

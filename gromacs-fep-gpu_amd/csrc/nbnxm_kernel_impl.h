@@ -309,12 +309,19 @@ NB_DEVINL void pruneEntry(const NBAtomDataGpu& atdat, const NBParamGpu& nbp, con
                                 else { ljFromComb(VDW, ljcpi[i], ljcp_j, c6, c12); } \
                                 float F_invr, E_lj_p = 0.0F, E_el_p = 0.0F, c6grid = 0.0F; \
                                 if constexpr (LJ_EWALD) { c6grid = ljGridC6(VDW, ljcpi[i], ljcp_j); } \
-                                nbPair<ELEC, TWIN, VDW, ENERGY, EXCL_FORCES, HAS_EXCL>(nbp, ewaldCorrLds, r2, intMask, xqi[i].w * xqj.w, c6, c12, \
-                                                                                       F_invr, E_lj_p, E_el_p, c6grid, ewaldTabScaleV); \
-                                if constexpr (ENERGY) \
+                                if constexpr (ENERGY_HEADLINE) \
                                 { \
-                                    E_lj += E_lj_p; \
-                                    E_el += E_el_p; \
+                                    nbPairEnergy<ELEC>(nbp, r2, intMask, xqi[i].w * xqj.w, c6, c12, ewaldTabScaleV, F_invr, eSums); \
+                                } \
+                                else \
+                                { \
+                                    nbPair<ELEC, TWIN, VDW, ENERGY, EXCL_FORCES, HAS_EXCL>(nbp, ewaldCorrLds, r2, intMask, xqi[i].w * xqj.w, c6, c12, \
+                                                                                           F_invr, E_lj_p, E_el_p, c6grid, ewaldTabScaleV); \
+                                    if constexpr (ENERGY) \
+                                    { \
+                                        E_lj += E_lj_p; \
+                                        E_el += E_el_p; \
+                                    } \
                                 } \
                                 const float3 f_ij = make_float3(rv.x * F_invr, rv.y * F_invr, rv.z * F_invr); \
                                 fcj_buf.x -= f_ij.x; \
@@ -390,6 +397,8 @@ __launch_bounds__(c_nbMaxBlockSize) __attribute__((amdgpu_waves_per_eu(c_nbWaves
     constexpr bool LJ_EWALD    = VdwTraits<VDW>::ljEwald;
     constexpr bool EXCL_FORCES = (ELEC != ELK_CUT) || ENERGY || LJ_EWALD; /* nbnxm_cuda_kernel.cuh:69-78 */
     constexpr bool USE_TABLE   = VdwTraits<VDW>::useTable;
+    /* energy steps of the headline flavours: the fused energy pair block (nbPairEnergy) */
+    constexpr bool ENERGY_HEADLINE = c_energyHeadlineBlock<ELEC, TWIN, VDW, ENERGY>;
 
 #ifdef NBNXM_WAVE_TIMELINE
     const unsigned long long tlTop = wall_clock64(); /* the wave's first instruction */
@@ -835,6 +844,17 @@ __launch_bounds__(c_nbMaxBlockSize) __attribute__((amdgpu_waves_per_eu(c_nbWaves
 #endif
 
     float E_lj = 0.0F, E_el = 0.0F;
+    /* the fused energy block (nbPairEnergy) leaves the scale of E_lj and the three potential shifts to the end of the wave (or piece) */
+    [[maybe_unused]] NbEnergySums eSums;
+    auto finishEnergies = [&]() {
+        if constexpr (ENERGY_HEADLINE)
+        {
+            E_lj += (eSums.ljTimes12 + fmaf(eSums.c12Masked, nbp.repulsion_shift.cpot, -2.0F * eSums.c6Masked * nbp.dispersion_shift.cpot)) * c_oneTwelfth;
+            E_el += eSums.el;
+            if constexpr (ELEC == ELK_EWALD_ANA) { E_el = fmaf(-nbp.sh_ewald, eSums.qqMasked, E_el); }
+            eSums = NbEnergySums();
+        }
+    };
 
     /* ---- the pieces of this wave's range: one per i-entry it touches ---------------------------------- */
 #pragma unroll 1
@@ -1058,6 +1078,7 @@ __launch_bounds__(c_nbMaxBlockSize) __attribute__((amdgpu_waves_per_eu(c_nbWaves
         {
             /* batched lambda windows: a range can run across the border of two windows, so the energies go to the window of the
              * i-entry piece by piece (a wave has one or two pieces) */
+            finishEnergies();
             const float sLj = waveSum(E_lj), sEl = waveSum(E_el);
             const float v   = (lane == 0U) ? sLj : sEl;
             if (lane < 2U)
@@ -1152,6 +1173,7 @@ __launch_bounds__(c_nbMaxBlockSize) __attribute__((amdgpu_waves_per_eu(c_nbWaves
 
     if constexpr (ENERGY)
     {
+        finishEnergies();
         E_lj = waveSum(E_lj);
         E_el = waveSum(E_el);
         const int   slot = workItem & (c_numEnergySlots - 1);
