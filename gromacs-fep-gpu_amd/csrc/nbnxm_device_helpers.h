@@ -740,6 +740,13 @@ NB_DEVINL void gapsysLJ(float c6, float c12, float r, float rsq, float lambdaFac
     }
 }
 
+/* erf(beta r) / r, the reciprocal-space part an Ewald pair's energy has to give back (nb_free_energy.cpp:1056-1101), with its r -> 0
+ * limit; r and 1 / r of the clamped distance as fepPair computes them */
+NB_DEVINL float fepEwaldPotentialLr(const float beta, const float r, const float rInv)
+{
+    return (beta * r > 1.0e-4F) ? erff(beta * r) * rInv : 2.0F * beta * c_oneOverSqrtPi;
+}
+
 /* Returns false when the pair is skipped (beyond the cut-off and not an exclusion, :665-678). */
 template<int ELEC, bool PSWITCH, bool FORCE, bool ENERGY>
 NB_DEVINL bool fepPair(const NBParamGpu& nbp,
@@ -755,7 +762,10 @@ NB_DEVINL bool fepPair(const NBParamGpu& nbp,
                        float&            eEl,
                        float&            dvdlLJ,
                        float&            dvdlEl,
-                       const float (&c6grid)[2] /* LJ-PME: grid C6 of the two states (ljGridC6AB) */)
+                       const float (&c6grid)[2] /* LJ-PME: grid C6 of the two states (ljGridC6AB) */,
+                       /* Ewald, ENERGY: erf(beta r) / r of this pair if the caller has it already (fepEwaldPotentialLr) — it does not depend
+                        * on lambda, and the foreign-lambda loops evaluate the pair a dozen times —; negative: compute it here */
+                       const float vLrKnown = -1.0F)
 {
     const bool  ljPme  = isLjPme(nbp);
     const float rcMax2 = fmaxf(nbp.rcoulomb_sq, nbp.rvdw_sq);
@@ -961,7 +971,7 @@ NB_DEVINL bool fepPair(const NBParamGpu& nbp,
             if constexpr (ENERGY)
             {
                 /* erf(beta r)/r, with its r -> 0 limit for the self pair */
-                v_lr = (beta * r > 1.0e-4F) ? erff(beta * r) * rInv : 2.0F * beta * c_oneOverSqrtPi;
+                v_lr = (vLrKnown >= 0.0F) ? vLrKnown : fepEwaldPotentialLr(beta, r, rInv);
                 if (iEqJ) { v_lr *= 0.5F; }
             }
 #pragma unroll

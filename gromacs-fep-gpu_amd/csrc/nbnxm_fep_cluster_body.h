@@ -111,6 +111,9 @@ NB_DEVINL void fepClusterPair(const NBAtomDataGpu& atdat,
 
     float E_lj = 0.0F, E_el = 0.0F, DVDL_lj = 0.0F, DVDL_el = 0.0F;
     float F_invr = 0.0F;
+    /* FOREIGN: this lane's own terms at the current lambda — the self term and the perturbed pair —, which are lambda index 0 of the
+     * foreign-lambda sums (E_lj .. DVDL_el also collect the plain pairs of the cluster pair, which do not belong there) */
+    [[maybe_unused]] float fep0[4] = { 0.0F, 0.0F, 0.0F, 0.0F };
     if constexpr (ENERGY && EXCL_FORCES)
     {
         /* perturbed atoms carry q = 0 in xq; their lambda-dependent self term is what the i == j entry of the
@@ -129,20 +132,23 @@ NB_DEVINL void fepClusterPair(const NBAtomDataGpu& atdat,
             }
         }
     }
-    if (inList)
+    if (inList && pert && !subDiag)
     {
-        if (pert)
-        {
-            if (!subDiag)
-            {
-                const FepLambda L     = makeFepLambda(lambdaQ, lambdaV, nbp.lam_power, nbp.alpha_coul, nbp.alpha_vdw);
-                float           fscal = 0.0F;
-                const bool      done  = fepPair<FEP_ELEC, VDW == VDK_PSWITCH, true, ENERGY>(nbp, L, r2, included, false, qq, c6AB, c12AB, fscal,
-                                                                                           E_lj, E_el, DVDL_lj, DVDL_el, c6gridAB);
-                F_invr = done ? fscal : 0.0F;
-            }
-        }
-        else
+        const FepLambda L     = makeFepLambda(lambdaQ, lambdaV, nbp.lam_power, nbp.alpha_coul, nbp.alpha_vdw);
+        float           fscal = 0.0F;
+        const bool      done  = fepPair<FEP_ELEC, VDW == VDK_PSWITCH, true, ENERGY>(nbp, L, r2, included, false, qq, c6AB, c12AB, fscal, E_lj, E_el,
+                                                                                   DVDL_lj, DVDL_el, c6gridAB);
+        F_invr = done ? fscal : 0.0F;
+    }
+    if constexpr (FOREIGN)
+    {
+        fep0[0] = E_lj;
+        fep0[1] = E_el;
+        fep0[2] = DVDL_lj;
+        fep0[3] = DVDL_el;
+    }
+    if (inList && !pert)
+    {
         {
             /* a plain pair inside a perturbed cluster pair */
             const int intMask = included ? -1 : 0;
@@ -204,39 +210,56 @@ NB_DEVINL void fepClusterPair(const NBAtomDataGpu& atdat,
         if (lane < 4U) { atomicAdd(energySlots + slot * c_energySlotStride + static_cast<int>(lane), v); }
     }
 
-    /* ---- foreign lambdas (dH/dl steps): the same pair's energies at every lambda index */
+    /* ---- foreign lambdas (dH/dl steps): the same pair's energies at every lambda index ---------------------------------------
+     * Index 0 is the current lambda: this lane's own terms of the pass above (fep0).  For the others only what depends on lambda is
+     * evaluated again: erf(beta r) / r — a libm call with two branches — is computed once; and a wave none of whose lanes has a
+     * perturbed pair within the cut-off or a self term has nothing to add at any lambda. */
     if constexpr (FOREIGN)
     {
-        for (int fidx = 0; fidx <= numForeignLambda; fidx++)
+        const bool  doPair  = inList && pert && !subDiag;
+        const float rcMax2  = fmaxf(nbp.rcoulomb_sq, nbp.rvdw_sq);
+        const bool  hasTerm = selfLane || (doPair && (!included || r2 < rcMax2));
+        if (__ballot(hasTerm) != 0ULL)
         {
-            const float     lc = (fidx == 0) ? lambdaQ : nbp.allLambdaCoul[fidx - 1];
-            const float     lv = (fidx == 0) ? lambdaV : nbp.allLambdaVdw[fidx - 1];
-            const FepLambda Lf = makeFepLambda(lc, lv, nbp.lam_power, nbp.alpha_coul, nbp.alpha_vdw);
-            float fE_lj = 0.0F, fE_el = 0.0F, fDVDL_lj = 0.0F, fDVDL_el = 0.0F, fscal = 0.0F;
-            if (selfLane)
+            float vLr = -1.0F;
+            if constexpr (FEP_ELEC >= ELK_EWALD_ANA)
             {
-                const float sA = qABi.x * qABi.x / nbp.epsfac * selfCoef;
-                const float sB = qABi.y * qABi.y / nbp.epsfac * selfCoef;
-                fE_el += (1.0F - lc) * sA + lc * sB;
-                fDVDL_el += sB - sA;
-                if constexpr (LJ_EWALD)
+                const float r2c  = fmaxf(r2, c_nbnxnMinDistanceSquared);
+                const float rInv = __frsqrt_rn(r2c);
+                vLr              = fepEwaldPotentialLr(nbp.ewald_beta, r2c * rInv, rInv);
+            }
+            float* slot = foreignSlots + (item & (c_numForeignSlots - 1)) * atdat.foreignSlotStride;
+            {
+                const float v = waveSum4Transposed(fep0[0], fep0[1], fep0[2], fep0[3], lane); /* lanes 0 .. 3: the four sums */
+                if (lane < 4U && v != 0.0F) { atomicAdd(slot + static_cast<int>(lane) * (numForeignLambda + 1), v); }
+            }
+            for (int fidx = 1; fidx <= numForeignLambda; fidx++)
+            {
+                const float     lc = nbp.allLambdaCoul[fidx - 1];
+                const float     lv = nbp.allLambdaVdw[fidx - 1];
+                const FepLambda Lf = makeFepLambda(lc, lv, nbp.lam_power, nbp.alpha_coul, nbp.alpha_vdw);
+                float fE_lj = 0.0F, fE_el = 0.0F, fDVDL_lj = 0.0F, fDVDL_el = 0.0F, fscal = 0.0F;
+                if (selfLane)
                 {
-                    fE_lj += ((1.0F - lv) * c6gridAB[0] + lv * c6gridAB[1]) * ljSelfCoef;
-                    fDVDL_lj += (c6gridAB[1] - c6gridAB[0]) * ljSelfCoef;
+                    const float sA = qABi.x * qABi.x / nbp.epsfac * selfCoef;
+                    const float sB = qABi.y * qABi.y / nbp.epsfac * selfCoef;
+                    fE_el += (1.0F - lc) * sA + lc * sB;
+                    fDVDL_el += sB - sA;
+                    if constexpr (LJ_EWALD)
+                    {
+                        fE_lj += ((1.0F - lv) * c6gridAB[0] + lv * c6gridAB[1]) * ljSelfCoef;
+                        fDVDL_lj += (c6gridAB[1] - c6gridAB[0]) * ljSelfCoef;
+                    }
                 }
-            }
-            if (inList && pert && !subDiag)
-            {
-                fepPair<FEP_ELEC, VDW == VDK_PSWITCH, false, true>(nbp, Lf, r2, included, false, qq, c6AB, c12AB, fscal, fE_lj, fE_el, fDVDL_lj,
-                                                                   fDVDL_el, c6gridAB);
-            }
-            const float v = waveSum4Transposed(fE_lj, fE_el, fDVDL_lj, fDVDL_el, lane); /* lanes 0 .. 3: the four sums */
-            if (lane < 4U)
-            {
+                if (doPair)
+                {
+                    fepPair<FEP_ELEC, VDW == VDK_PSWITCH, false, true>(nbp, Lf, r2, included, false, qq, c6AB, c12AB, fscal, fE_lj, fE_el, fDVDL_lj,
+                                                                       fDVDL_el, c6gridAB, vLr);
+                }
+                const float v = waveSum4Transposed(fE_lj, fE_el, fDVDL_lj, fDVDL_el, lane); /* lanes 0 .. 3: the four sums */
                 /* into this wave's accumulator slot (NBAtomDataGpu::foreignSlots): thousands of waves adding to the same
                  * 48 addresses serialise in L2 (measured +0.28 ms per dH/dl step) */
-                float*      slot = foreignSlots + (item & (c_numForeignSlots - 1)) * atdat.foreignSlotStride;
-                if (v != 0.0F) { atomicAdd(slot + static_cast<int>(lane) * (numForeignLambda + 1) + fidx, v); }
+                if (lane < 4U && v != 0.0F) { atomicAdd(slot + static_cast<int>(lane) * (numForeignLambda + 1) + fidx, v); }
             }
         }
     }
