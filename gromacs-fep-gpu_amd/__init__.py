@@ -87,6 +87,7 @@ class GpuTimings(C.Structure):
 # Every symbol include/nbnxm_hip.h declares (checked by tests/test_abi_symbols.py).
 HIP_SYMBOLS = [
     "nbnxm_gpu_init", "nbnxm_gpu_free", "nbnxm_gpu_copy_fepparams", "nbnxm_gpu_set_softcore", "nbnxm_gpu_pme_loadbal_update_param",
+    "nbnxm_gpu_set_kernel_routing",
     "nbnxm_gpu_init_atomdata", "nbnxm_gpu_init_pairlist", "nbnxm_gpu_init_feppairlist",
     "nbnxm_gpu_init_fep_cluster_bits", "nbnxm_gpu_upload_shiftvec", "nbnxm_gpu_copy_xq_to_gpu",
     "nbnxm_gpu_launch_kernel", "nbnxm_gpu_launch_kernel_pruneonly", "nbnxm_gpu_launch_cpyback",
@@ -398,6 +399,10 @@ class NbnxmGpu:
                                            C.c_int(lam_power), C.c_float(sc_sigma6_def), C.c_float(sc_sigma6_min),
                                            C.c_float(lambda_q), C.c_float(lambda_v), C.c_int(self.n_lambda),
                                            _p(alc), _p(alv))
+
+    def set_kernel_routing(self, keep_tabulated_kernels=False, keep_combination_kernels=False):
+        """run exactly the tabulated-Ewald / combination-rule kernels the interaction parameters pick instead of their faster equivalents"""
+        self._lib.nbnxm_gpu_set_kernel_routing(self.h, C.c_int(1 if keep_tabulated_kernels else 0), C.c_int(1 if keep_combination_kernels else 0))
 
     def set_softcore(self, softcore_type, gapsys_scale_linpoint_vdw=0.85, gapsys_scale_linpoint_coul=0.3, gapsys_sigma_vdw=0.3):
         """SOFTCORE_BEUTLER (default after init) | SOFTCORE_GAPSYS; the Gapsys parameters are mdp's sc-gapsys-scale-linpoint-lj / -q

@@ -42,6 +42,17 @@ void setLastError(const char* msg);
     std::abort();
 }
 
+/* Environment variables that change what the library does exist for measurements (A/B runs of one build) only: they are read when
+ * NBNXM_HIP_DIAGNOSTICS=1 and ignored otherwise, so that a drop-in's behaviour does not hinge on the environment it happens to run in
+ * (INTEGRATION.md has the table).  Not gated: NBNXM_HIP_FATAL_LOG, NBNXM_HIP_RCCL_LIB, HALO_GPU_PEER_TIMEOUT — where to write, what to
+ * load, how long to wait; none of them changes a result or a launch. */
+inline const char* diagnosticsEnv(const char* name)
+{
+    /* (read at every call — object creation, a handful per run —, so that a test can switch it on for one object) */
+    const char* v = std::getenv("NBNXM_HIP_DIAGNOSTICS");
+    return (v != nullptr && v[0] == '1') ? std::getenv(name) : nullptr;
+}
+
 #define NBNXM_HIP_CHECK(expr)                                                                        \
     do                                                                                               \
     {                                                                                                \

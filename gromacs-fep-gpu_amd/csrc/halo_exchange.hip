@@ -508,8 +508,8 @@ HaloGpu* halo_gpu_create(const void* uniqueId, int rank, int nranks, void* strea
     NBNXM_HIP_CHECK(hipEventCreateWithFlags(&h->recvBufConsumed, hipEventDisableTiming));
     /* the local launch of a domain step in two parts: on by default where the exchanges leave the device (see halo_gpu_domain_force_step) */
     h->localParts = (nranks > 1) ? 2 : 1;
-    if (const char* env = std::getenv("HALO_GPU_LOCAL_PARTS")) { h->localParts = (std::atoi(env) == 2) ? 2 : 1; }
-    if (const char* env = std::getenv("HALO_GPU_LOCAL_PART_FRACTION"))
+    if (const char* env = diagnosticsEnv("HALO_GPU_LOCAL_PARTS")) { h->localParts = (std::atoi(env) == 2) ? 2 : 1; }
+    if (const char* env = diagnosticsEnv("HALO_GPU_LOCAL_PART_FRACTION"))
     {
         const float v = static_cast<float>(std::atof(env));
         if (v > 0.05F && v < 0.95F) { h->localPartFraction = v; }
@@ -767,7 +767,7 @@ void halo_gpu_domain_force_step(HaloGpu* h, NbnxmGpu* nb, const nbnxm_step_workl
      * local kernel — which fills every wave slot — the RCCL kernel would wait for slots, and the peers with it (on one GPU the order
      * makes no difference: 0.141 ms either way) */
     /* diagnostics (HALO_GPU_HOST_TIMING=1): host time spent queueing each part, printed by halo_gpu_free */
-    static const bool s_hostTiming = (std::getenv("HALO_GPU_HOST_TIMING") != nullptr);
+    static const bool s_hostTiming = (diagnosticsEnv("HALO_GPU_HOST_TIMING") != nullptr);
     auto              tick         = [&](int part) {
         if (s_hostTiming)
         {

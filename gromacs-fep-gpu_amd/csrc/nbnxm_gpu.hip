@@ -414,9 +414,9 @@ NbnxmGpu* nbnxm_gpu_init(const nbnxm_interaction_params_t* ic, int numTypes, con
         NBNXM_HIP_CHECK(hipGetDevice(&device));
         NBNXM_HIP_CHECK(hipGetDeviceProperties(&prop, device));
         nb->numSimds = prop.multiProcessorCount * 4; /* CDNA: 4 SIMDs per CU */
-        if (const char* env = std::getenv("NBNXM_HIP_NUM_WORK_RANGES")) { nb->numWorkRangesOverride = std::atoi(env); }
-        if (const char* env = std::getenv("NBNXM_HIP_MIN_GROUPS_PER_WAVE")) { nb->minGroupsPerWave = std::max(1, std::atoi(env)); }
-        if (const char* env = std::getenv("NBNXM_HIP_WORK_WEIGHTS"))
+        if (const char* env = diagnosticsEnv("NBNXM_HIP_NUM_WORK_RANGES")) { nb->numWorkRangesOverride = std::atoi(env); }
+        if (const char* env = diagnosticsEnv("NBNXM_HIP_MIN_GROUPS_PER_WAVE")) { nb->minGroupsPerWave = std::max(1, std::atoi(env)); }
+        if (const char* env = diagnosticsEnv("NBNXM_HIP_WORK_WEIGHTS"))
         {
             if (std::sscanf(env, "%d,%d,%d", &nb->workWeightsOverride[0], &nb->workWeightsOverride[1], &nb->workWeightsOverride[2]) != 3)
             {
@@ -426,7 +426,7 @@ NbnxmGpu* nbnxm_gpu_init(const nbnxm_interaction_params_t* ic, int numTypes, con
         /* NBNXM_HIP_CLASS_SHARES4 / 5 = "s0,s1,.." in 1/1024 of an average range, oldest wave of a SIMD first (renormalised) */
         for (int p = 0; p < 2; p++)
         {
-            const char* env = std::getenv(p == 0 ? "NBNXM_HIP_CLASS_SHARES4" : "NBNXM_HIP_CLASS_SHARES5");
+            const char* env = diagnosticsEnv(p == 0 ? "NBNXM_HIP_CLASS_SHARES4" : "NBNXM_HIP_CLASS_SHARES5");
             if (env == nullptr) { continue; }
             int       v[5] = { 0, 0, 0, 0, 0 };
             const int got = std::sscanf(env, "%d,%d,%d,%d,%d", &v[0], &v[1], &v[2], &v[3], &v[4]);
@@ -444,28 +444,28 @@ NbnxmGpu* nbnxm_gpu_init(const nbnxm_interaction_params_t* ic, int numTypes, con
             }
         }
     }
-    if (const char* env = std::getenv("NBNXM_HIP_FEP_CONCURRENT"))
+    if (const char* env = diagnosticsEnv("NBNXM_HIP_FEP_CONCURRENT"))
     {
         nb->fepConcurrent      = (std::atoi(env) != 0);
         nb->fepConcurrentFused = (std::atoi(env) == 2);
     }
-    if (const char* env = std::getenv("NBNXM_HIP_F_DOUBLE_BUFFER"))
+    if (const char* env = diagnosticsEnv("NBNXM_HIP_F_DOUBLE_BUFFER"))
     {
         nb->fDoubleBuffer = (std::atoi(env) != 0);
     }
-    if (const char* env = std::getenv("NBNXM_HIP_PRUNE_MERGED"))
+    if (const char* env = diagnosticsEnv("NBNXM_HIP_PRUNE_MERGED"))
     {
         nb->pruneMerged = (std::atoi(env) != 0);
     }
-    if (const char* env = std::getenv("NBNXM_HIP_FEP_MERGED"))
+    if (const char* env = diagnosticsEnv("NBNXM_HIP_FEP_MERGED"))
     {
         nb->fepMergedFused = (std::atoi(env) != 0);
     }
-    if (const char* env = std::getenv("NBNXM_HIP_FEP_LIST_MERGED"))
+    if (const char* env = diagnosticsEnv("NBNXM_HIP_FEP_LIST_MERGED"))
     {
         nb->fepListMerged = (std::atoi(env) != 0);
     }
-    if (const char* env = std::getenv("NBNXM_HIP_ENERGY_TAIL"))
+    if (const char* env = diagnosticsEnv("NBNXM_HIP_ENERGY_TAIL"))
     {
         nb->energyTail = std::max(0, std::min(c_energyTailCompiled, std::atoi(env)));
     }
@@ -500,16 +500,16 @@ NbnxmGpu* nbnxm_gpu_init(const nbnxm_interaction_params_t* ic, int numTypes, con
     NBNXM_HIP_CHECK(hipGetDevice(&dev));
     NBNXM_HIP_CHECK(hipGetDeviceProperties(&prop, dev));
     nb->numCUs = prop.multiProcessorCount;
-    if (const char* env = std::getenv("NBNXM_HIP_WAVES_PER_BLOCK"))
+    if (const char* env = diagnosticsEnv("NBNXM_HIP_WAVES_PER_BLOCK"))
     {
         const int w = std::atoi(env);
         NBNXM_ASSERT(w == 1 || w == 2 || w == 4, "NBNXM_HIP_WAVES_PER_BLOCK must be 1, 2 or 4");
         nb->nbWavesPerBlock = w;
     }
 
-    if (const char* env = std::getenv("NBNXM_HIP_KEEP_COMB_KERNELS")) { nb->keepCombinationKernels = (std::atoi(env) != 0); }
-    if (const char* env = std::getenv("NBNXM_HIP_KEEP_TAB_KERNELS")) { nb->keepTabulatedKernels = (std::atoi(env) != 0); }
-    nb->debugLaunchShape = (std::getenv("NBNXM_HIP_DEBUG_LAUNCH_SHAPE") != nullptr);
+    if (const char* env = diagnosticsEnv("NBNXM_HIP_KEEP_COMB_KERNELS")) { nb->keepCombinationKernels = (std::atoi(env) != 0); }
+    if (const char* env = diagnosticsEnv("NBNXM_HIP_KEEP_TAB_KERNELS")) { nb->keepTabulatedKernels = (std::atoi(env) != 0); }
+    nb->debugLaunchShape = (diagnosticsEnv("NBNXM_HIP_DEBUG_LAUNCH_SHAPE") != nullptr);
 
     /* pinned staging (gpu_init :573-583) */
     auto pinned = [](float** p, size_t n) {
@@ -540,6 +540,8 @@ NbnxmGpu* nbnxm_gpu_init(const nbnxm_interaction_params_t* ic, int numTypes, con
     /* initNbparam :421-489 */
     NBParamGpu* nbp = nb->nbparam;
     NBNXM_ASSERT(ic->elecType >= 0 && ic->elecType < NBNXM_ELEC_COUNT, "unknown electrostatics kernel type");
+    nb->callerParams             = *ic;
+    nb->callerParams.coulomb_tab = nullptr; /* (kept for the kernel pick only, see nbnxm_gpu_set_kernel_routing) */
     nbp->elecType   = kernelElecType(nb, ic);
     nbp->vdwType    = ic->vdwType;
     nbp->bFEP       = bFEP != 0;
@@ -746,8 +748,17 @@ void nbnxm_gpu_copy_fepparams(NbnxmGpu* nb, int bFEP, float alpha_coul, float al
     }
 }
 
+void nbnxm_gpu_set_kernel_routing(NbnxmGpu* nb, int keepTabulatedKernels, int keepCombinationKernels)
+{
+    nb->keepTabulatedKernels   = (keepTabulatedKernels != 0);
+    nb->keepCombinationKernels = (keepCombinationKernels != 0);
+    nb->nbparam->elecType      = kernelElecType(nb, &nb->callerParams);
+}
+
 void nbnxm_gpu_pme_loadbal_update_param(NbnxmGpu* nb, const nbnxm_interaction_params_t* ic)
 {
+    nb->callerParams            = *ic;
+    nb->callerParams.coulomb_tab = nullptr; /* (the copy is kept for the kernel pick only: the caller's table pointer does not outlive the call) */
     nb->nbparam->elecType = kernelElecType(nb, ic);
     setCutoffParameters(nb->nbparam, ic);
     uploadCoulombTable(nb, ic);
@@ -1927,8 +1938,12 @@ void nbnxm_gpu_launch_cpyback(NbnxmGpu* nb, float* f_out, const nbnxm_step_workl
     NBNXM_ASSERT(iloc == NBNXM_LOCAL || (iloc == NBNXM_NONLOCAL && nb->bUseTwoStreams), "bad locality");
     hipStream_t s = nb->deviceStreams[iloc].stream;
     if (iloc == NBNXM_NONLOCAL && !nb->haveWork[iloc]) { return; }
-    const int begin = (iloc == NBNXM_LOCAL) ? 0 : ad->numAtomsLocal;
-    const int count = (iloc == NBNXM_LOCAL) ? ad->numAtomsLocal : ad->numAtoms - ad->numAtomsLocal;
+    /* merged localities: the ONE kernel of the step, launched for the local locality, has computed the halo atoms' forces too and the
+     * non-local device list is empty (the return above), so the local copy-back brings ALL atoms' forces — the halo rows the caller's
+     * force halo sends included.  (Round 3 copied the home rows only with this call sequence: the halo forces never reached f_out.) */
+    const bool all   = (iloc == NBNXM_LOCAL && nb->mergedLocalities);
+    const int  begin = (iloc == NBNXM_LOCAL) ? 0 : ad->numAtomsLocal;
+    const int  count = (iloc == NBNXM_LOCAL) ? (all ? ad->numAtoms : ad->numAtomsLocal) : ad->numAtoms - ad->numAtomsLocal;
 
     if (iloc == NBNXM_LOCAL && nb->bUseTwoStreams)
     {

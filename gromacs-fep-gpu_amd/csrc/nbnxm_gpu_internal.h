@@ -86,8 +86,11 @@ struct NbnxmGpu
     int  numCUs    = 256;
 
     int nbWavesPerBlock = c_nbWavesPerBlock; /* tunable: NBNXM_HIP_WAVES_PER_BLOCK = 1..4 */
-    bool keepCombinationKernels = false;     /* diagnostics: NBNXM_HIP_KEEP_COMB_KERNELS=1 */
-    bool keepTabulatedKernels   = false;     /* NBNXM_HIP_KEEP_TAB_KERNELS=1: a caller that picks the tabulated Ewald kernels gets them */
+    /* nbnxm_gpu_set_kernel_routing: the caller's pick of a tabulated-Ewald / combination-rule kernel is kept instead of running the
+     * faster equivalent (diagnostics: NBNXM_HIP_KEEP_TAB_KERNELS / NBNXM_HIP_KEEP_COMB_KERNELS set the initial values) */
+    bool keepCombinationKernels = false;
+    bool keepTabulatedKernels   = false;
+    nbnxm_interaction_params_t callerParams{}; /* the interaction parameters as the caller last passed them (the kernel pick is re-derived from them) */
     /* domain decomposition: the local force-only launch in two parts (nbnxm_gpu_set_local_launch_parts), the second one behind the
      * non-local kernel so that it runs beside the force halo */
     int   localLaunchParts    = 1;

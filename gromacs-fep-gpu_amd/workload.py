@@ -42,8 +42,11 @@ def make_case(nm=(8, 8, 8), num_perturbed_molecules=3, elec="rf", vdw="cut", see
               lambda_vdw=0.5, n_lambda=0, max_cjpacked_per_sci=0, identical_states=False, rvdw_switch=0.8,
               spacing=0.310736, jitter=0.03, num_extra_types=0, rvdw=None, softcore="beutler",
               gapsys=(0.85, 0.3, 0.3), build_lists=True):
-    """elec: 'rf' | 'cut' | 'ewald' | 'ewald_tab';  vdw: 'cut' | 'pswitch' | 'fswitch' | 'comb_geom' | 'comb_lb' |
+    """elec: 'rf' | 'cut' | 'ewald' | 'ewald_tab' | 'ewald_tab_kept' (the tabulated kernels themselves instead of the analytical ones a
+    tabulated pick runs by default: setup_gpu calls nbnxm_gpu_set_kernel_routing);  vdw: 'cut' | 'pswitch' | 'fswitch' | 'comb_geom' | 'comb_lb' |
     'ewald_geom' | 'ewald_lb' (LJ-PME real-space part; perturbed pairs as in the CPU kernel, with the grid correction)."""
+    keep_kernel_pick = elec.endswith("_kept")
+    elec = elec[:-len("_kept")] if keep_kernel_pick else elec
     sysd = pkg.make_water_box(nm[0], nm[1], nm[2], spacing=spacing, jitter=jitter, seed=seed,
                               num_perturbed_molecules=num_perturbed_molecules)
     n = len(sysd["qA"])
@@ -77,6 +80,7 @@ def make_case(nm=(8, 8, 8), num_perturbed_molecules=3, elec="rf", vdw="cut", see
     c.rvdw = rc if rvdw is None else float(rvdw)
     assert c.rvdw == rc or (c.rvdw < rc and elec in ("ewald", "ewald_tab"))
     c.elec, c.vdw = elec, vdw
+    c.keep_kernel_pick = keep_kernel_pick
     c.epsfac = ONE_4PI_EPS0
     c.k_rf = c.c_rf = c.beta = c.sh_ewald = 0.0
     if elec == "rf":          # epsilon_rf = infinity
@@ -220,12 +224,14 @@ def ewald_force_table(beta, rmax, scale=2000.0):
                - 2 * beta / math.sqrt(math.pi) * np.exp(-(beta * r1) ** 2) / r1)
     return tab.astype(np.float32), scale
 
-def setup_gpu(c, fused=False, use_dynamic_pruning=False, list_override=None):
+def setup_gpu(c, fused=False, use_dynamic_pruning=False, list_override=None, keep_combination_kernels=False):
     """list_override: (sci, cjPacked, excl) to upload instead of the case's own list (domain decomposition)."""
     g = c.grid
     ic = gpu_interaction_params(c, use_dynamic_pruning)
     nb = pkg.NbnxmGpu(ic, g.num_types, g.nbat_nbfp(c.sys["nbfp"]),
                       nbfp_comb=lj_type_params(c) if c.vdw in ("ewald_geom", "ewald_lb") else None, fep=True, n_lambda=c.n_lambda)
+    if getattr(c, "keep_kernel_pick", False) or keep_combination_kernels:
+        nb.set_kernel_routing(keep_tabulated_kernels=getattr(c, "keep_kernel_pick", False), keep_combination_kernels=keep_combination_kernels)
     sig6 = c.sc_sigma ** 6
     alpha_coul = c.sc_alpha if c.sc_coul else 0.0
     sig6_min = sig6 if c.sc_coul else 0.0

@@ -188,6 +188,13 @@ void nbnxm_gpu_copy_fepparams(NbnxmGpu* nb, int bFEP, float alpha_coul, float al
                               float lambda_q, float lambda_v, int n_lambda,
                               const double* all_lambda_coul, const double* all_lambda_vdw);
 
+/* MI355X extension: keep the caller's kernel pick.  By default two picks of the reference run a faster equivalent kernel: a tabulated
+ * Ewald pick (the reference's default on AMD devices, nbnxm_gpu_data_mgmt.cpp:120-145) runs the analytical Ewald kernels, and on
+ * force-only steps a combination-rule LJ pick (nbnxm.h:196-205) runs the type-table kernel while the table is small — same terms, same
+ * results within the parity bar.  keepTabulatedKernels / keepCombinationKernels != 0 run exactly
+ * the kernels the caller picked.  Takes effect from the next launch; nbnxm_gpu_is_kernel_ewald_analytical reports what runs. */
+void nbnxm_gpu_set_kernel_routing(NbnxmGpu* nb, int keepTabulatedKernels, int keepCombinationKernels);
+
 /* MI355X extension: the soft-core function of the perturbed pairs.  The reference's GPU kernels implement Beutler only (the
  * caller falls back to the CPU for anything else); its CPU kernel also has Gapsys (SoftcoreType, mdtypes/md_enums.h;
  * interaction_const_t::SoftCoreParameters{softcoreType, gapsysScaleLinpointVdW, gapsysScaleLinpointCoul, gapsysSigma6VdW},
@@ -391,11 +398,14 @@ void nbnxm_gpu_launch_kernel_part(NbnxmGpu* nb, const nbnxm_step_workload_t* ste
 /* MI355X extension for domain decomposition: the local and the non-local pair list of a domain as ONE device list.  The cluster
  * kernel's launch has one wave per wave slot of the device, each with a balanced share of the list, so a second launch for the
  * non-local list pays the start and the drain of the whole machine again (81 us for the two kernels of a 96k + 46k-atom domain
- * against 62 us for the same pairs as one list).  Set before the lists are uploaded.  The reference's call sequence stays —
- * gpu_init_pairlist(Local) then (NonLocal), pairlist.cpp:4450-4452; launches / prunes / copy-backs of both localities —: the
- * non-local device list is empty and everything about it is a no-op, the local launch evaluates both and therefore needs the
- * halo coordinates: queue it behind x -> xq of the halo slots (halo_gpu_domain_force_step does).  Perturbed pairs: fused mode
- * (nbnxm_gpu_set_fep_mode(nb, 1)); a non-local atom-pair list is refused. */
+ * against 62 us for the same pairs as one list).  Set before the lists are uploaded.  The reference's calls stay —
+ * gpu_init_pairlist(Local) then (NonLocal), pairlist.cpp:4450-4452; launches / prunes / copy-backs / finish of both localities —
+ * with this meaning: the non-local device list is empty, its launch, prune, copy-back and finish are no-ops; the LOCAL launch
+ * evaluates both lists and therefore needs the halo coordinates — queue it behind x -> xq of the halo slots, which is NOT where
+ * the reference's schedule has the local launch (sim_util.cpp:1783-1899 launches it before the coordinate halo arrives), so the
+ * schedule is halo_gpu_domain_force_step's (include/halo_hip.h) or a caller's own; the LOCAL copy-back (nbnxm_gpu_launch_cpyback)
+ * returns the forces of ALL atoms, home and halo, and the local finish is the step's only synchronisation point.  Perturbed pairs:
+ * fused mode (nbnxm_gpu_set_fep_mode(nb, 1)); a non-local atom-pair list is refused. */
 void nbnxm_gpu_set_merged_localities(NbnxmGpu* nb, int merged);
 int  nbnxm_gpu_get_merged_localities(const NbnxmGpu* nb);
 

@@ -17,9 +17,8 @@ def pytest_configure(config):
     out = os.path.join(ROOT, "gpurun_out")
     if os.path.isdir(out) and os.access(out, os.W_OK):
         os.environ.setdefault("NBNXM_HIP_FATAL_LOG", os.path.join(out, "nbnxm_hip_fatal.log"))
-    # a caller that picks the tabulated Ewald kernels (the reference's default on AMD devices) runs the faster analytical ones unless this is
-    # set (csrc/nbnxm_gpu.hip: kernelElecType); the tests with elec="ewald_tab" are there for the tabulated kernels themselves
-    os.environ.setdefault("NBNXM_HIP_KEEP_TAB_KERNELS", "1")
+    # (no switch of the library is set here: every test runs the product's default routing unless it asks for something else itself —
+    # elec="ewald_tab_kept" for the tabulated Ewald kernels, NBNXM_HIP_DIAGNOSTICS=1 plus a switch through monkeypatch for an A/B form)
 
 
 def have_gpu():

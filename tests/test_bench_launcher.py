@@ -45,6 +45,21 @@ def test_rank_count_mismatch_is_an_error():
     assert p.returncode != 0 and not lines
 
 
+@pytest.mark.parametrize("how", ["error", "wrong", "hang"])
+def test_a_failed_decomposition_leg_is_not_a_green_run(how):
+    """The leg failed, hung (watchdog) or computed other forces than the single domain: the complete line is still printed and
+    forwarded by the launcher, with "dd_leg_ok": false — and the job's exit code is 3.  BENCH_DD_LENIENT=1 restores exit code 0."""
+    p, lines = run_bench("--gpus", "2", "--steps", "2", "--warmup", "0", env_extra={"BENCH_DRY_RUN_DD_LEG": how})
+    assert p.returncode != 0, "a failed leg exited 0"
+    assert len(lines) == 1
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["dd_leg_ok"] is False and rec["dd_leg_error"]
+    assert "DOMAIN-DECOMPOSITION LEG FAILED" in p.stderr
+    if how == "error":
+        p, lines = run_bench("--gpus", "2", "--steps", "2", "--warmup", "0", env_extra={"BENCH_DRY_RUN_DD_LEG": how, "BENCH_DD_LENIENT": "1"})
+        assert p.returncode == 0 and json.loads(lines[0])["dd_leg_ok"] is False
+
+
 def test_decomposition_leg_state_is_at_the_top_level_of_the_line(capsys):
     """A failed, timed-out or wrong (first step differs from the single-domain forces) decomposition leg must show as "dd_leg_ok": false
     with its reason at the TOP level of the JSON line and on stderr — not only inside the nested record."""

@@ -20,7 +20,7 @@ pkg = tl.pkg
 SMALL = dict(nm=(10, 10, 10), num_perturbed_molecules=3)      # 3000 atoms, 9 perturbed
 
 
-@pytest.mark.parametrize("elec", ["rf", "cut", "ewald", "ewald_tab"])
+@pytest.mark.parametrize("elec", ["rf", "cut", "ewald", "ewald_tab", "ewald_tab_kept"])
 @pytest.mark.parametrize("energy", [False, True])
 def test_split_path_matches_oracle(elec, energy):
     c = tl.make_case(elec=elec, seed=21, **SMALL)
@@ -39,6 +39,7 @@ def test_split_path_with_the_atom_pair_kernel_of_its_own(elec, vdw, energy, monk
     want = tl.run_oracle(c, energy=True)
     merged = tl.run_gpu(c, energy=energy, fused=False)
     tl.assert_parity(merged, want, rel=1e-4, energy=energy, label="list in the tail " + elec)
+    monkeypatch.setenv("NBNXM_HIP_DIAGNOSTICS", "1")
     monkeypatch.setenv("NBNXM_HIP_FEP_LIST_MERGED", "0")
     own = tl.run_gpu(c, energy=energy, fused=False)
     tl.assert_parity(own, want, rel=1e-4, energy=energy, label="own kernel " + elec)
@@ -74,12 +75,13 @@ def test_atom_pair_lists_of_any_shape(seed, monkeypatch):
     want = tl.run_oracle(c, energy=True)
     merged = tl.run_gpu(c, energy=True, fused=False)
     tl.assert_parity(merged, want, rel=1e-4, label="regrouped list %d" % seed)
+    monkeypatch.setenv("NBNXM_HIP_DIAGNOSTICS", "1")
     monkeypatch.setenv("NBNXM_HIP_FEP_LIST_MERGED", "0")
     own = tl.run_gpu(c, energy=True, fused=False)
     tl.assert_parity(own, want, rel=1e-4, label="flattened list %d" % seed)
 
 
-@pytest.mark.parametrize("elec", ["rf", "cut", "ewald", "ewald_tab"])
+@pytest.mark.parametrize("elec", ["rf", "cut", "ewald", "ewald_tab", "ewald_tab_kept"])
 @pytest.mark.parametrize("energy", [False, True])
 def test_fused_path_matches_oracle(elec, energy):
     c = tl.make_case(elec=elec, seed=22, **SMALL)
@@ -195,6 +197,7 @@ def test_rolling_prune_with_moving_atoms(fused, merged, split, monkeypatch):
     split 3: the i-entries arrive cut into pieces of at most 3 groups (a list builder balancing for GPUs); the cluster kernel walks them
     joined again (gpu_plist::sciSorted) while the pruning works on the caller's entries."""
     import oracle_binding as ob
+    monkeypatch.setenv("NBNXM_HIP_DIAGNOSTICS", "1")
     monkeypatch.setenv("NBNXM_HIP_PRUNE_MERGED", "1" if merged else "0")
     c = tl.make_case(elec="ewald", seed=33, max_cjpacked_per_sci=split, **SMALL)
     c.rlist_inner = 1.03
@@ -341,7 +344,8 @@ def test_two_part_launch_on_a_list_too_short_for_two_sets(fused):
     nb.free()
 
 
-@pytest.mark.parametrize("elec,vdw", [("ewald", "cut"), ("rf", "cut"), ("ewald", "fswitch"), ("ewald", "pswitch"), ("ewald_tab", "cut"), ("ewald", "ewald_geom")])
+@pytest.mark.parametrize("elec,vdw", [("ewald", "cut"), ("rf", "cut"), ("ewald", "fswitch"), ("ewald", "pswitch"), ("ewald_tab", "cut"), ("ewald_tab_kept", "cut"),
+                                      ("ewald", "ewald_geom")])
 @pytest.mark.parametrize("fused", [False, True])
 def test_excluded_atoms_on_top_of_each_other(elec, vdw, fused):
     """Two EXCLUDED atoms at zero distance (a shell on its core; here hydrogens moved onto their oxygen, and one perturbed molecule
@@ -372,7 +376,7 @@ def test_excluded_atoms_on_top_of_each_other(elec, vdw, fused):
     nb.free()
 
 
-@pytest.mark.parametrize("elec,vdw", [("ewald", "cut"), ("rf", "cut"), ("ewald", "fswitch"), ("rf", "comb_geom"), ("ewald_tab", "cut")])
+@pytest.mark.parametrize("elec,vdw", [("ewald", "cut"), ("rf", "cut"), ("ewald", "fswitch"), ("rf", "comb_geom"), ("ewald_tab", "cut"), ("ewald_tab_kept", "cut")])
 @pytest.mark.parametrize("fused", [False, True])
 def test_filler_atoms_on_one_point(elec, vdw, fused):
     """The reference parks ALL filler atoms of its grid on one point (atomdata.cpp:148-184: x = y = z = -1e6) and the shim hands
@@ -435,9 +439,9 @@ def test_full_size_properties_100k():
     tl.assert_parity(fused, want, rel=1e-4, label="96k fused")
 
 
-@pytest.mark.parametrize("elec", ["rf", "ewald", "ewald_tab", "cut"])
+@pytest.mark.parametrize("elec", ["rf", "ewald", "ewald_tab", "ewald_tab_kept", "cut"])
 @pytest.mark.parametrize("vdw", ["cut", "fswitch", "pswitch", "comb_geom", "comb_lb", "ewald_geom"])
-def test_force_only_flavours(elec, vdw, monkeypatch):
+def test_force_only_flavours(elec, vdw):
     """The force-only instances are code of their own (one-mask pair block, 5 waves per SIMD for cut-off and switch flavours, the Ewald
     tables read first): every electrostatics x VdW combination as a force-only step, both modes, against the forces of the oracle's
     energy pass.  With few atom types the combination-rule flavours run the table kernel (nbnxm_gpu_launch_kernel); their own force
@@ -445,14 +449,14 @@ def test_force_only_flavours(elec, vdw, monkeypatch):
     c = tl.make_case(elec=elec, vdw=vdw, seed=57, **SMALL)
     want = tl.run_oracle(c, energy=True)
     for keep_comb in ((False, True) if vdw.startswith("comb") else (False,)):
-        if keep_comb:
-            monkeypatch.setenv("NBNXM_HIP_KEEP_COMB_KERNELS", "1")
         for fused in (False, True):
-            got = tl.run_gpu(c, energy=False, fused=fused)
+            nb = tl.setup_gpu(c, fused=fused, keep_combination_kernels=keep_comb)
+            got = tl.run_gpu(c, energy=False, fused=fused, nb=nb)
+            nb.free()
             tl.assert_parity(got, want, rel=1e-4, energy=False, label="F %s %s fused %d own comb kernel %d" % (elec, vdw, fused, keep_comb))
 
 
-@pytest.mark.parametrize("elec", ["ewald", "ewald_tab"])
+@pytest.mark.parametrize("elec", ["ewald", "ewald_tab", "ewald_tab_kept"])
 @pytest.mark.parametrize("vdw", ["cut", "pswitch", "fswitch", "comb_lb"])
 @pytest.mark.parametrize("fused", [False, True])
 def test_twin_range_kernels(elec, vdw, fused):
@@ -466,7 +470,7 @@ def test_twin_range_kernels(elec, vdw, fused):
     tl.assert_parity(got_f, want, rel=1e-4, energy=False, label="twin F %s %s" % (elec, vdw))
 
 
-@pytest.mark.parametrize("elec,vdw", [("rf", "cut"), ("ewald", "cut"), ("cut", "cut"), ("ewald_tab", "cut"), ("ewald", "pswitch"),
+@pytest.mark.parametrize("elec,vdw", [("rf", "cut"), ("ewald", "cut"), ("cut", "cut"), ("ewald_tab", "cut"), ("ewald_tab_kept", "cut"), ("ewald", "pswitch"),
                                       ("rf", "pswitch")])
 @pytest.mark.parametrize("fused", [False, True])
 def test_gapsys_softcore(elec, vdw, fused):
@@ -493,7 +497,7 @@ def test_gapsys_softcore_changes_the_result_and_zero_linpoints_switch_it_off():
     tl.assert_parity(gz, tl.run_oracle(z, energy=True), rel=1e-4, label="gapsys off")
 
 
-@pytest.mark.parametrize("elec", ["ewald", "rf", "cut", "ewald_tab"])
+@pytest.mark.parametrize("elec", ["ewald", "rf", "cut", "ewald_tab", "ewald_tab_kept"])
 @pytest.mark.parametrize("vdw", ["ewald_geom", "ewald_lb"])
 @pytest.mark.parametrize("fused", [False, True])
 def test_lj_pme_kernels(elec, vdw, fused):
@@ -610,10 +614,9 @@ def test_local_and_nonlocal_streams():
 
 
 @pytest.mark.parametrize("rvdw", [None, 0.9])
-def test_a_tabulated_ewald_pick_runs_the_analytical_kernels(rvdw, monkeypatch):
+def test_a_tabulated_ewald_pick_runs_the_analytical_kernels(rvdw):
     # the reference picks the tabulated flavours by default on AMD devices; here the analytical ones are faster and run instead
-    # (NBNXM_HIP_KEEP_TAB_KERNELS=1, set by conftest.py for every other test, keeps the caller's pick)
-    monkeypatch.delenv("NBNXM_HIP_KEEP_TAB_KERNELS", raising=False)
+    # (nbnxm_gpu_set_kernel_routing keeps the caller's pick: elec="ewald_tab_kept" in these tests)
     lib = pkg.hip_lib()
     got = {}
     for elec in ("ewald_tab", "ewald"):
@@ -628,9 +631,10 @@ def test_a_tabulated_ewald_pick_runs_the_analytical_kernels(rvdw, monkeypatch):
         assert abs(got["ewald_tab"][key] - got["ewald"][key]) <= 1e-5 * max(1.0, abs(got["ewald"][key])), key
     frms = math.sqrt(float(np.mean(np.sum(got["ewald"]["f"] ** 2, axis=1))))
     assert np.max(np.abs(got["ewald_tab"]["f"] - got["ewald"]["f"])) <= 2e-5 * frms     # same kernels; the adds arrive in a different order
-    monkeypatch.setenv("NBNXM_HIP_KEEP_TAB_KERNELS", "1")
-    nb = tl.setup_gpu(tl.make_case(elec="ewald_tab", rvdw=rvdw, seed=45, **SMALL), fused=True)
+    nb = tl.setup_gpu(tl.make_case(elec="ewald_tab_kept", rvdw=rvdw, seed=45, **SMALL), fused=True)
     assert lib.nbnxm_gpu_is_kernel_ewald_analytical(nb.h) == 0
+    nb.set_kernel_routing(keep_tabulated_kernels=False)
+    assert lib.nbnxm_gpu_is_kernel_ewald_analytical(nb.h) == 1
     nb.free()
 
 
@@ -964,6 +968,7 @@ def test_cpp_domain_step_with_real_peers_over_the_peer_copy_transport(ncells, pa
     GPU, each on its own host thread, exchanging through the library's in-process peer-copy transport (per-peer offsets, the
     event handshake, both streams of every rank, the local launch whole and in two parts: small domains have lists too short for
     two sets, so part 2 is empty there).  Three steps back to back without host synchronisation."""
+    monkeypatch.setenv("NBNXM_HIP_DIAGNOSTICS", "1")
     monkeypatch.setenv("HALO_GPU_LOCAL_PARTS", str(parts))
     nm = (14, 8, 8) if ncells[0] == 3 else (10, 10, 10)
     _check_virtual_rank_decomposition(tl.make_case(nm=nm, num_perturbed_molecules=3, elec="ewald", seed=78), ncells, peer_copy=True, repeats=3)
@@ -973,6 +978,7 @@ def test_cpp_domain_step_with_real_peers_over_the_peer_copy_transport(ncells, pa
 def test_cpp_domain_step_peer_copy_96k_box_two_part_launch(energy, monkeypatch):
     """2 x 2 x 2 ranks of the 96k box over the peer-copy transport: 12k home atoms per rank; and 2 x 1 x 1, where the local lists are
     long enough for the two-part launch to really cut them in two."""
+    monkeypatch.setenv("NBNXM_HIP_DIAGNOSTICS", "1")
     monkeypatch.setenv("HALO_GPU_LOCAL_PARTS", "2")
     c = tl.make_case(nm=(40, 40, 20), num_perturbed_molecules=16, elec="ewald", seed=2026, max_cjpacked_per_sci=16)
     _check_virtual_rank_decomposition(c, (2, 1, 1), oracle_threads=8, peer_copy=True, repeats=3, energy=energy)
@@ -1006,6 +1012,7 @@ def test_domain_step_over_rccl_with_the_local_launch_in_two_parts(energy, monkey
     """halo_gpu_domain_force_step with the local launch in two parts (the default with more than one rank: part 1 beside the coordinate
     halo, the non-local kernel, part 2 beside the force halo).  The 96k box is long enough for two sets of ranges; one rank that is its
     own neighbour along x, y and z runs the real RCCL groups.  Force-only steps (trailing workgroups ride with part 2) and energy steps."""
+    monkeypatch.setenv("NBNXM_HIP_DIAGNOSTICS", "1")
     monkeypatch.setenv("HALO_GPU_LOCAL_PARTS", "2")
     c = tl.make_case(nm=(40, 40, 20), num_perturbed_molecules=16, elec="ewald", seed=2026, max_cjpacked_per_sci=16)
     _check_virtual_rank_decomposition(c, (1, 1, 1), oracle_threads=8, self_links=(True, True, True), rccl=True, energy=energy)
@@ -1093,7 +1100,7 @@ def test_forces_are_the_gradient_of_the_energy(elec, vdw, fused):
 
 
 @pytest.mark.parametrize("fused", [False, True])
-@pytest.mark.parametrize("elec", ["ewald", "ewald_tab"])
+@pytest.mark.parametrize("elec", ["ewald", "ewald_tab", "ewald_tab_kept"])
 def test_pme_loadbal_update_param(elec, fused):
     """PME load balancing moves the Coulomb cut-off and the Ewald coefficient on a living object (gpu_pme_loadbal_update_param):
     scalars, the tabulated force and the LDS correction table must all follow.  Same box, same list (rlist unchanged)."""
@@ -1314,6 +1321,41 @@ def test_config1_24k_atom_box_reaction_field(fused):
     nb.free()
 
 
+@pytest.mark.parametrize("elec", ["rf", "ewald"])
+def test_the_same_perturbed_pairs_through_both_forms_24k(elec, monkeypatch):
+    """What pins the fused perturbed path: the pair math, fepPair, is shared with the atom-pair kernels, which the
+    reference's 72 known answers pin (test_gpu_fep_golden.py); the fused form's own part — the walk over the perturbed cluster pairs of
+    the list, fepClusterPair — cannot be fed that 4-atom system (it is not a cluster list).  So here the SAME perturbed pairs of the 24k
+    box go through all three forms — the fused cluster-pair form, the atom-pair list regrouped by cluster pair in the cluster kernel's
+    tail (fepListClusterItem) and the atom-pair kernel of its own (nbnxmFepKernel, the reference's shape) — and have to agree at 2e-5
+    per atom, five times tighter than the parity bar against the oracle; energies and dV/dlambda at 2e-5 of their terms' magnitude."""
+    c = tl.make_case(elec=elec, seed=2026, nm=(20, 20, 20), num_perturbed_molecules=3, n_lambda=11, max_cjpacked_per_sci=16)
+    want = tl.run_oracle(c, energy=True)
+    res = {}
+    res["fused"] = tl.run_gpu(c, energy=True, fused=True)
+    res["list in the tail"] = tl.run_gpu(c, energy=True, fused=False)
+    monkeypatch.setenv("NBNXM_HIP_DIAGNOSTICS", "1")
+    monkeypatch.setenv("NBNXM_HIP_FEP_LIST_MERGED", "0")
+    res["atom-pair kernel"] = tl.run_gpu(c, energy=True, fused=False)
+    ref = res["atom-pair kernel"]
+    frms = math.sqrt(float(np.mean(np.sum(ref["f"] ** 2, axis=1))))
+    pert_slots = np.flatnonzero(np.isin(c.grid.atomIndices, np.flatnonzero(c.perturbed)))
+    assert len(pert_slots) == 9
+    for name in ("fused", "list in the tail"):
+        got = res[name]
+        err = np.sqrt(np.sum((got["f"] - ref["f"]) ** 2, axis=1))
+        tol = 2e-5 * np.maximum(np.sqrt(np.sum(ref["f"] ** 2, axis=1)), frms)
+        worst = int(np.argmax(err / tol))
+        assert err[worst] <= tol[worst], "%s vs atom-pair kernel: atom slot %d differs by %.3e (|f| %.3e)" % (name, worst, err[worst], np.linalg.norm(ref["f"][worst]))
+        # the perturbed atoms themselves: every one of their pairs went through the form under test
+        assert np.all(err[pert_slots] <= tol[pert_slots])
+        for k in ("e_lj", "e_el"):
+            assert abs(got[k] - ref[k]) <= 2e-5 * max(abs(ref[k]), 1.0), (name, k, got[k], ref[k])
+        for k in ("dvdl_coul", "dvdl_vdw"):
+            assert abs(got[k] - ref[k]) <= 2e-5 * max(abs(ref[k]), want["fep_abs_sums"][k], 1e-3), (name, k, got[k], ref[k])
+    tl.assert_parity(res["fused"], want, rel=1e-4, label="24k %s fused" % elec)
+
+
 @pytest.mark.parametrize("fused", [False, True])
 def test_two_localities_force_only_sequence(fused):
     """F, F, VF, F, F with a Local and a NonLocal list on their two streams, copy-back and clear every step as mdrun does
@@ -1360,6 +1402,50 @@ def test_two_localities_force_only_sequence(fused):
         if not energy:
             got["fshift"] = want["fshift"]        # shift forces are only produced on virial steps
         tl.assert_parity(got, want, rel=1e-4, energy=energy, label="two localities, step %d" % step)
+    nb.free()
+
+
+def test_merged_localities_with_the_plain_call_sequence_return_the_halo_forces():
+    """nbnxm_gpu_set_merged_localities with the calls of the reference's sequence (advisor finding of round 3): the non-local list is
+    appended to the local device list, ONE launch evaluates both, and nbnxm_gpu_launch_cpyback(LOCAL) has to return the forces of ALL
+    atoms — with round 3's code it copied [0, numAtomsLocal) only and the non-local copy-back returned early, so the forces on the halo
+    atoms never reached the caller.  Local = the first half of the i-entries, NonLocal = the second, numAtomsLocal = half the atoms."""
+    c = tl.make_case(elec="ewald", seed=49, **SMALL)
+    g = c.grid
+    nb = pkg.NbnxmGpu(tl.gpu_interaction_params(c), g.num_types, g.nbat_nbfp(c.sys["nbfp"]), local_and_nonlocal=True, fep=True, n_lambda=0)
+    sig6 = c.sc_sigma ** 6
+    nb.copy_fepparams(c.sc_alpha, c.sc_alpha, c.sc_power, sig6, sig6, c.lambda_coul, c.lambda_vdw)
+    nb.set_merged_localities(True)
+    num_local = (g.num_atoms // 2) // 64 * 64
+    nb.init_atomdata(g.num_atoms, g.type, qA=g.qA, qB=g.qB, typeA=g.typeA, typeB=g.typeB, num_atoms_local=num_local)
+    pl = c.plist_fused
+    half = len(pl.sci) // 2
+    nb.init_pairlist(pl.sci[:half], pl.cjPacked, pl.excl, iloc=pkg.LOCAL)
+    nb.init_pairlist(pl.sci[half:], pl.cjPacked, pl.excl, iloc=pkg.NONLOCAL)
+    nb.init_fep_cluster_bits(g.fepBits)
+    nb.set_fep_mode(True)
+    nb.upload_shiftvec(g.shift_vec)
+    want = tl.run_oracle(c, energy=True)
+    nb.clear_outputs(True)
+    for step, energy in enumerate((False, True, False)):
+        sw = pkg.step_workload(energy=energy, virial=energy)
+        nb.copy_xq_to_gpu(g.xq, pkg.LOCAL)
+        nb.copy_xq_to_gpu(g.xq, pkg.NONLOCAL)
+        import torch
+        torch.cuda.synchronize()                   # (the halo coordinates arrive on the non-local stream: the caller orders the launch behind them)
+        nb.launch_kernel(sw, pkg.LOCAL)            # the one kernel of the step (all coordinates are in place)
+        nb.launch_kernel(sw, pkg.NONLOCAL)         # empty device list: nothing
+        f = np.zeros((g.num_atoms, 3), np.float32)
+        nb.launch_cpyback(f, sw, pkg.NONLOCAL)     # nothing
+        nb.launch_cpyback(f, sw, pkg.LOCAL)        # all atoms
+        nb.wait_finish_task(sw, c.have_soft_core, pkg.NONLOCAL)
+        res = nb.wait_finish_task(sw, c.have_soft_core, pkg.LOCAL)
+        nb.clear_outputs(energy)
+        assert np.any(f[num_local:] != 0.0), "no force on any atom behind numAtomsLocal"
+        dv = res["dvdl_nonlin"]
+        got = dict(f=f.astype(np.float64), fshift=res["fshift"].astype(np.float64) if energy else want["fshift"], e_lj=res["e_lj"], e_el=res["e_el"],
+                   dvdl_coul=dv[0], dvdl_vdw=dv[1])
+        tl.assert_parity(got, want, rel=1e-4, energy=energy, label="merged localities, plain sequence, step %d" % step)
     nb.free()
 
 

@@ -23,7 +23,7 @@ for elec, vdw, rvdw in FLAVOURS:
     if only and name not in only.split(","):
         continue
     # (a tabulated pick runs the analytical kernels by default, csrc/nbnxm_gpu.hip: kernelElecType; these rows time the tabulated kernels)
-    os.environ["NBNXM_HIP_KEEP_TAB_KERNELS"] = "1" if elec == "ewald_tab" else "0"
+    elec = "ewald_tab_kept" if elec == "ewald_tab" else elec   # the tabulated kernels themselves
     c = wl.make_case(nm=(40, 40, 20), num_perturbed_molecules=16, elec=elec, vdw=vdw, rvdw=rvdw, seed=2026, n_lambda=11, max_cjpacked_per_sci=16)
     nb = wl.setup_gpu(c, fused=True, use_dynamic_pruning=True)
     nb.set_timing(False)
