@@ -1996,6 +1996,10 @@ static int finishTask(NbnxmGpu* nb, const nbnxm_step_workload_t* stepWork, int a
         }
         else { nb->deviceStreams[iloc].synchronize(); }
         checkListErrorFlag(nb); /* (the list check runs on the device: gpu_init_pairlist) */
+        /* the count of perturbed cluster pairs of a new list is picked up without a wait (updateWorkPartition): the stream has just been
+         * synchronised, so it has arrived, and a list with more of them than the fused mode provides for ends the run HERE — before the
+         * caller consumes the outputs of a step whose kernels evaluated a truncated list (advisor finding of round 3) */
+        if (wait || nb->deviceStreams[iloc].completed()) { pickUpSlowCount(nb, iloc); }
         accumulateTimings(nb, iloc);
         if (iloc == NBNXM_LOCAL)
         {

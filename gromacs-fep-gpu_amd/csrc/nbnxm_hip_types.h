@@ -184,8 +184,9 @@ constexpr int c_coulombTabMaxLds = 16384; /* entries of the r-indexed table that
 /* waves per workgroup of nbnxmFepClusterKernel */
 constexpr int c_fepClusterWavesPerBlockDef = 4;
 /* What the ENERGY flavours of the cluster kernel carry in trailing workgroups (the force flavours carry everything): 0 nothing,
- * 1 a pending rolling-prune part and the clear of the spare force buffer, 2 also the perturbed cluster pairs (fused mode, not on
- * dH/dlambda steps with foreign lambdas).  Compile-time ceiling; NBNXM_HIP_ENERGY_TAIL lowers it at run time. */
+ * 1 a pending rolling-prune part and the clear of the spare force buffer, 2 also the perturbed cluster pairs (fused mode; on
+ * dH/dlambda steps with their energies at every foreign lambda, the FOREIGN flavour of fepClusterPair).  Compile-time ceiling;
+ * NBNXM_HIP_ENERGY_TAIL (diagnostics) lowers it at run time. */
 #ifndef NBNXM_ENERGY_TAIL
 #define NBNXM_ENERGY_TAIL 2
 #endif

@@ -19,6 +19,13 @@ def replica_lambda(rank, world_size, n_lambda=11, single_gpu_lambda=0.5):
     return float(lambda_schedule(n_lambda)[rank % n_lambda])
 
 
+def windows_of_rank(rank, world_size, n_windows=11):
+    """The lambda windows rank `rank` holds when ALL n_windows windows of a set are spread over world_size ranks (BASELINE configs[3]:
+    11 windows on the 8 GPUs of a node): windows rank, rank + world_size, ... — at most ceil(n_windows / world_size) per rank, every
+    window on exactly one rank.  A rank with several windows runs them as ONE object (batch_windows): one launch for all of them."""
+    return list(range(int(rank), int(n_windows), int(world_size)))
+
+
 def max_over_ranks(value, dist=None, device="cpu"):
     """Max of a python float over all ranks (the bench's timed interval)."""
     if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:

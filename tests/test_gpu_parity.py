@@ -1221,6 +1221,58 @@ def test_seed_and_shape_sweep(seed, nm, npert):
             tl.assert_parity(tl.run_gpu(c, energy=False, fused=fused), want, rel=1e-4, energy=False, label="%s fused=%s F" % (elec, fused))
 
 
+def test_two_lambda_windows_of_the_24k_box_in_one_object():
+    """BASELINE configs[1] / [3] at size: two lambda windows of the 24,000-atom reaction-field box as ONE object (what a rank of the
+    11-window set holds when there are fewer GPUs than windows) against the two windows run alone — forces per atom, energies and
+    dV/dlambda per window."""
+    import importlib
+    replica = importlib.import_module("gromacs_fep_gpu_amd.replica")
+    c = tl.make_case(elec="rf", seed=2026, nm=(20, 20, 20), num_perturbed_molecules=3, n_lambda=0, max_cjpacked_per_sci=16)
+    g = c.grid
+    lambdas = [(0.3, 0.3), (0.8, 0.8)]
+    sw_e = pkg.step_workload(energy=True, virial=True, dhdl=False)
+
+    def run(nb, natoms):
+        nb.clear_outputs(True)
+        nb.launch_kernel(sw_e)
+        f = np.zeros((natoms, 3), np.float32)
+        nb.launch_cpyback(f, sw_e)
+        return f, nb.wait_finish_task(sw_e, c.have_soft_core)
+
+    alone = []
+    for lq, lv in lambdas:
+        nb = tl.setup_gpu(c, fused=True)
+        _set_lambdas(nb, c, lq, lv)
+        alone.append(run(nb, g.num_atoms))
+        nb.free()
+    b = replica.batch_windows(g, c.plist_fused, len(lambdas))
+    nb = pkg.NbnxmGpu(tl.gpu_interaction_params(c), g.num_types, g.nbat_nbfp(c.sys["nbfp"]), fep=True, n_lambda=0)
+    _set_lambdas(nb, c, 0.0, 0.0)
+    nb.init_atomdata(len(b["type"]), b["type"], qA=b["qA"], qB=b["qB"], typeA=b["typeA"], typeB=b["typeB"])
+    nb.init_pairlist(b["sci"], b["cjPacked"], b["excl"])
+    nb.init_fep_cluster_bits(b["fepBits"])
+    nb.set_fep_mode(True)
+    nb.set_window_lambdas(b["clusters_per_window"], [l[0] for l in lambdas], [l[1] for l in lambdas])
+    nb.upload_shiftvec(g.shift_vec)
+    nb.copy_xq_to_gpu(b["xq"])
+    f, tot = run(nb, len(b["type"]))
+    ns = b["slots_per_window"]
+    for w, (fw, want) in enumerate(alone):
+        got = f[w * ns:(w + 1) * ns].astype(np.float64)
+        frms = np.sqrt(np.mean(np.sum(fw.astype(np.float64) ** 2, axis=1)))
+        err = np.linalg.norm(got - fw, axis=1)
+        assert (err <= 1e-4 * np.maximum(np.linalg.norm(fw, axis=1), frms)).all(), "window %d" % w
+        res = nb.get_window_energies(w, c.have_soft_core)
+        for k in ("e_lj", "e_el"):
+            assert abs(res[k] - want[k]) <= 1e-4 * max(abs(want[k]), 1.0), (w, k, res[k], want[k])
+        for k in range(2):
+            scale = max(max(abs(v) for v in want["dvdl_nonlin"]), 1.0)
+            assert abs(res["dvdl_nonlin"][k] - want["dvdl_nonlin"][k]) <= 1e-4 * scale, (w, k)
+    assert np.max(np.abs(alone[0][0] - alone[1][0])) > 1.0          # the windows do differ
+    assert abs(tot["e_el"] - (alone[0][1]["e_el"] + alone[1][1]["e_el"])) <= 1e-4 * abs(tot["e_el"])
+    nb.free()
+
+
 def test_lambda_windows_batched_into_one_object():
     """Three lambda windows of one system as ONE object (one list over 3 x N slots, per-window lambdas from a table): forces,
     energies, dV/dlambda and foreign-lambda terms of every window equal those of the window run alone with its own lambda and

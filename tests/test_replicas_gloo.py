@@ -70,3 +70,18 @@ def test_replica_lambda_assignment():
     lams = [replica.replica_lambda(r, 8) for r in range(8)]
     assert lams == pytest.approx([0.0, 0.1, 0.2, 0.3, 0.4, 0.5, 0.6, 0.7])
     assert replica.replica_lambda(11, 16) == 0.0
+
+
+@pytest.mark.parametrize("world,n", [(1, 11), (2, 11), (4, 11), (8, 11), (8, 5), (16, 11)])
+def test_every_window_of_the_set_is_on_exactly_one_rank(world, n):
+    """BASELINE configs[3]: 11 lambda windows on the 8 GPUs of a node — a rank with more than one window runs them as one object
+    (replica.batch_windows); the assignment has to cover every window once and be balanced to within one window."""
+    sys.path.insert(0, os.path.dirname(HERE))
+    from __graft_entry__ import load_package
+    load_package()
+    import importlib
+    replica = importlib.import_module("gromacs_fep_gpu_amd.replica")
+    held = [replica.windows_of_rank(r, world, n) for r in range(world)]
+    assert sorted(w for h in held for w in h) == list(range(n))
+    sizes = [len(h) for h in held]
+    assert max(sizes) - min(sizes) <= 1 and max(sizes) == -(-n // world)
