@@ -189,6 +189,199 @@ __global__ void domainHomeRowsKernel(float* __restrict__ f, const float3* __rest
     atomicAdd(d + 2, v.z);
 }
 
+/* ---- one-sided transport: stores into the peer's rows, sequence flags, no transfer kernel, no event ------------------------
+ *
+ * The exchanges of a step are sub-megabyte, latency-bound messages between GPUs that are all linked to each other (xGMI): the
+ * MI355X-native form is a store into the peer's memory, not a collective.  The sender's pack kernel writes the shifted coordinates
+ * STRAIGHT into the receiver's halo rows and then publishes the exchange's sequence number in a flag in the receiver's memory; the
+ * receiver's x -> xq kernel waits for the flags of its links before it reads the rows.  Forces go back the same way: the kernel that
+ * moves the forces to atom order stores the halo rows into their owners' receive buffers and sets their flags, the owners' unpack-add
+ * kernel waits for them.  Two more flags per link run the other way ("rows consumed"), so that the next step's stores cannot
+ * overtake this step's readers.  All waits are polls of the waiter's OWN memory; all stores to a peer are release-ordered at system
+ * scope behind the data (the last workgroup of the storing kernel, found with a counter, writes the flags).
+ *
+ * Flags of a rank (PushFlags, one 64-byte line each): [kind][link]
+ *   xReady[k]     my receive link k: the peer has stored the rows of exchange seq                  (polled by my x -> xq)
+ *   fConsumed[k]  my receive link k: the owner has added the forces I stored for exchange seq       (polled by my forces kernel)
+ *   fReady[k]     my send link k: the peer has stored the forces on my atoms for exchange seq      (polled by my unpack-add)
+ *   xConsumed[k]  my send link k: the peer's x -> xq has read the rows I stored for exchange seq    (polled by my pack kernel)
+ */
+constexpr int      c_pushMaxLinks   = 64;
+constexpr int      c_pushFlagStride = 16; /* unsigned per flag: one 64-byte line each */
+constexpr unsigned c_pushMaxSpins   = 4U << 20; /* x ~0.5 us of s_sleep: a wait of seconds is a lost peer — report it, do not hang the device */
+enum PushFlagKind
+{
+    c_flagXReady = 0,
+    c_flagFConsumed,
+    c_flagFReady,
+    c_flagXConsumed,
+    c_numPushFlagKinds
+};
+
+/* what the kernels of one rank need to know about its links (device copy, rebuilt by halo_gpu_reinit) */
+struct PushLinks
+{
+    int       numSend, numRecv;
+    int       sendOffset[c_pushMaxLinks + 1]; /* entries [sendOffset[k], sendOffset[k + 1]) of the send map go to send link k */
+    int       recvAtomOffset[c_pushMaxLinks]; /* rows [recvAtomOffset[k], + recvCount[k]) of d_x / d_f belong to receive link k */
+    int       recvCount[c_pushMaxLinks];
+    float3*   xDst[c_pushMaxLinks];           /* send link k: the peer's row of my entry 0 of that link, minus sendOffset[k] (so that dst = xDst[k] + i) */
+    unsigned* xReadyDst[c_pushMaxLinks];      /* ... and the peer's xReady flag of this link */
+    unsigned* fConsumedDst[c_pushMaxLinks];   /* send link k: the peer's fConsumed flag (I am the owner, the peer stored the forces) */
+    float3*   fDst[c_pushMaxLinks];           /* receive link k: the owner's receive-buffer entry of my row recvAtomOffset[k], minus that offset */
+    unsigned* fReadyDst[c_pushMaxLinks];      /* ... and the owner's fReady flag of this link */
+    unsigned* xConsumedDst[c_pushMaxLinks];   /* receive link k: the sender's xConsumed flag */
+};
+
+/* Everything another device (or another XCD of this one) has stored, or is to read, is moved with SYSTEM-scope accesses — the
+ * compiler gives them the cache-policy bits that bypass the caches between the wave and the memory (write-through stores, loads that
+ * cannot hit a stale line).  No fence instruction anywhere: a system-scope release or acquire FENCE on this hardware writes back or
+ * invalidates the whole L2 — measured with fences in these kernels: a 0.093 ms step became 0.241 ms.  Ordering comes from completion
+ * instead: a wave waits until its own stores have been acknowledged (s_waitcnt) before its workgroup is counted as done, the last
+ * workgroup then stores the flags; a waiter reads the rows only behind the barrier that follows the poll. */
+__device__ __forceinline__ unsigned loadFlag(const unsigned* flag)
+{
+    return __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+__device__ __forceinline__ void storeFlag(unsigned* flag, unsigned value)
+{
+    __hip_atomic_store(flag, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+/* (one 12-byte access per row, as asm: the scoped atomic builtins are 4 bytes wide — three transactions per row; measured at 168k halo
+ * atoms: 0.449 ms per step against 0.379 ms over RCCL) */
+typedef float nb_float3v __attribute__((ext_vector_type(3)));
+__device__ __forceinline__ void storeAcrossDevices(float3* dst, const float3 v)
+{
+    const nb_float3v d = { v.x, v.y, v.z };
+    asm volatile("global_store_dwordx3 %0, %1, off sc0 sc1" ::"v"(dst), "v"(d) : "memory");
+}
+__device__ __forceinline__ float3 loadAcrossDevices(const float3* src)
+{
+    nb_float3v d;
+    asm volatile("global_load_dwordx3 %0, %1, off sc0 sc1\n\ts_waitcnt vmcnt(0)" : "=v"(d) : "v"(src) : "memory");
+    return make_float3(d.x, d.y, d.z);
+}
+
+/* the workgroup waits until the n flags have reached `want` and goes on behind the barrier.  A flag that does
+ * not arrive within c_pushMaxSpins polls is reported in *error (mapped host memory; the host ends the run at its next call). */
+__device__ __forceinline__ void waitForFlags(const unsigned* flags, const int n, const unsigned want, unsigned* error)
+{
+    /* one lane per flag: the polls of a workgroup's links run side by side (a system-scope load is a round trip to the memory) */
+    if (static_cast<int>(threadIdx.x) < n)
+    {
+        const int k     = static_cast<int>(threadIdx.x);
+        unsigned  spins = 0;
+        while (static_cast<int>(loadFlag(flags + k * c_pushFlagStride) - want) < 0)
+        {
+            __builtin_amdgcn_s_sleep(32);
+            if (++spins > c_pushMaxSpins)
+            {
+                __hip_atomic_store(error, 1U + static_cast<unsigned>(k), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                break;
+            }
+        }
+    }
+    __syncthreads();
+}
+
+/* behind the stores of a kernel: the LAST workgroup to get here (a counter finds it) publishes `seq` in the n remote flags.  Every
+ * wave waits for the acknowledgement of its own stores before its workgroup counts itself. */
+__device__ __forceinline__ void publishWhenAllWorkgroupsAreDone(unsigned* const* flagDst, const int n, const unsigned seq, unsigned* doneCounter)
+{
+    __builtin_amdgcn_s_waitcnt(0); /* vmcnt(0): this wave's stores have been acknowledged */
+    __syncthreads();
+    if (threadIdx.x == 0)
+    {
+        const unsigned done = __hip_atomic_fetch_add(doneCounter, 1U, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (done == gridDim.x - 1U)
+        {
+            __hip_atomic_store(doneCounter, 0U, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            for (int k = 0; k < n; k++) { storeFlag(flagDst[k], seq); }
+        }
+    }
+}
+
+__device__ __forceinline__ int linkOfIndex(const int* __restrict__ offsets, const int n, const int i)
+{
+    int k = 0;
+    while (k + 1 < n && i >= offsets[k + 1]) { k++; }
+    return k;
+}
+
+/* coordinates out: x[map[i]] + shift stored into the receiver's halo row; flags: wait xConsumed(seq - 1), publish xReady(seq) */
+__global__ void haloPushCoordinatesKernel(const float3* __restrict__ x, const int* __restrict__ map, const int* __restrict__ shiftIndex,
+                                          const float3* __restrict__ shiftVectors, const int n, const PushLinks* __restrict__ links,
+                                          const unsigned* myFlags, const unsigned seq, unsigned* doneCounter, unsigned* error)
+{
+    if (seq > 1U) { waitForFlags(myFlags + c_flagXConsumed * c_pushMaxLinks * c_pushFlagStride, links->numSend, seq - 1U, error); }
+    for (int i = static_cast<int>(blockIdx.x * blockDim.x + threadIdx.x); i < n; i += static_cast<int>(gridDim.x * blockDim.x))
+    {
+        const int    k = linkOfIndex(links->sendOffset, links->numSend, i);
+        const float3 v = x[map[i]];
+        const float3 s = shiftVectors[shiftIndex[i]];
+        storeAcrossDevices(links->xDst[k] + i, make_float3(v.x + s.x, v.y + s.y, v.z + s.z));
+    }
+    publishWhenAllWorkgroupsAreDone(links->xReadyDst, links->numSend, seq, doneCounter);
+}
+
+/* x -> xq of all grid slots of the domain behind the arrival of the halo rows; flags: wait xReady(seq), publish xConsumed(seq) */
+__global__ void haloWaitXToXqKernel(float4* __restrict__ xq, const float3* x, const int* __restrict__ atomIndex, const int numSlots, const int numHome,
+                                    const PushLinks* __restrict__ links, const unsigned* myFlags, const unsigned seq, unsigned* doneCounter,
+                                    unsigned* error)
+{
+    waitForFlags(myFlags + c_flagXReady * c_pushMaxLinks * c_pushFlagStride, links->numRecv, seq, error);
+    for (int slot = static_cast<int>(blockIdx.x * blockDim.x + threadIdx.x); slot < numSlots; slot += static_cast<int>(gridDim.x * blockDim.x))
+    {
+        const int a = atomIndex[slot];
+        /* (home rows are this rank's own; halo rows were stored by the peers) */
+        if (a >= 0) { *reinterpret_cast<float3*>(&xq[slot]) = (a < numHome) ? x[a] : loadAcrossDevices(x + a); }
+    }
+    publishWhenAllWorkgroupsAreDone(links->xConsumedDst, links->numRecv, seq, doneCounter);
+}
+
+/* forces to atom order, the halo rows also stored into their owners' receive buffers; flags: wait fConsumed(seq - 1), publish fReady(seq) */
+__global__ void haloPushForcesKernel(float3* __restrict__ f, const float3* __restrict__ nbnxmForce, const int* __restrict__ cell, const int numHome,
+                                     const int numAtoms, const PushLinks* __restrict__ links, const unsigned* myFlags, const unsigned seq,
+                                     unsigned* doneCounter, unsigned* error)
+{
+    if (seq > 1U) { waitForFlags(myFlags + c_flagFConsumed * c_pushMaxLinks * c_pushFlagStride, links->numRecv, seq - 1U, error); }
+    for (int i = static_cast<int>(blockIdx.x * blockDim.x + threadIdx.x); i < numAtoms; i += static_cast<int>(gridDim.x * blockDim.x))
+    {
+        const float3 v = nbnxmForce[cell[i]];
+        f[i]           = v;
+        if (i >= numHome)
+        {
+            /* (a halo row that belongs to no link — none with a consistent plan — stays local) */
+            for (int k = 0; k < links->numRecv; k++)
+            {
+                if (i >= links->recvAtomOffset[k] && i < links->recvAtomOffset[k] + links->recvCount[k])
+                {
+                    storeAcrossDevices(links->fDst[k] + i, v);
+                    break;
+                }
+            }
+        }
+    }
+    publishWhenAllWorkgroupsAreDone(links->fReadyDst, links->numRecv, seq, doneCounter);
+}
+
+/* f[sendMap[j]] += what the peers computed on this rank's atoms; flags: wait fReady(seq), publish fConsumed(seq) */
+__global__ void haloWaitUnpackAddKernel(float* __restrict__ f, const float3* packed, const int* __restrict__ map, const int n,
+                                        const PushLinks* __restrict__ links, const unsigned* myFlags, const unsigned seq, unsigned* doneCounter,
+                                        unsigned* error)
+{
+    waitForFlags(myFlags + c_flagFReady * c_pushMaxLinks * c_pushFlagStride, links->numSend, seq, error);
+    for (int i = static_cast<int>(blockIdx.x * blockDim.x + threadIdx.x); i < n; i += static_cast<int>(gridDim.x * blockDim.x))
+    {
+        const float3 v = loadAcrossDevices(packed + i);
+        float*       d = f + 3 * static_cast<size_t>(map[i]);
+        atomicAdd(d + 0, v.x);
+        atomicAdd(d + 1, v.y);
+        atomicAdd(d + 2, v.z);
+    }
+    publishWhenAllWorkgroupsAreDone(links->fConsumedDst, links->numSend, seq, doneCounter);
+}
+
 /* ---- in-process peer-copy transport -------------------------------------------------------------------------------------- */
 
 /* what a receiver needs to know about the sender of a step: where its buffers are and how its links are laid out.  Immutable;
@@ -199,6 +392,11 @@ struct PeerLayout
     const float3*    d_f       = nullptr; /* forces in the rank's atom order: the halo rows are what the owners pull */
     const float3*    d_sendBuf = nullptr; /* packed coordinates: what the receivers pull */
     std::vector<int> sendPeer, sendOffset, recvPeer, recvAtomOffset, recvCount;
+    /* one-sided transport: what the peers store into */
+    float3*          d_x       = nullptr;
+    float3*          d_recvBuf = nullptr;
+    unsigned*        d_flags   = nullptr;
+    long             generation = 0; /* the rank's count of halo_gpu_reinit calls */
 };
 
 enum PeerPostKind
@@ -226,11 +424,19 @@ struct PeerWorld
     int                     nranks   = 0;
     int                     attached = 0;
     std::vector<PeerPost>   posts; /* [(rank * c_numPostKinds + kind) * c_peerRing + seq % c_peerRing] */
+    /* one-sided transport */
+    bool                                            push = false;
+    std::vector<std::shared_ptr<const PeerLayout>>  pushLayout;   /* [rank]: the layout of its last halo_gpu_reinit */
+    std::vector<int>                                devices;      /* [rank] or -1 */
+    bool                                            sharedDevice = false; /* two ranks of this world run on one device */
+    std::vector<void*>                              retired;      /* flags and receive buffers of ranks that have gone: peers may still store into them */
+    long                                            barrierCount = 0, barrierGeneration = 0;
 };
 
 std::mutex                                        g_worldsMutex;
 std::map<std::string, std::shared_ptr<PeerWorld>> g_worlds;
 constexpr char                                    c_peerIdMagic[8] = { 'H', 'A', 'L', 'O', 'P', 'E', 'E', 'R' };
+constexpr char                                    c_pushIdMagic[8] = { 'H', 'A', 'L', 'O', 'P', 'U', 'S', 'H' };
 
 } // namespace
 
@@ -280,6 +486,14 @@ struct HaloGpu
      * this rank's buffers, so the first exchange after a reinit also waits for their "pulled" posts */
     std::vector<int>                  formerSendPeer, formerRecvPeer;
     double                            peerTimeoutSeconds = 30.0;
+    /* one-sided transport (world->push) */
+    unsigned*  d_flags       = nullptr; /* c_numPushFlagKinds x c_pushMaxLinks flags of c_pushFlagStride unsigned: peers store, this rank polls */
+    unsigned*  d_doneCounter = nullptr; /* one per kernel of the step */
+    PushLinks* d_links       = nullptr;
+    unsigned*  h_pushError   = nullptr; /* mapped host memory: a poll that gave up */
+    unsigned*  d_pushError   = nullptr;
+    long       generation    = 0;
+    unsigned   pushSeq       = 0;       /* steps done */
 };
 
 namespace
@@ -402,6 +616,113 @@ void peerExchangeForces(HaloGpu* h)
     h->fSeq = q + 1;
 }
 
+/* all ranks of the world (one-sided transport: at the end of a reinit, and between the phases of a step when ranks share a device) */
+void worldBarrier(HaloGpu* h)
+{
+    PeerWorld&                   w = *h->world;
+    std::unique_lock<std::mutex> lock(w.mutex);
+    const long                   gen = w.barrierGeneration;
+    if (++w.barrierCount == w.nranks)
+    {
+        w.barrierCount = 0;
+        w.barrierGeneration++;
+        w.cv.notify_all();
+        return;
+    }
+    const bool ok = w.cv.wait_for(lock, std::chrono::duration<double>(h->peerTimeoutSeconds), [&] { return w.barrierGeneration != gen; });
+    if (!ok) { fatal(__FILE__, __LINE__, "halo one-sided transport", "a rank did not reach the barrier (every rank needs its own host thread and the same sequence of calls)"); }
+}
+
+void checkPushError(HaloGpu* h)
+{
+    if (h->h_pushError != nullptr && *h->h_pushError != 0U)
+    {
+        char msg[160];
+        std::snprintf(msg, sizeof(msg), "rank %d: a kernel gave up waiting for the flag of link %u (a peer never stored its side of an exchange)", h->rank,
+                      *h->h_pushError - 1U);
+        fatal(__FILE__, __LINE__, "halo one-sided transport", msg);
+    }
+}
+
+/* halo_gpu_reinit, one-sided transport: publish this rank's buffers, wait for the neighbours', derive every link's remote addresses */
+void pushReinit(HaloGpu* h)
+{
+    PeerWorld& w = *h->world;
+    NBNXM_ASSERT(static_cast<int>(h->sendPeer.size()) <= c_pushMaxLinks && static_cast<int>(h->recvPeer.size()) <= c_pushMaxLinks,
+                 "more links than the one-sided transport provides flags for");
+    h->generation++;
+    auto layout            = std::make_shared<PeerLayout>();
+    layout->device         = h->device;
+    layout->d_f            = h->d_f;
+    layout->d_sendBuf      = h->d_sendBuf;
+    layout->sendPeer       = h->sendPeer;
+    layout->sendOffset     = h->sendOffset;
+    layout->recvPeer       = h->recvPeer;
+    layout->recvAtomOffset = h->recvAtomOffset;
+    layout->recvCount      = h->recvCount;
+    layout->d_x            = h->d_x;
+    layout->d_recvBuf      = h->d_recvBuf;
+    layout->d_flags        = h->d_flags;
+    layout->generation     = h->generation;
+    h->layout              = layout;
+    {
+        std::lock_guard<std::mutex> lock(w.mutex);
+        w.pushLayout[h->rank] = layout;
+    }
+    w.cv.notify_all();
+    auto layoutOf = [&](int peer) {
+        std::unique_lock<std::mutex> lock(w.mutex);
+        const bool ok = w.cv.wait_for(lock, std::chrono::duration<double>(h->peerTimeoutSeconds),
+                                      [&] { return w.pushLayout[peer] && w.pushLayout[peer]->generation >= h->generation; });
+        if (!ok) { fatal(__FILE__, __LINE__, "halo one-sided transport", "a neighbour did not call halo_gpu_reinit (every rank re-registers at every search step)"); }
+        return w.pushLayout[peer];
+    };
+    PushLinks L;
+    std::memset(&L, 0, sizeof(L));
+    L.numSend = static_cast<int>(h->sendPeer.size());
+    L.numRecv = static_cast<int>(h->recvPeer.size());
+    auto flagOf = [](unsigned* flags, int kind, int link) { return flags + (static_cast<size_t>(kind) * c_pushMaxLinks + link) * c_pushFlagStride; };
+    for (int k = 0; k <= L.numSend; k++) { L.sendOffset[k] = h->sendOffset[k]; }
+    for (int k = 0; k < L.numSend; k++)
+    {
+        const std::shared_ptr<const PeerLayout> peer = layoutOf(h->sendPeer[k]);
+        const int                               link = linkTo(peer->recvPeer, h->rank);
+        NBNXM_ASSERT(link >= 0 && peer->recvCount[link] == h->sendOffset[k + 1] - h->sendOffset[k], "the two sides of a halo link disagree on its size");
+        if (peer->device != h->device)
+        {
+            int can = 0;
+            NBNXM_HIP_CHECK(hipDeviceCanAccessPeer(&can, h->device, peer->device));
+            NBNXM_ASSERT(can != 0, "the one-sided transport needs peer access between the devices of the ranks");
+            const hipError_t e = hipDeviceEnablePeerAccess(peer->device, 0);
+            if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) { NBNXM_HIP_CHECK(e); }
+            (void)hipGetLastError();
+        }
+        L.xDst[k]         = peer->d_x + peer->recvAtomOffset[link] - h->sendOffset[k];
+        L.xReadyDst[k]    = flagOf(peer->d_flags, c_flagXReady, link);
+        L.fConsumedDst[k] = flagOf(peer->d_flags, c_flagFConsumed, link);
+    }
+    for (int k = 0; k < L.numRecv; k++)
+    {
+        const std::shared_ptr<const PeerLayout> peer = layoutOf(h->recvPeer[k]);
+        const int                               link = linkTo(peer->sendPeer, h->rank);
+        NBNXM_ASSERT(link >= 0 && peer->sendOffset[link + 1] - peer->sendOffset[link] == h->recvCount[k], "the two sides of a halo link disagree on its size");
+        if (peer->device != h->device)
+        {
+            const hipError_t e = hipDeviceEnablePeerAccess(peer->device, 0);
+            if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) { NBNXM_HIP_CHECK(e); }
+            (void)hipGetLastError();
+        }
+        L.recvAtomOffset[k] = h->recvAtomOffset[k];
+        L.recvCount[k]      = h->recvCount[k];
+        L.fDst[k]           = peer->d_recvBuf + peer->sendOffset[link] - h->recvAtomOffset[k];
+        L.fReadyDst[k]      = flagOf(peer->d_flags, c_flagFReady, link);
+        L.xConsumedDst[k]   = flagOf(peer->d_flags, c_flagXConsumed, link);
+    }
+    NBNXM_HIP_CHECK(hipMemcpy(h->d_links, &L, sizeof(L), hipMemcpyHostToDevice));
+    /* every rank has published and read: from here on the old buffers of any rank are out of use, and the device set is known */
+    worldBarrier(h);
+}
+
 } // namespace
 
 extern "C"
@@ -415,7 +736,7 @@ const char* halo_gpu_last_error(void)
 int halo_gpu_get_unique_id_ex(void* uniqueId, int transport)
 {
     if (transport == HALO_GPU_TRANSPORT_RCCL) { return halo_gpu_get_unique_id(uniqueId); }
-    if (transport != HALO_GPU_TRANSPORT_PEER_COPY)
+    if (transport != HALO_GPU_TRANSPORT_PEER_COPY && transport != HALO_GPU_TRANSPORT_PEER_PUSH)
     {
         g_haloError = "unknown halo transport";
         return 3;
@@ -424,7 +745,7 @@ int halo_gpu_get_unique_id_ex(void* uniqueId, int transport)
     static std::mutex counterMutex;
     static long long  counter = 0;
     std::memset(uniqueId, 0, HALO_GPU_UNIQUE_ID_BYTES);
-    std::memcpy(uniqueId, c_peerIdMagic, sizeof(c_peerIdMagic));
+    std::memcpy(uniqueId, transport == HALO_GPU_TRANSPORT_PEER_PUSH ? c_pushIdMagic : c_peerIdMagic, sizeof(c_peerIdMagic));
     std::lock_guard<std::mutex> lock(counterMutex);
     const long long             value = ++counter;
     std::memcpy(static_cast<char*>(uniqueId) + sizeof(c_peerIdMagic), &value, sizeof(value));
@@ -453,7 +774,8 @@ HaloGpu* halo_gpu_create(const void* uniqueId, int rank, int nranks, void* strea
         g_haloError = "rank outside [0, nranks)";
         return nullptr;
     }
-    const bool peerCopyTransport = (std::memcmp(uniqueId, c_peerIdMagic, sizeof(c_peerIdMagic)) == 0);
+    const bool pushTransport     = (std::memcmp(uniqueId, c_pushIdMagic, sizeof(c_pushIdMagic)) == 0);
+    const bool peerCopyTransport = pushTransport || (std::memcmp(uniqueId, c_peerIdMagic, sizeof(c_peerIdMagic)) == 0);
     auto*      h                 = new HaloGpu;
     h->rank   = rank;
     h->nranks = nranks;
@@ -470,6 +792,9 @@ HaloGpu* halo_gpu_create(const void* uniqueId, int rank, int nranks, void* strea
             w         = std::make_shared<PeerWorld>();
             w->nranks = nranks;
             w->posts.resize(static_cast<size_t>(nranks) * c_numPostKinds * c_peerRing);
+            w->push = pushTransport;
+            w->pushLayout.resize(nranks);
+            w->devices.assign(nranks, -1);
         }
         if (w->nranks != nranks)
         {
@@ -478,7 +803,24 @@ HaloGpu* halo_gpu_create(const void* uniqueId, int rank, int nranks, void* strea
             return nullptr;
         }
         w->attached++;
+        for (int r = 0; r < nranks; r++)
+        {
+            if (r != rank && w->devices[r] == h->device) { w->sharedDevice = true; }
+        }
+        w->devices[rank] = h->device;
         h->world = w;
+        if (pushTransport)
+        {
+            const size_t numFlags = static_cast<size_t>(c_numPushFlagKinds) * c_pushMaxLinks * c_pushFlagStride;
+            NBNXM_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&h->d_flags), sizeof(unsigned) * numFlags));
+            NBNXM_HIP_CHECK(hipMemset(h->d_flags, 0, sizeof(unsigned) * numFlags));
+            NBNXM_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&h->d_doneCounter), sizeof(unsigned) * 4 * c_pushFlagStride));
+            NBNXM_HIP_CHECK(hipMemset(h->d_doneCounter, 0, sizeof(unsigned) * 4 * c_pushFlagStride));
+            NBNXM_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&h->d_links), sizeof(PushLinks)));
+            NBNXM_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&h->h_pushError), sizeof(unsigned), hipHostMallocMapped));
+            *h->h_pushError = 0U;
+            NBNXM_HIP_CHECK(hipHostGetDevicePointer(reinterpret_cast<void**>(&h->d_pushError), h->h_pushError, 0));
+        }
         for (int k = 0; k < c_numPostKinds; k++)
         {
             for (int i = 0; i < c_peerRing; i++) { NBNXM_HIP_CHECK(hipEventCreateWithFlags(&h->peerEvents[k][i], hipEventDisableTiming)); }
@@ -534,12 +876,28 @@ void halo_gpu_free(HaloGpu* h)
         /* peers may still have copies out of this rank's buffers in flight: the whole device goes idle first (free is rare) */
         (void)hipDeviceSynchronize();
         std::lock_guard<std::mutex> lock(g_worldsMutex);
-        if (--h->world->attached == 0) { g_worlds.erase(h->worldKey); }
+        if (h->world->push)
+        {
+            /* the peers' last kernels may still store flags (and forces) into this rank's memory: it lives until the last rank has gone */
+            h->world->retired.push_back(h->d_flags);
+            h->world->retired.push_back(h->d_recvBuf);
+            h->d_flags   = nullptr;
+            h->d_recvBuf = nullptr;
+        }
+        if (--h->world->attached == 0)
+        {
+            for (void* b : h->world->retired) { (void)hipFree(b); }
+            g_worlds.erase(h->worldKey);
+        }
         for (int k = 0; k < c_numPostKinds; k++)
         {
             for (int i = 0; i < c_peerRing; i++) { (void)hipEventDestroy(h->peerEvents[k][i]); }
         }
     }
+    (void)hipFree(h->d_flags);
+    (void)hipFree(h->d_doneCounter);
+    (void)hipFree(h->d_links);
+    if (h->h_pushError != nullptr) { (void)hipHostFree(h->h_pushError); }
     for (void* b : h->retiredBuffers) { (void)hipFree(b); }
     (void)hipFree(h->d_sendMap);
     (void)hipFree(h->d_sendShiftIndex);
@@ -601,7 +959,8 @@ void halo_gpu_reinit(HaloGpu* h, void* d_x, void* d_f, int numHome, int numSend,
     {
         (void)hipFree(h->d_sendMap);
         (void)hipFree(h->d_sendShiftIndex);
-        (void)hipFree(h->d_recvBuf);
+        if (h->world && h->world->push && h->d_recvBuf != nullptr) { h->retiredBuffers.push_back(h->d_recvBuf); }
+        else { (void)hipFree(h->d_recvBuf); }
         /* peer-copy transport: another rank may still be copying out of the old send buffer on ITS stream: it is kept until the
          * object goes (reallocation happens a few times per run at most) */
         if (h->world && h->d_sendBuf != nullptr) { h->retiredBuffers.push_back(h->d_sendBuf); }
@@ -612,7 +971,12 @@ void halo_gpu_reinit(HaloGpu* h, void* d_x, void* d_f, int numHome, int numSend,
         NBNXM_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&h->d_sendBuf), sizeof(float3) * h->sendAlloc));
         NBNXM_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&h->d_recvBuf), sizeof(float3) * h->sendAlloc));
     }
-    if (h->world)
+    if (h->world && h->world->push)
+    {
+        checkPushError(h);
+        pushReinit(h);
+    }
+    else if (h->world)
     {
         auto layout            = std::make_shared<PeerLayout>();
         layout->device         = h->device;
@@ -647,6 +1011,8 @@ void halo_gpu_communicate_coordinates(HaloGpu* h, void* dependencyEvent)
 {
     hipStream_t s = h->stream;
     if (dependencyEvent != nullptr) { NBNXM_HIP_CHECK(hipStreamWaitEvent(s, static_cast<hipEvent_t>(dependencyEvent), 0)); }
+    NBNXM_ASSERT(!(h->world && h->world->push), "the one-sided transport has no separate exchange calls: its stores and waits live in the kernels of "
+                                               "halo_gpu_domain_force_step (merged localities)");
     if (h->world)
     {
         peerExchangeCoordinates(h);
@@ -685,6 +1051,7 @@ static void exchangeForces(HaloGpu* h)
     hipStream_t s = h->stream;
     /* the receive buffer is overwritten: its reader of the previous step (possibly on another stream) must be done */
     if (h->recvBufConsumedRecorded) { NBNXM_HIP_CHECK(hipStreamWaitEvent(s, h->recvBufConsumed, 0)); }
+    NBNXM_ASSERT(!(h->world && h->world->push), "the one-sided transport has no separate exchange calls (halo_gpu_domain_force_step)");
     if (h->world)
     {
         peerExchangeForces(h);
@@ -787,6 +1154,56 @@ void halo_gpu_domain_force_step(HaloGpu* h, NbnxmGpu* nb, const nbnxm_step_workl
      * (read at halo_gpu_create: HALO_GPU_LOCAL_PARTS=1 / 2 switches it off / on — the default is on with more than one rank, where the
      * exchanges cross xGMI —, HALO_GPU_LOCAL_PART_FRACTION sets L1's share of the local work).  Lists too short for two sets of
      * one range per wave slot run as one launch. */
+    if (h->world && h->world->push)
+    {
+        /* One-sided transport (see the kernels above): five launches on ONE stream, no transfer kernel, no group call, no event —
+         *     store x into the peers' rows | wait + x to xq | merged cluster kernel | forces to atom order + store the halo rows into their
+         *     owners' buffers | wait + add what the peers computed on my atoms.
+         * Ranks that SHARE a device (tests on a one-GPU box) are a special case: their streams share the device's few hardware queues, and
+         * a kernel that waits for a flag in front of the kernel that sets it in the same queue would wait for ever; between the phases
+         * all ranks therefore meet at a host barrier, which makes every waiter's producer be queued first.  Ranks on devices of their own
+         * need none. */
+        NBNXM_ASSERT(nbnxm_gpu_get_merged_localities(nb) && h->stream == sLocal,
+                     "the one-sided transport runs the merged-localities schedule on the LOCAL stream of the non-bonded object");
+        checkPushError(h);
+        const bool     shared = h->world->sharedDevice && h->nranks > 1;
+        const unsigned seq    = ++h->pushSeq;
+        const unsigned* flags = h->d_flags;
+        auto counter = [&](int kernel) { return h->d_doneCounter + kernel * c_pushFlagStride; };
+        /* few, large workgroups with a grid-stride loop: every workgroup ends with one add to the kernel's counter, and adds to one address
+         * take ~10 ns each (555 workgroups of 256 threads: 5 us of a 10 us kernel) */
+        static constexpr int c_pushThreads = 1024, c_pushMaxBlocks = 64;
+        auto blocks = [](int n) { return dim3(static_cast<unsigned>(std::min<int>(c_pushMaxBlocks, std::max<int>(1, (n + c_pushThreads - 1) / c_pushThreads)))); };
+        nbnxm_gpu_set_local_launch_parts(nb, 1, h->localPartFraction);
+        if (coordinatesReadyEvent != nullptr) { NBNXM_HIP_CHECK(hipStreamWaitEvent(sLocal, static_cast<hipEvent_t>(coordinatesReadyEvent), 0)); }
+        hipLaunchKernelGGL(haloPushCoordinatesKernel, blocks(h->numSendAtoms), dim3(c_pushThreads), 0, sLocal, h->d_x, h->d_sendMap,
+                           h->d_sendShiftIndex, h->d_shiftVectors, h->numSendAtoms, h->d_links, flags, seq, counter(0), h->d_pushError);
+        NBNXM_HIP_CHECK(hipGetLastError());
+        tick(0);
+        if (shared) { worldBarrier(h); }
+        nbnxm_gpu_clear_outputs(nb, stepWork->computeVirial);
+        tick(1);
+        NBNXM_ASSERT(numSlots <= nb->atomIndicesSize, "grid slots outside the uploaded atomIndices (call nbnxm_gpu_init_x_to_nbat_x after each search)");
+        hipLaunchKernelGGL(haloWaitXToXqKernel, blocks(numSlots), dim3(c_pushThreads), 0, sLocal, nb->atdat->xq, h->d_x, nb->atomIndices, numSlots,
+                           h->numHome, h->d_links, flags, seq, counter(1), h->d_pushError);
+        NBNXM_HIP_CHECK(hipGetLastError());
+        tick(2);
+        nbnxm_gpu_launch_kernel(nb, stepWork, NBNXM_LOCAL);
+        tick(3);
+        NBNXM_ASSERT(nb->reductionAtomStart == 0 && nb->reductionNumAtoms >= numAtoms, "the cell map must cover home and halo atoms");
+        hipLaunchKernelGGL(haloPushForcesKernel, blocks(numAtoms), dim3(c_pushThreads), 0, sLocal, h->d_f,
+                           reinterpret_cast<const float3*>(nb->atdat->f), nb->cell, h->numHome, numAtoms, h->d_links, flags, seq, counter(2), h->d_pushError);
+        NBNXM_HIP_CHECK(hipGetLastError());
+        tick(6);
+        if (shared) { worldBarrier(h); }
+        hipLaunchKernelGGL(haloWaitUnpackAddKernel, blocks(h->numSendAtoms), dim3(c_pushThreads), 0, sLocal, reinterpret_cast<float*>(h->d_f),
+                           h->d_recvBuf, h->d_sendMap, h->numSendAtoms, h->d_links, flags, seq, counter(3), h->d_pushError);
+        NBNXM_HIP_CHECK(hipGetLastError());
+        tick(8);
+        /* (two barriers are enough: every kernel that waits — x to xq for the peers' coordinate stores, unpack-add for their force stores,
+         * the next step's two storing kernels for this step's "consumed" flags — is then queued behind the kernels it waits for) */
+        return;
+    }
     if (nbnxm_gpu_get_merged_localities(nb))
     {
         /* Merged localities (nbnxm_gpu_set_merged_localities): ONE cluster-kernel launch evaluates home x home and home x halo, and

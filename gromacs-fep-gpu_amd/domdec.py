@@ -260,7 +260,7 @@ class RankSystem:
 
 # ---- transports ---------------------------------------------------------------------------------------------------------
 
-TRANSPORT_RCCL, TRANSPORT_PEER_COPY = 0, 1      # include/halo_hip.h
+TRANSPORT_RCCL, TRANSPORT_PEER_COPY, TRANSPORT_PEER_PUSH = 0, 1, 2      # include/halo_hip.h
 
 
 def _halo_lib(pkg):
@@ -534,13 +534,16 @@ class DomainStep:
 
     d_x / d_f: float3 per atom in rank order (home, then halo) in HBM.  `halo` is an RcclHalo (or a test double)."""
 
-    def __init__(self, pkg, nb, system, halo, device="cuda"):
+    def __init__(self, pkg, nb, system, halo, device="cuda", poison_halo_rows=None):
         import torch
         self.pkg, self.nb, self.sys, self.halo = pkg, nb, system, halo
         plan, g = system.plan, system.grid
         self.num_home, self.num_all = plan.num_home, plan.num_home + plan.num_halo
         self.home_slots, self.all_slots = g.num_atoms_home, g.num_atoms
         self.d_x = torch.from_numpy(plan.x_rank.copy()).to(device)
+        if poison_halo_rows is not None:      # tests: the exchange has to supply every halo row (set BEFORE the peers may store into them)
+            self.d_x[plan.num_home:] = poison_halo_rows
+            torch.cuda.synchronize()
         self.d_f = torch.zeros((self.num_all, 3), dtype=torch.float32, device=device)
         nb.init_x_to_nbat_x(g.atomIndices)
         nb.force_reduction_reinit(system.cell, atom_start=0, accumulate=False)

@@ -45,6 +45,16 @@ int halo_gpu_get_unique_id(void* uniqueId);
  * that —, which is how the multi-rank schedule of halo_gpu_domain_force_step is tested on a one-GPU box. */
 #define HALO_GPU_TRANSPORT_RCCL 0
 #define HALO_GPU_TRANSPORT_PEER_COPY 1
+/* HALO_GPU_TRANSPORT_PEER_PUSH: one-sided.  Ranks as with PEER_COPY (host threads of one process, one device each on a node, peer access
+ * between the devices); but nothing is copied and no event is exchanged: the pack kernel of the sender stores the shifted coordinates
+ * straight into the receiver's halo rows and publishes the step's sequence number in a flag in the receiver's memory, the receiver's
+ * x -> xq kernel waits for the flags of its links; forces return the same way (forces-to-atom-order kernel -> the owners' receive
+ * buffers, their unpack-add kernel waits).  For sub-megabyte, latency-bound messages between GPUs that are all linked to each other
+ * this is the native form: five kernels per step on one stream, no transfer kernel, no group call.  The exchanges live inside
+ * halo_gpu_domain_force_step with merged localities; halo_gpu_communicate_coordinates / _forces are not available.
+ * halo_gpu_reinit is a rendezvous of the ranks here (every rank calls it at every search step).  Ranks sharing a device (tests)
+ * are kept deadlock-free by host barriers between the phases of a step. */
+#define HALO_GPU_TRANSPORT_PEER_PUSH 2
 int halo_gpu_get_unique_id_ex(void* uniqueId, int transport);
 
 /* RCCL id: ncclCommInitRank (collective over the nranks); peer-copy id: attaches to the process's mailbox of that id (not collective).

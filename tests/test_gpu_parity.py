@@ -831,11 +831,13 @@ def test_halo_pack_unpack_kernels():
 
 
 def _check_virtual_rank_decomposition(c, ncells, oracle_threads=1, self_links=(False, False, False), rccl=False, energy=True, peer_copy=False,
-                                      repeats=2, merged=False, reinit_between=False):
+                                      repeats=2, merged=False, reinit_between=False, push=False):
     """All ranks of a decomposition in one process on one GPU: per rank its own grid over home + halo atoms, local and non-local
     list, two streams, x -> xq per locality, fused cluster kernels, force reduction per locality.  The halo moves
       * peer_copy=True: through the library's in-process peer-copy transport, every rank on its own host thread calling the C++ step
         halo_gpu_domain_force_step `repeats` times back to back with no host synchronisation in between (include/halo_hip.h);
+      * push=True (with peer_copy=True): the one-sided transport instead — the senders' kernels store into the receivers' rows and set
+        sequence flags, the receivers' kernels wait for them (HALO_GPU_TRANSPORT_PEER_PUSH; merged localities);
       * rccl=True, ONE rank that is its own neighbour: through the real RCCL transport, same C++ step;
       * else: through the tensor-index test double and the schedule spelled out in Python.
     merged (C++ step only): the two lists of every rank as one device list, one cluster-kernel launch per step
@@ -862,16 +864,29 @@ def _check_virtual_rank_decomposition(c, ncells, oracle_threads=1, self_links=(F
                           + system.grid.xq.reshape(-1, 4) * np.array([0, 0, 0, 1], np.float32), pkg.NONLOCAL)
         if peer_copy:
             if r == 0:
-                peer_id = domdec.new_halo_id(pkg, domdec.TRANSPORT_PEER_COPY)
+                peer_id = domdec.new_halo_id(pkg, domdec.TRANSPORT_PEER_PUSH if push else domdec.TRANSPORT_PEER_COPY)
             halo = domdec.RcclHalo(pkg, None, r, dd.num_ranks, nb.stream(pkg.LOCAL if merged else pkg.NONLOCAL), unique_id=peer_id)
         elif rccl:
             halo = domdec.RcclHalo(pkg, None, 0, 1, nb.stream(pkg.LOCAL if merged else pkg.NONLOCAL))
         else:
             halo = domdec.TensorHalo(peers={})
-        st = domdec.DomainStep(pkg, nb, system, halo)
-        st.d_x[plan.num_home:] = 1.0e5
-        steps.append(st)
+        if push:
+            steps.append((nb, system, halo, plan))     # halo_gpu_reinit is a rendezvous of the ranks here: every rank on its own thread, below
+        else:
+            st = domdec.DomainStep(pkg, nb, system, halo)
+            st.d_x[plan.num_home:] = 1.0e5
+            steps.append(st)
         halos.append(halo)
+    if push:
+        made = [None] * len(steps)
+
+        def make(i):
+            def run():
+                nb_, system_, halo_, plan_ = steps[i]
+                made[i] = domdec.DomainStep(pkg, nb_, system_, halo_, poison_halo_rows=1.0e5)
+            return run
+        domdec.run_ranks_in_threads([make(i) for i in range(len(steps))])
+        steps = made
     torch.cuda.synchronize()
     if peer_copy:
         def rank_thread(st):
@@ -941,6 +956,27 @@ def test_cpp_domain_step_merged_localities_with_real_peers(ncells, energy):
     nm = (14, 8, 8) if ncells[0] == 3 else (10, 10, 10)
     _check_virtual_rank_decomposition(tl.make_case(nm=nm, num_perturbed_molecules=3, elec="ewald", seed=78), ncells, peer_copy=True, repeats=3,
                                       merged=True, energy=energy)
+
+
+@pytest.mark.parametrize("ncells", [(1, 1, 1), (2, 1, 1), (3, 1, 1), (2, 2, 1), (2, 2, 2)])
+@pytest.mark.parametrize("energy", [False, True])
+def test_cpp_domain_step_one_sided_transport(ncells, energy):
+    """halo_gpu_domain_force_step over the one-sided transport (HALO_GPU_TRANSPORT_PEER_PUSH): coordinates stored straight into the
+    receivers' halo rows by the senders' pack kernels, forces into the owners' receive buffers by the forces-to-atom-order kernels, sequence
+    flags instead of transfer kernels and events, waits inside the consuming kernels; 1 (its own neighbour), 2, 3, 4 and 8 ranks as host
+    threads on this one GPU, three steps back to back with no host synchronisation, home forces and summed energies against the oracle."""
+    nm = (14, 8, 8) if ncells[0] == 3 else (10, 10, 10)
+    links = (True, True, True) if ncells == (1, 1, 1) else (False, False, False)
+    c = tl.make_case(nm=nm, num_perturbed_molecules=3, elec="ewald", seed=79)
+    _check_virtual_rank_decomposition(c, ncells, self_links=links, peer_copy=True, push=True, merged=True, repeats=3, energy=energy)
+
+
+def test_cpp_domain_step_one_sided_transport_with_a_reinit_between_steps_and_at_size():
+    """a search step in the middle (halo_gpu_reinit is a rendezvous of the ranks in this transport), and 2 x 2 x 2 ranks of the 96k box"""
+    c = tl.make_case(nm=(10, 10, 10), num_perturbed_molecules=3, elec="ewald", seed=88)
+    _check_virtual_rank_decomposition(c, (2, 2, 1), peer_copy=True, push=True, merged=True, repeats=2, reinit_between=True)
+    c = tl.make_case(nm=(40, 40, 20), num_perturbed_molecules=16, elec="ewald", seed=2026, max_cjpacked_per_sci=16)
+    _check_virtual_rank_decomposition(c, (2, 2, 2), oracle_threads=8, peer_copy=True, push=True, merged=True, repeats=3)
 
 
 @pytest.mark.parametrize("merged", [False, True])

@@ -1,6 +1,6 @@
 """One-GPU rehearsal of bench.py's domain-decomposition leg: ONE rank that is its own neighbour along x (self-links), the real RCCL
 transport (or, third argument "peer", the in-process peer-copy transport), the real two-stream step, timed like the leg.  Numbers are
-for orientation only (a self-exchange is a device copy).  usage: dd_single_gpu_probe.py [24k|96k|768k] [x|xyz] [rccl|peer] [two|merged]"""
+for orientation only (a self-exchange is a device copy).  usage: dd_single_gpu_probe.py [24k|96k|768k] [x|xyz] [rccl|peer|push] [two|merged]"""
 import importlib
 import json
 import os
@@ -33,7 +33,8 @@ merged = len(sys.argv) > 4 and sys.argv[4] == "merged"
 nb = domdec.make_rank_gpu(pkg, wl, case, system, merged=merged)
 nb.set_timing(False)
 transport = sys.argv[3] if len(sys.argv) > 3 else "rccl"
-uid = domdec.new_halo_id(pkg, domdec.TRANSPORT_PEER_COPY) if transport == "peer" else None
+uid = (domdec.new_halo_id(pkg, domdec.TRANSPORT_PEER_COPY) if transport == "peer"
+       else domdec.new_halo_id(pkg, domdec.TRANSPORT_PEER_PUSH) if transport == "push" else None)   # push: the one-sided transport (merged only)
 halo = domdec.RcclHalo(pkg, None, 0, 1, nb.stream(pkg.LOCAL if merged else pkg.NONLOCAL), unique_id=uid)
 st = domdec.DomainStep(pkg, nb, system, halo)
 sw = pkg.step_workload()

@@ -14,13 +14,14 @@ rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 
 
 def short(n):
-    n = n.split("(")[0]
     for a, b in (("void ", ""), ("(anonymous namespace)::", ""), ("nbnxm_hip::", "")):
         n = n.replace(a, b)
-    return n[:48]
+    return n.split("(")[0][:48]
 
 
-starts = [i for i, r in enumerate(rows) if "haloPackShifted" in r["Kernel_Name"]]
+# the first kernel of a step: the pack kernel (RCCL and peer-copy transports) or the coordinate-storing kernel (one-sided transport)
+first = "haloPushCoordinatesKernel" if any("haloPushCoordinatesKernel" in r["Kernel_Name"] for r in rows) else "haloPackShifted"
+starts = [i for i, r in enumerate(rows) if first in r["Kernel_Name"]]
 steps = []
 for a, b in zip(starts[:-1], starts[1:]):
     steps.append(rows[a:b])
