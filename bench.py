@@ -646,7 +646,18 @@ def guarded_dd_leg(args, rank, world, dist, torch, out, reduce_device):
     import importlib
     import threading
 
+    state = {"primary": None}    # the RCCL leg's record once it is complete: what follows it (the one-sided transport) cannot cost it
+
     def give_up():
+        primary = state["primary"]
+        if primary is not None:
+            # the decomposition leg itself is done; what did not finish is the additional measurement over the one-sided transport
+            primary["one_sided_transport"] = {"error": "no result within %.0f s of the leg's start" % args.dd_timeout}
+            if rank == 0:
+                out["domain_decomposition"] = primary
+                mark_dd_leg(out, primary)
+                print(json.dumps(out), flush=True)
+            os._exit(0 if (rank != 0 or out.get("dd_leg_ok")) else dd_leg_failure_exit_code())
         if rank == 0:
             out["domain_decomposition"] = {"error": "no result within %.0f s" % args.dd_timeout}
             mark_dd_leg(out, out["domain_decomposition"])
@@ -666,6 +677,16 @@ def guarded_dd_leg(args, rank, world, dist, torch, out, reduce_device):
             rec2 = bench_dd.measure(args, rank, world, dist, torch, nm, npert, reduce_device, args.dd_steps, 10, grid_text="2x2x2")
             if rank == 0 and rec2["domain_grid"] != rec["domain_grid"]:
                 rec["grid_2x2x2"] = rec2
+        state["primary"] = rec if rank == 0 else {}
+        # the same decomposition over the ONE-SIDED transport (stores into the peers' buffers over hipIpc, sequence flags, no transfer
+        # kernel; halo_hip.h): an additional measurement — its failure is recorded inside the leg's record and changes nothing else
+        if os.environ.get("BENCH_DD_ONE_SIDED", "1") != "0" and os.environ.get("BENCH_DD_MERGED", "1") != "0":
+            try:
+                rec3 = bench_dd.measure(args, rank, world, dist, torch, nm, npert, reduce_device, args.dd_steps, 10, check_parity=True, transport="push")
+            except Exception as e:      # noqa: BLE001
+                rec3 = {"error": repr(e)[:400]}
+            if rank == 0:
+                rec["one_sided_transport"] = rec3
         if rank != 0:
             rec = None
     except BaseException as e:      # noqa: BLE001 — whatever happens here must not cost the line

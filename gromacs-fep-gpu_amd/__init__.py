@@ -109,6 +109,7 @@ HALO_SYMBOLS = [
     "halo_gpu_get_unique_id", "halo_gpu_get_unique_id_ex", "halo_gpu_create", "halo_gpu_free", "halo_gpu_last_error", "halo_gpu_reinit",
     "halo_gpu_communicate_coordinates", "halo_gpu_communicate_forces", "halo_gpu_coordinates_ready_event", "halo_gpu_forces_ready_event",
     "halo_gpu_bytes_per_step", "halo_gpu_pack_shifted", "halo_gpu_domain_force_step",
+    "halo_gpu_push_export_bytes", "halo_gpu_push_export", "halo_gpu_push_import", "halo_gpu_push_status",
 ]
 UPDATE_SYMBOLS = [
     "langevin_gpu_create", "langevin_gpu_free", "langevin_gpu_set", "langevin_gpu_integrate",

@@ -51,7 +51,7 @@ def step_parity(pkg, wl, case_args, st, plan, rank, world, dist, torch, reduce_d
             "how": "home forces of every rank after one decomposed step against the same box as a single domain on rank 0 (1e-4 of max(|f_i|, rms |f|)); sum of all forces"}
 
 
-def measure(args, rank, world, dist, torch, nm, npert, reduce_device, steps, warmup, grid_text=None, check_parity=False):
+def measure(args, rank, world, dist, torch, nm, npert, reduce_device, steps, warmup, grid_text=None, check_parity=False, transport="rccl"):
     """A step = halo x (pack, RCCL send / receive) on the non-local stream beside the local kernel, x -> xq per locality, local
     and non-local fused cluster kernels, forces to atom order per locality, halo f.  Returns the record of the leg (rank 0) —
     pair interactions of the WHOLE system per second (strong scaling)."""
@@ -80,10 +80,24 @@ def measure(args, rank, world, dist, torch, nm, npert, reduce_device, steps, war
     nb = domdec.make_rank_gpu(pkg, wl, case, system, use_dynamic_pruning=not args.no_prune, merged=merged)
     nb.set_timing(False)
     # (dist.peer_copy_id: the ranks are threads of this process — domdec.ThreadRanks, a rehearsal — and use the in-process transport)
-    halo = domdec.RcclHalo(pkg, dist, rank, world, nb.stream(pkg.LOCAL if merged else pkg.NONLOCAL), unique_id=getattr(dist, "peer_copy_id", None))
+    # transport: RCCL send / receive groups, or (transport="push", merged localities only) the one-sided transport between the ranks'
+    # processes — stores into the peers' buffers opened over hipIpc, sequence flags, no transfer kernel (halo_hip.h)
+    ipc_push = (transport == "push" and merged and getattr(dist, "peer_copy_id", None) is None)
+    halo = domdec.RcclHalo(pkg, dist, rank, world, nb.stream(pkg.LOCAL if merged else pkg.NONLOCAL), unique_id=getattr(dist, "peer_copy_id", None),
+                           ipc_push=ipc_push)
     st = domdec.DomainStep(pkg, nb, system, halo)
     sw = pkg.step_workload(energy=False, virial=False, dhdl=False)
     st.step(sw)
+    if ipc_push:
+        # a peer that never stores its side makes the waiting kernels give up after seconds (they do not hang): found here, not 1,200 steps later
+        torch.cuda.synchronize()
+        bad = torch.tensor([float(halo.push_status())], device=reduce_device, dtype=torch.float64)
+        if world > 1:
+            dist.all_reduce(bad, op=dist.ReduceOp.MAX)
+        if bad.item() != 0:
+            halo.free()
+            nb.free()
+            raise RuntimeError("one-sided transport: a kernel gave up waiting for a peer's flag in the first step (status %d)" % int(bad.item()))
     parity = None
     if check_parity:
         parity = step_parity(pkg, wl, dict(natoms=case.natoms, make_case=dict(nm=nm, num_perturbed_molecules=npert, elec="ewald", seed=2026,
@@ -123,7 +137,9 @@ def measure(args, rank, world, dist, torch, nm, npert, reduce_device, steps, war
                "halo_atoms_per_rank_mean": float(tot[1].item()) / world, "home_atoms_per_rank_mean": float(tot[2].item()) / world,
                "halo_bytes_sent_and_received_rank0_per_step": halo.bytes_per_step(),
                "transport": ("in-process peer copies between rank threads (halo_hip.h; a rehearsal)" if getattr(dist, "peer_copy_id", None) is not None
+                             else "one-sided: stores into the peers' buffers (hipIpc), sequence flags, no transfer kernel (halo_hip.h)" if ipc_push
                              else "RCCL ncclSend/ncclRecv groups (halo_hip.h)"),
+               "one_sided_status": halo.push_status() if ipc_push else None,
                "schedule": ("merged localities: one list, one launch, one stream per rank" if merged else "two localities on two streams"),
                "local_launch": ("one launch" if merged else
                                 "two parts, the second behind the non-local kernel (HALO_GPU_LOCAL_PARTS)" if world > 1 and os.environ.get("HALO_GPU_LOCAL_PARTS", "2") == "2"

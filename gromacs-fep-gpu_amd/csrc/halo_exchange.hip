@@ -325,7 +325,8 @@ __global__ void haloPushCoordinatesKernel(const float3* __restrict__ x, const in
 }
 
 /* x -> xq of all grid slots of the domain behind the arrival of the halo rows; flags: wait xReady(seq), publish xConsumed(seq) */
-__global__ void haloWaitXToXqKernel(float4* __restrict__ xq, const float3* x, const int* __restrict__ atomIndex, const int numSlots, const int numHome,
+__global__ void haloWaitXToXqKernel(float4* __restrict__ xq, float3* x, const float3* xRecv /* halo rows from numHome on, or nullptr: in x */,
+                                    const int* __restrict__ atomIndex, const int numSlots, const int numHome,
                                     const PushLinks* __restrict__ links, const unsigned* myFlags, const unsigned seq, unsigned* doneCounter,
                                     unsigned* error)
 {
@@ -334,7 +335,18 @@ __global__ void haloWaitXToXqKernel(float4* __restrict__ xq, const float3* x, co
     {
         const int a = atomIndex[slot];
         /* (home rows are this rank's own; halo rows were stored by the peers) */
-        if (a >= 0) { *reinterpret_cast<float3*>(&xq[slot]) = (a < numHome) ? x[a] : loadAcrossDevices(x + a); }
+        if (a >= 0)
+        {
+            float3 v;
+            if (a < numHome) { v = x[a]; }
+            else if (xRecv == nullptr) { v = loadAcrossDevices(x + a); }
+            else
+            {
+                v    = loadAcrossDevices(xRecv + (a - numHome));
+                x[a] = v; /* the caller's array gets its halo rows too */
+            }
+            *reinterpret_cast<float3*>(&xq[slot]) = v;
+        }
     }
     publishWhenAllWorkgroupsAreDone(links->xConsumedDst, links->numRecv, seq, doneCounter);
 }
@@ -437,6 +449,7 @@ std::mutex                                        g_worldsMutex;
 std::map<std::string, std::shared_ptr<PeerWorld>> g_worlds;
 constexpr char                                    c_peerIdMagic[8] = { 'H', 'A', 'L', 'O', 'P', 'E', 'E', 'R' };
 constexpr char                                    c_pushIdMagic[8] = { 'H', 'A', 'L', 'O', 'P', 'U', 'S', 'H' };
+constexpr char                                    c_ipcIdMagic[8]  = { 'H', 'A', 'L', 'O', 'I', 'P', 'C', 'P' };
 
 } // namespace
 
@@ -494,6 +507,19 @@ struct HaloGpu
     unsigned*  d_pushError   = nullptr;
     long       generation    = 0;
     unsigned   pushSeq       = 0;       /* steps done */
+    /* one-sided transport between PROCESSES (HALO_GPU_TRANSPORT_IPC_PUSH): the peers' buffers are opened through IPC handles that travel
+     * over the caller's out-of-band channel (halo_gpu_push_export / _import).  Peers store the halo coordinates into d_xRecv — memory of
+     * this library, exportable — instead of the caller's d_x; the x -> xq kernel reads them there and fills the halo rows of d_x. */
+    bool                               ipcPush  = false;
+    float3*                            d_xRecv  = nullptr;
+    int                                xRecvAlloc = 0;
+    struct IpcPeer
+    {
+        hipIpcMemHandle_t handle[3];     /* flags, receive buffer of the forces, receive buffer of the coordinates */
+        void*             opened[3] = { nullptr, nullptr, nullptr };
+        bool              valid     = false;
+    };
+    std::vector<IpcPeer>               ipcPeers; /* [rank] */
 };
 
 namespace
@@ -736,6 +762,13 @@ const char* halo_gpu_last_error(void)
 int halo_gpu_get_unique_id_ex(void* uniqueId, int transport)
 {
     if (transport == HALO_GPU_TRANSPORT_RCCL) { return halo_gpu_get_unique_id(uniqueId); }
+    if (transport == HALO_GPU_TRANSPORT_IPC_PUSH)
+    {
+        /* nothing to agree on: every rank builds the same id */
+        std::memset(uniqueId, 0, HALO_GPU_UNIQUE_ID_BYTES);
+        std::memcpy(uniqueId, c_ipcIdMagic, sizeof(c_ipcIdMagic));
+        return 0;
+    }
     if (transport != HALO_GPU_TRANSPORT_PEER_COPY && transport != HALO_GPU_TRANSPORT_PEER_PUSH)
     {
         g_haloError = "unknown halo transport";
@@ -781,7 +814,27 @@ HaloGpu* halo_gpu_create(const void* uniqueId, int rank, int nranks, void* strea
     h->nranks = nranks;
     h->stream = static_cast<hipStream_t>(stream);
     NBNXM_HIP_CHECK(hipGetDevice(&h->device));
-    if (peerCopyTransport)
+    auto allocatePushState = [&]() {
+        const size_t numFlags = static_cast<size_t>(c_numPushFlagKinds) * c_pushMaxLinks * c_pushFlagStride;
+        NBNXM_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&h->d_flags), sizeof(unsigned) * numFlags));
+        NBNXM_HIP_CHECK(hipMemset(h->d_flags, 0, sizeof(unsigned) * numFlags));
+        NBNXM_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&h->d_doneCounter), sizeof(unsigned) * 4 * c_pushFlagStride));
+        NBNXM_HIP_CHECK(hipMemset(h->d_doneCounter, 0, sizeof(unsigned) * 4 * c_pushFlagStride));
+        NBNXM_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&h->d_links), sizeof(PushLinks)));
+        NBNXM_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&h->h_pushError), sizeof(unsigned), hipHostMallocMapped));
+        *h->h_pushError = 0U;
+        NBNXM_HIP_CHECK(hipHostGetDevicePointer(reinterpret_cast<void**>(&h->d_pushError), h->h_pushError, 0));
+    };
+    if (std::memcmp(uniqueId, c_ipcIdMagic, sizeof(c_ipcIdMagic)) == 0)
+    {
+        /* one-sided transport between processes: nothing collective here; the buffers are exchanged at halo_gpu_reinit time
+         * (halo_gpu_push_export / halo_gpu_push_import) */
+        h->ipcPush = true;
+        h->ipcPeers.resize(nranks);
+        allocatePushState();
+        if (const char* env = std::getenv("HALO_GPU_PEER_TIMEOUT")) { h->peerTimeoutSeconds = std::max(1.0, std::atof(env)); }
+    }
+    else if (peerCopyTransport)
     {
         /* in-process peer copies: attach to the mailbox of this id (the first rank makes it); nothing collective happens here */
         h->worldKey.assign(static_cast<const char*>(uniqueId), HALO_GPU_UNIQUE_ID_BYTES);
@@ -809,18 +862,7 @@ HaloGpu* halo_gpu_create(const void* uniqueId, int rank, int nranks, void* strea
         }
         w->devices[rank] = h->device;
         h->world = w;
-        if (pushTransport)
-        {
-            const size_t numFlags = static_cast<size_t>(c_numPushFlagKinds) * c_pushMaxLinks * c_pushFlagStride;
-            NBNXM_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&h->d_flags), sizeof(unsigned) * numFlags));
-            NBNXM_HIP_CHECK(hipMemset(h->d_flags, 0, sizeof(unsigned) * numFlags));
-            NBNXM_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&h->d_doneCounter), sizeof(unsigned) * 4 * c_pushFlagStride));
-            NBNXM_HIP_CHECK(hipMemset(h->d_doneCounter, 0, sizeof(unsigned) * 4 * c_pushFlagStride));
-            NBNXM_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&h->d_links), sizeof(PushLinks)));
-            NBNXM_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&h->h_pushError), sizeof(unsigned), hipHostMallocMapped));
-            *h->h_pushError = 0U;
-            NBNXM_HIP_CHECK(hipHostGetDevicePointer(reinterpret_cast<void**>(&h->d_pushError), h->h_pushError, 0));
-        }
+        if (pushTransport) { allocatePushState(); }
         for (int k = 0; k < c_numPostKinds; k++)
         {
             for (int i = 0; i < c_peerRing; i++) { NBNXM_HIP_CHECK(hipEventCreateWithFlags(&h->peerEvents[k][i], hipEventDisableTiming)); }
@@ -894,6 +936,14 @@ void halo_gpu_free(HaloGpu* h)
             for (int i = 0; i < c_peerRing; i++) { (void)hipEventDestroy(h->peerEvents[k][i]); }
         }
     }
+    for (HaloGpu::IpcPeer& p : h->ipcPeers)
+    {
+        for (void* o : p.opened)
+        {
+            if (o != nullptr) { (void)hipIpcCloseMemHandle(o); }
+        }
+    }
+    (void)hipFree(h->d_xRecv);
     (void)hipFree(h->d_flags);
     (void)hipFree(h->d_doneCounter);
     (void)hipFree(h->d_links);
@@ -959,7 +1009,7 @@ void halo_gpu_reinit(HaloGpu* h, void* d_x, void* d_f, int numHome, int numSend,
     {
         (void)hipFree(h->d_sendMap);
         (void)hipFree(h->d_sendShiftIndex);
-        if (h->world && h->world->push && h->d_recvBuf != nullptr) { h->retiredBuffers.push_back(h->d_recvBuf); }
+        if (((h->world && h->world->push) || h->ipcPush) && h->d_recvBuf != nullptr) { h->retiredBuffers.push_back(h->d_recvBuf); }
         else { (void)hipFree(h->d_recvBuf); }
         /* peer-copy transport: another rank may still be copying out of the old send buffer on ITS stream: it is kept until the
          * object goes (reallocation happens a few times per run at most) */
@@ -971,7 +1021,22 @@ void halo_gpu_reinit(HaloGpu* h, void* d_x, void* d_f, int numHome, int numSend,
         NBNXM_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&h->d_sendBuf), sizeof(float3) * h->sendAlloc));
         NBNXM_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&h->d_recvBuf), sizeof(float3) * h->sendAlloc));
     }
-    if (h->world && h->world->push)
+    if (h->ipcPush)
+    {
+        checkPushError(h);
+        int numHalo = 0;
+        for (int k = 0; k < numRecv; k++) { numHalo = std::max(numHalo, recvAtomOffset[k] + recvCount[k] - numHome); }
+        if (numHalo > h->xRecvAlloc || h->d_xRecv == nullptr)
+        {
+            if (h->d_xRecv != nullptr) { h->retiredBuffers.push_back(h->d_xRecv); } /* a peer may still have it open */
+            h->xRecvAlloc = static_cast<int>(numHalo * 1.2) + 1024;
+            NBNXM_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&h->d_xRecv), sizeof(float3) * h->xRecvAlloc));
+        }
+        if (h->d_recvBuf == nullptr) { NBNXM_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&h->d_recvBuf), sizeof(float3) * 1024)); } /* (a rank that sends nothing still exports a buffer) */
+        h->generation++;
+        /* (the links' remote addresses follow with halo_gpu_push_import, once the ranks have exchanged what halo_gpu_push_export gives) */
+    }
+    else if (h->world && h->world->push)
     {
         checkPushError(h);
         pushReinit(h);
@@ -1007,11 +1072,136 @@ void halo_gpu_reinit(HaloGpu* h, void* d_x, void* d_f, int numHome, int numSend,
     }
 }
 
+/* what a rank tells the others about itself, one-sided transport between processes: fixed-size record, plain bytes */
+struct PushExportRecord
+{
+    char              magic[8];
+    int               rank, numSend, numRecv, numHome;
+    long long         generation;
+    hipIpcMemHandle_t handle[3]; /* flags, receive buffer of the forces, receive buffer of the coordinates */
+    int               sendPeer[c_pushMaxLinks], sendOffset[c_pushMaxLinks + 1];
+    int               recvPeer[c_pushMaxLinks], recvAtomOffset[c_pushMaxLinks], recvCount[c_pushMaxLinks];
+};
+
+int halo_gpu_push_export_bytes(void)
+{
+    return static_cast<int>(sizeof(PushExportRecord));
+}
+
+int halo_gpu_push_export(HaloGpu* h, void* record)
+{
+    if (!h->ipcPush)
+    {
+        g_haloError = "halo_gpu_push_export: the object was not created with the HALO_GPU_TRANSPORT_IPC_PUSH id";
+        return 1;
+    }
+    NBNXM_ASSERT(static_cast<int>(h->sendPeer.size()) <= c_pushMaxLinks && static_cast<int>(h->recvPeer.size()) <= c_pushMaxLinks,
+                 "more links than the one-sided transport provides flags for");
+    PushExportRecord r;
+    std::memset(&r, 0, sizeof(r));
+    std::memcpy(r.magic, c_ipcIdMagic, sizeof(r.magic));
+    r.rank       = h->rank;
+    r.numSend    = static_cast<int>(h->sendPeer.size());
+    r.numRecv    = static_cast<int>(h->recvPeer.size());
+    r.numHome    = h->numHome;
+    r.generation = h->generation;
+    NBNXM_HIP_CHECK(hipIpcGetMemHandle(&r.handle[0], h->d_flags));
+    NBNXM_HIP_CHECK(hipIpcGetMemHandle(&r.handle[1], h->d_recvBuf));
+    NBNXM_HIP_CHECK(hipIpcGetMemHandle(&r.handle[2], h->d_xRecv));
+    for (int k = 0; k < r.numSend; k++) { r.sendPeer[k] = h->sendPeer[k]; }
+    for (int k = 0; k <= r.numSend; k++) { r.sendOffset[k] = h->sendOffset[k]; }
+    for (int k = 0; k < r.numRecv; k++)
+    {
+        r.recvPeer[k]       = h->recvPeer[k];
+        r.recvAtomOffset[k] = h->recvAtomOffset[k];
+        r.recvCount[k]      = h->recvCount[k];
+    }
+    std::memcpy(record, &r, sizeof(r));
+    return 0;
+}
+
+int halo_gpu_push_import(HaloGpu* h, const void* records, int numRanks)
+{
+    if (!h->ipcPush || numRanks != h->nranks)
+    {
+        g_haloError = "halo_gpu_push_import: not a HALO_GPU_TRANSPORT_IPC_PUSH object, or a record count that differs from the number of ranks";
+        return 1;
+    }
+    const PushExportRecord* all = static_cast<const PushExportRecord*>(records);
+    for (int r = 0; r < numRanks; r++)
+    {
+        if (std::memcmp(all[r].magic, c_ipcIdMagic, sizeof(c_ipcIdMagic)) != 0 || all[r].rank != r || all[r].generation != h->generation)
+        {
+            g_haloError = "halo_gpu_push_import: record " + std::to_string(r) + " is not that rank's export of this search step";
+            return 2;
+        }
+    }
+    /* pointers into a peer's three buffers; this rank's own are used directly (a handle cannot be opened by the process that made it) */
+    auto opened = [&](int peer, int which) -> char* {
+        if (peer == h->rank) { return reinterpret_cast<char*>(which == 0 ? static_cast<void*>(h->d_flags) : which == 1 ? static_cast<void*>(h->d_recvBuf) : static_cast<void*>(h->d_xRecv)); }
+        HaloGpu::IpcPeer& p = h->ipcPeers[peer];
+        if (!p.valid || std::memcmp(&p.handle[which], &all[peer].handle[which], sizeof(hipIpcMemHandle_t)) != 0 || p.opened[which] == nullptr)
+        {
+            if (p.opened[which] != nullptr) { (void)hipIpcCloseMemHandle(p.opened[which]); }
+            p.handle[which] = all[peer].handle[which];
+            NBNXM_HIP_CHECK(hipIpcOpenMemHandle(&p.opened[which], p.handle[which], hipIpcMemLazyEnablePeerAccess));
+        }
+        return static_cast<char*>(p.opened[which]);
+    };
+    auto linkIn = [](const int* peers, int n, int me) {
+        for (int k = 0; k < n; k++)
+        {
+            if (peers[k] == me) { return k; }
+        }
+        return -1;
+    };
+    auto flagOf = [](char* flags, int kind, int link) {
+        return reinterpret_cast<unsigned*>(flags) + (static_cast<size_t>(kind) * c_pushMaxLinks + link) * c_pushFlagStride;
+    };
+    PushLinks L;
+    std::memset(&L, 0, sizeof(L));
+    L.numSend = static_cast<int>(h->sendPeer.size());
+    L.numRecv = static_cast<int>(h->recvPeer.size());
+    for (int k = 0; k <= L.numSend; k++) { L.sendOffset[k] = h->sendOffset[k]; }
+    for (int k = 0; k < L.numSend; k++)
+    {
+        const int               peer = h->sendPeer[k];
+        const PushExportRecord& p    = all[peer];
+        const int               link = linkIn(p.recvPeer, p.numRecv, h->rank);
+        NBNXM_ASSERT(link >= 0 && p.recvCount[link] == h->sendOffset[k + 1] - h->sendOffset[k], "the two sides of a halo link disagree on its size");
+        /* my entries of this link land in the peer's coordinate buffer at (row - numHome of the peer) */
+        L.xDst[k]         = reinterpret_cast<float3*>(opened(peer, 2)) + (p.recvAtomOffset[link] - p.numHome) - h->sendOffset[k];
+        L.xReadyDst[k]    = flagOf(opened(peer, 0), c_flagXReady, link);
+        L.fConsumedDst[k] = flagOf(opened(peer, 0), c_flagFConsumed, link);
+    }
+    for (int k = 0; k < L.numRecv; k++)
+    {
+        const int               peer = h->recvPeer[k];
+        const PushExportRecord& p    = all[peer];
+        const int               link = linkIn(p.sendPeer, p.numSend, h->rank);
+        NBNXM_ASSERT(link >= 0 && p.sendOffset[link + 1] - p.sendOffset[link] == h->recvCount[k], "the two sides of a halo link disagree on its size");
+        L.recvAtomOffset[k] = h->recvAtomOffset[k];
+        L.recvCount[k]      = h->recvCount[k];
+        L.fDst[k]           = reinterpret_cast<float3*>(opened(peer, 1)) + p.sendOffset[link] - h->recvAtomOffset[k];
+        L.fReadyDst[k]      = flagOf(opened(peer, 0), c_flagFReady, link);
+        L.xConsumedDst[k]   = flagOf(opened(peer, 0), c_flagXConsumed, link);
+    }
+    for (HaloGpu::IpcPeer& p : h->ipcPeers) { p.valid = true; }
+    NBNXM_HIP_CHECK(hipMemcpy(h->d_links, &L, sizeof(L), hipMemcpyHostToDevice));
+    return 0;
+}
+
+/* 0: fine; otherwise 1 + the link whose flag a kernel of the one-sided transport gave up waiting for (the results of that step are void) */
+int halo_gpu_push_status(const HaloGpu* h)
+{
+    return (h->h_pushError != nullptr) ? static_cast<int>(*h->h_pushError) : 0;
+}
+
 void halo_gpu_communicate_coordinates(HaloGpu* h, void* dependencyEvent)
 {
     hipStream_t s = h->stream;
     if (dependencyEvent != nullptr) { NBNXM_HIP_CHECK(hipStreamWaitEvent(s, static_cast<hipEvent_t>(dependencyEvent), 0)); }
-    NBNXM_ASSERT(!(h->world && h->world->push), "the one-sided transport has no separate exchange calls: its stores and waits live in the kernels of "
+    NBNXM_ASSERT(!(h->world && h->world->push) && !h->ipcPush, "the one-sided transport has no separate exchange calls: its stores and waits live in the kernels of "
                                                "halo_gpu_domain_force_step (merged localities)");
     if (h->world)
     {
@@ -1051,7 +1241,7 @@ static void exchangeForces(HaloGpu* h)
     hipStream_t s = h->stream;
     /* the receive buffer is overwritten: its reader of the previous step (possibly on another stream) must be done */
     if (h->recvBufConsumedRecorded) { NBNXM_HIP_CHECK(hipStreamWaitEvent(s, h->recvBufConsumed, 0)); }
-    NBNXM_ASSERT(!(h->world && h->world->push), "the one-sided transport has no separate exchange calls (halo_gpu_domain_force_step)");
+    NBNXM_ASSERT(!(h->world && h->world->push) && !h->ipcPush, "the one-sided transport has no separate exchange calls (halo_gpu_domain_force_step)");
     if (h->world)
     {
         peerExchangeForces(h);
@@ -1154,7 +1344,7 @@ void halo_gpu_domain_force_step(HaloGpu* h, NbnxmGpu* nb, const nbnxm_step_workl
      * (read at halo_gpu_create: HALO_GPU_LOCAL_PARTS=1 / 2 switches it off / on — the default is on with more than one rank, where the
      * exchanges cross xGMI —, HALO_GPU_LOCAL_PART_FRACTION sets L1's share of the local work).  Lists too short for two sets of
      * one range per wave slot run as one launch. */
-    if (h->world && h->world->push)
+    if ((h->world && h->world->push) || h->ipcPush)
     {
         /* One-sided transport (see the kernels above): five launches on ONE stream, no transfer kernel, no group call, no event —
          *     store x into the peers' rows | wait + x to xq | merged cluster kernel | forces to atom order + store the halo rows into their
@@ -1166,7 +1356,7 @@ void halo_gpu_domain_force_step(HaloGpu* h, NbnxmGpu* nb, const nbnxm_step_workl
         NBNXM_ASSERT(nbnxm_gpu_get_merged_localities(nb) && h->stream == sLocal,
                      "the one-sided transport runs the merged-localities schedule on the LOCAL stream of the non-bonded object");
         checkPushError(h);
-        const bool     shared = h->world->sharedDevice && h->nranks > 1;
+        const bool     shared = h->world && h->world->sharedDevice && h->nranks > 1; /* (ranks in processes of their own: their queues are their own) */
         const unsigned seq    = ++h->pushSeq;
         const unsigned* flags = h->d_flags;
         auto counter = [&](int kernel) { return h->d_doneCounter + kernel * c_pushFlagStride; };
@@ -1184,8 +1374,8 @@ void halo_gpu_domain_force_step(HaloGpu* h, NbnxmGpu* nb, const nbnxm_step_workl
         nbnxm_gpu_clear_outputs(nb, stepWork->computeVirial);
         tick(1);
         NBNXM_ASSERT(numSlots <= nb->atomIndicesSize, "grid slots outside the uploaded atomIndices (call nbnxm_gpu_init_x_to_nbat_x after each search)");
-        hipLaunchKernelGGL(haloWaitXToXqKernel, blocks(numSlots), dim3(c_pushThreads), 0, sLocal, nb->atdat->xq, h->d_x, nb->atomIndices, numSlots,
-                           h->numHome, h->d_links, flags, seq, counter(1), h->d_pushError);
+        hipLaunchKernelGGL(haloWaitXToXqKernel, blocks(numSlots), dim3(c_pushThreads), 0, sLocal, nb->atdat->xq, h->d_x, h->ipcPush ? h->d_xRecv : nullptr,
+                           nb->atomIndices, numSlots, h->numHome, h->d_links, flags, seq, counter(1), h->d_pushError);
         NBNXM_HIP_CHECK(hipGetLastError());
         tick(2);
         nbnxm_gpu_launch_kernel(nb, stepWork, NBNXM_LOCAL);

@@ -260,7 +260,7 @@ class RankSystem:
 
 # ---- transports ---------------------------------------------------------------------------------------------------------
 
-TRANSPORT_RCCL, TRANSPORT_PEER_COPY, TRANSPORT_PEER_PUSH = 0, 1, 2      # include/halo_hip.h
+TRANSPORT_RCCL, TRANSPORT_PEER_COPY, TRANSPORT_PEER_PUSH, TRANSPORT_IPC_PUSH = 0, 1, 2, 3      # include/halo_hip.h
 
 
 def _halo_lib(pkg):
@@ -291,11 +291,16 @@ class RcclHalo:
     TRANSPORT_PEER_COPY the ranks are threads of this process and copy device to device out of each other's buffers; every rank then
     needs its own host thread for the calls that exchange data (run_ranks_in_threads)."""
 
-    def __init__(self, pkg, dist, rank, num_ranks, stream, unique_id=None):
+    def __init__(self, pkg, dist, rank, num_ranks, stream, unique_id=None, ipc_push=False):
         import ctypes as C
         import torch
         self._C, self._lib = C, _halo_lib(pkg)
         lib = self._lib
+        # ipc_push: the one-sided transport between processes (HALO_GPU_TRANSPORT_IPC_PUSH): reinit() exchanges the ranks' export
+        # records over `dist` (an all-gather) — the only use of the process group; the steps themselves have no collective
+        self._ipc_push, self._dist, self._rank, self._num_ranks = bool(ipc_push), dist, int(rank), int(num_ranks)
+        if ipc_push:
+            unique_id = new_halo_id(pkg, TRANSPORT_IPC_PUSH)
         if unique_id is not None:
             uid = np.ascontiguousarray(unique_id, np.uint8)
         else:
@@ -322,6 +327,37 @@ class RcclHalo:
                                   C.c_int(len(a["send_peer"])), p(a["send_peer"]), p(a["send_offset"]), p(a["send_map"]),
                                   p(a["send_shift_index"]), C.c_int(len(a["shift_vectors"])), p(a["shift_vectors"]),
                                   C.c_int(len(a["recv_peer"])), p(a["recv_peer"]), p(a["recv_offset"]), p(a["recv_count"]))
+        if self._ipc_push:
+            self._exchange_push_records()
+
+    def _exchange_push_records(self):
+        """halo_gpu_push_export on every rank, an all-gather of the records, halo_gpu_push_import"""
+        import torch
+        C, lib = self._C, self._lib
+        lib.halo_gpu_push_export_bytes.restype = C.c_int
+        nbytes = int(lib.halo_gpu_push_export_bytes())
+        mine = np.zeros(nbytes, np.uint8)
+        if lib.halo_gpu_push_export(C.c_void_p(self._h), mine.ctypes.data_as(C.c_void_p)) != 0:
+            raise RuntimeError("halo_gpu_push_export: %s" % lib.halo_gpu_last_error().decode())
+        if self._num_ranks > 1:
+            dist = self._dist
+            dev = "cuda" if dist.get_backend() == "nccl" else "cpu"
+            t = torch.from_numpy(mine).to(dev)
+            parts = [torch.empty_like(t) for _ in range(self._num_ranks)]
+            dist.all_gather(parts, t)
+            everyone = np.concatenate([q.cpu().numpy() for q in parts])
+        else:
+            everyone = mine
+        everyone = np.ascontiguousarray(everyone, np.uint8)
+        if lib.halo_gpu_push_import(C.c_void_p(self._h), everyone.ctypes.data_as(C.c_void_p), C.c_int(self._num_ranks)) != 0:
+            raise RuntimeError("halo_gpu_push_import: %s" % lib.halo_gpu_last_error().decode())
+        if self._num_ranks > 1:
+            self._dist.barrier()      # every rank has opened the others' buffers before any rank stores into them
+
+    def push_status(self):
+        """0, or 1 + the link a kernel of the one-sided transport gave up waiting for"""
+        self._lib.halo_gpu_push_status.restype = self._C.c_int
+        return int(self._lib.halo_gpu_push_status(self._C.c_void_p(self._h)))
 
     def communicate_coordinates(self, dependency_event=None):
         self._lib.halo_gpu_communicate_coordinates(self._C.c_void_p(self._h), self._C.c_void_p(dependency_event))

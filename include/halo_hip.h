@@ -55,6 +55,12 @@ int halo_gpu_get_unique_id(void* uniqueId);
  * halo_gpu_reinit is a rendezvous of the ranks here (every rank calls it at every search step).  Ranks sharing a device (tests)
  * are kept deadlock-free by host barriers between the phases of a step. */
 #define HALO_GPU_TRANSPORT_PEER_PUSH 2
+/* HALO_GPU_TRANSPORT_IPC_PUSH: the same one-sided exchange between PROCESSES, one per GPU (the bench's and mdrun's shape).  The peers'
+ * buffers are opened through hipIpc handles: after every halo_gpu_reinit each rank calls halo_gpu_push_export, the ranks exchange the
+ * records over whatever channel they have (an all-gather: MPI, torch.distributed), and each calls halo_gpu_push_import with all of
+ * them, in rank order.  The coordinates are stored into a buffer of this library (exportable, unlike the caller's array); the waiting
+ * x -> xq kernel copies them into the halo rows of d_x as well.  halo_gpu_get_unique_id_ex needs no agreement for this transport. */
+#define HALO_GPU_TRANSPORT_IPC_PUSH 3
 int halo_gpu_get_unique_id_ex(void* uniqueId, int transport);
 
 /* RCCL id: ncclCommInitRank (collective over the nranks); peer-copy id: attaches to the process's mailbox of that id (not collective).
@@ -62,6 +68,13 @@ int halo_gpu_get_unique_id_ex(void* uniqueId, int transport);
  * (halo_gpu_last_error() has the text). */
 HaloGpu* halo_gpu_create(const void* uniqueId, int rank, int nranks, void* stream);
 void     halo_gpu_free(HaloGpu* h);
+/* HALO_GPU_TRANSPORT_IPC_PUSH: the bytes of one export record; this rank's record (after halo_gpu_reinit); all ranks' records in rank order.
+ * Return 0 on success (halo_gpu_last_error() has the text otherwise).  halo_gpu_push_status: 0, or 1 + the link a kernel of the one-sided
+ * transports gave up waiting for (a peer that never stored its side; the step's results are void, the next call into the object is fatal). */
+int      halo_gpu_push_export_bytes(void);
+int      halo_gpu_push_export(HaloGpu* h, void* record);
+int      halo_gpu_push_import(HaloGpu* h, const void* records, int numRanks);
+int      halo_gpu_push_status(const HaloGpu* h);
 const char* halo_gpu_last_error(void);
 
 /* reinitHalo — after every domain repartitioning / search.

@@ -49,7 +49,7 @@ def test_hip_library_exports_every_update_symbol():
 def test_hip_library_exports_every_halo_exchange_symbol():
     lib = pkg.hip_lib()
     names = declared_functions("halo_hip.h", "halo_gpu_")
-    assert len(names) == 13
+    assert len(names) == 17
     for n in names:
         assert hasattr(lib, n), "libnbnxm_hip.so does not export %s" % n
     assert sorted(names) == sorted(pkg.HALO_SYMBOLS)

@@ -69,3 +69,50 @@ def test_decomposition_leg_with_several_ranks_as_threads(ncells, merged, monkeyp
     assert abs(rec["home_atoms_per_rank_mean"] * world - 24000) < 1e-6
     assert rec["halo_atoms_per_rank_mean"] > 0
     assert 0.9 * 271960 < rec["cluster_pairs_all_ranks"] < 1.5 * 271960     # 271,960 cluster pairs as one domain (profiles/r03/sizes.txt)
+
+
+def _ipc_rank(rank, world, port, out_path, ncells):
+    """one PROCESS per rank (all on cuda:0), gloo for the out-of-band channel: the shape of a node run with the one-sided transport"""
+    import importlib
+    import types
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ["BENCH_DD_CONDITION_STEPS"] = "3"
+    os.environ["HALO_GPU_PEER_TIMEOUT"] = "120"
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from __graft_entry__ import load_package
+    load_package()
+    bench_dd = importlib.import_module("gromacs_fep_gpu_amd.bench_dd")
+    args = types.SimpleNamespace(dd_grid="%dx%dx%d" % ncells, max_cjpacked_per_sci=16, no_prune=False)
+    rec = bench_dd.measure(args, rank, world, dist, torch, (20, 20, 20), 3, "cpu", 5, 2, check_parity=True, transport="push")
+    if rank == 0:
+        with open(out_path, "w") as f:
+            json.dump(rec, f)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("ncells", [(2, 1, 1), (2, 2, 1)])
+def test_one_sided_transport_between_processes(ncells, tmp_path):
+    """HALO_GPU_TRANSPORT_IPC_PUSH as a node run uses it: one PROCESS per rank, the ranks' buffers opened through hipIpc handles that
+    travel over the process group (halo_gpu_push_export / _import at every halo_gpu_reinit), coordinates stored into the peers' receive
+    buffers and forces into the owners', sequence flags across processes.  All ranks share this box's one GPU (the device time-slices
+    the processes), so only correctness is looked at: the first step of bench_dd.measure against the single-domain forces."""
+    import socket
+    import torch.multiprocessing as mp
+    world = ncells[0] * ncells[1] * ncells[2]
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    out = str(tmp_path / "rec.json")
+    mp.spawn(_ipc_rank, args=(world, port, out, ncells), nprocs=world, join=True)
+    rec = json.load(open(out))
+    assert rec["domain_grid"] == "%dx%dx%d" % ncells and rec["atoms"] == 24000
+    assert "one-sided" in rec["transport"] and rec["one_sided_status"] == 0
+    assert rec["parity_of_first_step"]["ok"], rec["parity_of_first_step"]
+    assert rec["halo_atoms_per_rank_mean"] > 0
