@@ -61,6 +61,9 @@ def parse_args(argv=None):
                     help="untimed steps ahead of the --warmup steps that bring the device out of its idle power state (the list statistics "
                          "are computed on the host in between: a 20-step measurement right after would run entirely on the clock ramp)")
     ap.add_argument("--no-prune", action="store_true")
+    ap.add_argument("--timed-step", choices=["force", "energy", "dhdl"], default="force",
+                    help="profiling runs: the step of the timed loop — force-only (the contract's measurement), energy + virial, or dH/dlambda with 11 "
+                         "foreign lambdas; anything but force makes the line a diagnostics line (it says so)")
     ap.add_argument("--primary-only", action="store_true",
                     help="skip the secondary figures (energy / dH/dl / virial steps, MD loops): the profile of such a run holds "
                          "the force-only kernels of the timed loop and nothing else")
@@ -317,9 +320,13 @@ def main(argv=None):
     sw_f = pkg.step_workload(energy=False, virial=False, dhdl=False)
     kernel_stream = torch.cuda.ExternalStream(nb.stream())   # the stream the library launches on (not torch's current one)
 
+    sw_timed = {"force": sw_f, "energy": pkg.step_workload(energy=True, virial=True, dhdl=False),
+                "dhdl": pkg.step_workload(energy=True, virial=True, dhdl=True)}[args.timed_step]
+    timed_virial = args.timed_step != "force"
+
     def one_step():
-        nb.clear_outputs(False)
-        nb.launch_kernel(sw_f)
+        nb.clear_outputs(timed_virial)
+        nb.launch_kernel(sw_timed)
 
     # first step prunes the fresh list (not timed), then warm up
     one_step()
@@ -549,6 +556,7 @@ def main(argv=None):
 
     out = {
         "metric": METRIC, "value": value, "unit": "pair-interactions/s",
+        "timed_step": args.timed_step if args.timed_step == "force" else args.timed_step + " (a profiling run: NOT the contract's force-only measurement)",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "device_conditioning_steps_before_warmup": max(0, args.condition_steps),
         # the same W + K steps with NO conditioning ahead of them (the device's clock is still ramping up): what the driver's protocol reads
         # by itself, with its own fraction of the HBM roofline on the algorithmic bytes

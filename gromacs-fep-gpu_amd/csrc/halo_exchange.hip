@@ -800,6 +800,16 @@ int halo_gpu_get_unique_id(void* uniqueId)
     return 0;
 }
 
+/* Buffers that other PROCESSES open through hipIpc handles get an allocation of their own: the runtime carves requests below 2 MB
+ * out of shared 2 MB blocks, a handle then stands for the whole block, and a process that opens two handles into one block gets
+ * "invalid device pointer" for the second (seen with four ranks on one device, whose small buffers shared a block).  A request of a
+ * multiple of 2 MB is never carved. */
+static size_t ipcExportableBytes(size_t bytes)
+{
+    constexpr size_t c_block = size_t(2) << 20;
+    return ((bytes + c_block - 1) / c_block) * c_block;
+}
+
 HaloGpu* halo_gpu_create(const void* uniqueId, int rank, int nranks, void* stream)
 {
     if (rank < 0 || rank >= nranks)
@@ -816,7 +826,7 @@ HaloGpu* halo_gpu_create(const void* uniqueId, int rank, int nranks, void* strea
     NBNXM_HIP_CHECK(hipGetDevice(&h->device));
     auto allocatePushState = [&]() {
         const size_t numFlags = static_cast<size_t>(c_numPushFlagKinds) * c_pushMaxLinks * c_pushFlagStride;
-        NBNXM_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&h->d_flags), sizeof(unsigned) * numFlags));
+        NBNXM_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&h->d_flags), ipcExportableBytes(sizeof(unsigned) * numFlags)));
         NBNXM_HIP_CHECK(hipMemset(h->d_flags, 0, sizeof(unsigned) * numFlags));
         NBNXM_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&h->d_doneCounter), sizeof(unsigned) * 4 * c_pushFlagStride));
         NBNXM_HIP_CHECK(hipMemset(h->d_doneCounter, 0, sizeof(unsigned) * 4 * c_pushFlagStride));
@@ -1019,7 +1029,7 @@ void halo_gpu_reinit(HaloGpu* h, void* d_x, void* d_f, int numHome, int numSend,
         NBNXM_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&h->d_sendMap), sizeof(int) * h->sendAlloc));
         NBNXM_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&h->d_sendShiftIndex), sizeof(int) * h->sendAlloc));
         NBNXM_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&h->d_sendBuf), sizeof(float3) * h->sendAlloc));
-        NBNXM_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&h->d_recvBuf), sizeof(float3) * h->sendAlloc));
+        NBNXM_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&h->d_recvBuf), h->ipcPush ? ipcExportableBytes(sizeof(float3) * h->sendAlloc) : sizeof(float3) * h->sendAlloc));
     }
     if (h->ipcPush)
     {
@@ -1030,9 +1040,9 @@ void halo_gpu_reinit(HaloGpu* h, void* d_x, void* d_f, int numHome, int numSend,
         {
             if (h->d_xRecv != nullptr) { h->retiredBuffers.push_back(h->d_xRecv); } /* a peer may still have it open */
             h->xRecvAlloc = static_cast<int>(numHalo * 1.2) + 1024;
-            NBNXM_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&h->d_xRecv), sizeof(float3) * h->xRecvAlloc));
+            NBNXM_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&h->d_xRecv), ipcExportableBytes(sizeof(float3) * h->xRecvAlloc)));
         }
-        if (h->d_recvBuf == nullptr) { NBNXM_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&h->d_recvBuf), sizeof(float3) * 1024)); } /* (a rank that sends nothing still exports a buffer) */
+        if (h->d_recvBuf == nullptr) { NBNXM_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&h->d_recvBuf), ipcExportableBytes(sizeof(float3) * 1024))); } /* (a rank that sends nothing still exports a buffer) */
         h->generation++;
         /* (the links' remote addresses follow with halo_gpu_push_import, once the ranks have exchanged what halo_gpu_push_export gives) */
     }

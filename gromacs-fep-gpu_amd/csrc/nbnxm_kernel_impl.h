@@ -416,10 +416,12 @@ __launch_bounds__(c_nbMaxBlockSize) __attribute__((amdgpu_waves_per_eu(c_nbWaves
     const int        workItem = __builtin_amdgcn_readfirstlane(static_cast<int>((blockIdx.x << wavesPerBlockLog2) + wave));
     const bool       inLaunch = (workItem < numWorkRanges);
     /* (as asm: left to the compiler the load sinks to its first use, behind the trailing workgroups' branch and behind the round trip of the
-     * other kernel arguments; its wait is the s_waitcnt where the record is unpacked, NBNXM_DESC_ARRIVED) */
+     * other kernel arguments.  Load and wait in ONE statement: with the wait in a statement of its own the compiler takes the registers for
+     * written when the load is ISSUED and may copy them before the data is there.  The address needs preloaded arguments only, so the wait
+     * costs this one round trip, and the other kernel arguments' loads, issued ahead of it, travel beside it.) */
     typedef int nb_int16 __attribute__((ext_vector_type(16)));
     nb_int16 descWords;
-    asm volatile("s_load_dwordx16 %0, %1, 0x0" : "=s"(descWords) : "s"(workDesc + (inLaunch ? workItem : 0)) : "memory");
+    asm volatile("s_load_dwordx16 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(descWords) : "s"(workDesc + (inLaunch ? workItem : 0)) : "memory");
 
     /* LDS (all dynamic, sized by nbLdsBytes()): the LJ parameter table shared by the waves of the workgroup,
      * then per wave: two staging buffers for the j-side of a packed group (filled by LDS-direct loads, see the
@@ -569,7 +571,6 @@ __launch_bounds__(c_nbMaxBlockSize) __attribute__((amdgpu_waves_per_eu(c_nbWaves
     unsigned long long       tlFirst = 0; /* first group's data has arrived */
     unsigned long long       tlTransReduce = 0, tlTransWait = 0, tlTransCollect = 0, tlTransCount = 0; /* piece transitions of this wave */
 #endif
-    asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(descWords)::"memory");
     NbWorkDesc desc;
     desc.rangeBegin = descWords[0];
     desc.rangeEnd   = descWords[1];

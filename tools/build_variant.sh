@@ -6,7 +6,7 @@ cd "$(dirname "$0")/../gromacs-fep-gpu_amd"
 NAME=$1; shift
 B=../variants/build_$NAME
 mkdir -p $B
-FLAGS="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wall -Wno-unused-function -ffp-contract=fast -fno-honor-nans -fno-slp-vectorize -mllvm -amdgpu-kernarg-preload-count=4 -I../include -Icsrc $@"
+FLAGS="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wall -Wno-unused-function -ffp-contract=fast -fno-honor-nans -fno-slp-vectorize ${PRELOAD--mllvm -amdgpu-kernarg-preload-count=4} -I../include -Icsrc $@"
 pids=()
 for f in csrc/*.hip; do
   o=$B/$(basename ${f%.hip}).o

@@ -6,7 +6,7 @@ OUT=gpurun_out; mkdir -p $OUT; cd "$(dirname "$0")/.."
 export TMPDIR=/tmp
 rm -rf $OUT/traffic_*
 for c in FETCH_SIZE WRITE_SIZE; do
-  timeout -k 10 300 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $OUT/traffic_$c -- python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --primary-only > $OUT/traffic_$c.log 2>&1
+  timeout -k 10 300 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $OUT/traffic_$c -- python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --primary-only ${BENCH_EXTRA:-} > $OUT/traffic_$c.log 2>&1
   rc=$?; echo "--- $c exit $rc"
   if [ $rc -eq 124 ] || [ $rc -eq 137 ] || [ $rc -eq 139 ] || [ $rc -eq 134 ]; then exit $rc; fi
 done
@@ -22,7 +22,8 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
         for k, v in vals.items():
             # the force-only flavour: nbnxmKernel<ELEC, TWIN, VDW, ENERGY = false, FUSED>
             import re
-            if re.search(r'nbnxmKernel<\d+, (false|true), \d+, false, ', k):
+            import os
+            if re.search(r'nbnxmKernel<\d+, (false|true), \d+, %s, ' % os.environ.get('PMC_FLAVOUR_ENERGY', 'false'), k):
                 res[c] = sum(v) / len(v)
                 res['kernel'] = k[:70]
                 res['n_' + c] = len(v)

@@ -17,7 +17,8 @@ def main():
     src = sys.argv[1] if len(sys.argv) > 1 else "gpurun_out"
     commit = sys.argv[2] if len(sys.argv) > 2 else "?"
     out = sys.argv[3] if len(sys.argv) > 3 else os.path.join("profiles", "r03", "counters_fused_force_kernel.json")
-    want = re.compile(r"nbnxmKernel<\d+, (false|true), \d+, false, ")     # the force-only flavour
+    flavour = sys.argv[4] if len(sys.argv) > 4 else "force"      # force: the force-only flavour; energy: the VF flavour (bench.py --timed-step energy)
+    want = re.compile(r"nbnxmKernel<\d+, (false|true), \d+, %s, " % ("true" if flavour == "energy" else "false"))
     acc = collections.defaultdict(list)
     kernel = None
     for fn in glob.glob(os.path.join(src, "pmc_*", "**", "*counter_collection.csv"), recursive=True) \
@@ -29,7 +30,7 @@ def main():
     c = {k: sum(v) / len(v) for k, v in acc.items()}
     n = {k: len(v) for k, v in acc.items()}
     rec = {"kernel": kernel, "commit": commit, "launches_averaged": n, "counters": c,
-           "how": "rocprofv3 --kernel-trace --pmc <one group per run> -- python3 bench.py --primary-only --no-cpu-baseline; averages per launch"}
+           "how": "rocprofv3 --kernel-trace --pmc <one group per run> -- python3 bench.py --primary-only --no-cpu-baseline%s; averages per launch" % (" --timed-step energy" if flavour == "energy" else "")}
     g = c.get
     if g("SQ_INSTS_VALU") and g("SQ_BUSY_CYCLES"):
         # a wave64 VALU instruction occupies its SIMD for 2 cycles on gfx950 (MI355X_MICROARCH.md); 4 SIMDs x 256 CUs issue in parallel;

@@ -15,14 +15,15 @@ elec = sys.argv[2] if len(sys.argv) > 2 else "ewald"
 nm = {"3k": (10, 10, 10), "12k": (20, 20, 10), "24k": (20, 20, 20), "48k": (40, 20, 20), "96k": (40, 40, 20), "1m": (88, 88, 44)}[size]
 case = tl.make_case(nm=nm, num_perturbed_molecules=16 if size != "24k" else 3, elec=elec, seed=2026, n_lambda=11, max_cjpacked_per_sci=16)
 nb = tl.setup_gpu(case, fused=True, use_dynamic_pruning=True)   # the bench's list: dynamically pruned
-sw = pkg.step_workload(energy=False, virial=False, dhdl=False)
+step = os.environ.get("TIMELINE_STEP", "force")     # force | energy | dhdl: which flavour of the step is timed (energy flavours: 4 waves per SIMD)
+sw = pkg.step_workload(energy=(step != "force"), virial=(step != "force"), dhdl=(step == "dhdl"))
 for _ in range(300):
-    nb.clear_outputs(False); nb.launch_kernel(sw)
+    nb.clear_outputs(step != "force"); nb.launch_kernel(sw)
 torch.cuda.synchronize()
 K = 200
 t0 = time.perf_counter()
 for _ in range(K):
-    nb.clear_outputs(False); nb.launch_kernel(sw)
+    nb.clear_outputs(step != "force"); nb.launch_kernel(sw)
 torch.cuda.synchronize()
 step_us = (time.perf_counter() - t0) / K * 1e6
 lib = pkg.hip_lib()
@@ -79,7 +80,13 @@ print("        wave duration p10 %.1f p50 %.1f p90 %.1f max %.1f; sum of wave du
 if len(tail):
     ts = (tail[:, 0] - t0).astype(np.float64) / 100.0
     te = (tail[:, 2] - t0).astype(np.float64) / 100.0
-    print("        trailing waves %d: start min %.1f p50 %.1f | end p50 %.1f max %.1f" % (len(tail), ts.min(), np.median(ts), np.median(te), te.max()))
+    print("        trailing waves %d: start min %.1f p50 %.1f | end p50 %.1f max %.1f | duration p50 %.1f p90 %.1f max %.1f" % (
+        len(tail), ts.min(), np.median(ts), np.median(te), te.max(), np.median(te - ts), np.percentile(te - ts, 90), (te - ts).max()))
+    for kind, name in ((1, "rolling prune"), (2, "perturbed pairs"), (3, "buffer clear")):
+        m = tail[:, 1] == kind
+        if m.any():
+            print("           %-16s %5d waves: start p10 %.1f p50 %.1f p90 %.1f | end p50 %.1f p90 %.1f max %.1f | duration p50 %.1f max %.1f" % (
+                name, int(m.sum()), *np.percentile(ts[m], [10, 50, 90]), *np.percentile(te[m], [50, 90, 100]), np.median((te - ts)[m]), (te - ts)[m].max()))
 np.save(os.path.join(ROOT, "gpurun_out", "timeline_budget_%s_%s.npy" % (size, elec)), allrec)
 # the steps of the prologue (second half of the buffer; builds that record them)
 buf2 = (ctypes.c_ulonglong * (4 * 49152))()
