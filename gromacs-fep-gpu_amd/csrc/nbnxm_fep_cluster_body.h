@@ -19,7 +19,14 @@ NB_DEVINL void fepClusterPair(const NBAtomDataGpu& atdat,
                               const unsigned* __restrict__ fepWords,
                               const int     numForeignLambda, /* FOREIGN: lambda indices 0 .. numForeignLambda */
                               const int     item,
-                              const float2* nbfpLds)
+                              const float2* nbfpLds,
+                              /* FOREIGN: c_fepForeignLdsBytes of LDS of this wave's own (the cluster kernel's trailing workgroups: the wave's
+                               * staging buffers; nbnxmFepClusterKernel: behind the LJ table), or nullptr: the foreign lambdas one after the other */
+                              float*        waveLds = nullptr,
+                              /* FOREIGN: -1: this wave does all of the cluster pair; c in [0, c_fepForeignHeavyChunks): one of the waves a HEAVY
+                               * cluster pair is split over (the front of gpu_plist::slowPairs) — lambda indices 1 + c, 1 + c + chunks, ...;
+                               * wave 0 also does what is not a foreign-lambda term: forces, energies, index 0 */
+                              const int     foreignChunk = -1)
 {
     static_assert(!FOREIGN || ENERGY, "the foreign-lambda flavour is an energy flavour");
     constexpr bool LJ_EWALD    = VdwTraits<VDW>::ljEwald;
@@ -109,6 +116,7 @@ NB_DEVINL void fepClusterPair(const NBAtomDataGpu& atdat,
         foreignSlots        = energySlots + atdat.windowForeignOffset;
     }
 
+    const bool primary = !FOREIGN || foreignChunk <= 0;
     float E_lj = 0.0F, E_el = 0.0F, DVDL_lj = 0.0F, DVDL_el = 0.0F;
     float F_invr = 0.0F;
     /* FOREIGN: this lane's own terms at the current lambda — the self term and the perturbed pair —, which are lambda index 0 of the
@@ -118,7 +126,7 @@ NB_DEVINL void fepClusterPair(const NBAtomDataGpu& atdat,
     {
         /* perturbed atoms carry q = 0 in xq; their lambda-dependent self term is what the i == j entry of the
          * atom-pair list contributes (nb_free_energy.cpp:1035-1052,1079-1100) */
-        if (selfLane)
+        if (primary && selfLane)
         {
             const float sA = qABi.x * qABi.x / nbp.epsfac * selfCoef;
             const float sB = qABi.y * qABi.y / nbp.epsfac * selfCoef;
@@ -132,7 +140,7 @@ NB_DEVINL void fepClusterPair(const NBAtomDataGpu& atdat,
             }
         }
     }
-    if (inList && pert && !subDiag)
+    if (primary && inList && pert && !subDiag)
     {
         const FepLambda L     = makeFepLambda(lambdaQ, lambdaV, nbp.lam_power, nbp.alpha_coul, nbp.alpha_vdw);
         float           fscal = 0.0F;
@@ -147,7 +155,7 @@ NB_DEVINL void fepClusterPair(const NBAtomDataGpu& atdat,
         fep0[2] = DVDL_lj;
         fep0[3] = DVDL_el;
     }
-    if (inList && !pert)
+    if (primary && inList && !pert)
     {
         {
             /* a plain pair inside a perturbed cluster pair */
@@ -179,6 +187,7 @@ NB_DEVINL void fepClusterPair(const NBAtomDataGpu& atdat,
         }
     }
     const float3 f_ij = make_float3(rv.x * F_invr, rv.y * F_invr, rv.z * F_invr);
+    if (primary)
     {
         /* i-forces: sum over tidxj, lanes tidxj 0..2 carry x, y, z; j-forces: sum over tidxi, lanes tidxi 0..2 */
         const float fix = reduceOverTidxj(f_ij.x), fiy = reduceOverTidxj(f_ij.y), fiz = reduceOverTidxj(f_ij.z);
@@ -191,7 +200,7 @@ NB_DEVINL void fepClusterPair(const NBAtomDataGpu& atdat,
         __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(vj, fRsrc, oj, 0, 0);
     }
 
-    if (bCalcFshift && !central)
+    if (primary && bCalcFshift && !central)
     {
         const float sx = waveSum(f_ij.x);
         const float sy = waveSum(f_ij.y);
@@ -207,7 +216,7 @@ NB_DEVINL void fepClusterPair(const NBAtomDataGpu& atdat,
     {
         const int   slot = item & (c_numEnergySlots - 1);
         const float v    = waveSum4Transposed(E_lj, E_el, DVDL_lj, DVDL_el, lane); /* lanes 0 .. 3: the four sums */
-        if (lane < 4U) { atomicAdd(energySlots + slot * c_energySlotStride + static_cast<int>(lane), v); }
+        if (primary && lane < 4U) { atomicAdd(energySlots + slot * c_energySlotStride + static_cast<int>(lane), v); }
     }
 
     /* ---- foreign lambdas (dH/dl steps): the same pair's energies at every lambda index ---------------------------------------
@@ -229,37 +238,130 @@ NB_DEVINL void fepClusterPair(const NBAtomDataGpu& atdat,
                 vLr              = fepEwaldPotentialLr(nbp.ewald_beta, r2c * rInv, rInv);
             }
             float* slot = foreignSlots + (item & (c_numForeignSlots - 1)) * atdat.foreignSlotStride;
+            const float v0 = waveSum4Transposed(fep0[0], fep0[1], fep0[2], fep0[3], lane); /* lanes 0 .. 3: the four sums at index 0 */
+            const int   numIdx = numForeignLambda + 1;
+            /* this wave's lambda indices: idxFirst, idxFirst + idxStep, ... (numMine of them) */
+            const int idxFirst = (foreignChunk < 0) ? 1 : 1 + foreignChunk;
+            const int idxStep  = (foreignChunk < 0) ? 1 : c_fepForeignHeavyChunks;
+            const int numMine  = (numForeignLambda >= idxFirst) ? (numForeignLambda - idxFirst) / idxStep + 1 : 0;
+            /* The lanes with a term are few — a cluster pair with one perturbed atom has 8 perturbed atom pairs in its 64 lanes —, and
+             * walking the lambda indices one after the other evaluates the soft-core pair 11 times with most lanes idle (16 us per wave
+             * on the 96k box, the whole tail of a dH/dlambda step).  Instead the (pair, lambda index) combinations are dealt out over
+             * the 64 lanes: the lanes with a term leave their pair in LDS (8 values), every lane picks up combination
+             * w = pass * 64 + lane -> pair w / numForeignLambda at index 1 + w mod numForeignLambda with ITS lambdas, and adds its four results to per-index
+             * accumulators in LDS (ds_add_f32), which lanes 0 .. 4 numIdx - 1 then add to the wave's slot with one atomic each.
+             * 8 pairs x 11 indices: 2 passes instead of 11.  Not for LJ-PME (two more values per pair than the staging buffers hold). */
+            const unsigned long long termMask = __ballot(hasTerm);
+            const int                n        = __builtin_popcountll(termMask);
+            /* (from ~40 pairs on the passes are nearly as many as the indices, and the lanes' own bookkeeping costs more than it saves) */
+            /* lane k holds the lambdas of index k + 1 (one load for all indices): fetched through the crossbar, or lane by lane */
+            const bool  lamLane = static_cast<int>(lane) < numForeignLambda;
+            const float lcLane  = lamLane ? nbp.allLambdaCoul[lane] : 0.0F;
+            const float lvLane  = lamLane ? nbp.allLambdaVdw[lane] : 0.0F;
+            const bool compact = !LJ_EWALD && waveLds != nullptr && 4 * numIdx <= static_cast<int>(c_waveSize) && n <= c_fepForeignCompactMaxPairs;
+            if (compact)
             {
-                const float v = waveSum4Transposed(fep0[0], fep0[1], fep0[2], fep0[3], lane); /* lanes 0 .. 3: the four sums */
-                if (lane < 4U && v != 0.0F) { atomicAdd(slot + static_cast<int>(lane) * (numForeignLambda + 1), v); }
-            }
-            for (int fidx = 1; fidx <= numForeignLambda; fidx++)
-            {
-                const float     lc = nbp.allLambdaCoul[fidx - 1];
-                const float     lv = nbp.allLambdaVdw[fidx - 1];
-                const FepLambda Lf = makeFepLambda(lc, lv, nbp.lam_power, nbp.alpha_coul, nbp.alpha_vdw);
-                float fE_lj = 0.0F, fE_el = 0.0F, fDVDL_lj = 0.0F, fDVDL_el = 0.0F, fscal = 0.0F;
-                if (selfLane)
+                typedef __attribute__((address_space(3))) float LdsF;
+                LdsF* rec = (LdsF*)waveLds;       /* [8][64] */
+                LdsF* acc = rec + 8 * c_waveSize; /* [4][numIdx] */
+                const int rank = static_cast<int>(__builtin_amdgcn_mbcnt_hi(static_cast<unsigned>(termMask >> 32),
+                                                                            __builtin_amdgcn_mbcnt_lo(static_cast<unsigned>(termMask), 0U)));
+                acc[lane] = 0.0F;
+                if (lane < 4U) { acc[static_cast<int>(lane) * numIdx] = v0; }
+                if (hasTerm)
                 {
+                    /* (a lane is either an atom's self term or a pair: the diagonal lanes of a cluster's pair with itself are not pairs.
+                     * Two flags ride in sign bits: r^2 and 12 C12 are not negative) */
                     const float sA = qABi.x * qABi.x / nbp.epsfac * selfCoef;
                     const float sB = qABi.y * qABi.y / nbp.epsfac * selfCoef;
-                    fE_el += (1.0F - lc) * sA + lc * sB;
-                    fDVDL_el += sB - sA;
-                    if constexpr (LJ_EWALD)
+                    rec[0 * c_waveSize + rank] = included ? r2 : -r2;
+                    rec[1 * c_waveSize + rank] = selfLane ? sA : qq[0];
+                    rec[2 * c_waveSize + rank] = selfLane ? sB : qq[1];
+                    rec[3 * c_waveSize + rank] = c6AB[0];
+                    rec[4 * c_waveSize + rank] = c6AB[1];
+                    rec[5 * c_waveSize + rank] = selfLane ? -c12AB[0] : c12AB[0];
+                    rec[6 * c_waveSize + rank] = c12AB[1];
+                    rec[7 * c_waveSize + rank] = vLr;
+                }
+                const int   numComb = n * numMine;
+                const float nfInv   = 1.0F / static_cast<float>(max(numMine, 1));
+#pragma clang loop unroll(disable)
+                for (int w0 = 0; w0 < numComb; w0 += static_cast<int>(c_waveSize))
+                {
+                    const int w     = w0 + static_cast<int>(lane);
+                    const int wc    = max(min(w, numComb - 1), 0);
+                    /* the index runs fastest: the lanes of a pass spread over all accumulators, and the lanes of a pair read one address */
+                    const int a     = static_cast<int>((static_cast<float>(wc) + 0.5F) * nfInv); /* exact: (w + 1/2) / numMine is no integer */
+                    const int fi    = idxFirst - 1 + (wc - a * numMine) * idxStep;          /* lambda index - 1 */
+                    const float lc  = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(fi << 2, __builtin_bit_cast(int, lcLane)));
+                    const float lv  = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(fi << 2, __builtin_bit_cast(int, lvLane)));
+                    if (w < numComb)
                     {
-                        fE_lj += ((1.0F - lv) * c6gridAB[0] + lv * c6gridAB[1]) * ljSelfCoef;
-                        fDVDL_lj += (c6gridAB[1] - c6gridAB[0]) * ljSelfCoef;
+                        const float sr2   = rec[0 * c_waveSize + a];
+                        const float pq[2] = { rec[1 * c_waveSize + a], rec[2 * c_waveSize + a] };
+                        const float pc6[2]  = { rec[3 * c_waveSize + a], rec[4 * c_waveSize + a] };
+                        const float sc12    = rec[5 * c_waveSize + a];
+                        const float pc12[2] = { fabsf(sc12), rec[6 * c_waveSize + a] };
+                        const float pvLr    = rec[7 * c_waveSize + a];
+                        float fE_lj = 0.0F, fE_el = 0.0F, fDVDL_lj = 0.0F, fDVDL_el = 0.0F, fscal = 0.0F;
+                        if (__builtin_bit_cast(int, sc12) < 0)
+                        {
+                            fE_el    = (1.0F - lc) * pq[0] + lc * pq[1];
+                            fDVDL_el = pq[1] - pq[0];
+                        }
+                        else
+                        {
+                            const FepLambda Lf        = makeFepLambda(lc, lv, nbp.lam_power, nbp.alpha_coul, nbp.alpha_vdw);
+                            const float     noGrid[2] = { 0.0F, 0.0F };
+                            fepPair<FEP_ELEC, VDW == VDK_PSWITCH, false, true>(nbp, Lf, fabsf(sr2), __builtin_bit_cast(int, sr2) >= 0, false, pq, pc6, pc12, fscal,
+                                                                               fE_lj, fE_el, fDVDL_lj, fDVDL_el, noGrid, pvLr);
+                        }
+                        LdsF* dst = acc + fi + 1;
+                        if (fE_lj != 0.0F) { __builtin_amdgcn_ds_faddf(dst, fE_lj, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT, false); }
+                        if (fE_el != 0.0F) { __builtin_amdgcn_ds_faddf(dst + numIdx, fE_el, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT, false); }
+                        if (fDVDL_lj != 0.0F) { __builtin_amdgcn_ds_faddf(dst + 2 * numIdx, fDVDL_lj, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT, false); }
+                        if (fDVDL_el != 0.0F) { __builtin_amdgcn_ds_faddf(dst + 3 * numIdx, fDVDL_el, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT, false); }
                     }
                 }
-                if (doPair)
+                /* (the accumulators have the slot's layout: [E_lj | E_el | dV/dl_lj | dV/dl_el][index]) */
+                if (static_cast<int>(lane) < 4 * numIdx)
                 {
-                    fepPair<FEP_ELEC, VDW == VDK_PSWITCH, false, true>(nbp, Lf, r2, included, false, qq, c6AB, c12AB, fscal, fE_lj, fE_el, fDVDL_lj,
-                                                                       fDVDL_el, c6gridAB, vLr);
+                    const float v = acc[lane];
+                    if (v != 0.0F) { atomicAdd(slot + static_cast<int>(lane), v); }
                 }
-                const float v = waveSum4Transposed(fE_lj, fE_el, fDVDL_lj, fDVDL_el, lane); /* lanes 0 .. 3: the four sums */
-                /* into this wave's accumulator slot (NBAtomDataGpu::foreignSlots): thousands of waves adding to the same
-                 * 48 addresses serialise in L2 (measured +0.28 ms per dH/dl step) */
-                if (lane < 4U && v != 0.0F) { atomicAdd(slot + static_cast<int>(lane) * (numForeignLambda + 1) + fidx, v); }
+            }
+            else
+            {
+                if (lane < 4U && v0 != 0.0F) { atomicAdd(slot + static_cast<int>(lane) * numIdx, v0); }
+                for (int fidx = idxFirst; fidx <= numForeignLambda; fidx += idxStep)
+                {
+                    const bool  inLanes = numForeignLambda <= static_cast<int>(c_waveSize);
+                    const float lc = inLanes ? __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, lcLane), fidx - 1)) : nbp.allLambdaCoul[fidx - 1];
+                    const float lv = inLanes ? __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, lvLane), fidx - 1)) : nbp.allLambdaVdw[fidx - 1];
+                    const FepLambda Lf = makeFepLambda(lc, lv, nbp.lam_power, nbp.alpha_coul, nbp.alpha_vdw);
+                    float fE_lj = 0.0F, fE_el = 0.0F, fDVDL_lj = 0.0F, fDVDL_el = 0.0F, fscal = 0.0F;
+                    if (selfLane)
+                    {
+                        const float sA = qABi.x * qABi.x / nbp.epsfac * selfCoef;
+                        const float sB = qABi.y * qABi.y / nbp.epsfac * selfCoef;
+                        fE_el += (1.0F - lc) * sA + lc * sB;
+                        fDVDL_el += sB - sA;
+                        if constexpr (LJ_EWALD)
+                        {
+                            fE_lj += ((1.0F - lv) * c6gridAB[0] + lv * c6gridAB[1]) * ljSelfCoef;
+                            fDVDL_lj += (c6gridAB[1] - c6gridAB[0]) * ljSelfCoef;
+                        }
+                    }
+                    if (doPair)
+                    {
+                        fepPair<FEP_ELEC, VDW == VDK_PSWITCH, false, true>(nbp, Lf, r2, included, false, qq, c6AB, c12AB, fscal, fE_lj, fE_el, fDVDL_lj,
+                                                                           fDVDL_el, c6gridAB, vLr);
+                    }
+                    const float v = waveSum4Transposed(fE_lj, fE_el, fDVDL_lj, fDVDL_el, lane); /* lanes 0 .. 3: the four sums */
+                    /* into this wave's accumulator slot (NBAtomDataGpu::foreignSlots): thousands of waves adding to the same
+                     * 48 addresses serialise in L2 (measured +0.28 ms per dH/dl step) */
+                    if (lane < 4U && v != 0.0F) { atomicAdd(slot + static_cast<int>(lane) * numIdx + fidx, v); }
+                }
             }
         }
     }

@@ -49,6 +49,13 @@ __launch_bounds__(c_fepClusterWavesPerBlock* c_waveSize) __global__
         __syncthreads();
     }
 
+    /* FOREIGN: a scratch area per wave behind the table (fepClusterPair; the host sizes the launch's LDS: fepClusterLdsBytes) */
+    float* waveLds = nullptr;
+    if constexpr (FOREIGN)
+    {
+        const int tabBytes = USE_TABLE ? ((numTypes * numTypes * static_cast<int>(sizeof(float2)) + 15) & ~15) : 0;
+        waveLds            = reinterpret_cast<float*>(fepLds + tabBytes + wave * c_fepForeignLdsBytes);
+    }
     /* few, short, latency-bound waves next to (or between) kernels with thousands: top priority */
     __builtin_amdgcn_s_setprio(3);
     /* the launch is sized by the host's figure (the previous list's while a new list's count is still on its way), the items are
@@ -56,10 +63,27 @@ __launch_bounds__(c_fepClusterWavesPerBlock* c_waveSize) __global__
     const int firstItem = __builtin_amdgcn_readfirstlane(static_cast<int>(blockIdx.x) * c_fepClusterWavesPerBlock + static_cast<int>(wave));
     const int numItems  = __builtin_amdgcn_readfirstlane(min(*plist.slowCount, plist.slowPairs_nalloc));
     const int stride    = static_cast<int>(gridDim.x) * c_fepClusterWavesPerBlock;
-    for (int item = firstItem; item < numItems; item += stride)
+    if constexpr (FOREIGN)
     {
-        fepClusterPair<ELEC, TWIN, VDW, ENERGY, FOREIGN>(atdat, nbp, plist, bCalcFshift, cjPackedList, exclList, xq, ljComb, fepWords,
-                                                         numForeignLambda, item, nbfpLds);
+        /* the heavy cluster pairs at the front of the list: c_fepForeignHeavyChunks waves each, by lambda index (see the cluster kernel's tail) */
+        const int numHeavy   = __builtin_amdgcn_readfirstlane(min(plist.slowCount[1], numItems));
+        const int numVirtual = numItems + numHeavy * (c_fepForeignHeavyChunks - 1);
+        for (int v = firstItem; v < numVirtual; v += stride)
+        {
+            const bool heavy = v < numHeavy * c_fepForeignHeavyChunks;
+            const int  item  = heavy ? v / c_fepForeignHeavyChunks : v - numHeavy * (c_fepForeignHeavyChunks - 1);
+            const int  chunk = heavy ? v - item * c_fepForeignHeavyChunks : -1;
+            fepClusterPair<ELEC, TWIN, VDW, ENERGY, FOREIGN>(atdat, nbp, plist, bCalcFshift, cjPackedList, exclList, xq, ljComb, fepWords,
+                                                             numForeignLambda, item, nbfpLds, waveLds, chunk);
+        }
+    }
+    else
+    {
+        for (int item = firstItem; item < numItems; item += stride)
+        {
+            fepClusterPair<ELEC, TWIN, VDW, ENERGY, FOREIGN>(atdat, nbp, plist, bCalcFshift, cjPackedList, exclList, xq, ljComb, fepWords,
+                                                             numForeignLambda, item, nbfpLds, waveLds);
+        }
     }
 }
 

@@ -448,6 +448,7 @@ NbnxmGpu* nbnxm_gpu_init(const nbnxm_interaction_params_t* ic, int numTypes, con
     {
         nb->fepConcurrent      = (std::atoi(env) != 0);
         nb->fepConcurrentFused = (std::atoi(env) == 2);
+        nb->fepBehindFused     = (std::atoi(env) == 3);
     }
     if (const char* env = diagnosticsEnv("NBNXM_HIP_F_DOUBLE_BUFFER"))
     {
@@ -1419,7 +1420,8 @@ static void pickUpSlowCount(NbnxmGpu* nb, int iloc)
         (void)hipGetLastError(); /* "not ready" is an answer, not an error for the launch checks that follow */
         return;
     }
-    d->numSlowPairs     = nb->h_slowCount.data[iloc];
+    d->numSlowPairs     = nb->h_slowCount.data[2 * iloc];
+    d->numSlowHeavy     = std::min(nb->h_slowCount.data[2 * iloc + 1], d->numSlowPairs);
     d->slowCountPending = false;
     d->slowCountKnown   = true;
     NBNXM_ASSERT(d->numSlowPairs <= d->slowPairs_nalloc,
@@ -1461,7 +1463,11 @@ static void updateWorkPartition(NbnxmGpu* nb, int iloc)
         allocateDeviceBuffer(&d->slowPairSci, d->slowPairs_nalloc);
         d->slowListDirty = true;
     }
-    if (d->slowCount == nullptr) { allocateDeviceBuffer(&d->slowCount, 1); }
+    if (d->slowCount == nullptr)
+    {
+        allocateDeviceBuffer(&d->slowCount, 2);
+        clearDeviceBufferAsync(&d->slowCount, 0, 2, s);
+    }
     reallocateDeviceBuffer(&d->weightBlockSum, numBlocks + 1, &dummy, &d->weightBlockSum_nalloc);
     const bool fused     = nb->fusedFep && nb->nbparam->bFEP && nb->atdat->fepBits != nullptr;
     const bool buildSlow = fused && d->slowListDirty;
@@ -1489,6 +1495,16 @@ static void updateWorkPartition(NbnxmGpu* nb, int iloc)
     hipLaunchKernelGGL(nbnxmWorkWeightKernel, dim3(numBlocks), dim3(c_workBlockSize), 0, s, d->cjPacked, d->ncjPacked, d->sciSorted,
                        d->nsciWork, fused ? nb->atdat->fepBits : nullptr, buildSlow ? 1 : 0, outerMask, d->groupSlowMask, d->slowPairs, d->slowPairSci,
                        d->slowPairs_nalloc, d->slowCount, d->groupWeight, d->weightBlockSum, weights);
+    if (buildSlow && fused)
+    {
+        /* what the first pass has counted is the number of heavy pairs: kept beside the count (the kernels split those over several waves
+         * on dH/dlambda steps) */
+        NBNXM_HIP_CHECK(hipMemcpyAsync(d->slowCount + 1, d->slowCount, sizeof(int), hipMemcpyDeviceToDevice, s));
+        /* the second pass of the slow-pair list: the light pairs behind the heavy ones (weights and masks: the same values again) */
+        hipLaunchKernelGGL(nbnxmWorkWeightKernel, dim3(numBlocks), dim3(c_workBlockSize), 0, s, d->cjPacked, d->ncjPacked, d->sciSorted,
+                           d->nsciWork, nb->atdat->fepBits, 2, outerMask, d->groupSlowMask, d->slowPairs, d->slowPairSci, d->slowPairs_nalloc,
+                           d->slowCount, d->groupWeight, d->weightBlockSum, weights);
+    }
     hipLaunchKernelGGL(nbnxmWorkScanKernel, dim3(1), dim3(c_workBlockSize), 0, s, d->weightBlockSum, numBlocks);
     NBNXM_HIP_CHECK(hipGetLastError());
     if (buildSlow)
@@ -1496,9 +1512,9 @@ static void updateWorkPartition(NbnxmGpu* nb, int iloc)
         /* The host only needs the count to SIZE launches (the kernels stride over the device's count).  The first list of an object
          * waits for it; later lists queue the copy, size their first launches from the previous count plus a margin, and pick the
          * exact figure up when it has arrived (pickUpSlowCount): no host round trip in a search step. */
-        if (nb->h_slowCount.size < 2) { nb->h_slowCount.resize(2); }
+        if (nb->h_slowCount.size < 4) { nb->h_slowCount.resize(4); } /* per locality: the count, and how many of them are heavy */
         if (nb->slowCountReady[iloc] == nullptr) { NBNXM_HIP_CHECK(hipEventCreateWithFlags(&nb->slowCountReady[iloc], hipEventDisableTiming)); }
-        NBNXM_HIP_CHECK(hipMemcpyAsync(nb->h_slowCount.data + iloc, d->slowCount, sizeof(int), hipMemcpyDeviceToHost, s));
+        NBNXM_HIP_CHECK(hipMemcpyAsync(nb->h_slowCount.data + 2 * iloc, d->slowCount, 2 * sizeof(int), hipMemcpyDeviceToHost, s));
         NBNXM_HIP_CHECK(hipEventRecord(nb->slowCountReady[iloc], s));
         d->slowCountPending = true;
         d->slowListDirty    = false;
@@ -1509,6 +1525,7 @@ static void updateWorkPartition(NbnxmGpu* nb, int iloc)
     if (!fused)
     {
         d->numSlowPairs     = 0;
+        d->numSlowHeavy     = 0;
         d->slowCountPending = false;
     }
 
@@ -1778,8 +1795,12 @@ void nbnxm_gpu_launch_kernel(NbnxmGpu* nb, const nbnxm_step_workload_t* stepWork
         /* force-only steps: the perturbed cluster pairs ride in trailing workgroups of the cluster kernel (nbnxm_kernel_impl.h) */
         /* (foreign-lambda energies ride only with an energy flavour; a dH/dl step without energies keeps the kernel of its own) */
         const bool mergeFep = fused && plist->numSlowPairs > 0 && nb->fepMergedFused && tailFep && (!wantForeign || energyFlavour);
-        if (fused && plist->numSlowPairs > 0 && !mergeFep && !secondPartOnly)
-        {
+        const bool fepKernelOfItsOwn = fused && plist->numSlowPairs > 0 && !mergeFep && !secondPartOnly;
+        /* NBNXM_HIP_FEP_CONCURRENT=3 (diagnostics): that kernel on the second stream BEHIND the cluster kernel's launch — its workgroups
+         * are four waves with a table of a few hundred bytes and start in the first wave slots the ranges' waves free, where a
+         * trailing workgroup of the cluster kernel needs a whole workgroup's slots and LDS */
+        const bool fepBehindClusterKernel = fepKernelOfItsOwn && nb->fepBehindFused && nb->fepStreams[iloc].stream != nullptr;
+        auto launchFepClusterKernel = [&]() {
             /* (energy / dH/dl steps, or NBNXM_HIP_FEP_MERGED=0; force-only steps: trailing workgroups of the cluster kernel, below)
              * the cluster pairs that touch a perturbed atom: a few thousand short latency-bound waves, ~10 us on the 96k
              * box.  On the same stream, ahead of the cluster kernel: measured on MI355X a second stream does not help here
@@ -1789,7 +1810,13 @@ void nbnxm_gpu_launch_kernel(NbnxmGpu* nb, const nbnxm_step_workload_t* stepWork
             const FepClusterKernelPtr fk = selectFepClusterKernel(nbp->elecType, nbp->vdwType, stepWork->computeEnergy != 0 || wantForeign, wantForeign);
             NBNXM_ASSERT(fk != nullptr, "no perturbed-cluster-pair kernel for this electrostatics / VdW combination");
             hipStream_t fs = s;
-            if (nb->fepConcurrentFused && nb->fepStreams[iloc].stream != nullptr)
+            if (fepBehindClusterKernel)
+            {
+                fs = nb->fepStreams[iloc].stream;
+                NBNXM_HIP_CHECK(hipStreamWaitEvent(fs, nb->fepFork[iloc], 0));
+                fepForked = true;
+            }
+            else if (nb->fepConcurrentFused && nb->fepStreams[iloc].stream != nullptr)
             {
                 fs = nb->fepStreams[iloc].stream;
                 NBNXM_HIP_CHECK(hipEventRecord(nb->fepFork[iloc], s));
@@ -1798,14 +1825,17 @@ void nbnxm_gpu_launch_kernel(NbnxmGpu* nb, const nbnxm_step_workload_t* stepWork
             }
             const bool fepUseTable = (nbp->vdwType == NBNXM_VDW_CUT || nbp->vdwType == NBNXM_VDW_FSWITCH || nbp->vdwType == NBNXM_VDW_PSWITCH
                                       || nbp->vdwType == NBNXM_VDW_EWALD_GEOM || nbp->vdwType == NBNXM_VDW_EWALD_LB);
-            const int  fepLds      = fepUseTable ? ((adat->numTypes * adat->numTypes * 8 + 15) & ~15) : 0;
+            /* the LJ table of the workgroup; dH/dlambda steps: and a scratch area per wave (fepClusterPair's foreign-lambda terms) */
+            const int  fepLds      = (fepUseTable ? ((adat->numTypes * adat->numTypes * 8 + 15) & ~15) : 0)
+                               + (wantForeign ? c_fepClusterWavesPerBlockDef * c_fepForeignLdsBytes : 0);
             NBNXM_ASSERT(fepLds <= 160 * 1024, "too many atom types: the LJ parameter table does not fit the 160 KB LDS");
             if (fepLds > 64 * 1024)
             {
                 NBNXM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(fk), hipFuncAttributeMaxDynamicSharedMemorySize, fepLds));
             }
             if (nb->bDoTime) { t.fep_k.openTimingRegion(fs); }
-            const int numFepWaves = plist->numSlowPairs; /* one wave per perturbed cluster pair */
+            /* one wave per perturbed cluster pair; dH/dlambda steps: c_fepForeignHeavyChunks per heavy one */
+            const int numFepWaves = plist->numSlowPairs + (wantForeign ? plist->numSlowHeavy * (c_fepForeignHeavyChunks - 1) : 0);
             hipLaunchKernelGGL(fk, dim3((numFepWaves + c_fepClusterWavesPerBlockDef - 1) / c_fepClusterWavesPerBlockDef),
                                dim3(c_fepClusterWavesPerBlockDef * c_waveSize), fepLds, fs, *adat, *nbp, *plist, stepWork->computeVirial,
                                plist->sciSorted, plist->cjPacked, plist->excl, adat->xq, adat->atomTypes, adat->ljComb,
@@ -1813,7 +1843,13 @@ void nbnxm_gpu_launch_kernel(NbnxmGpu* nb, const nbnxm_step_workload_t* stepWork
             NBNXM_HIP_CHECK(hipGetLastError());
             if (nb->bDoTime) { t.fep_k.closeTimingRegion(fs); }
             if (fepForked) { NBNXM_HIP_CHECK(hipEventRecord(nb->fepJoin[iloc], fs)); }
+        };
+        if (fepBehindClusterKernel)
+        {
+            /* the fork is recorded AHEAD of the cluster kernel: the perturbed pairs depend on what came before it only */
+            NBNXM_HIP_CHECK(hipEventRecord(nb->fepFork[iloc], s));
         }
+        else if (fepKernelOfItsOwn) { launchFepClusterKernel(); }
         if (nb->bDoTime) { t.nb_k.openTimingRegion(s); }
         /* The LJ table lives in LDS (up to ~140 types in the 160 KB; large tables cost occupancy) */
         const bool ljEwald = (nbp->vdwType == NBNXM_VDW_EWALD_GEOM || nbp->vdwType == NBNXM_VDW_EWALD_LB);
@@ -1849,7 +1885,7 @@ void nbnxm_gpu_launch_kernel(NbnxmGpu* nb, const nbnxm_step_workload_t* stepWork
         const bool         withTail = plan.withTail; /* false whenever nothing is launched: no state is consumed then */
         NBNXM_ASSERT(plan.numSets == 0 || (firstSet + plan.numSets) * setRanges <= numRanges, "launch plan beyond the range arrays");
         const int mergedFepItems = !withTail ? 0
-                                   : mergeFep ? plist->numSlowPairs
+                                   : mergeFep ? plist->numSlowPairs + ((wantForeign && energyFlavour) ? plist->numSlowHeavy * (c_fepForeignHeavyChunks - 1) : 0)
                                    : mergeFepList ? nb->feplist[iloc]->numClusterItems
                                                   : 0;
         const int pruneEntries   = (plist->pendingPrunePart >= 0 && withTail) ? plist->pendingPruneEntries : 0;
@@ -1902,6 +1938,7 @@ void nbnxm_gpu_launch_kernel(NbnxmGpu* nb, const nbnxm_step_workload_t* stepWork
             NBNXM_HIP_CHECK(hipGetLastError());
         }
         if (nb->bDoTime) { t.nb_k.closeTimingRegion(s); }
+        if (fepBehindClusterKernel) { launchFepClusterKernel(); }
         if (iloc == NBNXM_NONLOCAL && nb->fDoubleBuffer)
         {
             NBNXM_HIP_CHECK(hipEventRecord(nb->nonlocalKernelDone, s));

@@ -71,6 +71,7 @@ struct NbnxmGpu
     bool           pruneMerged                 = true;  /* rolling pruning rides in trailing workgroups of the next force-only
                                                           * cluster kernel (NBNXM_HIP_PRUNE_MERGED=0: own kernel, at once) */
     bool           fepConcurrentFused          = false; /* fused mode: perturbed-cluster-pair kernel on the FEP stream */
+    bool           fepBehindFused              = false; /* ... and launched behind the cluster kernel (energy / dH/dlambda steps) */
     hipEvent_t     nonlocal_done               = nullptr;
     hipEvent_t     misc_ops_and_local_H2D_done = nullptr;
     hipEvent_t     nonlocalKernelDone          = nullptr; /* after the last non-local cluster kernel (double-buffered forces) */

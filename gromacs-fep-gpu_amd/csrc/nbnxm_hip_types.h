@@ -255,7 +255,8 @@ struct gpu_plist
     unsigned*    groupSlowMask;   /* ncjPacked: fused mode, the cluster pairs of each group that touch a perturbed atom */
     int*         slowPairs;       /* numSlowPairs: group * 32 + jm * 8 + i of every listed cluster pair with a perturbed atom */
     int*         slowPairSci;     /* ... and its i-entry as sci * 64 + shift index */
-    int*         slowCount;       /* the number of entries of slowPairs, counted on the device */
+    int*         slowCount;       /* [0] the number of entries of slowPairs, counted on the device; [1] how many of them, at the front, are heavy */
+    int          numSlowHeavy;    /* ... and for how many of them, at the front, are heavy (split over several waves on dH/dlambda steps) */
     int          numSlowPairs;    /* the host's figure for sizing launches: exact once the count of this list has arrived, the previous
                                    * list's (plus a margin) until then — the kernels stride over *slowCount items either way */
     bool         slowCountPending; /* host bookkeeping: the copy of *slowCount for this list has been queued, not read yet */
@@ -327,6 +328,24 @@ constexpr int c_iStageBytes      = c_superClSize * static_cast<int>(sizeof(float
 /* ring of 4 list-word records per wave (32 bytes of nbnxn_cj_packed_t + 4 bytes of fepBits, padded) */
 constexpr int c_ringRecordBytes  = 64;
 constexpr int c_jRingBytes       = 4 * c_ringRecordBytes;
+/* LDS of one wave for the foreign-lambda terms of a perturbed cluster pair (fepClusterPair): 8 values of up to 64 pairs and 64
+ * accumulators — what a wave of the cluster kernel has as staging buffers and ring */
+constexpr int c_fepForeignLdsBytes = (8 + 1) * 64 * static_cast<int>(sizeof(float));
+/* a perturbed cluster pair with more perturbed atom pairs than this goes to the front of gpu_plist::slowPairs (nbnxmWorkWeightKernel) */
+#ifndef NBNXM_SLOW_PAIR_HEAVY
+#define NBNXM_SLOW_PAIR_HEAVY 32
+#endif
+constexpr int c_slowPairHeavy = NBNXM_SLOW_PAIR_HEAVY;
+/* ... and on a dH/dlambda step is split over this many waves by lambda index (fepClusterPair) */
+#ifndef NBNXM_FEP_FOREIGN_HEAVY_CHUNKS
+#define NBNXM_FEP_FOREIGN_HEAVY_CHUNKS 3
+#endif
+constexpr int c_fepForeignHeavyChunks = NBNXM_FEP_FOREIGN_HEAVY_CHUNKS;
+#ifndef NBNXM_FEP_FOREIGN_COMPACT_MAX_PAIRS
+#define NBNXM_FEP_FOREIGN_COMPACT_MAX_PAIRS 40
+#endif
+constexpr int c_fepForeignCompactMaxPairs = NBNXM_FEP_FOREIGN_COMPACT_MAX_PAIRS; /* more pairs with a term in one cluster pair: index by index */
+static_assert(c_fepForeignLdsBytes <= 2 * c_jStageBytes + c_jRingBytes, "the foreign-lambda scratch must fit a wave's staging area");
 
 /* Dynamic LDS bytes of one workgroup of the cluster-pair kernel (must match the carve-up in the kernel). */
 /* LDS bytes of the reference's r-indexed Ewald force table (tabulated flavours) */

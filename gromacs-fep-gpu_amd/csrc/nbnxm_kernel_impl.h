@@ -497,15 +497,32 @@ __launch_bounds__(c_nbMaxBlockSize) __attribute__((amdgpu_waves_per_eu(c_nbWaves
                     const int firstItem = __builtin_amdgcn_readfirstlane(static_cast<int>((blockIdx.x - mainBlocks - pruneBlocks) * wavesPerBlock + wave));
                     const int numItems  = __builtin_amdgcn_readfirstlane(min(*plist.slowCount, plist.slowPairs_nalloc));
                     const int stride    = static_cast<int>(fepBlocks * wavesPerBlock);
-#pragma clang loop unroll(disable)
-                    for (int item = firstItem; item < numItems; item += stride)
+                    /* this wave's staging area (unused in a trailing workgroup): scratch of the foreign-lambda terms */
+                    constexpr bool LJ_EWALD_T = VdwTraits<VDW>::ljEwald;
+                    const int      tabBytesT  = c_ewaldTabBytes + rTabBytes
+                                          + (VdwTraits<VDW>::useTable ? (((numTypes * numTypes + (LJ_EWALD_T ? numTypes : 0)) * static_cast<int>(sizeof(float2)) + 15) & ~15) : 0);
+                    float* waveLds = reinterpret_cast<float*>(nbLds + tabBytesT + wave * (2 * c_jStageBytes + c_jRingBytes));
+                    if (ENERGY && mergedFepForeignLambdas >= 0)
                     {
-                        if (ENERGY && mergedFepForeignLambdas >= 0)
+                        /* dH/dlambda step: the heavy cluster pairs at the front of the list (slowCount[1] of them) are split over
+                         * c_fepForeignHeavyChunks waves each by lambda index — one wave takes 20 us for such a pair, three times what the
+                         * others take, and the kernel would end with it */
+                        const int numHeavy   = __builtin_amdgcn_readfirstlane(min(plist.slowCount[1], numItems));
+                        const int numVirtual = numItems + numHeavy * (c_fepForeignHeavyChunks - 1);
+#pragma clang loop unroll(disable)
+                        for (int v = firstItem; v < numVirtual; v += stride)
                         {
+                            const bool heavy = v < numHeavy * c_fepForeignHeavyChunks;
+                            const int  item  = heavy ? v / c_fepForeignHeavyChunks : v - numHeavy * (c_fepForeignHeavyChunks - 1);
+                            const int  chunk = heavy ? v - item * c_fepForeignHeavyChunks : -1;
                             fepClusterPair<ELEC, TWIN, VDW, ENERGY, ENERGY>(atdat, nbp, plist, bCalcFshiftIn, cjPackedList, exclList, xq, ljComb,
-                                                                            fepWords, mergedFepForeignLambdas, item, nbfpLds);
+                                                                            fepWords, mergedFepForeignLambdas, item, nbfpLds, waveLds, chunk);
                         }
-                        else
+                    }
+                    else
+                    {
+#pragma clang loop unroll(disable)
+                        for (int item = firstItem; item < numItems; item += stride)
                         {
                             fepClusterPair<ELEC, TWIN, VDW, ENERGY, false>(atdat, nbp, plist, bCalcFshiftIn, cjPackedList, exclList, xq, ljComb,
                                                                            fepWords, -1, item, nbfpLds);

@@ -85,7 +85,9 @@ __launch_bounds__(c_workBlockSize) __global__
                                    const nbnxn_sci_t* __restrict__       sciSorted,
                                    const int                             nsci,
                                    const unsigned char* __restrict__     fepBits, /* nullptr: not the fused mode */
-                                   const int                             buildSlowList, /* 0: groupSlowMask is up to date */
+                                   const int                             buildSlowList, /* 0: groupSlowMask is up to date; 1: build the mask and append the
+                                                                                         * HEAVY slow pairs (c_slowPairHeavy); 2: append the others
+                                                                                         * (a second launch: the heavy ones come first in the list) */
                                    const unsigned* __restrict__          outerMask, /* gpu_plist::imask of a list that has been pruned, else nullptr */
                                    unsigned* __restrict__                groupSlowMask,
                                    int* __restrict__                     slowPairs,   /* group * 32 + jm * 8 + i of every listed slow pair ... */
@@ -126,6 +128,20 @@ __launch_bounds__(c_workBlockSize) __global__
              * launcher builds this before the first prune; once the list has been pruned (a mode or fepBits change on a live
              * list), the outer-pruned masks the rolling pass re-adds pairs from — the working mask is checked at run time */
             unsigned  todo = slow & (outerMask != nullptr ? outerMask[g * NBNXM_GPU_CLUSTERPAIR_SPLIT] : imask);
+            /* The list starts with the cluster pairs that hold MANY perturbed atom pairs (both clusters carry perturbed atoms: a ligand's
+             * pairs with itself): on a dH/dlambda step such a pair is the longest chain of the kernel's trailing work (20 us against 7),
+             * and the waves take the list in order — the long ones must not be the last to start. */
+            {
+                unsigned heavy = 0U;
+                for (unsigned rest = todo; rest != 0U; rest &= rest - 1U)
+                {
+                    const int bit = __ffs(rest) - 1;
+                    const int pi  = __popc(static_cast<unsigned>(fepBits[sci * c_numClPerSupercl + (bit & 7)]));
+                    const int pj  = __popc(static_cast<unsigned>(fepBits[cjPacked[g].cj[bit >> 3]]));
+                    if (c_clSize * c_clSize - (c_clSize - pi) * (c_clSize - pj) > c_slowPairHeavy) { heavy |= 1U << bit; }
+                }
+                todo = (buildSlowList == 1) ? heavy : (todo & ~heavy);
+            }
             const int n    = __popc(todo);
             if (n > 0)
             {
@@ -140,7 +156,7 @@ __launch_bounds__(c_workBlockSize) __global__
                 }
             }
         }
-        if (buildSlowList) { groupSlowMask[g] = slow; }
+        if (buildSlowList == 1) { groupSlowMask[g] = slow; }
         /* cost model in units of 1/8 cluster pair (fitted to per-SIMD finish times, tools/calibrate_weights.py): a
          * cluster pair, a non-empty j-cluster slot (staged reads, j-force reduction, atomic), a group (staging loads,
          * waits), and the start of an i-entry (i-atom loads, i-force reduction and atomics) */

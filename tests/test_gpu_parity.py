@@ -125,6 +125,25 @@ def test_foreign_lambda_energies(elec, vdw, fused):
     assert abs(got["foreign"]["energies"][0] - (fep["Vv"] + fep["Vc"])) <= 1e-4 * scale
 
 
+@pytest.mark.parametrize("own_kernel", [False, True])
+@pytest.mark.parametrize("elec", ["rf", "ewald"])
+def test_foreign_lambda_energies_of_heavy_cluster_pairs(elec, own_kernel, monkeypatch):
+    """dH/dlambda step of a box with a compact region of 40 perturbed molecules: whole clusters are perturbed, their pairs hold 64 perturbed
+    atom pairs (evaluated index by index, not dealt out over the lanes), and the ones with more than 32 stand at the front of the
+    slow-pair list and are split over three waves by lambda index — in the cluster kernel's trailing workgroups and (own_kernel) in
+    nbnxmFepClusterKernel's FOREIGN flavour."""
+    if own_kernel:
+        monkeypatch.setenv("NBNXM_HIP_DIAGNOSTICS", "1")
+        monkeypatch.setenv("NBNXM_HIP_ENERGY_TAIL", "1")     # the perturbed pairs of energy steps in the kernel of their own
+    c = tl.make_case(elec=elec, seed=29, n_lambda=11, nm=(10, 10, 10), num_perturbed_molecules=40)
+    bits = np.asarray(c.grid.fepBits).reshape(-1)
+    assert np.count_nonzero(np.array([bin(int(b)).count("1") for b in bits]) >= 5) >= 10    # clusters that make heavy pairs
+    got = tl.run_gpu(c, energy=True, fused=True, dhdl=True)
+    want = tl.run_oracle(c, energy=True, foreign=True)
+    tl.assert_parity(got, want, rel=1e-4, label="heavy")
+    tl.assert_foreign(got, want, rel=1e-4)
+
+
 def test_empty_and_ragged_lists():
     # no perturbed atoms at all: the FEP list is empty, only the cluster kernel runs
     c = tl.make_case(elec="rf", seed=26, nm=(10, 10, 10), num_perturbed_molecules=0)
