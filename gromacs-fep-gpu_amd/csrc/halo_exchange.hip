@@ -29,6 +29,7 @@
 #include <memory>
 #include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include <rccl/rccl.h> /* types and prototypes only: the library is opened with dlopen */
@@ -1154,7 +1155,18 @@ int halo_gpu_push_import(HaloGpu* h, const void* records, int numRanks)
         {
             if (p.opened[which] != nullptr) { (void)hipIpcCloseMemHandle(p.opened[which]); }
             p.handle[which] = all[peer].handle[which];
-            NBNXM_HIP_CHECK(hipIpcOpenMemHandle(&p.opened[which], p.handle[which], hipIpcMemLazyEnablePeerAccess));
+            /* (four ranks on one device: the open now and then fails with "invalid device pointer" while the exporting process is still busy
+             * with its own opens, and succeeds a moment later: a few attempts before giving up) */
+            hipError_t err = hipSuccess;
+            for (int attempt = 0; attempt < 40; attempt++)
+            {
+                err = hipIpcOpenMemHandle(&p.opened[which], p.handle[which], hipIpcMemLazyEnablePeerAccess);
+                if (err == hipSuccess) { break; }
+                (void)hipGetLastError();
+                p.opened[which] = nullptr;
+                std::this_thread::sleep_for(std::chrono::milliseconds(25));
+            }
+            NBNXM_HIP_CHECK(err);
         }
         return static_cast<char*>(p.opened[which]);
     };

@@ -380,6 +380,26 @@ const char* nbnxm_hip_last_error(void)
     return g_lastError.c_str();
 }
 
+/* the kernels' small outputs live in outputsBlock[which]: [scalar-output block | shift-force block] */
+static void pointOutputsAt(NbnxmGpu* nb, int which)
+{
+    NBAtomDataGpu* ad   = nb->atdat;
+    const int      n1   = nb->n_lambda + 1;
+    nb->outputsActive   = which;
+    nb->scalarOutputs   = nb->outputsBlock[which];
+    ad->eLJ             = nb->scalarOutputs + 0;
+    ad->eElec           = nb->scalarOutputs + 1;
+    ad->dvdlLJ          = nb->scalarOutputs + 2;
+    ad->dvdlElec        = nb->scalarOutputs + 3;
+    ad->eLJForeign      = nb->scalarOutputs + 4;
+    ad->eElecForeign    = ad->eLJForeign + n1;
+    ad->dvdlLJForeign   = ad->eElecForeign + n1;
+    ad->dvdlElecForeign = ad->dvdlLJForeign + n1;
+    ad->energySlots     = nb->scalarOutputs + nb->slotOffset;
+    ad->foreignSlots    = nb->scalarOutputs + nb->foreignSlotOffset;
+    ad->fShift          = reinterpret_cast<decltype(ad->fShift)>(nb->scalarOutputs + nb->numScalarOutputs);
+}
+
 NbnxmGpu* nbnxm_gpu_init(const nbnxm_interaction_params_t* ic, int numTypes, const float* nbfp,
                          const float* nbfp_comb, int bLocalAndNonlocal, int bFEP, int n_lambda,
                          void* localStream, void* nonLocalStream)
@@ -574,27 +594,16 @@ NbnxmGpu* nbnxm_gpu_init(const nbnxm_interaction_params_t* ic, int numTypes, con
     NBAtomDataGpu* ad = nb->atdat;
     ad->numTypes      = numTypes;
     allocateDeviceBuffer(&ad->shiftVec, c_numShiftVectors);
-    /* all scalar outputs live in one block (layout above) so that one kernel clears them */
-    allocateDeviceBuffer(&nb->scalarOutputs, nb->numScalarOutputs);
-    ad->eLJ             = nb->scalarOutputs + 0;
-    ad->eElec           = nb->scalarOutputs + 1;
-    ad->dvdlLJ          = nb->scalarOutputs + 2;
-    ad->dvdlElec        = nb->scalarOutputs + 3;
-    ad->eLJForeign      = nb->scalarOutputs + 4;
-    ad->eElecForeign    = ad->eLJForeign + (n_lambda + 1);
-    ad->dvdlLJForeign   = ad->eElecForeign + (n_lambda + 1);
-    ad->dvdlElecForeign = ad->dvdlLJForeign + (n_lambda + 1);
-    ad->energySlots     = nb->scalarOutputs + nb->slotOffset;
-    ad->foreignSlots      = nb->scalarOutputs + nb->foreignSlotOffset;
-    ad->foreignSlotStride = nb->foreignSlotStride;
+    /* all scalar outputs live in one block (layout above) with the shift forces behind them — primary shift forces + the cluster kernel's
+     * accumulator slots (c_fshiftBlockFloats floats) —, so that one kernel clears them; two copies (NbnxmGpu::outputsBlock) */
+    for (int k = 0; k < 2; k++)
     {
-        /* primary shift forces + the cluster kernel's accumulator slots (c_fshiftBlockFloats floats) */
-        float* block = nullptr;
-        allocateDeviceBuffer(&block, c_fshiftBlockFloats);
-        clearDeviceBufferAsync(&block, 0, c_fshiftBlockFloats, s);
-        ad->fShift = reinterpret_cast<decltype(ad->fShift)>(block);
+        allocateDeviceBuffer(&nb->outputsBlock[k], nb->numScalarOutputs + c_fshiftBlockFloats);
+        clearDeviceBufferAsync(&nb->outputsBlock[k], 0, nb->numScalarOutputs + c_fshiftBlockFloats, s);
     }
-    clearDeviceBufferAsync(&nb->scalarOutputs, 0, nb->numScalarOutputs, s);
+    pointOutputsAt(nb, 0);
+    nb->outputsSpareCleared = true;
+    ad->foreignSlotStride = nb->foreignSlotStride;
     ad->shiftVecUploaded = false;
     NBNXM_HIP_CHECK(hipStreamSynchronize(s));
     return nb;
@@ -622,8 +631,10 @@ void nbnxm_gpu_free(NbnxmGpu* nb)
     freeDeviceBuffer(&ad->q4);
     freeDeviceBuffer(&ad->f);
     freeDeviceBuffer(&nb->fSpare);
-    freeDeviceBuffer(&nb->scalarOutputs);
-    freeDeviceBuffer(&ad->fShift);
+    freeDeviceBuffer(&nb->outputsBlock[0]);
+    freeDeviceBuffer(&nb->outputsBlock[1]);
+    nb->scalarOutputs = nullptr;
+    ad->fShift = nullptr; /* (part of outputsBlock) */
     freeDeviceBuffer(&ad->atomTypes);
     freeDeviceBuffer(&ad->ljComb);
     freeDeviceBuffer(&ad->atomTypes4);
@@ -1369,16 +1380,28 @@ void nbnxm_gpu_clear_outputs(NbnxmGpu* nb, int computeVirial)
         numFloat4         = 0;
         numTail           = 0;
     }
+    int numFshift = computeVirial ? c_fshiftBlockFloats : 0;
+    if (nb->fDoubleBuffer && nb->outputsDoubleBuffer && nb->outputsSpareCleared && nb->numWindows == 0 && (nb->scalarsDirty || (computeVirial && nb->fshiftDirty)))
+    {
+        /* ... and the other copy of the scalar outputs and shift forces: the same swap (results of the last step have been copied back by
+         * now: the copy-back and this call are on the same stream, or the caller has waited for the step) */
+        pointOutputsAt(nb, 1 - nb->outputsActive);
+        nb->outputsSpareCleared = false;
+        nb->scalarsDirty        = false;
+        nb->fshiftDirty         = false;
+        numFshift               = 0;
+    }
     const int numScalars = nb->scalarsDirty ? nb->numScalarOutputs : 0;
     const int numWindow  = nb->scalarsDirty ? nb->numWindows * ad->windowSlotStride : 0;
     nb->scalarsDirty     = false;
-    if (numFloat4 == 0 && numTail == 0 && numScalars == 0 && numWindow == 0 && !computeVirial) { return; } /* nothing to clear */
+    if (numFshift > 0) { nb->fshiftDirty = false; }
+    if (numFloat4 == 0 && numTail == 0 && numScalars == 0 && numWindow == 0 && numFshift == 0) { return; } /* nothing to clear */
     /* (sized by the largest of the arrays: after a swap of the force buffers only the few thousand scalars are left) */
-    const int numMost = std::max(std::max(numFloat4, numScalars), std::max(computeVirial ? c_fshiftBlockFloats : 0, numWindow));
+    const int numMost = std::max(std::max(numFloat4, numScalars), std::max(numFshift, numWindow));
     const int nblock  = std::max(1, std::min(2048, (numMost + 255) / 256));
     hipLaunchKernelGGL(nbnxmClearOutputsKernel, dim3(nblock), dim3(256), 0, s, reinterpret_cast<float4*>(ad->f), numFloat4,
                        reinterpret_cast<float*>(ad->f) + 4 * static_cast<size_t>(numFloat4), numTail, nb->scalarOutputs, numScalars,
-                       reinterpret_cast<float*>(ad->fShift), computeVirial ? c_fshiftBlockFloats : 0, ad->windowSlots, numWindow);
+                       reinterpret_cast<float*>(ad->fShift), numFshift, ad->windowSlots, numWindow);
     NBNXM_HIP_CHECK(hipGetLastError());
 }
 
@@ -1687,6 +1710,7 @@ void nbnxm_gpu_launch_kernel(NbnxmGpu* nb, const nbnxm_step_workload_t* stepWork
     InteractionTimers& t     = nb->timers[iloc];
     NBNXM_ASSERT(adat->shiftVecUploaded, "shift vectors have not been uploaded");
     if (stepWork->computeEnergy || stepWork->computeDhdl) { nb->scalarsDirty = true; } /* see nbnxm_gpu_clear_outputs */
+    if (stepWork->computeVirial) { nb->fshiftDirty = true; }
     /* nbnxm_gpu_launch_kernel_part: 1 = everything up to and including the first set of ranges (or the whole launch when the list is
      * not partitioned in two), 2 = the second set of ranges with the trailing workgroups (or nothing) */
     const int launchPart = nb->launchPartNow;
@@ -1912,12 +1936,23 @@ void nbnxm_gpu_launch_kernel(NbnxmGpu* nb, const nbnxm_step_workload_t* stepWork
             nb->fSpareCleared = true;
         }
         const int clearChunk     = wavesPerBlock * c_waveSize * static_cast<int>(c_clearFloat4PerThread);
+        /* ... and the spare copy of the scalar outputs and shift forces, whenever it is not clean (after a swap: the previous step's) */
+        float* clearB          = nullptr;
+        int    clearNumFloat4B = 0;
+        if (nb->fDoubleBuffer && nb->outputsDoubleBuffer && tailPruneAndClear && iloc == NBNXM_LOCAL && withTail && !nb->outputsSpareCleared
+            && nb->numWindows == 0)
+        {
+            if (nb->bUseTwoStreams && nb->nonlocalKernelRecorded) { NBNXM_HIP_CHECK(hipStreamWaitEvent(s, nb->nonlocalKernelDone, 0)); }
+            clearB                  = nb->outputsBlock[1 - nb->outputsActive];
+            clearNumFloat4B         = (nb->numScalarOutputs + c_fshiftBlockFloats) / 4;
+            nb->outputsSpareCleared = true;
+        }
         for (int set = firstSet; set <= lastSet; set++)
         {
             const bool tail      = withTail && set == lastSet;
             const int  numBlocks = (setRanges + wavesPerBlock - 1) / wavesPerBlock
                                   + (tail ? (mergedFepItems + wavesPerBlock - 1) / wavesPerBlock + (pruneEntries + wavesPerBlock - 1) / wavesPerBlock
-                                                    + (clearNumFloat4 + clearChunk - 1) / clearChunk
+                                                    + (clearNumFloat4 + clearChunk - 1) / clearChunk + (clearNumFloat4B + clearChunk - 1) / clearChunk
                                           : 0);
             NBNXM_ASSERT(numBlocks > 0, "empty cluster-kernel launch");
 #ifdef NBNXM_HOST_LAUNCH_TIMING /* diagnostics: host microseconds inside hipLaunchKernelGGL of the cluster kernel */
@@ -1929,7 +1964,8 @@ void nbnxm_gpu_launch_kernel(NbnxmGpu* nb, const nbnxm_step_workload_t* stepWork
                                *adat, *nbp, *plist, stepWork->computeVirial, plist->sciSorted, plist->cjPacked, plist->excl, adat->xq,
                                adat->atomTypes, adat->ljComb, reinterpret_cast<const unsigned*>(adat->fepBits), plist->groupSlowMask,
                                tail ? mergedFepItems : 0, std::max(plist->rollingPruningNumParts, 1), prunePart, tail ? pruneEntries : 0,
-                               reinterpret_cast<float4*>(nb->fSpare), tail ? clearNumFloat4 : 0, (wantForeign && energyFlavour) ? nb->n_lambda : -1,
+                               reinterpret_cast<float4*>(nb->fSpare), tail ? clearNumFloat4 : 0, reinterpret_cast<float4*>(clearB),
+                               tail ? clearNumFloat4B : 0, (wantForeign && energyFlavour) ? nb->n_lambda : -1,
                                *nb->feplist[iloc]);
 #ifdef NBNXM_HOST_LAUNCH_TIMING
             s_us += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0_).count();
@@ -2185,6 +2221,7 @@ void* nbnxm_gpu_get_f(NbnxmGpu* nb)
 
 void* nbnxm_gpu_get_fshift(NbnxmGpu* nb)
 {
+    nb->outputsDoubleBuffer = false; /* the caller may keep the pointer: no more swaps of the output blocks */
     return nb->atdat->fShift;
 }
 

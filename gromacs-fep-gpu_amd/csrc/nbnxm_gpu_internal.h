@@ -64,6 +64,13 @@ struct NbnxmGpu
     float3*        fSpare                      = nullptr;
     int            fSpareAlloc                 = 0;
     bool           fSpareCleared               = false;
+    /* ... and the same for the small outputs: two copies of [scalar-output block | shift-force block]; nbnxm_gpu_clear_outputs swaps to the
+     * one a kernel's trailing workgroups have zeroed instead of launching a kernel for 80 KB (2.5 us of an energy step of the 96k box) */
+    float*         outputsBlock[2]             = { nullptr, nullptr };
+    int            outputsActive               = 0;
+    bool           outputsDoubleBuffer         = true;  /* false once a caller holds a pointer into the block (nbnxm_gpu_get_fshift) */
+    bool           outputsSpareCleared         = false;
+    bool           fshiftDirty                 = false; /* a launch with shift forces since the last clear */
     bool           scalarsDirty                = true;  /* energies / dV/dl / foreign / window slots written since the last clear */
     int            energyTail                  = c_energyTailCompiled; /* see NBNXM_ENERGY_TAIL (nbnxm_hip_types.h) */
     bool           fepListMerged               = true;  /* atom-pair list mode: the list's force / energy kernel rides in trailing

@@ -386,6 +386,9 @@ __launch_bounds__(c_nbMaxBlockSize) __attribute__((amdgpu_waves_per_eu(c_nbWaves
                          /* force flavour: the spare force buffer, zeroed by the last trailing workgroups (or 0 float4) */
                          float4* __restrict__ clearF4,
                          const int clearNumFloat4,
+                         /* ... and a second, small area: the spare copy of the scalar outputs and shift forces (or 0 float4) */
+                         float4* __restrict__ clearB,
+                         const int clearNumFloat4B,
                          /* energy flavour, dH/dlambda step: the perturbed cluster pairs of the trailing workgroups also accumulate their energies
                           * at lambda indices 0 .. mergedFepForeignLambdas (the FOREIGN flavour of fepClusterPair); -1: not such a step */
                          const int mergedFepForeignLambdas,
@@ -534,12 +537,21 @@ __launch_bounds__(c_nbMaxBlockSize) __attribute__((amdgpu_waves_per_eu(c_nbWaves
             {
                 /* 3. the OTHER force buffer (clearNumFloat4 > 0), zeroed for the next step: nbnxm_gpu_clear_outputs then swaps the
                  *    two buffers instead of launching a kernel */
-                const unsigned idx   = blockIdx.x - mainBlocks - pruneBlocks - fepBlocks;
-                const unsigned chunk = blockSize * c_clearFloat4PerThread;
-                const unsigned end   = min((idx + 1U) * chunk, static_cast<unsigned>(clearNumFloat4));
+                const unsigned chunk   = blockSize * c_clearFloat4PerThread;
+                const unsigned blocksA = (static_cast<unsigned>(clearNumFloat4) + chunk - 1U) / chunk;
+                unsigned       idx     = blockIdx.x - mainBlocks - pruneBlocks - fepBlocks;
+                float4*        dst     = clearF4;
+                unsigned       num     = static_cast<unsigned>(clearNumFloat4);
+                if (idx >= blocksA)
+                {
+                    idx -= blocksA;
+                    dst = clearB;
+                    num = static_cast<unsigned>(clearNumFloat4B);
+                }
+                const unsigned end = min((idx + 1U) * chunk, num);
                 /* (streaming stores — `nt` — so that the 1.2 MB leave no dirty lines for the end of the kernel to write back: measured flat,
                  * 50.15 vs 50.27 us at 96k atoms, 18.5 vs 18.5 us at 24k; the 2 - 3 us between two launches are not a write-back) */
-                for (unsigned i = idx * chunk + threadIdx.x; i < end; i += blockSize) { clearF4[i] = make_float4(0.0F, 0.0F, 0.0F, 0.0F); }
+                for (unsigned i = idx * chunk + threadIdx.x; i < end; i += blockSize) { dst[i] = make_float4(0.0F, 0.0F, 0.0F, 0.0F); }
             }
 #ifdef NBNXM_WAVE_TIMELINE
             {

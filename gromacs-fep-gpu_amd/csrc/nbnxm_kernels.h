@@ -10,7 +10,7 @@
 
 using NbKernelPtr = void (*)(const NbWorkDesc*, int, int, NBAtomDataGpu, NBParamGpu, gpu_plist, int, const nbnxn_sci_t*, const nbnxn_cj_packed_t*,
                              const nbnxn_excl_t*, const float4*, const int*, const float2*, const unsigned*,
-                             const unsigned*, int, int, int, int, float4*, int, int, gpu_feplist);
+                             const unsigned*, int, int, int, int, float4*, int, float4*, int, int, gpu_feplist);
 using FepClusterKernelPtr = void (*)(NBAtomDataGpu, NBParamGpu, gpu_plist, int, const nbnxn_sci_t*, const nbnxn_cj_packed_t*,
                                      const nbnxn_excl_t*, const float4*, const int*, const float2*, const unsigned*, int);
 using FepKernelPtr   = void (*)(NBAtomDataGpu, NBParamGpu, gpu_feplist, int);
