@@ -37,7 +37,7 @@ DT_FS = 2.0                # MD time step for the kernel-bound ns/day figure
 METRIC = "ns/day + pair-interactions/s, 100k-atom FEP box @ λ=0.5, 1/2/4/8 MI355X"
 # molecules per box edge of the synthetic water boxes (3 atoms each): configs[1], configs[2], 8 x configs[2], configs[4]'s 1.02 M atoms
 BOXES = {"3k": (10, 10, 10), "12k": (20, 20, 10), "24k": (20, 20, 20), "48k": (40, 20, 20), "96k": (40, 40, 20), "192k": (40, 40, 40), "768k": (80, 80, 40), "1m": (88, 88, 44)}
-COUNTERS_FILE = os.path.join("profiles", "r03", "counters_fused_force_kernel.json")   # written by tools/summarize_counters.py
+COUNTERS_FILE = os.path.join("profiles", "r04", "counters_fused_force_kernel.json")   # written by tools/summarize_counters.py
 # the two other roofs of the dominant kernel ("which roof"):
 PEAK_CLOCK_GHZ = 2.4                 # MI355X_MICROARCH.md; under this kernel's load the chip holds ~2.0 GHz
 VALU_CYCLES_PER_WAVE64_INSTRUCTION = 2   # SIMD-32 issues a wave64 VALU instruction over 2 cycles (quarter-rate ones take 8)

@@ -48,7 +48,7 @@ uk = np.unique(key)
 simd_end = np.array([end[key == k].max() for k in uk])
 simd_first = np.array([first[key == k].min() for k in uk])
 tail = allrec[n:]
-tail = tail[(tail[:, 0] != 0) & (tail[:, 1] <= 3)]
+tail = tail[(tail[:, 0] != 0) & (tail[:, 1] <= 3) & (tail[:, 0] >= t0)]   # (records older than this launch: left by a launch with more trailing waves)
 tail_end = ((tail[:, 2] - t0).astype(np.float64) / 100.0).max() if len(tail) else 0.0
 last = max(end.max(), tail_end)
 print("box %s %s: %d range waves (%d with work), %d SIMDs, waves per SIMD %.2f" % (size, elec, n, len(a), len(uk), len(a) / len(uk)))
