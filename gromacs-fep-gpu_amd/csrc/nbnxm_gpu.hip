@@ -221,8 +221,10 @@ void uploadEwaldCorrectionTable(NbnxmGpu* nb)
      * Force flavours {intercept, slope} of beta^3 F, energy flavours the same for beta^3 F and beta V: value = a + b r^2, one FMA with
      * the r^2 the pair block already holds. */
     const double uMax = xMax / (beta * beta), du = uMax / (n - 1);
+    const int    nE   = c_ewaldCorrTabSizeEnergy;
+    const double duE  = uMax / (nE - 1); /* the energy flavours' table: fewer, wider intervals (c_ewaldCorrTabSizeEnergy) */
     /* (the 16-byte entries of the energy flavours: 16 r^2 / h rounded, four bits dropped: spans from (k - 1/32) h) */
-    auto line = [&](auto&& fn, double scale, int k, double eighth, double& a, double& b) {
+    auto line = [&](auto&& fn, double scale, int k, double eighth, double du, double& a, double& b) {
         const double uL = (k - eighth) * du, uR = (k + 1.0 - eighth) * du;
         const double y0 = scale * fn(beta * beta * uL), y1 = scale * fn(beta * beta * uR);
         b = (y1 - y0) / du;
@@ -231,10 +233,12 @@ void uploadEwaldCorrectionTable(NbnxmGpu* nb)
     for (int k = 0; k < n; k++)
     {
         double a, b, aV, bV;
-        line(F, b3, k, 1.0 / 16.0, a, b);
+        line(F, b3, k, 1.0 / 16.0, du, a, b);
         nb->h_ewaldCorrTab.data[k] = make_float2(static_cast<float>(a), static_cast<float>(b));
-        line(F, b3, k, 1.0 / 32.0, a, b);
-        line(V, beta, k, 1.0 / 32.0, aV, bV);
+        /* (entries nE .. n - 1 of the energy table are never addressed: r^2 stays below the cut-off; filled with the last interval) */
+        const int kE = std::min(k, nE - 1);
+        line(F, b3, kE, 1.0 / 32.0, duE, a, b);
+        line(V, beta, kE, 1.0 / 32.0, duE, aV, bV);
         nb->h_ewaldCorrTabFV.data[k] = make_float4(static_cast<float>(a), static_cast<float>(b), static_cast<float>(aV), static_cast<float>(bV));
     }
     if (nbp->ewaldCorrTab == nullptr)
@@ -245,7 +249,7 @@ void uploadEwaldCorrectionTable(NbnxmGpu* nb)
     copyToDeviceBuffer(&nbp->ewaldCorrTab, nb->h_ewaldCorrTab.data, 0, n, nb->deviceStreams[0].stream, true);
     copyToDeviceBuffer(&nbp->ewaldCorrTabFV, nb->h_ewaldCorrTabFV.data, 0, n, nb->deviceStreams[0].stream, true);
     nbp->ewaldCorrTabScale8  = static_cast<float>(8.0 / du);
-    nbp->ewaldCorrTabScale16 = static_cast<float>(16.0 / du);
+    nbp->ewaldCorrTabScale16 = static_cast<float>(16.0 / duE);
 }
 
 bool canSkipNonbondedWork(const NbnxmGpu& nb, int iloc)
@@ -291,9 +295,9 @@ static NbLaunchShape chooseNbLaunchShape(int elecType, int vdwType, bool energy,
     const bool ewaldRTable    = (elecType == NBNXM_ELEC_EWALD_TAB || elecType == NBNXM_ELEC_EWALD_TAB_TWIN);
     /* analytical: {F, step} or, on energy steps, {F, step, V, step}; tabulated: the caller's r-indexed force table, on energy steps behind
      * the {V, step} part of the correction table */
-    const int  ewaldTableBytes = ewaldCorrTable ? c_ewaldCorrTabSize * static_cast<int>(energy ? sizeof(float4) : sizeof(float2))
+    const int  ewaldTableBytes = ewaldCorrTable ? (energy ? c_ewaldCorrTabSizeEnergy * static_cast<int>(sizeof(float4)) : c_ewaldCorrTabSize * static_cast<int>(sizeof(float2)))
                                                 : (ewaldRTable ? coulombTabLdsBytes(coulombTabSize)
-                                                                         + (energy ? c_ewaldCorrTabSize * static_cast<int>(sizeof(float2)) : 0)
+                                                                         + (energy ? c_ewaldCorrTabSizeEnergy * static_cast<int>(sizeof(float2)) : 0)
                                                                : 0);
     const int  compiledWavesPerSimd = nbKernelWavesPerEu(vdwType, energy, false);
     NbLaunchShape shape{ 0, 0, 0 };

@@ -180,6 +180,10 @@ struct NBParamGpu
 };
 
 constexpr int c_ewaldCorrTabSize = 2048;
+/* ... and of the energy flavours' table {F intercept, F slope, V intercept, V slope}: 30 KB instead of 32, so that FOUR workgroups of four
+ * waves fit a CU's 160 KB with their staging areas (two of eight waves before): a trailing workgroup then starts when four of a CU's
+ * range waves have retired, not eight (round 4).  The interpolation error grows by (2047 / 1919)^2. */
+constexpr int c_ewaldCorrTabSizeEnergy = 1920;
 constexpr int c_coulombTabMaxLds = 16384; /* entries of the r-indexed table that the tabulated flavours stage into LDS (64 KB) */
 /* waves per workgroup of nbnxmFepClusterKernel */
 constexpr int c_fepClusterWavesPerBlockDef = 4;

@@ -437,8 +437,8 @@ __launch_bounds__(c_nbMaxBlockSize) __attribute__((amdgpu_waves_per_eu(c_nbWaves
     /* tabulated Ewald, energy steps: the potential correction {beta V, step} of the analytical flavours' table in front of the r-indexed
      * force table (the reference calls erff there, two divergent branches per pair) */
     constexpr bool EWALD_V_TABLE    = (ELEC == ELK_EWALD_TAB) && ENERGY;
-    constexpr int  c_ewaldTabBytes  = EWALD_CORR_TABLE ? c_ewaldCorrTabSize * static_cast<int>(ENERGY ? sizeof(float4) : sizeof(float2))
-                                                       : (EWALD_V_TABLE ? c_ewaldCorrTabSize * static_cast<int>(sizeof(float2)) : 0);
+    constexpr int  c_ewaldTabBytes  = EWALD_CORR_TABLE ? (ENERGY ? c_ewaldCorrTabSizeEnergy * static_cast<int>(sizeof(float4)) : c_ewaldCorrTabSize * static_cast<int>(sizeof(float2)))
+                                                       : (EWALD_V_TABLE ? c_ewaldCorrTabSizeEnergy * static_cast<int>(sizeof(float2)) : 0);
     /* tabulated Ewald: the reference's r-indexed force table (run-time size) takes the same place; the LJ table's row offsets
      * (trow) carry its size, so that a table read still needs no base-address add */
     constexpr bool EWALD_R_TABLE = (ELEC == ELK_EWALD_TAB);
@@ -840,7 +840,7 @@ __launch_bounds__(c_nbMaxBlockSize) __attribute__((amdgpu_waves_per_eu(c_nbWaves
     if constexpr (EWALD_V_TABLE)
     {
         float2* dst = reinterpret_cast<float2*>(nbLds);
-        for (int t = threadIdx.x; t < c_ewaldCorrTabSize; t += blockSize)
+        for (int t = threadIdx.x; t < c_ewaldCorrTabSizeEnergy; t += blockSize)
         {
             const float4 fv = nbp.ewaldCorrTabFV[t];
             dst[t]          = make_float2(fv.z, fv.w);

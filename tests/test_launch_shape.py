@@ -55,6 +55,9 @@ def test_many_types_switch_to_larger_workgroups():
     assert shape(pkg.ELEC_EWALD_ANA, pkg.VDW_CUT, False, 40) [:2] == (4, 4)
     assert shape(pkg.ELEC_EWALD_ANA, pkg.VDW_CUT, False, 64)[:2] == (8, 4)
     assert shape(pkg.ELEC_EWALD_ANA, pkg.VDW_CUT, False, 100)[:2] == (16, 4)
-    # the energy flavours carry the 32 KB force + potential table: two 8-wave workgroups instead of three 4-wave ones
-    assert shape(pkg.ELEC_EWALD_ANA, pkg.VDW_CUT, True, 3)[:2] == (8, 4)
+    # the energy flavours carry the 30 KB force + potential table (1,920 entries: round 4): four 4-wave workgroups fit a CU with a small
+    # type table, two 8-wave ones beyond 11 types
+    assert shape(pkg.ELEC_EWALD_ANA, pkg.VDW_CUT, True, 3)[:2] == (4, 4)
+    assert shape(pkg.ELEC_EWALD_ANA, pkg.VDW_CUT, True, 11)[:2] == (4, 4)
+    assert shape(pkg.ELEC_EWALD_ANA, pkg.VDW_CUT, True, 12)[:2] == (8, 4)
     assert shape(pkg.ELEC_RF, pkg.VDW_CUT, True, 3)[:2] == (4, 4)
