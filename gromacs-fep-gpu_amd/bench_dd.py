@@ -130,6 +130,18 @@ def measure(args, rank, world, dist, torch, nm, npert, reduce_device, steps, war
     if world > 1:
         dist.barrier()
     elapsed = replica.max_over_ranks(time.perf_counter() - t_start, dist if world > 1 else None, device=reduce_device)
+    status_all = None
+    if ipc_push:
+        # ... and at the end: a kernel that gave up in a later step made the object skip the steps behind it (halo_exchange.hip), so the time
+        # above would be meaningless — every rank learns it, the record says so and carries no rate
+        bad = torch.tensor([float(halo.push_status())], device=reduce_device, dtype=torch.float64)
+        if world > 1:
+            dist.all_reduce(bad, op=dist.ReduceOp.MAX)
+        status_all = int(bad.item())
+        if status_all != 0:
+            halo.free()
+            nb.free()
+            raise RuntimeError("one-sided transport: a kernel gave up waiting for a peer's flag during the timed steps (status %d)" % status_all)
     rec = None
     if rank == 0:
         rec = {"pair_interactions_per_s": 64.0 * float(tot[0].item()) * steps / elapsed, "ms_per_step": 1e3 * elapsed / steps, "steps": steps,
@@ -139,7 +151,7 @@ def measure(args, rank, world, dist, torch, nm, npert, reduce_device, steps, war
                "transport": ("in-process peer copies between rank threads (halo_hip.h; a rehearsal)" if getattr(dist, "peer_copy_id", None) is not None
                              else "one-sided: stores into the peers' buffers (hipIpc), sequence flags, no transfer kernel (halo_hip.h)" if ipc_push
                              else "RCCL ncclSend/ncclRecv groups (halo_hip.h)"),
-               "one_sided_status": halo.push_status() if ipc_push else None,
+               "one_sided_status": status_all,
                "schedule": ("merged localities: one list, one launch, one stream per rank" if merged else "two localities on two streams"),
                "local_launch": ("one launch" if merged else
                                 "two parts, the second behind the non-local kernel (HALO_GPU_LOCAL_PARTS)" if world > 1 and os.environ.get("HALO_GPU_LOCAL_PARTS", "2") == "2"

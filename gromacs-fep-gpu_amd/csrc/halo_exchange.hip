@@ -512,6 +512,7 @@ struct HaloGpu
      * over the caller's out-of-band channel (halo_gpu_push_export / _import).  Peers store the halo coordinates into d_xRecv — memory of
      * this library, exportable — instead of the caller's d_x; the x -> xq kernel reads them there and fills the halo rows of d_x. */
     bool                               ipcPush  = false;
+    bool                               pushErrorReported = false;
     float3*                            d_xRecv  = nullptr;
     int                                xRecvAlloc = 0;
     struct IpcPeer
@@ -660,15 +661,22 @@ void worldBarrier(HaloGpu* h)
     if (!ok) { fatal(__FILE__, __LINE__, "halo one-sided transport", "a rank did not reach the barrier (every rank needs its own host thread and the same sequence of calls)"); }
 }
 
-void checkPushError(HaloGpu* h)
+/* true: a kernel of an earlier step has given up waiting for a peer.  Ranks that are threads of one process (tests, rehearsals) stop there;
+ * between processes (a node run) it is not fatal: the step is skipped, halo_gpu_push_status() says why, and the caller goes on with another
+ * transport (bench.py's decomposition leg) — an abort here would take the rest of the job's output with it. */
+bool checkPushError(HaloGpu* h)
 {
-    if (h->h_pushError != nullptr && *h->h_pushError != 0U)
+    if (h->h_pushError == nullptr || *h->h_pushError == 0U) { return false; }
+    char msg[160];
+    std::snprintf(msg, sizeof(msg), "rank %d: a kernel gave up waiting for the flag of link %u (a peer never stored its side of an exchange)", h->rank,
+                  *h->h_pushError - 1U);
+    if (!h->ipcPush) { fatal(__FILE__, __LINE__, "halo one-sided transport", msg); }
+    if (!h->pushErrorReported)
     {
-        char msg[160];
-        std::snprintf(msg, sizeof(msg), "rank %d: a kernel gave up waiting for the flag of link %u (a peer never stored its side of an exchange)", h->rank,
-                      *h->h_pushError - 1U);
-        fatal(__FILE__, __LINE__, "halo one-sided transport", msg);
+        std::fprintf(stderr, "halo one-sided transport: %s; the steps of this object are skipped from here on\n", msg);
+        h->pushErrorReported = true;
     }
+    return true;
 }
 
 /* halo_gpu_reinit, one-sided transport: publish this rank's buffers, wait for the neighbours', derive every link's remote addresses */
@@ -811,6 +819,21 @@ static size_t ipcExportableBytes(size_t bytes)
     return ((bytes + c_block - 1) / c_block) * c_block;
 }
 
+/* Memory that OTHER devices store into while this device's kernels poll or read it (flags, receive buffers of the one-sided transports):
+ * fine-grained device memory, so that this device's L2 does not keep lines a peer has written behind its back — on one device
+ * everything goes through the same L2 and any memory would do; across xGMI a remote store lands in HBM, not in the owner's L2.
+ * (hipMalloc's coarse-grained memory is only coherent between devices at kernel boundaries.)  Falls back to hipMalloc where the
+ * runtime has no fine-grained pool. */
+static void mallocForPeerStores(void** p, size_t bytes)
+{
+    const size_t n = ipcExportableBytes(bytes);
+    if (hipExtMallocWithFlags(p, n, hipDeviceMallocFinegrained) != hipSuccess)
+    {
+        (void)hipGetLastError();
+        NBNXM_HIP_CHECK(hipMalloc(p, n));
+    }
+}
+
 HaloGpu* halo_gpu_create(const void* uniqueId, int rank, int nranks, void* stream)
 {
     if (rank < 0 || rank >= nranks)
@@ -827,7 +850,7 @@ HaloGpu* halo_gpu_create(const void* uniqueId, int rank, int nranks, void* strea
     NBNXM_HIP_CHECK(hipGetDevice(&h->device));
     auto allocatePushState = [&]() {
         const size_t numFlags = static_cast<size_t>(c_numPushFlagKinds) * c_pushMaxLinks * c_pushFlagStride;
-        NBNXM_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&h->d_flags), ipcExportableBytes(sizeof(unsigned) * numFlags)));
+        mallocForPeerStores(reinterpret_cast<void**>(&h->d_flags), sizeof(unsigned) * numFlags);
         NBNXM_HIP_CHECK(hipMemset(h->d_flags, 0, sizeof(unsigned) * numFlags));
         NBNXM_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&h->d_doneCounter), sizeof(unsigned) * 4 * c_pushFlagStride));
         NBNXM_HIP_CHECK(hipMemset(h->d_doneCounter, 0, sizeof(unsigned) * 4 * c_pushFlagStride));
@@ -1030,26 +1053,27 @@ void halo_gpu_reinit(HaloGpu* h, void* d_x, void* d_f, int numHome, int numSend,
         NBNXM_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&h->d_sendMap), sizeof(int) * h->sendAlloc));
         NBNXM_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&h->d_sendShiftIndex), sizeof(int) * h->sendAlloc));
         NBNXM_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&h->d_sendBuf), sizeof(float3) * h->sendAlloc));
-        NBNXM_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&h->d_recvBuf), h->ipcPush ? ipcExportableBytes(sizeof(float3) * h->sendAlloc) : sizeof(float3) * h->sendAlloc));
+        if (h->ipcPush || (h->world && h->world->push)) { mallocForPeerStores(reinterpret_cast<void**>(&h->d_recvBuf), sizeof(float3) * h->sendAlloc); }
+        else { NBNXM_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&h->d_recvBuf), sizeof(float3) * h->sendAlloc)); }
     }
     if (h->ipcPush)
     {
-        checkPushError(h);
+        (void)checkPushError(h);
         int numHalo = 0;
         for (int k = 0; k < numRecv; k++) { numHalo = std::max(numHalo, recvAtomOffset[k] + recvCount[k] - numHome); }
         if (numHalo > h->xRecvAlloc || h->d_xRecv == nullptr)
         {
             if (h->d_xRecv != nullptr) { h->retiredBuffers.push_back(h->d_xRecv); } /* a peer may still have it open */
             h->xRecvAlloc = static_cast<int>(numHalo * 1.2) + 1024;
-            NBNXM_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&h->d_xRecv), ipcExportableBytes(sizeof(float3) * h->xRecvAlloc)));
+            mallocForPeerStores(reinterpret_cast<void**>(&h->d_xRecv), sizeof(float3) * h->xRecvAlloc);
         }
-        if (h->d_recvBuf == nullptr) { NBNXM_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&h->d_recvBuf), ipcExportableBytes(sizeof(float3) * 1024))); } /* (a rank that sends nothing still exports a buffer) */
+        if (h->d_recvBuf == nullptr) { mallocForPeerStores(reinterpret_cast<void**>(&h->d_recvBuf), sizeof(float3) * 1024); } /* (a rank that sends nothing still exports a buffer) */
         h->generation++;
         /* (the links' remote addresses follow with halo_gpu_push_import, once the ranks have exchanged what halo_gpu_push_export gives) */
     }
     else if (h->world && h->world->push)
     {
-        checkPushError(h);
+        (void)checkPushError(h);
         pushReinit(h);
     }
     else if (h->world)
@@ -1147,6 +1171,7 @@ int halo_gpu_push_import(HaloGpu* h, const void* records, int numRanks)
             return 2;
         }
     }
+    std::string openFailure;
     /* pointers into a peer's three buffers; this rank's own are used directly (a handle cannot be opened by the process that made it) */
     auto opened = [&](int peer, int which) -> char* {
         if (peer == h->rank) { return reinterpret_cast<char*>(which == 0 ? static_cast<void*>(h->d_flags) : which == 1 ? static_cast<void*>(h->d_recvBuf) : static_cast<void*>(h->d_xRecv)); }
@@ -1166,10 +1191,25 @@ int halo_gpu_push_import(HaloGpu* h, const void* records, int numRanks)
                 p.opened[which] = nullptr;
                 std::this_thread::sleep_for(std::chrono::milliseconds(25));
             }
-            NBNXM_HIP_CHECK(err);
+            if (err != hipSuccess)
+            {
+                /* not fatal: the caller falls back to another transport (bench.py's decomposition leg does) */
+                openFailure = std::string("halo_gpu_push_import: hipIpcOpenMemHandle of rank ") + std::to_string(peer) + "'s buffer " + std::to_string(which)
+                              + ": " + hipGetErrorString(err);
+                return nullptr;
+            }
         }
         return static_cast<char*>(p.opened[which]);
     };
+    /* open everything first: nothing of the links is touched when a peer's buffer cannot be opened */
+    for (int k = 0; k < static_cast<int>(h->sendPeer.size()); k++)
+    {
+        for (int which : { 0, 2 }) { if (opened(h->sendPeer[k], which) == nullptr) { g_haloError = openFailure; return 3; } }
+    }
+    for (int k = 0; k < static_cast<int>(h->recvPeer.size()); k++)
+    {
+        for (int which : { 0, 1 }) { if (opened(h->recvPeer[k], which) == nullptr) { g_haloError = openFailure; return 3; } }
+    }
     auto linkIn = [](const int* peers, int n, int me) {
         for (int k = 0; k < n; k++)
         {
@@ -1377,7 +1417,7 @@ void halo_gpu_domain_force_step(HaloGpu* h, NbnxmGpu* nb, const nbnxm_step_workl
          * need none. */
         NBNXM_ASSERT(nbnxm_gpu_get_merged_localities(nb) && h->stream == sLocal,
                      "the one-sided transport runs the merged-localities schedule on the LOCAL stream of the non-bonded object");
-        checkPushError(h);
+        if (checkPushError(h)) { return; }
         const bool     shared = h->world && h->world->sharedDevice && h->nranks > 1; /* (ranks in processes of their own: their queues are their own) */
         const unsigned seq    = ++h->pushSeq;
         const unsigned* flags = h->d_flags;

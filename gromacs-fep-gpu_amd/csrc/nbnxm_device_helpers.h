@@ -240,7 +240,10 @@ NB_DEVINL unsigned ewaldTabAddress(const float r2, const float scaleTimesStride)
      * addend — v_fmaak — at full rate: tools/ubench/valu_rate3.hip, 1.90 against 1.18 ns per wave instruction and SIMD.  Measured and not
      * kept: the AND's mask from an SGPR instead of a literal, +1.1 us) */
     const float y = fmaf(r2, scaleTimesStride, 8388608.0F);
-    return __builtin_bit_cast(unsigned, y) & static_cast<unsigned>((c_ewaldCorrTabSize * STRIDE - 1) & ~(STRIDE - 1));
+    /* (the 16-byte entries are the energy flavours' table: c_ewaldCorrTabSizeEnergy entries, masked with the power of two above it) */
+    constexpr int c_maskEntries = (STRIDE == 16) ? 2048 : c_ewaldCorrTabSize;
+    static_assert(c_ewaldCorrTabSizeEnergy <= 2048, "the energy table's address mask");
+    return __builtin_bit_cast(unsigned, y) & static_cast<unsigned>((c_maskEntries * STRIDE - 1) & ~(STRIDE - 1));
 }
 
 /* ---- non-perturbed atom pair (nbnxm_cuda_kernel.cuh:518-645) ---------------------------------- */

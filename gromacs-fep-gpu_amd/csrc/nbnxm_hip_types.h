@@ -179,7 +179,10 @@ struct NBParamGpu
     int     coulombTabSize;
 };
 
-constexpr int c_ewaldCorrTabSize = 2048;
+#ifndef NBNXM_EWALD_CORR_TAB_SIZE
+#define NBNXM_EWALD_CORR_TAB_SIZE 2048
+#endif
+constexpr int c_ewaldCorrTabSize = NBNXM_EWALD_CORR_TAB_SIZE; /* a power of two (ewaldTabAddress masks with it) */
 /* ... and of the energy flavours' table {F intercept, F slope, V intercept, V slope}: 30 KB instead of 32, so that FOUR workgroups of four
  * waves fit a CU's 160 KB with their staging areas (two of eight waves before): a trailing workgroup then starts when four of a CU's
  * range waves have retired, not eight (round 4).  The interpolation error grows by (2047 / 1919)^2. */

@@ -349,10 +349,17 @@ class RcclHalo:
         else:
             everyone = mine
         everyone = np.ascontiguousarray(everyone, np.uint8)
-        if lib.halo_gpu_push_import(C.c_void_p(self._h), everyone.ctypes.data_as(C.c_void_p), C.c_int(self._num_ranks)) != 0:
-            raise RuntimeError("halo_gpu_push_import: %s" % lib.halo_gpu_last_error().decode())
+        rc = lib.halo_gpu_push_import(C.c_void_p(self._h), everyone.ctypes.data_as(C.c_void_p), C.c_int(self._num_ranks))
+        message = lib.halo_gpu_last_error().decode() if rc != 0 else ""
         if self._num_ranks > 1:
-            self._dist.barrier()      # every rank has opened the others' buffers before any rank stores into them
+            # every rank has opened the others' buffers before any rank stores into them — and every rank learns whether ALL could:
+            # a rank that cannot open a peer's buffer must not leave the others waiting inside the next collective
+            ok = torch.tensor([1 if rc == 0 else 0], dtype=torch.int32, device=dev)
+            self._dist.all_reduce(ok, op=self._dist.ReduceOp.MIN)
+            if int(ok.item()) == 0:
+                raise RuntimeError("halo_gpu_push_import failed on %s: %s" % ("this rank" if rc != 0 else "another rank", message))
+        elif rc != 0:
+            raise RuntimeError("halo_gpu_push_import: %s" % message)
 
     def push_status(self):
         """0, or 1 + the link a kernel of the one-sided transport gave up waiting for"""
