@@ -465,6 +465,7 @@ NbnxmGpu* nbnxm_gpu_init(const nbnxm_interaction_params_t* ic, int numTypes, con
                     acc += nb->waveClassShare[p][k];
                 }
                 nb->waveClassShare[p][4 + p - 1] += 1024 * (4 + p) - acc;
+                nb->waveClassShareFixed[p] = true;
             }
         }
     }
@@ -1583,15 +1584,23 @@ static void updateWorkPartition(NbnxmGpu* nb, int iloc)
         /* shares: only for the launch they are meant for, one wave per slot of every SIMD; they start from the age classes
          * (the waves of a SIMD are dispatched numRanges / classes apart) and survive new lists of the same size */
         const float fraction = twoParts ? nb->localPartFraction : 1.0F;
-        if (d->numWorkRanges[p] == want && !shortList && (d->workShareCount[p] != want || d->workPartFraction[p] != fraction))
+        /* how long the ranges are, in sixteenths between the short-range and the long-range shares of the age classes */
+        const int groupsPerRange = d->ncjPacked / std::max(1, want);
+        const int taper16        = nb->waveClassShareFixed[p]
+                                           ? 0
+                                           : std::max(0, std::min(16, (groupsPerRange - c_shortRangeGroups) * 16 / (c_longRangeGroups - c_shortRangeGroups)));
+        if (d->numWorkRanges[p] == want && !shortList
+            && (d->workShareCount[p] != want || d->workPartFraction[p] != fraction || d->workShareTaper16[p] != taper16))
         {
             const int          classes = 4 + p, perClass = slots / classes;
             std::vector<float> share(want);
+            d->workShareTaper16[p] = taper16;
             /* the age-class shares were measured for the fused mode; with the atom-pair kernels running beside the cluster
              * kernel (split mode) equal shares are the better start (0.1037 vs 0.1055 ms per step) */
             for (int r = 0; r < want; r++)
             {
-                const float ofClass = nb->fusedFep ? nb->waveClassShare[p][std::min(classes - 1, (r % slots) / perClass)] / 1024.0F : 1.0F;
+                const int   k       = std::min(classes - 1, (r % slots) / perClass);
+                const float ofClass = nb->fusedFep ? (nb->waveClassShare[p][k] * (16 - taper16) + nb->waveClassShareLong[p][k] * taper16) / (16.0F * 1024.0F) : 1.0F;
                 share[r]            = ofClass * (twoParts ? (r < slots ? fraction : 1.0F - fraction) : 1.0F);
             }
             setWorkShares(d, p, share.data(), want, s);

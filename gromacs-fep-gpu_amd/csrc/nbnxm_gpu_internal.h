@@ -117,6 +117,12 @@ struct NbnxmGpu
     int minGroupsPerWave  = 1; /* (3k-atom box: 0.0156 -> 0.0133 ms per step with 1 instead of 2; larger boxes have more groups than wave slots anyway) */
     /* share of work per age class of the waves of a SIMD, [0]: 4 waves per SIMD, [1]: 5 (see WorkPartitionOut) */
     int waveClassShare[2][5] = { { 1024, 1024, 1024, 1024, 0 }, { 1100, 1060, 1024, 990, 946 } };
+    /* ... of LONG ranges (from c_longRangeGroups packed groups per range on; 768k atoms and up): the older waves of a SIMD are favoured at a
+     * RATE, so the longer the ranges, the more of the kernel's end is the youngest wave running alone — measured optimum at 1.02 M atoms
+     * (round 4: force step 0.4177 -> 0.4078 ms, energy step 0.552 -> 0.533 ms); between c_shortRangeGroups and c_longRangeGroups the
+     * shares are interpolated */
+    int  waveClassShareLong[2][5] = { { 1225, 1110, 970, 791, 0 }, { 1350, 1185, 1024, 865, 696 } };
+    bool waveClassShareFixed[2]   = { false, false }; /* set from the environment (diagnostics): no interpolation */
     int numWorkRangesOverride = 0; /* experiments: NBNXM_HIP_NUM_WORK_RANGES */
     int workWeightsOverride[3] = { -1, -1, -1 }; /* experiments: NBNXM_HIP_WORK_WEIGHTS=slot,group,entry (relative to 8 per cluster pair) */
     PinnedBuffer<nbnxn_sci_t> h_sciSorted;

@@ -286,6 +286,7 @@ struct gpu_plist
     int          workShareCount[2]; /* the number of ranges the shares were set up for */
     int          workParts[2];      /* 2: the ranges are two sets of one-per-wave-slot, for a launch in two parts (nbnxm_gpu_launch_kernel_part) */
     float        workPartFraction[2]; /* ... and the first set's share of the weight the shares were set up for */
+    int          workShareTaper16[2]; /* ... and how long the ranges were (sixteenths between the short- and long-range class shares) */
     bool         workRangesDirty;
     unsigned long long* debugTimeline; /* diagnostics builds (NBNXM_WAVE_TIMELINE) only, else nullptr */
 };
@@ -337,6 +338,9 @@ constexpr int c_ringRecordBytes  = 64;
 constexpr int c_jRingBytes       = 4 * c_ringRecordBytes;
 /* LDS of one wave for the foreign-lambda terms of a perturbed cluster pair (fepClusterPair): 8 values of up to 64 pairs and 64
  * accumulators — what a wave of the cluster kernel has as staging buffers and ring */
+/* packed groups per work range below / above which the age-class shares of short / long ranges apply (NbnxmGpu::waveClassShare, ..Long) */
+constexpr int c_shortRangeGroups = 12;  /* 96k atoms: 11.7 */
+constexpr int c_longRangeGroups  = 110; /* 768k atoms: 109, 1.02 M atoms: 145 */
 constexpr int c_fepForeignLdsBytes = (8 + 1) * 64 * static_cast<int>(sizeof(float));
 /* a perturbed cluster pair with more perturbed atom pairs than this goes to the front of gpu_plist::slowPairs (nbnxmWorkWeightKernel) */
 #ifndef NBNXM_SLOW_PAIR_HEAVY
