@@ -340,7 +340,7 @@ constexpr int c_jRingBytes       = 4 * c_ringRecordBytes;
  * accumulators — what a wave of the cluster kernel has as staging buffers and ring */
 /* packed groups per work range below / above which the age-class shares of short / long ranges apply (NbnxmGpu::waveClassShare, ..Long) */
 constexpr int c_shortRangeGroups = 12;  /* 96k atoms: 11.7 */
-constexpr int c_longRangeGroups  = 110; /* 768k atoms: 109, 1.02 M atoms: 145 */
+constexpr int c_longRangeGroups  = 27;  /* 192k atoms: 23 (measured optimum there: 0.8 of the way); 768k atoms: 109, 1.02 M atoms: 145 */
 constexpr int c_fepForeignLdsBytes = (8 + 1) * 64 * static_cast<int>(sizeof(float));
 /* a perturbed cluster pair with more perturbed atom pairs than this goes to the front of gpu_plist::slowPairs (nbnxmWorkWeightKernel) */
 #ifndef NBNXM_SLOW_PAIR_HEAVY
