@@ -447,6 +447,14 @@ NbnxmGpu* nbnxm_gpu_init(const nbnxm_interaction_params_t* ic, int numTypes, con
                 nb->workWeightsOverride[0] = -1;
             }
         }
+        if (const char* env = diagnosticsEnv("NBNXM_HIP_CLASS_SHARES_SHORT"))
+        {
+            /* (experiment: shares of the age classes of a SHORT list's partition, three or four ranges per SIMD, oldest first) */
+            if (std::sscanf(env, "%d,%d,%d,%d", &nb->waveClassShareShort[0], &nb->waveClassShareShort[1], &nb->waveClassShareShort[2], &nb->waveClassShareShort[3]) < 3)
+            {
+                nb->waveClassShareShort[0] = 0;
+            }
+        }
         /* NBNXM_HIP_CLASS_SHARES4 / 5 = "s0,s1,.." in 1/1024 of an average range, oldest wave of a SIMD first (renormalised) */
         for (int p = 0; p < 2; p++)
         {
@@ -1607,6 +1615,19 @@ static void updateWorkPartition(NbnxmGpu* nb, int iloc)
             d->workPartFraction[p] = fraction;
         }
         out[p].shareCum = (d->numWorkRanges[p] == want && !shortList) ? d->workShareCum[p] : nullptr;
+        /* short lists, force flavours: one range fewer per SIMD, with age-class shares of their own (the energy flavours' three ranges: equal) */
+        if (shortList && p == 1 && nb->fusedFep && nb->waveClassShareShort[0] > 0 && d->numWorkRanges[p] == nb->numSimds * (3 + p))
+        {
+            const int n = d->numWorkRanges[p], classes = 3 + p, perClass = n / classes;
+            if (d->workShareCount[p] != n)
+            {
+                std::vector<float> share(n);
+                for (int r = 0; r < n; r++) { share[r] = nb->waveClassShareShort[std::min(classes - 1, r / perClass)] / 1024.0F; }
+                setWorkShares(d, p, share.data(), n, s);
+                d->workShareTaper16[p] = -1;
+            }
+            out[p].shareCum = d->workShareCum[p];
+        }
     }
     /* workFirstSci shares work_nalloc with workRangeStart: reallocate when that one grew */
     for (int p = 0; p < 2; p++)

@@ -122,6 +122,8 @@ struct NbnxmGpu
      * (round 4: force step 0.4177 -> 0.4078 ms, energy step 0.552 -> 0.533 ms); between c_shortRangeGroups and c_longRangeGroups the
      * shares are interpolated */
     int  waveClassShareLong[2][5] = { { 1225, 1110, 970, 791, 0 }, { 1350, 1185, 1024, 865, 696 } };
+    /* ... of a SHORT list's force partition (four ranges per SIMD; 24k atoms: 18.9 -> 18.6 us; steeper ones lose); [0] = 0: equal shares */
+    int  waveClassShareShort[4]   = { 1200, 1100, 980, 816 };
     bool waveClassShareFixed[2]   = { false, false }; /* set from the environment (diagnostics): no interpolation */
     int numWorkRangesOverride = 0; /* experiments: NBNXM_HIP_NUM_WORK_RANGES */
     int workWeightsOverride[3] = { -1, -1, -1 }; /* experiments: NBNXM_HIP_WORK_WEIGHTS=slot,group,entry (relative to 8 per cluster pair) */
