@@ -103,6 +103,19 @@ def measure(args, rank, world, dist, torch, nm, npert, reduce_device, steps, war
         parity = step_parity(pkg, wl, dict(natoms=case.natoms, make_case=dict(nm=nm, num_perturbed_molecules=npert, elec="ewald", seed=2026,
                                                                                  n_lambda=11, max_cjpacked_per_sci=args.max_cjpacked_per_sci)),
                              st, plan, rank, world, dist, torch, reduce_device)
+    # the same warm-up + timed steps with NO conditioning ahead of them: what a short protocol reads by itself (bench.py does the same)
+    for _ in range(warmup):
+        st.step(sw)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    t_cold = time.perf_counter()
+    for _ in range(steps):
+        st.step(sw)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed_cold = replica.max_over_ranks(time.perf_counter() - t_cold, dist if world > 1 else None, device=reduce_device)
     # untimed device conditioning ahead of the warm-up (the host has been building plans and lists for seconds with the GPU idle: the
     # device's clock needs a few hundred ms of work to settle, see bench.py)
     for _ in range(int(os.environ.get("BENCH_DD_CONDITION_STEPS", "1000"))):
@@ -145,6 +158,8 @@ def measure(args, rank, world, dist, torch, nm, npert, reduce_device, steps, war
     rec = None
     if rank == 0:
         rec = {"pair_interactions_per_s": 64.0 * float(tot[0].item()) * steps / elapsed, "ms_per_step": 1e3 * elapsed / steps, "steps": steps,
+               "ms_per_step_cold": 1e3 * elapsed_cold / steps,
+               "device_conditioning_steps_before_warmup": int(os.environ.get("BENCH_DD_CONDITION_STEPS", "1000")),
                "domain_grid": "%dx%dx%d" % ncells, "atoms": int(case.natoms), "cluster_pairs_all_ranks": int(tot[0].item()),
                "halo_atoms_per_rank_mean": float(tot[1].item()) / world, "home_atoms_per_rank_mean": float(tot[2].item()) / world,
                "halo_bytes_sent_and_received_rank0_per_step": halo.bytes_per_step(),
