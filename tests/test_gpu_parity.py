@@ -184,6 +184,42 @@ def test_outputs_accumulate_and_clear():
     nb.free()
 
 
+@pytest.mark.parametrize("fused", [False, True])
+def test_small_outputs_are_swapped_not_stale(fused):
+    """The scalar outputs and the shift forces exist twice (round 4): nbnxm_gpu_clear_outputs swaps to the copy a kernel's trailing workgroups
+    have zeroed.  A sequence that mixes energy, virial-only, dH/dlambda and force-only steps on ONE object must give every step the oracle's
+    energies, dV/dlambda, shift forces and foreign-lambda terms — nothing left over from a step two swaps back, nothing missing; and after
+    nbnxm_gpu_get_fshift (a caller that keeps the pointer) the same without swaps."""
+    c = tl.make_case(elec="ewald", seed=33, n_lambda=11, **SMALL)
+    want = tl.run_oracle(c, energy=True, foreign=True)
+    nb = tl.setup_gpu(c, fused=fused, use_dynamic_pruning=True)
+    f0 = None
+    for round_ in range(2):
+        for kind in ("energy", "force", "energy", "dhdl", "virial", "energy", "force", "force", "dhdl", "energy"):
+            if kind == "virial":
+                sw = pkg.step_workload(energy=False, virial=True, dhdl=False)
+                nb.clear_outputs(True)
+                nb.launch_kernel(sw)
+                f = np.zeros((c.grid.num_atoms, 3), np.float32)
+                nb.launch_cpyback(f, sw)
+                res = nb.wait_finish_task(sw, c.have_soft_core)
+                got = dict(f=f.astype(np.float64), fshift=res["fshift"].astype(np.float64))
+                tl.assert_parity(dict(got, e_lj=0, e_el=0, dvdl_coul=0, dvdl_vdw=0), want, rel=1e-4, energy=False, label="virial-only step")   # forces and shift forces
+                continue
+            got = tl.run_gpu(c, energy=(kind != "force"), fused=fused, dhdl=(kind == "dhdl"), nb=nb)
+            tl.assert_parity(got, want, rel=1e-4, energy=(kind != "force"), label="%s step, round %d" % (kind, round_))
+            if kind == "dhdl":
+                tl.assert_foreign(got, want, rel=1e-4)
+            if f0 is None:
+                f0 = got["f"]
+        if round_ == 0:
+            # from here on the caller holds the pointer of the shift forces: no more swaps of the output blocks, same results
+            lib = pkg.hip_lib()
+            lib.nbnxm_gpu_get_fshift.restype = C.c_void_p
+            assert lib.nbnxm_gpu_get_fshift(nb.h)
+    nb.free()
+
+
 def test_prune_kernel_matches_oracle_and_keeps_forces():
     import oracle_binding as ob
     c = tl.make_case(elec="rf", seed=29, **SMALL)
