@@ -439,6 +439,7 @@ NbnxmGpu* nbnxm_gpu_init(const nbnxm_interaction_params_t* ic, int numTypes, con
         NBNXM_HIP_CHECK(hipGetDeviceProperties(&prop, device));
         nb->numSimds = prop.multiProcessorCount * 4; /* CDNA: 4 SIMDs per CU */
         if (const char* env = diagnosticsEnv("NBNXM_HIP_NUM_WORK_RANGES")) { nb->numWorkRangesOverride = std::atoi(env); }
+        if (const char* env = diagnosticsEnv("NBNXM_HIP_NUM_WORK_RANGES4")) { nb->numWorkRangesEnergy = std::atoi(env); }
         if (const char* env = diagnosticsEnv("NBNXM_HIP_MIN_GROUPS_PER_WAVE")) { nb->minGroupsPerWave = std::max(1, std::atoi(env)); }
         if (const char* env = diagnosticsEnv("NBNXM_HIP_WORK_WEIGHTS"))
         {
@@ -679,7 +680,7 @@ void nbnxm_gpu_free(NbnxmGpu* nb)
             freeDeviceBuffer(&nb->plist[i]->slowPairSci);
             freeDeviceBuffer(&nb->plist[i]->slowCount);
             freeDeviceBuffer(&nb->plist[i]->weightBlockSum);
-            for (int p = 0; p < 2; p++)
+            for (int p = 0; p < c_numWorkPartitions; p++)
             {
                 freeDeviceBuffer(&nb->plist[i]->workRangeStart[p]);
                 freeDeviceBuffer(&nb->plist[i]->workFirstSci[p]);
@@ -1565,10 +1566,11 @@ static void updateWorkPartition(NbnxmGpu* nb, int iloc)
         d->slowCountPending = false;
     }
 
-    WorkPartitionOut out[2];
-    for (int p = 0; p < 2; p++)
+    WorkPartitionOut out[c_numWorkPartitions];
+    for (int p = 0; p < c_numWorkPartitions; p++)
     {
-        const int slots = nb->numSimds * (4 + p);
+        const int pw    = (p == c_partitionForce) ? 1 : 0; /* which of the two sets of age-class shares */
+        const int slots = nb->numSimds * workPartitionWaves(p);
         /* a launch in two parts (the local list of a decomposed run, force flavour): two sets of one range per wave slot, the first
          * set holding localPartFraction of the weight */
         const bool twoParts = (iloc == NBNXM_LOCAL && nb->localLaunchParts == 2 && nb->numWorkRangesOverride <= 0
@@ -1583,10 +1585,24 @@ static void updateWorkPartition(NbnxmGpu* nb, int iloc)
         /* (the four-waves-per-SIMD partition of the energy flavours: three ranges per SIMD under 2.5 groups per slot — 12k atoms, energy
          * step 0.0270 -> 0.0232 ms; 24k atoms the other way, 0.0297 -> 0.0333) */
         const bool shortList = !twoParts && nb->numWorkRangesOverride <= 0
-                               && ((p == 1 && 2 * static_cast<long long>(d->ncjPacked) < 9LL * slots)
-                                   || (p == 0 && 2 * static_cast<long long>(d->ncjPacked) < 5LL * slots));
-        if (shortList) { d->numWorkRanges[p] = std::max(1, std::min(nb->numSimds * (3 + p), d->ncjPacked / nb->minGroupsPerWave)); }
+                               && ((p == c_partitionForce && 2 * static_cast<long long>(d->ncjPacked) < 9LL * slots)
+                                   || (p != c_partitionForce && 2 * static_cast<long long>(d->ncjPacked) < 5LL * slots));
+        if (shortList) { d->numWorkRanges[p] = std::max(1, std::min(nb->numSimds * (workPartitionWaves(p) - 1), d->ncjPacked / nb->minGroupsPerWave)); }
+        /* (energy steps of a 12k-atom box — 7.5 k groups —: 2.5 ranges per SIMD, 0.0214 -> 0.0193 ms; dH/dlambda steps and the 3k box: flat) */
+        if (shortList && p == c_partitionEnergy && nb->fusedFep && d->ncjPacked >= 5 * nb->numSimds && nb->numWorkRangesOverride <= 0)
+        {
+            d->numWorkRanges[p] = nb->numSimds * 5 / 2;
+        }
+        /* Energy flavours, up to 6 packed groups per wave slot (24k atoms: 3.7; 48k: 7.3): fewer ranges than wave slots.  The trailing
+         * workgroups — perturbed pairs with their energies, on dH/dlambda steps at every foreign lambda — are a fifth to a half of such a
+         * kernel, and with a range in every slot they only start when range waves retire; with 15 of 16 (dH/dlambda: 3 of 4) slots taken they
+         * run beside the ranges from the start.  24k atoms: energy step 0.0247 -> 0.0231 ms, dH/dlambda step 0.0325 -> 0.0257 ms; at 96k
+         * atoms and up fewer ranges only lose (the ranges' age classes need one range per slot). */
+        const bool leaveSlots = !shortList && !twoParts && p != c_partitionForce && nb->fusedFep && nb->numWorkRangesOverride <= 0
+                                && static_cast<long long>(d->ncjPacked) < 6LL * slots && d->numWorkRanges[p] == want;
+        if (leaveSlots) { d->numWorkRanges[p] = (p == c_partitionDhdl) ? want * 3 / 4 : want * 15 / 16; }
         if (nb->numWorkRangesOverride > 0) { d->numWorkRanges[p] = std::min(nb->numWorkRangesOverride, d->ncjPacked); }
+        if (p != c_partitionForce && nb->numWorkRangesEnergy > 0) { d->numWorkRanges[p] = std::max(1, std::min(nb->numWorkRangesEnergy, d->ncjPacked / nb->minGroupsPerWave)); }
         reallocateDeviceBuffer(&d->workRangeStart[p], d->numWorkRanges[p] + 1, &dummy, &d->work_nalloc[p]);
         out[p].numRanges = d->numWorkRanges[p];
         /* shares: only for the launch they are meant for, one wave per slot of every SIMD; they start from the age classes
@@ -1594,13 +1610,13 @@ static void updateWorkPartition(NbnxmGpu* nb, int iloc)
         const float fraction = twoParts ? nb->localPartFraction : 1.0F;
         /* how long the ranges are, in sixteenths between the short-range and the long-range shares of the age classes */
         const int groupsPerRange = d->ncjPacked / std::max(1, want);
-        const int taper16        = nb->waveClassShareFixed[p]
+        const int taper16        = nb->waveClassShareFixed[pw]
                                            ? 0
                                            : std::max(0, std::min(16, (groupsPerRange - c_shortRangeGroups) * 16 / (c_longRangeGroups - c_shortRangeGroups)));
         if (d->numWorkRanges[p] == want && !shortList
             && (d->workShareCount[p] != want || d->workPartFraction[p] != fraction || d->workShareTaper16[p] != taper16))
         {
-            const int          classes = 4 + p, perClass = slots / classes;
+            const int          classes = workPartitionWaves(p), perClass = slots / classes;
             std::vector<float> share(want);
             d->workShareTaper16[p] = taper16;
             /* the age-class shares were measured for the fused mode; with the atom-pair kernels running beside the cluster
@@ -1608,7 +1624,7 @@ static void updateWorkPartition(NbnxmGpu* nb, int iloc)
             for (int r = 0; r < want; r++)
             {
                 const int   k       = std::min(classes - 1, (r % slots) / perClass);
-                const float ofClass = nb->fusedFep ? (nb->waveClassShare[p][k] * (16 - taper16) + nb->waveClassShareLong[p][k] * taper16) / (16.0F * 1024.0F) : 1.0F;
+                const float ofClass = nb->fusedFep ? (nb->waveClassShare[pw][k] * (16 - taper16) + nb->waveClassShareLong[pw][k] * taper16) / (16.0F * 1024.0F) : 1.0F;
                 share[r]            = ofClass * (twoParts ? (r < slots ? fraction : 1.0F - fraction) : 1.0F);
             }
             setWorkShares(d, p, share.data(), want, s);
@@ -1616,9 +1632,9 @@ static void updateWorkPartition(NbnxmGpu* nb, int iloc)
         }
         out[p].shareCum = (d->numWorkRanges[p] == want && !shortList) ? d->workShareCum[p] : nullptr;
         /* short lists, force flavours: one range fewer per SIMD, with age-class shares of their own (the energy flavours' three ranges: equal) */
-        if (shortList && p == 1 && nb->fusedFep && nb->waveClassShareShort[0] > 0 && d->numWorkRanges[p] == nb->numSimds * (3 + p))
+        if (shortList && p == c_partitionForce && nb->fusedFep && nb->waveClassShareShort[0] > 0 && d->numWorkRanges[p] == nb->numSimds * (workPartitionWaves(p) - 1))
         {
-            const int n = d->numWorkRanges[p], classes = 3 + p, perClass = n / classes;
+            const int n = d->numWorkRanges[p], classes = workPartitionWaves(p) - 1, perClass = n / classes;
             if (d->workShareCount[p] != n)
             {
                 std::vector<float> share(n);
@@ -1630,7 +1646,7 @@ static void updateWorkPartition(NbnxmGpu* nb, int iloc)
         }
     }
     /* workFirstSci shares work_nalloc with workRangeStart: reallocate when that one grew */
-    for (int p = 0; p < 2; p++)
+    for (int p = 0; p < c_numWorkPartitions; p++)
     {
         if (d->workFirstSciAlloc[p] < d->work_nalloc[p])
         {
@@ -1642,10 +1658,10 @@ static void updateWorkPartition(NbnxmGpu* nb, int iloc)
         out[p].firstSci   = d->workFirstSci[p];
     }
     hipLaunchKernelGGL(nbnxmWorkRangesKernel, dim3(numBlocks), dim3(c_workBlockSize), 0, s, d->groupWeight, d->weightBlockSum,
-                       d->ncjPacked, numBlocks, d->sciSorted, d->nsciWork, out[0], out[1]);
+                       d->ncjPacked, numBlocks, d->sciSorted, d->nsciWork, out[0], out[1], out[2]);
     NBNXM_HIP_CHECK(hipGetLastError());
     /* the start record of every range (NbWorkDesc): one scalar load at the top of a wave instead of four dependent round trips */
-    for (int p = 0; p < 2; p++)
+    for (int p = 0; p < c_numWorkPartitions; p++)
     {
         reallocateDeviceBuffer(&d->workDesc[p], d->numWorkRanges[p], &dummy, &d->workDesc_nalloc[p]);
         hipLaunchKernelGGL(nbnxmWorkDescKernel, dim3((d->numWorkRanges[p] + c_workBlockSize - 1) / c_workBlockSize), dim3(c_workBlockSize), 0, s,
@@ -1933,7 +1949,8 @@ void nbnxm_gpu_launch_kernel(NbnxmGpu* nb, const nbnxm_step_workload_t* stepWork
         }
         /* one wave per resident wave slot, each with its share of the list (see updateWorkPartition) */
         /* (fewer than 4 resident waves per SIMD — 118 to 131 types — run the 4-wave partition in rounds) */
-        const int p         = std::max(0, wavesPerSimd - 4);
+        /* (dH/dlambda steps of the energy flavours have a partition of their own: c_partitionDhdl) */
+        const int p         = (wavesPerSimd >= 5) ? c_partitionForce : ((wantForeign && energyFlavour) ? c_partitionDhdl : c_partitionEnergy);
         const int numRanges = plist->numWorkRanges[p];
         NBNXM_ASSERT(numRanges > 0, "work partition missing");
         /* two sets of ranges (workParts 2): one launch per set; the trailing workgroups ride with the second.  A caller that does
@@ -2372,7 +2389,7 @@ void nbnxm_gpu_debug_graph_steps(NbnxmGpu* nb, const nbnxm_step_workload_t* step
 
 void* nbnxm_gpu_debug_get_work_ranges(NbnxmGpu* nb, int iloc, int p, int* numRanges)
 {
-    NBNXM_ASSERT(p == 0 || p == 1, "partition index is 0 or 1");
+    NBNXM_ASSERT(p >= 0 && p < c_numWorkPartitions, "partition index is 0, 1 or 2");
     if (nb->plist[iloc]->workRangesDirty) { updateWorkPartition(nb, iloc); }
     *numRanges = nb->plist[iloc]->numWorkRanges[p];
     return nb->plist[iloc]->workRangeStart[p];
@@ -2380,10 +2397,10 @@ void* nbnxm_gpu_debug_get_work_ranges(NbnxmGpu* nb, int iloc, int p, int* numRan
 
 void nbnxm_gpu_debug_set_work_shares(NbnxmGpu* nb, int iloc, int p, const float* shares, int numRanges)
 {
-    NBNXM_ASSERT(p == 0 || p == 1, "partition index is 0 or 1");
+    NBNXM_ASSERT(p >= 0 && p < c_numWorkPartitions, "partition index is 0, 1 or 2");
     gpu_plist* d = nb->plist[iloc];
     if (d->workRangesDirty) { updateWorkPartition(nb, iloc); }
-    NBNXM_ASSERT(numRanges == d->numWorkRanges[p] && numRanges == nb->numSimds * (4 + p), "one share per wave slot of the device");
+    NBNXM_ASSERT(numRanges == d->numWorkRanges[p] && numRanges == nb->numSimds * workPartitionWaves(p), "one share per wave slot of the device");
     setWorkShares(d, p, shares, numRanges, nb->deviceStreams[iloc].stream);
 }
 

@@ -126,6 +126,7 @@ struct NbnxmGpu
     int  waveClassShareShort[4]   = { 1200, 1100, 980, 816 };
     bool waveClassShareFixed[2]   = { false, false }; /* set from the environment (diagnostics): no interpolation */
     int numWorkRangesOverride = 0; /* experiments: NBNXM_HIP_NUM_WORK_RANGES */
+    int numWorkRangesEnergy   = 0; /* ranges of the energy flavours' partition (0: one per wave slot) */
     int workWeightsOverride[3] = { -1, -1, -1 }; /* experiments: NBNXM_HIP_WORK_WEIGHTS=slot,group,entry (relative to 8 per cluster pair) */
     PinnedBuffer<nbnxn_sci_t> h_sciSorted;
     PinnedBuffer<int>         h_slowCount;        /* one per locality */

@@ -205,6 +205,13 @@ constexpr unsigned c_clearFloat4PerThread = 4; /* trailing clear workgroups of t
  * j data, four dependent round trips).  Written by nbnxmWorkDescKernel behind the range borders, whenever the partition changes.
  * Only what no pruning changes is copied: the i-entry record, the first group's j-cluster indices and exclusion-mask indices (the
  * group's imask — rewritten by every rolling-prune part — is read through the list-word ring like any other group's). */
+/* Work partitions of a list: 0 the energy flavours' (four waves per SIMD), 1 the force flavours' (five), 2 the energy flavours' on dH/dlambda
+ * steps (four; round 4: on short lists fewer ranges than wave slots, so that the foreign-lambda work of the trailing workgroups — three
+ * times the perturbed pairs' work of an energy step — runs beside the ranges from the start of the kernel) */
+constexpr int c_numWorkPartitions = 3;
+constexpr int c_partitionEnergy = 0, c_partitionForce = 1, c_partitionDhdl = 2;
+inline int workPartitionWaves(int p) { return p == c_partitionForce ? 5 : 4; }
+
 struct NbWorkDesc
 {
     int         rangeBegin, rangeEnd; /* packed j-groups [rangeBegin, rangeEnd); empty when no i-entry owns a group of the range */
@@ -274,19 +281,19 @@ struct gpu_plist
     int          groupWeight_nalloc;
     int*         weightBlockSum;  /* per 256 groups, then its exclusive scan; last entry = total */
     int          weightBlockSum_nalloc;
-    int*         workRangeStart[2];
-    int*         workFirstSci[2];
-    NbWorkDesc*  workDesc[2];       /* numWorkRanges: what a wave needs to start its range, in one 64-byte record (nbnxmWorkDescKernel) */
-    int          workDesc_nalloc[2];
-    int          numWorkRanges[2];
-    int          work_nalloc[2];
-    int          workFirstSciAlloc[2];
-    float*       workShare[2];      /* numWorkRanges: share of the total weight of each range, mean 1 (see WorkPartitionOut) */
-    float*       workShareCum[2];   /* numWorkRanges + 1: its running sum, normalised to 1 */
-    int          workShareCount[2]; /* the number of ranges the shares were set up for */
-    int          workParts[2];      /* 2: the ranges are two sets of one-per-wave-slot, for a launch in two parts (nbnxm_gpu_launch_kernel_part) */
-    float        workPartFraction[2]; /* ... and the first set's share of the weight the shares were set up for */
-    int          workShareTaper16[2]; /* ... and how long the ranges were (sixteenths between the short- and long-range class shares) */
+    int*         workRangeStart[c_numWorkPartitions];
+    int*         workFirstSci[c_numWorkPartitions];
+    NbWorkDesc*  workDesc[c_numWorkPartitions];       /* numWorkRanges: what a wave needs to start its range, in one 64-byte record (nbnxmWorkDescKernel) */
+    int          workDesc_nalloc[c_numWorkPartitions];
+    int          numWorkRanges[c_numWorkPartitions];
+    int          work_nalloc[c_numWorkPartitions];
+    int          workFirstSciAlloc[c_numWorkPartitions];
+    float*       workShare[c_numWorkPartitions];      /* numWorkRanges: share of the total weight of each range, mean 1 (see WorkPartitionOut) */
+    float*       workShareCum[c_numWorkPartitions];   /* numWorkRanges + 1: its running sum, normalised to 1 */
+    int          workShareCount[c_numWorkPartitions]; /* the number of ranges the shares were set up for */
+    int          workParts[c_numWorkPartitions];      /* 2: the ranges are two sets of one-per-wave-slot, for a launch in two parts (nbnxm_gpu_launch_kernel_part) */
+    float        workPartFraction[c_numWorkPartitions]; /* ... and the first set's share of the weight the shares were set up for */
+    int          workShareTaper16[c_numWorkPartitions]; /* ... and how long the ranges were (sixteenths between the short- and long-range class shares) */
     bool         workRangesDirty;
     unsigned long long* debugTimeline; /* diagnostics builds (NBNXM_WAVE_TIMELINE) only, else nullptr */
 };

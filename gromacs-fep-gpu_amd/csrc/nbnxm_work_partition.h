@@ -228,7 +228,8 @@ __launch_bounds__(c_workBlockSize) __global__
                                    const nbnxn_sci_t* __restrict__ sciSorted,
                                    const int                       nsci,
                                    const WorkPartitionOut          out0,
-                                   const WorkPartitionOut          out1)
+                                   const WorkPartitionOut          out1,
+                                   const WorkPartitionOut          out2)
 {
     __shared__ int lds[c_workBlockSize];
     const int      g = static_cast<int>(blockIdx.x) * c_workBlockSize + static_cast<int>(threadIdx.x);
@@ -241,9 +242,9 @@ __launch_bounds__(c_workBlockSize) __global__
     const long long ePrev = (g == 0) ? -1 : e - groupWeight[g - 1];     /* ... and before the previous one */
     int             sciOfGroup = -2;
 #pragma unroll
-    for (int p = 0; p < 2; p++)
+    for (int p = 0; p < c_numWorkPartitions; p++)
     {
-        const WorkPartitionOut& out = (p == 0) ? out0 : out1;
+        const WorkPartitionOut& out = (p == 0) ? out0 : ((p == 1) ? out1 : out2);
         const int               nW  = out.numRanges;
         if (nW <= 0) { continue; }
         /* range a owns the groups whose preceding weight lies in its share of the total (equal shares: [a, a + 1) total / nW) */
