@@ -77,6 +77,11 @@ print("        wave end min %.1f p10 %.1f p50 %.1f p90 %.1f max %.1f | per-SIMD 
     end.min(), *np.percentile(end, [10, 50, 90, 100]), *np.percentile(simd_end, [10, 50, 90, 100]), simd_end.mean()))
 print("        wave duration p10 %.1f p50 %.1f p90 %.1f max %.1f; sum of wave durations / (SIMDs x last end) = %.3f" % (
     *np.percentile(end - start, [10, 50, 90, 100]), (end - start).sum() / (len(uk) * last * (len(a) / len(uk)))))
+# the same by XCD: mean over an XCD's SIMDs of their last range wave's end, and whether workgroup b of the launch runs on XCD b mod 8
+kx = np.array([int(xcc[key == k][0]) for k in uk])
+print("        per-SIMD last end by XCD: " + " ".join("%.2f" % simd_end[kx == x].mean() for x in range(8)) + " | mean %.2f" % simd_end.mean())
+wi = np.nonzero((allrec[:n, 0] != 0))[0]
+print("        XCD of the first 24 workgroups (4 waves each): " + " ".join(str(int(xcc[wi == 4 * b][0])) if (wi == 4 * b).any() else "-" for b in range(24)))
 if len(tail):
     ts = (tail[:, 0] - t0).astype(np.float64) / 100.0
     te = (tail[:, 2] - t0).astype(np.float64) / 100.0
