@@ -1461,6 +1461,20 @@ def test_config1_24k_atom_box_reaction_field(fused):
     tl.assert_foreign(got, want, rel=1e-4)
     got_f2 = tl.run_gpu(c, energy=False, fused=fused, nb=nb)      # after an energy step: the clear kernel instead of the swap
     tl.assert_parity(got_f2, want, rel=1e-4, energy=False, label="24k rf F again")
+    got_e = tl.run_gpu(c, energy=True, fused=fused, nb=nb)          # an energy step without foreign lambdas: the energy flavours' own partition
+    tl.assert_parity(got_e, want, rel=1e-4, label="24k rf VF, energy partition")
+    # the three work partitions of this list (round 4): the force flavours' short-list one (four ranges per SIMD), and in fused mode the
+    # energy flavours' with 15/16, on dH/dlambda steps with 3/4 of the wave slots — the trailing workgroups run beside the ranges there
+    lib = pkg.hip_lib()
+    lib.nbnxm_gpu_debug_get_work_ranges.restype = C.c_void_p
+    counts = []
+    for p in (0, 1, 2):
+        n = C.c_int()
+        assert lib.nbnxm_gpu_debug_get_work_ranges(nb.h, C.c_int(pkg.LOCAL), C.c_int(p), C.byref(n))
+        counts.append(n.value)
+    slots4 = counts[1]      # the force partition of a short list: four ranges on each of the 1,024 SIMDs = the energy flavours' wave slots
+    assert slots4 % 1024 == 0
+    assert counts == ([slots4 * 15 // 16, slots4, slots4 * 3 // 4] if fused else [slots4, slots4, slots4]), counts
     nb.free()
 
 
