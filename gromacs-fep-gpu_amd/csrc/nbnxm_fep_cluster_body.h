@@ -42,22 +42,25 @@ NB_DEVINL void fepClusterPair(const NBAtomDataGpu& atdat,
 
     /* one wave per perturbed cluster pair: the waves are latency-bound chains, so the kernel lasts as long as its
      * longest wave, and one cluster pair is the shortest unit there is */
-    const int         entry    = __builtin_amdgcn_readfirstlane(plist.slowPairs[item]); /* group * 32 + jm * 8 + i */
+    /* the pair's record: one scalar load (the item is wave-uniform), and everything below depends on nothing but it — the list word that
+     * says whether the pair survives the current pruning travels beside the atoms' data, it is looked at when they are on their way */
+    typedef int nb_int8 __attribute__((ext_vector_type(8)));
+    const nb_int8     rec      = *reinterpret_cast<const nb_int8*>(&plist.slowPairs[__builtin_amdgcn_readfirstlane(item)]);
+    const int         entry    = __builtin_amdgcn_readfirstlane(rec[0]); /* group * 32 + jm * 8 + i */
     const int         group    = entry >> 5;
     const int         jm       = (entry >> 3) & 3;
     const int         i        = entry & 7;
-    const int         sciShift = __builtin_amdgcn_readfirstlane(plist.slowPairSci[item]); /* sci * 64 + shift index */
+    const int         sciShift = __builtin_amdgcn_readfirstlane(rec[1]); /* sci * 64 + shift index */
     const int         sci      = sciShift >> 6;
     const int         shiftIdx = sciShift & 63;
     const bool        central  = (shiftIdx == c_centralShiftIndex);
+    const int         cj       = __builtin_amdgcn_readfirstlane(rec[2]);
+    const int         exclIndOfHalf[2] = { __builtin_amdgcn_readfirstlane(rec[3]), __builtin_amdgcn_readfirstlane(rec[4]) };
 
     const nbnxn_cj_packed_t* __restrict__ grp = &cjPackedList[group];
-    const int  cj       = grp->cj[jm];
-    const int  ci       = sci * c_numClPerSupercl + i;
-    const bool inList   = ((grp->imei[0].imask >> (jm * c_numClPerSupercl + i)) & 1U) != 0U; /* survives the current pruning */
-    const bool diagPair = central && (ci == cj);
-    /* the atoms' own (i == j) terms belong to the cluster's pair with itself, whether or not that pair is in range */
-    if (!inList && !(ENERGY && EXCL_FORCES && diagPair)) { return; }
+    const int      ci        = sci * c_numClPerSupercl + i;
+    const unsigned imaskNow  = grp->imei[0].imask;
+    const bool     diagPair  = central && (ci == cj);
 
     const unsigned iBits    = (fepWords[ci >> 2] >> ((ci & 3) * 8)) & 0xFFU;
     const unsigned jFepBits = (fepWords[cj >> 2] >> ((cj & 3) * 8)) & 0xFFU;
@@ -81,7 +84,10 @@ NB_DEVINL void fepClusterPair(const NBAtomDataGpu& atdat,
     xi.y += sh.y;
     xi.z += sh.z;
     const float2   qABi     = make_float2(q4i.x * nbp.epsfac, q4i.y * nbp.epsfac);
-    const unsigned wexcl    = exclList[half ? grp->imei[1].excl_ind : grp->imei[0].excl_ind].pair[lane & 31U];
+    const unsigned wexcl    = exclList[half ? exclIndOfHalf[1] : exclIndOfHalf[0]].pair[lane & 31U];
+    const bool     inList   = ((imaskNow >> (jm * c_numClPerSupercl + i)) & 1U) != 0U; /* survives the current pruning */
+    /* the atoms' own (i == j) terms belong to the cluster's pair with itself, whether or not that pair is in range */
+    if (!inList && !(ENERGY && EXCL_FORCES && diagPair)) { return; }
     const bool     included = ((wexcl >> (jm * c_numClPerSupercl + i)) & 1U) != 0U;
     const float3   rv       = make_float3(xi.x - xqj.x, xi.y - xqj.y, xi.z - xqj.z);
     const float    r2       = rv.x * rv.x + rv.y * rv.y + rv.z * rv.z;

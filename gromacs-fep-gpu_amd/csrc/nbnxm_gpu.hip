@@ -677,7 +677,6 @@ void nbnxm_gpu_free(NbnxmGpu* nb)
             freeDeviceBuffer(&nb->plist[i]->groupWeight);
             freeDeviceBuffer(&nb->plist[i]->groupSlowMask);
             freeDeviceBuffer(&nb->plist[i]->slowPairs);
-            freeDeviceBuffer(&nb->plist[i]->slowPairSci);
             freeDeviceBuffer(&nb->plist[i]->slowCount);
             freeDeviceBuffer(&nb->plist[i]->weightBlockSum);
             for (int p = 0; p < c_numWorkPartitions; p++)
@@ -1492,12 +1491,10 @@ static void updateWorkPartition(NbnxmGpu* nb, int iloc)
     {
         freeDeviceBuffer(&d->groupSlowMask);
         freeDeviceBuffer(&d->slowPairs);
-        freeDeviceBuffer(&d->slowPairSci);
         d->slowPairs_nalloc = std::max(8192, 2 * d->groupWeight_nalloc); /* a ligand-sized region has a few thousand */
         allocateDeviceBuffer(&d->groupSlowMask, d->groupWeight_nalloc);
 
         allocateDeviceBuffer(&d->slowPairs, d->slowPairs_nalloc);
-        allocateDeviceBuffer(&d->slowPairSci, d->slowPairs_nalloc);
         d->slowListDirty = true;
     }
     if (d->slowCount == nullptr)
@@ -1530,7 +1527,7 @@ static void updateWorkPartition(NbnxmGpu* nb, int iloc)
         weights.entry = nb->workWeightsOverride[2];
     }
     hipLaunchKernelGGL(nbnxmWorkWeightKernel, dim3(numBlocks), dim3(c_workBlockSize), 0, s, d->cjPacked, d->ncjPacked, d->sciSorted,
-                       d->nsciWork, fused ? nb->atdat->fepBits : nullptr, buildSlow ? 1 : 0, outerMask, d->groupSlowMask, d->slowPairs, d->slowPairSci,
+                       d->nsciWork, fused ? nb->atdat->fepBits : nullptr, buildSlow ? 1 : 0, outerMask, d->groupSlowMask, d->slowPairs,
                        d->slowPairs_nalloc, d->slowCount, d->groupWeight, d->weightBlockSum, weights);
     if (buildSlow && fused)
     {
@@ -1539,7 +1536,7 @@ static void updateWorkPartition(NbnxmGpu* nb, int iloc)
         NBNXM_HIP_CHECK(hipMemcpyAsync(d->slowCount + 1, d->slowCount, sizeof(int), hipMemcpyDeviceToDevice, s));
         /* the second pass of the slow-pair list: the light pairs behind the heavy ones (weights and masks: the same values again) */
         hipLaunchKernelGGL(nbnxmWorkWeightKernel, dim3(numBlocks), dim3(c_workBlockSize), 0, s, d->cjPacked, d->ncjPacked, d->sciSorted,
-                           d->nsciWork, nb->atdat->fepBits, 2, outerMask, d->groupSlowMask, d->slowPairs, d->slowPairSci, d->slowPairs_nalloc,
+                           d->nsciWork, nb->atdat->fepBits, 2, outerMask, d->groupSlowMask, d->slowPairs, d->slowPairs_nalloc,
                            d->slowCount, d->groupWeight, d->weightBlockSum, weights);
     }
     hipLaunchKernelGGL(nbnxmWorkScanKernel, dim3(1), dim3(c_workBlockSize), 0, s, d->weightBlockSum, numBlocks);

@@ -205,6 +205,19 @@ constexpr unsigned c_clearFloat4PerThread = 4; /* trailing clear workgroups of t
  * j data, four dependent round trips).  Written by nbnxmWorkDescKernel behind the range borders, whenever the partition changes.
  * Only what no pruning changes is copied: the i-entry record, the first group's j-cluster indices and exclusion-mask indices (the
  * group's imask — rewritten by every rolling-prune part — is read through the list-word ring like any other group's). */
+/* A cluster pair that touches a perturbed atom (fused mode; gpu_plist::slowPairs), as the wave that evaluates it reads it — one 32-byte
+ * scalar load: with only the pair's position in the list, the j-cluster and the exclusion indices were a dependent round trip more
+ * before the first atom could be loaded, and these waves are nothing but a chain of round trips (round 4) */
+struct NbSlowPair
+{
+    int entry;      /* group * 32 + jm * 8 + i */
+    int sciShift;   /* its i-entry: sci * 64 + shift index */
+    int cj;         /* cjPacked[group].cj[jm] */
+    int exclInd[2]; /* cjPacked[group].imei[0 / 1].excl_ind */
+    int pad[3];
+};
+static_assert(sizeof(NbSlowPair) == 32, "one s_load_dwordx8");
+
 /* Work partitions of a list: 0 the energy flavours' (four waves per SIMD), 1 the force flavours' (five), 2 the energy flavours' on dH/dlambda
  * steps (four; round 4: on short lists fewer ranges than wave slots, so that the foreign-lambda work of the trailing workgroups — three
  * times the perturbed pairs' work of an energy step — runs beside the ranges from the start of the kernel) */
@@ -267,8 +280,7 @@ struct gpu_plist
     nbnxn_sci_t* sciSorted;
     int          sciSorted_nalloc;
     unsigned*    groupSlowMask;   /* ncjPacked: fused mode, the cluster pairs of each group that touch a perturbed atom */
-    int*         slowPairs;       /* numSlowPairs: group * 32 + jm * 8 + i of every listed cluster pair with a perturbed atom */
-    int*         slowPairSci;     /* ... and its i-entry as sci * 64 + shift index */
+    NbSlowPair*  slowPairs;       /* numSlowPairs: every listed cluster pair with a perturbed atom, with what its wave needs to start (NbSlowPair) */
     int*         slowCount;       /* [0] the number of entries of slowPairs, counted on the device; [1] how many of them, at the front, are heavy */
     int          numSlowHeavy;    /* ... and for how many of them, at the front, are heavy (split over several waves on dH/dlambda steps) */
     int          numSlowPairs;    /* the host's figure for sizing launches: exact once the count of this list has arrived, the previous

@@ -90,8 +90,7 @@ __launch_bounds__(c_workBlockSize) __global__
                                                                                          * (a second launch: the heavy ones come first in the list) */
                                    const unsigned* __restrict__          outerMask, /* gpu_plist::imask of a list that has been pruned, else nullptr */
                                    unsigned* __restrict__                groupSlowMask,
-                                   int* __restrict__                     slowPairs,   /* group * 32 + jm * 8 + i of every listed slow pair ... */
-                                   int* __restrict__                     slowPairSci, /* ... and its i-entry: sci * 64 + shift index */
+                                   NbSlowPair* __restrict__              slowPairs,   /* every listed slow pair with what its wave needs to start */
                                    const int                             slowCapacity,
                                    int* __restrict__                     slowCount,
                                    int* __restrict__                     groupWeight,
@@ -149,8 +148,14 @@ __launch_bounds__(c_workBlockSize) __global__
                 while (todo != 0U && idx < slowCapacity)
                 {
                     const int bit    = __ffs(todo) - 1;
-                    slowPairs[idx]   = g * 32 + bit;
-                    slowPairSci[idx] = sciSorted[k].sci * 64 + (sciSorted[k].shift & NBNXM_CI_SHIFT_MASK);
+                    NbSlowPair rec;
+                    rec.entry      = g * 32 + bit;
+                    rec.sciShift   = sciSorted[k].sci * 64 + (sciSorted[k].shift & NBNXM_CI_SHIFT_MASK);
+                    rec.cj         = cjPacked[g].cj[bit >> 3];
+                    rec.exclInd[0] = cjPacked[g].imei[0].excl_ind;
+                    rec.exclInd[1] = cjPacked[g].imei[1].excl_ind;
+                    rec.pad[0] = rec.pad[1] = rec.pad[2] = 0;
+                    slowPairs[idx] = rec;
                     todo &= todo - 1U;
                     idx++;
                 }
