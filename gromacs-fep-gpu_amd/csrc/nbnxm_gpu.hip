@@ -1480,7 +1480,7 @@ static void updateWorkPartition(NbnxmGpu* nb, int iloc)
 #endif
     if (d->nsci == 0 || d->ncjPacked == 0)
     {
-        d->numWorkRanges[0] = d->numWorkRanges[1] = 0;
+        for (int p = 0; p < c_numWorkPartitions; p++) { d->numWorkRanges[p] = 0; }
         return;
     }
     const int numBlocks = (d->ncjPacked + c_workBlockSize - 1) / c_workBlockSize;
