@@ -427,7 +427,7 @@ NbnxmGpu* nbnxm_gpu_init(const nbnxm_interaction_params_t* ic, int numTypes, con
         std::memset(nb->plist[i], 0, sizeof(gpu_plist));
         nb->plist[i]->sci_nalloc = nb->plist[i]->cjPacked_nalloc = nb->plist[i]->imask_nalloc = nb->plist[i]->excl_nalloc = -1;
         nb->plist[i]->sciSorted_nalloc = nb->plist[i]->groupWeight_nalloc = nb->plist[i]->weightBlockSum_nalloc = -1;
-        nb->plist[i]->work_nalloc[0] = nb->plist[i]->work_nalloc[1] = -1;
+        for (int p = 0; p < c_numWorkPartitions; p++) { nb->plist[i]->work_nalloc[p] = -1; }
         nb->feplist[i] = new gpu_feplist;
         initFeplist(nb->feplist[i]);
     }
